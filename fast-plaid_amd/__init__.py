@@ -1,0 +1,14 @@
+"""MI355X-native PLAID search engine: drop-in for the fast-plaid *search* hot path.
+
+Layout:
+  csrc/                 hand-written HIP kernels (gfx950) + host engine + C ABI (include/fastplaid.h)
+  _native.py            ctypes loader of libfastplaid_hip.so (fails loudly when it is missing)
+  fast_plaid_rust.py    mirror of the reference's PyO3 module `fast_plaid.fast_plaid_rust`
+                        (rust/lib.rs:366-383): construct_index / pysearch / SearchParameters / QueryResult
+  search/               mirror of `fast_plaid.search` (class FastPlaid)
+  synth.py              synthetic compressed-domain corpora (numpy twin of csrc/fp_synth.hip)
+  sharded.py            one-process-per-GPU document-sharded search over torch.distributed (RCCL)
+"""
+from . import fast_plaid_rust, search, synth  # noqa: F401
+
+__all__ = ["fast_plaid_rust", "search", "synth"]

@@ -1,0 +1,778 @@
+// Host engine + C ABI (include/fastplaid.h) of the MI355X PLAID search library.
+// Replaces, for the search path, rust/search/{search,load,tensor,padding}.rs and
+// rust/utils/residual_codec.rs of the reference: index construction = upload + re-layout,
+// search_many = one batched, stream-ordered pipeline of HIP kernels (fp_kernels.hip).
+// No torch / tch; only the HIP runtime.
+#include "../../include/fastplaid.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fp_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// errors (rust/utils/errors.rs:5-7: every failure becomes one message string)
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                                      \
+  do {                                                                                                 \
+    hipError_t e_ = (x);                                                                               \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x);            \
+  } while (0)
+
+extern "C" const char* fp_last_error(void) { return g_err.c_str(); }
+extern "C" const char* fp_version(void) { return "fastplaid-hip 0.1 (gfx950)"; }
+extern "C" int fp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// grow-only device buffer
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t need) {
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = need + need / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APPROX, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
+static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
+                                        "S3 compact",  "S4 approx",        "S5 select",     "S6+S7 maxsim",
+                                        "S8 topk+download"};
+
+struct Scratch {
+  hipStream_t st = nullptr;
+  hipEvent_t ev[ST_N + 1] = {};
+  DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
+      cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
+      tok_idx, recon;
+  void destroy() {
+    DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
+                     &sub_off,  &bitmap,   &blkcnt,   &ncand,   &cand_off, &cand_pid,  &approx,  &hist,     &selstate, &sel_pid,
+                     &sel_approx, &sel_cnt, &exact,   &out_pid, &out_score, &out_cnt,  &tmpf,    &tmpp,     &tok_idx, &recon};
+    for (DevBuf* b : all) b->release();
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+struct fp_index {
+  FpIndexDev d{};
+  int device = 0;
+  bool has_ivf = false;
+  std::vector<void*> owned;
+  std::vector<int64_t> h_doc_off;
+  int64_t bytes = 0;
+  std::mutex mu;
+  std::vector<Scratch*> pool;
+  bool synthetic = false;
+};
+
+static thread_local float g_last_ms[ST_N];
+static thread_local bool g_have_ms = false;
+
+static Scratch* acquire(fp_index* ix) {
+  {
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->pool.empty()) {
+      Scratch* s = ix->pool.back();
+      ix->pool.pop_back();
+      return s;
+    }
+  }
+  Scratch* s = new Scratch();
+  if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
+    delete s;
+    return nullptr;
+  }
+  for (auto& e : s->ev) (void)hipEventCreate(&e);
+  return s;
+}
+static void release(fp_index* ix, Scratch* s) {
+  std::lock_guard<std::mutex> g(ix->mu);
+  ix->pool.push_back(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// index construction (load.rs:124-186)
+// ------------------------------------------------------------------------------------------
+static void build_lut_host(int nbits, const uint16_t* weights, std::vector<uint16_t>& lut) {
+  // residual_codec.rs:83-140 folded: byte -> rev_map -> idx_lookup[rev][j] -> weights
+  const int per = 8 / nbits, mask = (1 << nbits) - 1;
+  lut.assign((size_t)256 * per, 0);
+  for (int v = 0; v < 256; ++v) {
+    unsigned out = 0;
+    int pos = 8;
+    while (pos >= nbits) {
+      unsigned seg = ((unsigned)v >> (pos - nbits)) & (unsigned)mask, rev = 0;
+      for (int k = 0; k < nbits; ++k)
+        if (seg & (1u << k)) rev |= 1u << (nbits - 1 - k);
+      out |= rev;
+      if (pos > nbits) out <<= nbits;
+      pos -= nbits;
+    }
+    out &= 0xFF;
+    int j = 0;
+    for (int k = per - 1; k >= 0; --k) lut[(size_t)v * per + j++] = weights[(out >> (k * nbits)) & mask];
+  }
+}
+
+template <typename T>
+static hipError_t dev_alloc(fp_index* ix, T** p, size_t n) {
+  void* q = nullptr;
+  size_t bytes = (n ? n : 1) * sizeof(T) + 64;  // slack: vector loads may touch past the end
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return e;
+  ix->owned.push_back(q);
+  ix->bytes += (int64_t)bytes;
+  *p = reinterpret_cast<T*>(q);
+  return hipSuccess;
+}
+
+static int upload_narrow(const int64_t* host, int32_t* dev, int64_t n, hipStream_t st) {
+  // chunked i64 -> i32 through a device staging buffer
+  if (n <= 0) return FP_OK;
+  const int64_t chunk = 32ll << 20;  // 32M entries = 256 MiB
+  int64_t* stage = nullptr;
+  HIPCHK(hipMalloc((void**)&stage, (size_t)std::min(chunk, n) * 8));
+  for (int64_t s = 0; s < n; s += chunk) {
+    int64_t m = std::min(chunk, n - s);
+    hipError_t e = hipMemcpyAsync(stage, host + s, (size_t)m * 8, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { (void)hipFree(stage); return fail(FP_EHIP, hipGetErrorString(e)); }
+    fpk_narrow_i64_i32(stage, dev + s, m, 0, st);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(stage); return fail(FP_EHIP, hipGetErrorString(e)); }
+  }
+  (void)hipFree(stage);
+  return FP_OK;
+}
+
+static int check_shape(int nbits, int dim) {
+  if (!(nbits == 2 || nbits == 4))
+    return fail(FP_EUNSUPPORTED, "nbits must be 2 or 4 (kernels are instantiated for these)");
+  if (!(dim == 64 || dim == 128)) return fail(FP_EUNSUPPORTED, "dim must be 64 or 128 (kernels are instantiated for these)");
+  return FP_OK;
+}
+
+extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index** out) {
+  if (!d || !out) return fail(FP_EINVAL, "null argument");
+  *out = nullptr;
+  if (int rc = check_shape(d->nbits, d->dim)) return rc;
+  if (d->n_centroids <= 0 || !d->centroids || !d->bucket_weights) return fail(FP_EINVAL, "centroids / bucket_weights missing");
+  if (d->n_docs < 0 || (d->n_docs > 0 && (!d->doc_lengths || !d->doc_codes || !d->doc_residuals)))
+    return fail(FP_EINVAL, "document arrays missing");
+  if (d->n_docs >= 0x7FFFFFFFll) return fail(FP_EUNSUPPORTED, "more than 2^31-1 documents per index shard");
+  HIPCHK(hipSetDevice(device_id));
+  fp_index* ix = new fp_index();
+  ix->device = device_id;
+  auto bail = [&](int rc) {
+    fp_index_destroy(ix);
+    return rc;
+  };
+  hipStream_t st = nullptr;
+  FpIndexDev& D = ix->d;
+  D.nbits = d->nbits; D.dim = d->dim; D.pr = d->dim * d->nbits / 8;
+  D.C = d->n_centroids; D.N = d->n_docs; D.pid_offset = d->pid_offset;
+  // doc offsets (tensor.rs:221-224)
+  ix->h_doc_off.assign((size_t)D.N + 1, 0);
+  int maxlen = 0;
+  for (int64_t i = 0; i < D.N; ++i) {
+    int64_t l = d->doc_lengths[i];
+    if (l < 0) return bail(fail(FP_EINVAL, "negative document length"));
+    ix->h_doc_off[i + 1] = ix->h_doc_off[i] + l;
+    if (l > maxlen) maxlen = (int)l;
+  }
+  D.T = ix->h_doc_off[D.N];
+  D.max_doc_len = maxlen;
+  uint16_t* cent = nullptr; uint16_t* lut = nullptr; int64_t* doc_off = nullptr; int32_t* codes = nullptr; uint8_t* res = nullptr;
+  int64_t* ivf_off = nullptr; int32_t* ivf_pids = nullptr;
+#define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x)); } while (0)
+  ICHK(hipStreamCreate(&st));
+  ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
+  ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
+  std::vector<uint16_t> hlut;
+  build_lut_host(D.nbits, d->bucket_weights, hlut);
+  ICHK(dev_alloc(ix, &lut, hlut.size()));
+  ICHK(hipMemcpy(lut, hlut.data(), hlut.size() * 2, hipMemcpyHostToDevice));
+  ICHK(dev_alloc(ix, &doc_off, (size_t)D.N + 1));
+  ICHK(hipMemcpy(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice));
+  ICHK(dev_alloc(ix, &codes, (size_t)D.T));
+  if (int rc = upload_narrow(d->doc_codes, codes, D.T, st)) { (void)hipStreamDestroy(st); return bail(rc); }
+  ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
+  if (D.T > 0) ICHK(hipMemcpy(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice));
+  ix->has_ivf = d->ivf != nullptr && d->ivf_lengths != nullptr;
+  D.P = ix->has_ivf ? d->n_ivf_lists : 0;
+  {
+    std::vector<int64_t> hoff((size_t)D.P + 1, 0);
+    for (int64_t i = 0; i < D.P; ++i) {
+      if (d->ivf_lengths[i] < 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EINVAL, "negative ivf length")); }
+      hoff[i + 1] = hoff[i] + d->ivf_lengths[i];
+    }
+    ICHK(dev_alloc(ix, &ivf_off, hoff.size()));
+    ICHK(hipMemcpy(ivf_off, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice));
+    const int64_t tot = hoff[D.P];
+    ICHK(dev_alloc(ix, &ivf_pids, (size_t)tot));
+    if (tot > 0)
+      if (int rc = upload_narrow(d->ivf, ivf_pids, tot, st)) { (void)hipStreamDestroy(st); return bail(rc); }
+  }
+  ICHK(hipStreamDestroy(st));
+#undef ICHK
+  D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res; D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
+  *out = ix;
+  return FP_OK;
+}
+
+extern "C" void fp_index_destroy(fp_index* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  for (Scratch* s : ix->pool) {
+    s->destroy();
+    delete s;
+  }
+  for (void* p : ix->owned) (void)hipFree(p);
+  delete ix;
+}
+
+extern "C" int64_t fp_index_num_docs(const fp_index* ix) { return ix ? ix->d.N : 0; }
+extern "C" int64_t fp_index_num_tokens(const fp_index* ix) { return ix ? ix->d.T : 0; }
+extern "C" int64_t fp_index_num_centroids(const fp_index* ix) { return ix ? ix->d.C : 0; }
+extern "C" int32_t fp_index_dim(const fp_index* ix) { return ix ? ix->d.dim : 0; }
+extern "C" int32_t fp_index_nbits(const fp_index* ix) { return ix ? ix->d.nbits : 0; }
+extern "C" int64_t fp_index_device_bytes(const fp_index* ix) { return ix ? ix->bytes : 0; }
+
+// ------------------------------------------------------------------------------------------
+// synthetic device-resident corpora
+// ------------------------------------------------------------------------------------------
+extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, fp_index** out) {
+  if (!d || !out) return fail(FP_EINVAL, "null argument");
+  *out = nullptr;
+  if (int rc = check_shape(d->nbits, d->dim)) return rc;
+  if (d->n_centroids <= 1 || (d->n_centroids & (d->n_centroids - 1))) return fail(FP_EINVAL, "n_centroids must be a power of two");
+  if (d->doc_begin < 0 || d->doc_end < d->doc_begin || d->doc_end > d->n_docs_total) return fail(FP_EINVAL, "bad document range");
+  if (d->doc_len < 1) return fail(FP_EINVAL, "doc_len < 1");
+  HIPCHK(hipSetDevice(device_id));
+  fp_index* ix = new fp_index();
+  ix->device = device_id;
+  ix->synthetic = true;
+  auto bail = [&](int rc) {
+    fp_index_destroy(ix);
+    return rc;
+  };
+  FpSynthParams p{};
+  p.nbits = d->nbits; p.dim = d->dim; p.pr = d->dim * d->nbits / 8; p.C = d->n_centroids;
+  p.lgC = 0;
+  while ((1ll << p.lgC) < p.C) ++p.lgC;
+  p.n_docs_total = d->n_docs_total; p.doc_begin = d->doc_begin; p.doc_end = d->doc_end;
+  p.doc_len = d->doc_len; p.variable_len = d->variable_len; p.seed = d->seed;
+  FpIndexDev& D = ix->d;
+  D.nbits = p.nbits; D.dim = p.dim; D.pr = p.pr; D.C = p.C; D.P = p.C; D.N = p.doc_end - p.doc_begin; D.pid_offset = p.doc_begin;
+  std::vector<int64_t> hoff((size_t)D.N + 2, 0);
+  int maxlen = 0;
+  D.T = fps_doc_offsets_host(p, hoff.data(), &maxlen);
+  const int64_t tok_base = hoff[(size_t)D.N + 1];
+  D.max_doc_len = maxlen;
+  ix->h_doc_off.assign(hoff.begin(), hoff.begin() + D.N + 1);
+#define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x)); } while (0)
+  uint16_t* cent = nullptr; uint16_t* lut = nullptr; int64_t* doc_off = nullptr; int32_t* codes = nullptr; uint8_t* res = nullptr;
+  int64_t* ivf_off = nullptr; int32_t* ivf_pids = nullptr;
+  hipStream_t st = nullptr;
+  ICHK(hipStreamCreate(&st));
+  ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
+  ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
+  std::vector<uint16_t> hlut;
+  build_lut_host(D.nbits, d->bucket_weights, hlut);
+  ICHK(dev_alloc(ix, &lut, hlut.size()));
+  ICHK(hipMemcpy(lut, hlut.data(), hlut.size() * 2, hipMemcpyHostToDevice));
+  ICHK(dev_alloc(ix, &doc_off, (size_t)D.N + 1));
+  ICHK(hipMemcpy(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice));
+  ICHK(dev_alloc(ix, &codes, (size_t)D.T));
+  ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
+  fps_generate(p, doc_off, D.N, D.T, tok_base, codes, res, st);
+  ICHK(hipStreamSynchronize(st));
+  ICHK(dev_alloc(ix, &ivf_off, (size_t)D.P + 1));
+  int64_t tot = 0;
+  int rc = fps_build_ivf(codes, doc_off, D.N, D.T, D.P, &ivf_pids, &tot, ivf_off, st);
+  if (rc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "IVF build failed (hip/hipcub error " + std::to_string(rc) + ")")); }
+  ix->owned.push_back(ivf_pids);
+  ix->bytes += tot * 4;
+  ICHK(hipStreamDestroy(st));
+#undef ICHK
+  ix->has_ivf = true;
+  D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res; D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
+  *out = ix;
+  return FP_OK;
+}
+
+extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* codes, uint8_t* residuals, int64_t cap) {
+  if (!ix || doc < 0 || doc >= ix->d.N) return fail(FP_EINVAL, "bad document id");
+  (void)hipSetDevice(ix->device);
+  const int64_t off = ix->h_doc_off[doc], len = ix->h_doc_off[doc + 1] - off;
+  if (len > cap) return fail(FP_EINVAL, "capacity too small");
+  std::vector<int32_t> tmp((size_t)len);
+  if (len > 0) {
+    HIPCHK(hipMemcpy(tmp.data(), ix->d.codes + off, (size_t)len * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(residuals, ix->d.residuals + off * ix->d.pr, (size_t)len * ix->d.pr, hipMemcpyDeviceToHost));
+  }
+  for (int64_t i = 0; i < len; ++i) codes[i] = tmp[i];
+  return len;
+}
+
+extern "C" int64_t fp_index_read_ivf(const fp_index* ix, int64_t cell, int64_t* pids, int64_t cap) {
+  if (!ix || !ix->has_ivf || cell < 0 || cell >= ix->d.P) return fail(FP_EINVAL, "bad cell");
+  (void)hipSetDevice(ix->device);
+  int64_t be[2];
+  HIPCHK(hipMemcpy(be, ix->d.ivf_off + cell, 16, hipMemcpyDeviceToHost));
+  const int64_t len = be[1] - be[0];
+  if (len > cap) return fail(FP_EINVAL, "capacity too small");
+  std::vector<int32_t> tmp((size_t)len);
+  if (len > 0) HIPCHK(hipMemcpy(tmp.data(), ix->d.ivf_pids + be[0], (size_t)len * 4, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < len; ++i) pids[i] = tmp[i];
+  return len;
+}
+
+// ------------------------------------------------------------------------------------------
+// search pipeline
+// ------------------------------------------------------------------------------------------
+struct TraceOut {
+  uint16_t* S; int64_t* cells; int64_t* cand; float* approx; int64_t* rerank; float* exact; int64_t* counts;
+};
+
+static int validate_search(const fp_index* ix, int32_t nq, int32_t q_len, int32_t dim, const fp_search_params* p) {
+  if (!ix || !p) return fail(FP_EINVAL, "null argument");
+  if (!ix->has_ivf)  // search.rs:227-232
+    return fail(FP_ECOMPRESS_ONLY,
+                "This index was built with compress_only=True and does not support search. Rebuild with compress_only=False "
+                "to enable search.");
+  if (nq < 0 || q_len < 1) return fail(FP_EINVAL, "Expected a 3D tensor for queries with at least one token per query");
+  if (dim != ix->d.dim) return fail(FP_EINVAL, "query dim does not match the index dim");
+  if (p->top_k < 0 || p->n_full_scores < 0 || p->n_ivf_probe < 0) return fail(FP_EINVAL, "negative search parameter");
+  if (p->n_ivf_probe > FP_MAX_PROBE) return fail(FP_EUNSUPPORTED, "n_ivf_probe > 32 is not supported by the probe kernel");
+  if ((int64_t)q_len * std::max<int64_t>(p->n_ivf_probe, 1) > FP_MAX_CELLS)
+    return fail(FP_EUNSUPPORTED, "q_len * n_ivf_probe > 8192 is not supported");
+  const int64_t R = std::max<int64_t>(p->n_full_scores / 4, 1);
+  if (R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_full_scores > 32768 is not supported by the LDS sort");
+  return FP_OK;
+}
+
+struct Pipe {
+  fp_index* ix;
+  Scratch* s;
+  FpSearchShape sh;
+  int64_t W, Cw;
+  int nblk, nchunk;
+  bool degenerate;  // reference errs for every query (topk k out of range) -> all results empty
+  int64_t M;
+};
+
+// stages S1..S5 for one sub-batch whose fp16 queries are already in s->qin
+static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off /*B+1 rebased*/, bool has_subset) {
+  fp_index* ix = P.ix;
+  Scratch* s = P.s;
+  const FpIndexDev& D = ix->d;
+  const FpSearchShape& sh = P.sh;
+  hipStream_t st = s->st;
+  const int B = sh.B;
+  HIPCHK(s->qpad.ensure((size_t)B * sh.Qp * D.dim * 2));
+  fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st);
+  HIPCHK(hipEventRecord(s->ev[ST_CENTROID], st));
+  HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
+  if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, st)) return fail(FP_EUNSUPPORTED, "dim");
+  HIPCHK(hipEventRecord(s->ev[ST_PROBE], st));
+  // subset bitmaps
+  P.W = ((D.N + 31) / 32 + 63) & ~63ll;
+  if (P.W < 64) P.W = 64;
+  P.Cw = (D.C + 31) / 32;
+  HIPCHK(s->invalid.ensure((size_t)B * 4));
+  HIPCHK(hipMemsetAsync(s->invalid.p, 0, (size_t)B * 4, st));
+  if (has_subset) {
+    const int64_t ns = h_sub_off[B];
+    HIPCHK(s->sub_ids.ensure((size_t)std::max<int64_t>(ns, 1) * 8));
+    HIPCHK(s->sub_off.ensure((size_t)(B + 1) * 8));
+    if (ns > 0) HIPCHK(hipMemcpyAsync(s->sub_ids.p, h_sub_ids, (size_t)ns * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->sub_off.p, h_sub_off, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(s->subbm.ensure((size_t)B * P.W * 4));
+    HIPCHK(s->allow.ensure((size_t)B * P.Cw * 4));
+    HIPCHK(hipMemsetAsync(s->subbm.p, 0, (size_t)B * P.W * 4, st));
+    HIPCHK(hipMemsetAsync(s->allow.p, 0, (size_t)B * P.Cw * 4, st));
+    fpk_subset_prepare(D, s->sub_ids.as<int64_t>(), s->sub_off.as<int64_t>(), B, s->subbm.as<uint32_t>(), P.W, s->allow.as<uint32_t>(),
+                       P.Cw, s->invalid.as<int32_t>(), st);
+  }
+  // S2
+  const int np = (int)std::max<int64_t>(sh.n_probe, 1);
+  int NP = 1;
+  while (NP < np) NP <<= 1;
+  P.nchunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, D.C / 2048));
+  HIPCHK(s->partial.ensure((size_t)B * sh.Qp * P.nchunk * 8 * NP * 8));
+  HIPCHK(s->cells.ensure((size_t)B * sh.Q * np * 4));
+  HIPCHK(s->ucells.ensure((size_t)B * sh.Q * np * 4));
+  HIPCHK(s->ncells.ensure((size_t)B * 4));
+  if (sh.n_probe >= 1) {
+    if (fpk_probe(D, s->S.as<uint16_t>(), sh, has_subset ? s->allow.as<uint32_t>() : nullptr, s->partial.as<unsigned long long>(),
+                  P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), st))
+      return fail(FP_EUNSUPPORTED, "n_ivf_probe");
+  } else {
+    HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result
+  }
+  HIPCHK(hipEventRecord(s->ev[ST_IVF], st));
+  // S3
+  HIPCHK(s->bitmap.ensure((size_t)B * P.W * 4));
+  HIPCHK(hipMemsetAsync(s->bitmap.p, 0, (size_t)B * P.W * 4, st));
+  if (sh.n_probe >= 1)
+    fpk_ivf_mark(D, s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), sh.Q * np, B, s->bitmap.as<uint32_t>(), P.W, st);
+  P.nblk = (int)((P.W + 1023) / 1024);
+  HIPCHK(s->blkcnt.ensure((size_t)B * P.nblk * 4));
+  HIPCHK(s->ncand.ensure((size_t)B * 4));
+  HIPCHK(s->cand_off.ensure((size_t)(B + 1) * 8));
+  fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
+                 s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st);
+  int64_t M = 0;
+  HIPCHK(hipMemcpyAsync(&M, s->cand_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(s->ev[ST_COMPACT], st));
+  HIPCHK(hipStreamSynchronize(st));  // the one mid-pipeline host sync: candidate total sizes the buffers
+  P.M = M;
+  HIPCHK(s->cand_pid.ensure((size_t)std::max<int64_t>(M, 1) * 4));
+  HIPCHK(s->approx.ensure((size_t)std::max<int64_t>(M, 1) * 4));
+  fpk_cand_compact(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
+                   s->blkcnt.as<int32_t>(), P.nblk, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), st);
+  HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
+  // S4
+  fpk_approx(D, s->S.as<uint16_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->approx.as<float>(), st);
+  HIPCHK(hipEventRecord(s->ev[ST_SELECT], st));
+  // S5
+  HIPCHK(s->hist.ensure((size_t)3 * B * FP_SEL_BINS * 4));
+  HIPCHK(s->selstate.ensure((size_t)B * 8 * 4));
+  HIPCHK(s->sel_pid.ensure((size_t)B * sh.R * 4));
+  HIPCHK(s->sel_approx.ensure((size_t)B * sh.R * 4));
+  HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
+  fpk_select(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), s->approx.as<float>(), s->hist.as<uint32_t>(),
+             s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(), st);
+  HIPCHK(hipEventRecord(s->ev[ST_MAXSIM], st));
+  return FP_OK;
+}
+
+static FpSearchShape make_shape(int B, int Q, const fp_search_params* p) {
+  FpSearchShape sh{};
+  sh.B = B;
+  sh.Q = Q;
+  sh.Qp = (Q + 31) & ~31;
+  sh.n_probe = (int)p->n_ivf_probe;
+  sh.n_full = p->n_full_scores;
+  sh.R = std::max<int64_t>(p->n_full_scores / 4, 1);
+  return sh;
+}
+
+static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_t Q, const fp_search_params* p,
+                       const int64_t* subset_ids, const int64_t* subset_off, int64_t* out_pids, float* out_scores,
+                       int32_t* out_counts, TraceOut* tr) {
+  const FpIndexDev& D = ix->d;
+  HIPCHK(hipSetDevice(ix->device));
+  for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+  if (nq == 0 || p->top_k == 0) return FP_OK;
+  const bool has_subset = subset_off != nullptr;
+  // reference: topk(k > C) errs inside search() -> per-query empty result (search.rs:268)
+  if (!has_subset && p->n_ivf_probe > D.C) return FP_OK;
+  if (D.N == 0) return FP_OK;
+  Scratch* s = acquire(ix);
+  if (!s) return fail(FP_EHIP, "could not create a HIP stream");
+  struct Rel { fp_index* ix; Scratch* s; ~Rel() { release(ix, s); } } rel{ix, s};
+  const int Qp = (Q + 31) & ~31;
+  // sub-batch so that the centroid-score table stays within a budget
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t budget = std::max<size_t>((size_t)1 << 30, std::min<size_t>((size_t)24 << 30, free_b / 3));
+  const size_t perq = (size_t)D.C * Qp * 2;
+  int maxB = (int)std::max<size_t>(1, budget / perq);
+  if (tr) maxB = 1;
+  std::vector<int64_t> sub_off_local;
+  for (int b0 = 0; b0 < nq; b0 += maxB) {
+    const int B = std::min(maxB, nq - b0);
+    Pipe P{};
+    P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
+    hipStream_t st = s->st;
+    HIPCHK(hipEventRecord(s->ev[ST_UPLOAD], st));
+    HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
+    HIPCHK(hipMemcpyAsync(s->qin.p, queries + (size_t)b0 * Q * D.dim, (size_t)B * Q * D.dim * 2, hipMemcpyHostToDevice, st));
+    const int64_t* sids = nullptr;
+    if (has_subset) {
+      sub_off_local.resize((size_t)B + 1);
+      for (int i = 0; i <= B; ++i) sub_off_local[i] = subset_off[b0 + i] - subset_off[b0];
+      sids = subset_ids + subset_off[b0];
+    }
+    if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
+    // S6+S7
+    const int64_t R = P.sh.R;
+    HIPCHK(s->exact.ensure((size_t)B * R * 4));
+    if (fpk_maxsim(D, s->qpad.as<uint16_t>(), P.sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(), st))
+      return fail(FP_EUNSUPPORTED, "dim/nbits");
+    HIPCHK(hipEventRecord(s->ev[ST_TOPK], st));
+    // S8
+    const int64_t K = p->top_k;
+    HIPCHK(s->out_pid.ensure((size_t)B * K * 8));
+    HIPCHK(s->out_score.ensure((size_t)B * K * 4));
+    HIPCHK(s->out_cnt.ensure((size_t)B * 4));
+    fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
+                   s->out_pid.as<int64_t>(), s->out_score.as<float>(), s->out_cnt.as<int32_t>(), st);
+    HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, s->out_pid.p, (size_t)B * K * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, s->out_score.p, (size_t)B * K * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_counts + b0, s->out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(s->ev[ST_N], st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (b0 == 0) {
+      for (int i = 0; i < ST_N; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) != hipSuccess) ms = 0.f;
+        g_last_ms[i] = ms;
+      }
+      g_have_ms = true;
+    } else {
+      for (int i = 0; i < ST_N; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) == hipSuccess) g_last_ms[i] += ms;
+      }
+    }
+    if (tr) {  // B == 1
+      std::vector<int32_t> t32;
+      int32_t nc = 0, ncand = 0, nr = 0;
+      HIPCHK(hipMemcpy(&nc, s->ncells.p, 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ncand, s->ncand.p, 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&nr, s->sel_cnt.p, 4, hipMemcpyDeviceToHost));
+      if (tr->counts) { tr->counts[0] = nc; tr->counts[1] = ncand; tr->counts[2] = nr; }
+      if (tr->S) {
+        std::vector<uint16_t> hs((size_t)D.C * Qp);
+        HIPCHK(hipMemcpy(hs.data(), s->S.p, hs.size() * 2, hipMemcpyDeviceToHost));
+        for (int64_t c = 0; c < D.C; ++c)
+          for (int q = 0; q < Q; ++q) tr->S[c * Q + q] = hs[(size_t)c * Qp + q];
+      }
+      if (tr->cells && nc > 0) {
+        t32.resize((size_t)nc);
+        HIPCHK(hipMemcpy(t32.data(), s->ucells.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nc; ++i) tr->cells[i] = t32[i];
+      }
+      if (tr->cand && ncand > 0) {
+        t32.resize((size_t)ncand);
+        HIPCHK(hipMemcpy(t32.data(), s->cand_pid.p, (size_t)ncand * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < ncand; ++i) tr->cand[i] = (int64_t)t32[i] + D.pid_offset;
+      }
+      if (tr->approx && ncand > 0) HIPCHK(hipMemcpy(tr->approx, s->approx.p, (size_t)ncand * 4, hipMemcpyDeviceToHost));
+      if (tr->rerank && nr > 0) {
+        t32.resize((size_t)nr);
+        HIPCHK(hipMemcpy(t32.data(), s->sel_pid.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nr; ++i) tr->rerank[i] = (int64_t)t32[i] + D.pid_offset;
+      }
+      if (tr->exact && nr > 0) HIPCHK(hipMemcpy(tr->exact, s->exact.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  return FP_OK;
+}
+
+extern "C" int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                         const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets, int64_t* out_pids,
+                         float* out_scores, int32_t* out_counts) {
+  if (int rc = validate_search(index, n_queries, q_len, dim, params)) return rc;
+  if (n_queries > 0 && (!queries || !out_counts || (params->top_k > 0 && (!out_pids || !out_scores))))
+    return fail(FP_EINVAL, "null buffer");
+  return search_impl(const_cast<fp_index*>(index), queries, n_queries, q_len, params, subset_ids, subset_offsets, out_pids, out_scores,
+                     out_counts, nullptr);
+}
+
+extern "C" int fp_search_trace(const fp_index* index, const uint16_t* query, int32_t q_len, int32_t dim, const fp_search_params* params,
+                               const int64_t* subset_ids, int64_t n_subset, int32_t has_subset, int64_t* out_pids, float* out_scores,
+                               int32_t* out_count, uint16_t* S, int64_t* cells, int64_t* cand, float* approx, int64_t* rerank,
+                               float* exact, int64_t* counts) {
+  if (int rc = validate_search(index, 1, q_len, dim, params)) return rc;
+  TraceOut tr{S, cells, cand, approx, rerank, exact, counts};
+  if (counts) counts[0] = counts[1] = counts[2] = 0;
+  int64_t off[2] = {0, n_subset};
+  return search_impl(const_cast<fp_index*>(index), query, 1, q_len, params, subset_ids, has_subset ? off : nullptr, out_pids, out_scores,
+                     out_count, &tr);
+}
+
+extern "C" int fp_last_search_timings(const char** names, float* ms, int cap) {
+  if (!g_have_ms) return 0;
+  int n = std::min(cap, (int)ST_N);
+  for (int i = 0; i < n; ++i) {
+    if (names) names[i] = kStageNames[i];
+    if (ms) ms[i] = g_last_ms[i];
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// reconstruct_embeddings (embeddings.rs:12-69)
+// ------------------------------------------------------------------------------------------
+extern "C" int fp_reconstruct_embeddings(const fp_index* cix, const int64_t* doc_ids, int64_t n, float* out, int64_t cap_rows,
+                                         int64_t* out_lengths) {
+  fp_index* ix = const_cast<fp_index*>(cix);
+  if (!ix || (n > 0 && (!doc_ids || !out_lengths))) return fail(FP_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(ix->device));
+  std::vector<int64_t> tok;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t d = doc_ids[i] - ix->d.pid_offset;
+    if (d < 0 || d >= ix->d.N) return fail(FP_EINVAL, "document id out of range");
+    out_lengths[i] = ix->h_doc_off[d + 1] - ix->h_doc_off[d];
+    for (int64_t t = ix->h_doc_off[d]; t < ix->h_doc_off[d + 1]; ++t) tok.push_back(t);
+  }
+  const int64_t rows = (int64_t)tok.size();
+  if (rows > cap_rows) return fail(FP_EINVAL, "output capacity too small");
+  if (rows == 0) return FP_OK;
+  Scratch* s = acquire(ix);
+  if (!s) return fail(FP_EHIP, "could not create a HIP stream");
+  struct Rel { fp_index* ix; Scratch* s; ~Rel() { release(ix, s); } } rel{ix, s};
+  HIPCHK(s->tok_idx.ensure((size_t)rows * 8));
+  HIPCHK(s->recon.ensure((size_t)rows * ix->d.dim * 4));
+  HIPCHK(hipMemcpyAsync(s->tok_idx.p, tok.data(), (size_t)rows * 8, hipMemcpyHostToDevice, s->st));
+  fpk_reconstruct(ix->d, s->tok_idx.as<int64_t>(), rows, s->recon.as<float>(), s->st);
+  HIPCHK(hipMemcpyAsync(out, s->recon.p, (size_t)rows * ix->d.dim * 4, hipMemcpyDeviceToHost, s->st));
+  HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// document-sharded search (see fastplaid.h)
+// ------------------------------------------------------------------------------------------
+struct fp_shard_ctx {
+  fp_index* ix;
+  Scratch* s;
+  Pipe P;
+  fp_search_params params;
+  int B, Q;
+  bool empty_all;
+};
+
+extern "C" int fp_shard_begin(const fp_index* cix, const uint16_t* queries, int32_t nq, int32_t Q, int32_t dim,
+                              const fp_search_params* p, fp_shard_ctx** out) {
+  if (!out) return fail(FP_EINVAL, "null argument");
+  *out = nullptr;
+  if (int rc = validate_search(cix, nq, Q, dim, p)) return rc;
+  fp_index* ix = const_cast<fp_index*>(cix);
+  if (nq < 1) return fail(FP_EINVAL, "need at least one query");
+  const int64_t R = std::max<int64_t>(p->n_full_scores / 4, 1);
+  HIPCHK(hipSetDevice(ix->device));
+  Scratch* s = acquire(ix);
+  if (!s) return fail(FP_EHIP, "could not create a HIP stream");
+  fp_shard_ctx* c = new fp_shard_ctx();
+  c->ix = ix; c->s = s; c->params = *p; c->B = nq; c->Q = Q;
+  c->P = Pipe{};
+  c->P.ix = ix; c->P.s = s; c->P.sh = make_shape(nq, Q, p);
+  c->empty_all = (p->n_ivf_probe > ix->d.C) || p->top_k == 0 || ix->d.N == 0;
+  (void)R;
+  hipError_t e = s->qin.ensure((size_t)nq * Q * ix->d.dim * 2);
+  if (e == hipSuccess) e = hipMemcpyAsync(s->qin.p, queries, (size_t)nq * Q * ix->d.dim * 2, hipMemcpyHostToDevice, s->st);
+  if (e != hipSuccess) {
+    release(ix, s);
+    delete c;
+    return fail(FP_EHIP, hipGetErrorString(e));
+  }
+  *out = c;
+  return FP_OK;
+}
+
+extern "C" int64_t fp_shard_R(const fp_shard_ctx* c) { return c ? c->P.sh.R : 0; }
+
+extern "C" void fp_shard_end(fp_shard_ctx* c) {
+  if (!c) return;
+  (void)hipStreamSynchronize(c->s->st);
+  release(c->ix, c->s);
+  delete c;
+}
+
+extern "C" int fp_shard_stage1(fp_shard_ctx* c, float* dev_top_approx, int64_t* dev_top_pid) {
+  if (!c || !dev_top_approx || !dev_top_pid) return fail(FP_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  Scratch* s = c->s;
+  const int64_t R = c->P.sh.R;
+  const int B = c->B;
+  if (c->empty_all) {
+    HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
+    HIPCHK(s->sel_pid.ensure((size_t)B * R * 4));
+    HIPCHK(s->sel_approx.ensure((size_t)B * R * 4));
+    HIPCHK(hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, s->st));
+  } else {
+    if (int rc = run_front(c->P, nullptr, nullptr, false)) return rc;
+  }
+  fpk_shard_pack_top(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, c->ix->d.pid_offset,
+                     dev_top_approx, dev_top_pid, s->st);
+  HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}
+
+extern "C" int fp_shard_stage2(fp_shard_ctx* c, const float* all_approx, const int64_t* all_pid, int32_t G, float* dev_loc_score,
+                               int64_t* dev_loc_pid) {
+  if (!c || !all_approx || !all_pid || !dev_loc_score || !dev_loc_pid || G < 1) return fail(FP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  Scratch* s = c->s;
+  const FpIndexDev& D = c->ix->d;
+  const int64_t R = c->P.sh.R;
+  const int B = c->B;
+  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 8192 is not supported");
+  HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
+  HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
+  fpk_transpose_ranks(all_approx, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);
+  fpk_shard_global_cut(s->tmpf.as<float>(), s->tmpp.as<int64_t>(), G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(),
+                       s->sel_cnt.as<int32_t>(), s->st);
+  HIPCHK(s->exact.ensure((size_t)B * R * 4));
+  if (!c->empty_all) {
+    if (fpk_maxsim(D, s->qpad.as<uint16_t>(), c->P.sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(), s->st))
+      return fail(FP_EUNSUPPORTED, "dim/nbits");
+  }
+  fpk_shard_pack_scores(s->exact.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_loc_score,
+                        dev_loc_pid, s->st);
+  HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}
+
+extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const int64_t* all_pid, int32_t G, int64_t* out_pids,
+                               float* out_scores, int32_t* out_counts) {
+  if (!c || !all_score || !all_pid || G < 1 || !out_counts) return fail(FP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  Scratch* s = c->s;
+  const int64_t R = c->P.sh.R;
+  const int B = c->B;
+  const int64_t K = c->params.top_k;
+  for (int i = 0; i < B; ++i) out_counts[i] = 0;
+  if (K == 0) return FP_OK;
+  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 8192 is not supported");
+  HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
+  HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
+  fpk_transpose_ranks(all_score, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);
+  HIPCHK(s->out_pid.ensure((size_t)B * K * 8));
+  HIPCHK(s->out_score.ensure((size_t)B * K * 4));
+  HIPCHK(s->out_cnt.ensure((size_t)B * 4));
+  fpk_final_topk(s->tmpf.as<float>(), nullptr, s->tmpp.as<int64_t>(), nullptr, (int64_t)G * R, B, K, 0, s->out_pid.as<int64_t>(),
+                 s->out_score.as<float>(), s->out_cnt.as<int32_t>(), s->st);
+  HIPCHK(hipMemcpyAsync(out_pids, s->out_pid.p, (size_t)B * K * 8, hipMemcpyDeviceToHost, s->st));
+  HIPCHK(hipMemcpyAsync(out_scores, s->out_score.p, (size_t)B * K * 4, hipMemcpyDeviceToHost, s->st));
+  HIPCHK(hipMemcpyAsync(out_counts, s->out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, s->st));
+  HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}

@@ -1,0 +1,112 @@
+// Internal declarations shared by the HIP kernels (fp_kernels.hip, fp_synth.hip) and the
+// host engine (fp_engine.cpp).  Not part of the C ABI (see include/fastplaid.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FP_WAVE 64
+#define FP_MAX_PROBE 32          // n_ivf_probe supported by the register top-k kernel
+#define FP_MAX_CELLS 8192        // q_len * n_ivf_probe cap (LDS sort of probed cells)
+#define FP_MAX_SORT 8192         // entries the LDS bitonic sort handles (R, or G*R when sharded)
+#define FP_SEL_BINS 2048
+
+// Device-resident index (all pointers are device memory).  Layout in HBM:
+//   centroids  [C][D]      f16   row-major
+//   lut        [256][8/nbits] f16  byte -> bucket weights (bit-reversal + index tables of
+//                                  residual_codec.rs:83-140 folded into one table)
+//   ivf_pids   [sum ivf_lengths] i32 local doc ids, per cell ascending
+//   ivf_off    [P+1]       i64
+//   codes      [T]         i32   (narrowed from the reference's i64: C < 2^31)
+//   residuals  [T][PR]     u8    PR = D*nbits/8
+//   doc_off    [N+1]       i64   (tensor.rs:221-224 cumulative lengths)
+struct FpIndexDev {
+  int nbits, dim, pr;
+  int64_t C, P, N, T;
+  int64_t pid_offset;
+  const uint16_t* centroids;
+  const uint16_t* lut;
+  const int32_t* ivf_pids;
+  const int64_t* ivf_off;
+  const int32_t* codes;
+  const uint8_t* residuals;
+  const int64_t* doc_off;
+  int max_doc_len;
+};
+
+// ---- launch wrappers implemented in fp_kernels.hip -----------------------------------------
+// All run on `st`; none synchronises.
+struct FpSearchShape {
+  int B;       // queries in this sub-batch
+  int Q;       // real query tokens
+  int Qp;      // Q rounded up to a multiple of 32 (zero rows appended)
+  int n_probe;
+  int64_t R;   // exact-scoring budget per query = max(n_full/4, 1)
+  int64_t n_full;
+};
+
+void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B*Qp,D]*/, int B, int Q, int Qp, int D,
+                      hipStream_t st);
+int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* q_pad, uint16_t* S /*[B][C][Qp]*/, int B, int Qp,
+                        hipStream_t st);
+int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow /*[B][Cw] or null*/,
+              unsigned long long* partial, int nchunk, int32_t* cells /*[B][Q][n_probe]*/, int32_t* ucells /*[B][Q*n_probe]*/,
+              int32_t* ncells /*[B]*/, hipStream_t st);
+void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off /*[B+1] dev*/, int B,
+                        uint32_t* subbm /*[B][W]*/, int64_t W, uint32_t* allow /*[B][Cw]*/, int64_t Cw,
+                        int32_t* invalid /*[B]*/, hipStream_t st);
+void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B,
+                  uint32_t* bitmap, int64_t W, hipStream_t st);
+// candidate compaction: count -> scan -> offsets -> compact (ascending doc ids)
+void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
+                    int32_t* blkcnt, int nblk, int32_t* ncand, int64_t* cand_off /*[B+1]*/, hipStream_t st);
+void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
+                      const int32_t* blkcnt /*exclusive-scanned*/, int nblk, const int64_t* cand_off, int32_t* cand_pid,
+                      hipStream_t st);
+void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
+                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st);
+// top-R selection by (approx desc, doc id asc); output in ascending doc id order
+void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
+                uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
+                float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, hipStream_t st);
+int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid,
+               const int32_t* sel_cnt, int64_t Rcap, float* exact /*[B][Rcap]*/, hipStream_t st);
+// final ranking: sort (score desc, id asc), emit top_k with pid_offset applied
+void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local /*[B][stride] or null*/,
+                    const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,
+                    int64_t stride, int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid /*[B][top_k]*/,
+                    float* out_score, int32_t* out_cnt, hipStream_t st);
+// sharded helpers
+void fpk_shard_pack_top(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
+                        int64_t pid_offset, float* top_approx, int64_t* top_pid, hipStream_t st);
+void fpk_shard_global_cut(const float* all_approx /*[G][B][R]*/, const int64_t* all_pid, int G, int B, int64_t R,
+                          int64_t pid_lo, int64_t pid_hi, int32_t* sel_pid /*[B][R] local*/, int32_t* sel_cnt,
+                          hipStream_t st);
+void fpk_shard_pack_scores(const float* exact, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
+                           int64_t pid_offset, float* loc_score, int64_t* loc_pid, hipStream_t st);
+void fpk_transpose_ranks(const float* in_f /*[G][B][R]*/, const int64_t* in_p, int G, int B, int64_t R,
+                         float* out_f /*[B][G*R]*/, int64_t* out_p, hipStream_t st);
+// misc
+void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
+void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx /*[n] global token rows*/, int64_t n, float* out,
+                     hipStream_t st);
+
+// ---- fp_synth.hip ----------------------------------------------------------------------------
+struct FpSynthParams {
+  int nbits, dim, pr;
+  int64_t C;
+  int lgC;
+  int64_t n_docs_total, doc_begin, doc_end;
+  int doc_len;
+  int variable_len;
+  uint64_t seed;
+};
+// Fills doc_off (N+1) on the HOST (caller uploads) -- lengths are a pure hash; returns T.
+int64_t fps_doc_offsets_host(const FpSynthParams& p, int64_t* doc_off_host, int* max_len);
+// Device generation of codes/residuals for the shard; tok_base = global index of the
+// shard's first token.
+void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t tok_base,
+                  int32_t* codes, uint8_t* residuals, hipStream_t st);
+// Builds the IVF (per-cell ascending unique local doc ids) from device codes.  Allocates
+// *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
+int fps_build_ivf(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t P,
+                  int32_t** ivf_pids, int64_t* ivf_total, int64_t* ivf_off_dev, hipStream_t st);

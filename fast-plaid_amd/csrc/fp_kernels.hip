@@ -1,0 +1,1159 @@
+// HIP kernels of the PLAID search hot path for gfx950 (MI355X, CDNA4).  wave = 64.
+//
+// Stage map (reference rust/search/search.rs):
+//   S1 k_centroid_scores   :491        fp16 MFMA GEMM  S[b][c][q] = h(sum_k cent[c,k]*Q[b,q,k])
+//   S2 k_probe_*           :518-532    per query token top-n_probe centroids -> sorted unique cells
+//   S3 k_ivf_mark/k_cand_* :535-547    IVF gather + sort + unique  == per-query doc bitmap + ordered compaction
+//   S4 k_approx            :553-600    sum_q max_t S[code_t, q]   (fp16 max, fp32 sum)
+//   S5 k_sel_*             :602-623    top-R by approx (radix select, ties -> lower doc id)
+//   S6+S7 k_maxsim         :626-656    decompress (search.rs:53-107) fused with the exact MaxSim
+//   S8 k_final_topk        :658-692    sort by (score desc, doc id asc), truncate to top_k
+//
+// Numerical contract (measured on ATen 2.10 CPU, see oracle/plaid_oracle.c): every fp16
+// tensor op = fp32 arithmetic + one round-to-nearest-even to fp16; matmuls accumulate in
+// fp32 and round once.  The MFMA accumulation ORDER differs from the CPU's ascending-k
+// chain, which is the only source of (<= 1 fp16 ulp, rare) differences.
+#include "fp_internal.h"
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define NEG_MASK_F (-10000.0f)  // masked_fill(-9999.0) stored in fp16 (search.rs:395)
+
+__device__ __forceinline__ uint32_t h2_as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ h2 u32_as_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ h2 pk_max(h2 a, h2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+
+// order-preserving maps (larger float <-> larger unsigned)
+__device__ __forceinline__ uint32_t mono16(uint16_t h) {
+  if ((h & 0x7FFF) == 0) h = 0;  // -0 == +0
+  return (h & 0x8000) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000);
+}
+__device__ __forceinline__ uint32_t mono32(float f) {
+  uint32_t b = __float_as_uint(f + 0.0f);  // -0 -> +0
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unmono32(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+// ============================================================================================
+// query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
+// ============================================================================================
+__global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Q, int Qp, int D) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
+  int64_t per_row = D / 8;
+  int64_t total = (int64_t)B * Qp * per_row;
+  if (i >= total) return;
+  int64_t row = i / per_row;
+  int c8 = (int)(i % per_row);
+  int b = (int)(row / Qp), q = (int)(row % Qp);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (q < Q) v = *reinterpret_cast<const uint4*>(in + ((int64_t)b * Q + q) * D + c8 * 8);
+  *reinterpret_cast<uint4*>(out + row * D + c8 * 8) = v;
+}
+
+void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st) {
+  int64_t total = (int64_t)B * Qp * (D / 8);
+  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D);
+}
+
+// ============================================================================================
+// S1  centroid scores: 128(n = b*Qp+q) x 128(c) tile per 256-thread block, K = D in one go.
+// MFMA rows = query columns n, MFMA cols = centroids c, so that each lane ends up with 4
+// consecutive q for one centroid and can store 8 bytes of the [b][c][q] layout at once.
+// LDS tiles are XOR-swizzled at 16-byte granularity (row-major D-halfs rows would put a
+// whole ds_read_b128 lane group on one bank slot).
+// ============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
+                                                         uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp) {
+  constexpr int CH = D / 8;              // 16-byte chunks per row
+  constexpr int ROWB = D * 2;            // bytes per row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem;              // [128][ROWB]
+  unsigned char* Cs = smem + 128 * ROWB; // [128][ROWB]
+  const int tid = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.y * 128;
+  const int64_t c0 = (int64_t)blockIdx.x * 128;
+  // stage both tiles (coalesced 16 B per thread), swizzled
+  for (int i = tid; i < 128 * CH; i += 256) {
+    int row = i / CH, j = i % CH;
+    int js = j ^ (row & (CH - 1));
+    uint4 vq = make_uint4(0, 0, 0, 0), vc = make_uint4(0, 0, 0, 0);
+    if (n0 + row < Ntot) vq = *reinterpret_cast<const uint4*>(qpad + (n0 + row) * D + j * 8);
+    if (c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + j * 8);
+    *reinterpret_cast<uint4*>(Qs + row * ROWB + js * 16) = vq;
+    *reinterpret_cast<uint4*>(Cs + row * ROWB + js * 16) = vc;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
+  const int l31 = lane & 31, hi = lane >> 5;
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < D / 16; ++ks) {
+    h8 af[2], bf[2];
+    const int j = ks * 2 + hi;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int rq = wr * 64 + t * 32 + l31;
+      int rc = wc * 64 + t * 32 + l31;
+      af[t] = *reinterpret_cast<const h8*>(Qs + rq * ROWB + ((j ^ (rq & (CH - 1))) * 16));
+      bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+  // epilogue: D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int64_t nb = n0 + wr * 64 + a * 32;  // first n of this 32-row MFMA tile (32-aligned, Qp%32==0)
+    if (nb >= Ntot) continue;
+    const int64_t bq = nb / Qp;
+    const int q0 = (int)(nb % Qp);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t c = c0 + wc * 64 + b * 32 + l31;
+      if (c >= C) continue;
+      uint16_t* dst = S + (bq * C + c) * Qp + q0 + 4 * hi;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h2 lo, hi2;
+        lo.x = (half_t)acc[a][b][4 * g + 0];
+        lo.y = (half_t)acc[a][b][4 * g + 1];
+        hi2.x = (half_t)acc[a][b][4 * g + 2];
+        hi2.y = (half_t)acc[a][b][4 * g + 3];
+        *reinterpret_cast<uint2*>(dst + 8 * g) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
+      }
+    }
+  }
+}
+
+int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, hipStream_t st) {
+  const int64_t Ntot = (int64_t)B * Qp;
+  dim3 grid((unsigned)((ix.C + 127) / 128), (unsigned)((Ntot + 127) / 128));
+  if (ix.dim == 128) {
+    hipLaunchKernelGGL(k_centroid_scores<128>, grid, dim3(256), 2 * 128 * 256, st, ix.centroids, qpad, S, ix.C, Ntot, Qp);
+  } else if (ix.dim == 64) {
+    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), 2 * 128 * 128, st, ix.centroids, qpad, S, ix.C, Ntot, Qp);
+  } else {
+    return -1;
+  }
+  return 0;
+}
+
+// ============================================================================================
+// S2  probe selection.  key = mono16(score) << 32 | (0xFFFFFFFF - c): larger key = higher
+// score, ties -> lower centroid id.  key 0 = "none".
+// ============================================================================================
+template <int NP>
+__global__ __launch_bounds__(256) void k_probe_partial(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp, int nchunk,
+                                                        const uint32_t* __restrict__ allow, int64_t Cw,
+                                                        unsigned long long* __restrict__ partial) {
+  // grid: x = chunk, y = b * (Qp/32) + colgroup.  thread: col = tid&31, slice = tid>>5 (8 slices)
+  const int groups = Qp / 32;
+  const int b = blockIdx.y / groups, g = blockIdx.y % groups;
+  const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int q = g * 32 + col;
+  const int chunk = blockIdx.x;
+  const int64_t per = ((C + nchunk - 1) / nchunk + 7) & ~(int64_t)7;
+  const int64_t cb = chunk * per;
+  const int64_t ce = (cb + per < C) ? cb + per : C;
+  unsigned long long best[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) best[i] = 0ull;
+  if (q < Q) {
+    const uint16_t* Sb = S + (int64_t)b * C * Qp + q;
+    const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
+    for (int64_t c = cb + slice; c < ce; c += 8) {
+      if (al && !((al[c >> 5] >> (c & 31)) & 1u)) continue;
+      uint16_t s = Sb[c * Qp];
+      unsigned long long key = ((unsigned long long)mono16(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)c);
+      if (key > best[NP - 1]) {
+        best[NP - 1] = key;
+#pragma unroll
+        for (int i = NP - 1; i > 0; --i) {
+          if (best[i] > best[i - 1]) {
+            unsigned long long t = best[i];
+            best[i] = best[i - 1];
+            best[i - 1] = t;
+          }
+        }
+      }
+    }
+  }
+  unsigned long long* dst = partial + ((((int64_t)b * Qp + q) * nchunk + chunk) * 8 + slice) * NP;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) dst[i] = best[i];
+}
+
+// one wave per (b, q) column: n_probe rounds of "largest key below the previous pick"
+__global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __restrict__ partial, int Q, int Qp, int entries,
+                                                    int n_probe, int32_t* __restrict__ cells) {
+  const int b = blockIdx.x / Q, q = blockIdx.x % Q;
+  const int lane = threadIdx.x;
+  const unsigned long long* src = partial + ((int64_t)b * Qp + q) * entries;
+  unsigned long long bound = ~0ull;
+  for (int r = 0; r < n_probe; ++r) {
+    unsigned long long m = 0ull;
+    for (int i = lane; i < entries; i += 64) {
+      unsigned long long k = src[i];
+      if (k < bound && k > m) m = k;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      unsigned long long o = __shfl_xor(m, s, 64);
+      m = o > m ? o : m;
+    }
+    if (lane == 0) cells[((int64_t)b * Q + q) * n_probe + r] = m ? (int32_t)(0xFFFFFFFFu - (uint32_t)m) : -1;
+    if (m == 0ull) {
+      for (int r2 = r + 1; r2 < n_probe && lane == 0; ++r2) cells[((int64_t)b * Q + q) * n_probe + r2] = -1;
+      break;
+    }
+    bound = m;
+  }
+}
+
+// LDS bitonic sort (ascending) of n <= cap int32 values, then unique.  one block per query.
+__global__ __launch_bounds__(256) void k_cells_unique(const int32_t* __restrict__ cells, int n, int npow2,
+                                                      int32_t* __restrict__ ucells, int32_t* __restrict__ ncells) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* v = reinterpret_cast<int32_t*>(smem);  // [npow2]
+  const int b = blockIdx.x;
+  const int32_t* src = cells + (int64_t)b * n;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    int32_t x = (i < n) ? src[i] : -1;
+    v[i] = (x < 0) ? 0x7FFFFFFF : x;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          int32_t a = v[i], c = v[ixj];
+          bool up = ((i & k) == 0);
+          if ((a > c) == up) { v[i] = c; v[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ordered unique: position = number of distinct values before i.  Serial over chunks of
+  // blockDim with a running base (n is small: <= 8192).
+  int32_t* out = ucells + (int64_t)b * n;
+  __shared__ int s_scan[256];
+  int base = 0;
+  for (int start = 0; start < npow2; start += blockDim.x) {
+    int i = start + threadIdx.x;
+    int flag = 0;
+    if (i < npow2) {
+      int32_t x = v[i];
+      flag = (x != 0x7FFFFFFF) && (i == 0 || v[i - 1] != x);
+    }
+    s_scan[threadIdx.x] = flag;
+    __syncthreads();
+    for (int off = 1; off < (int)blockDim.x; off <<= 1) {
+      int t = (threadIdx.x >= (unsigned)off) ? s_scan[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int incl = s_scan[threadIdx.x];
+    if (flag) out[base + incl - 1] = v[i];
+    int tot = s_scan[blockDim.x - 1];
+    __syncthreads();
+    base += tot;
+  }
+  if (threadIdx.x == 0) ncells[b] = base;
+}
+
+template <int NP>
+static void launch_probe_partial(const uint16_t* S, const FpIndexDev& ix, const FpSearchShape& sh, int nchunk,
+                                 const uint32_t* allow, int64_t Cw, unsigned long long* partial, hipStream_t st) {
+  dim3 grid((unsigned)nchunk, (unsigned)(sh.B * (sh.Qp / 32)));
+  hipLaunchKernelGGL(k_probe_partial<NP>, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, nchunk, allow, Cw, partial);
+}
+
+static int next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
+              unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells, hipStream_t st) {
+  const int64_t Cw = (ix.C + 31) / 32;
+  int NP = 1;
+  while (NP < sh.n_probe) NP <<= 1;
+  switch (NP) {
+    case 1: launch_probe_partial<1>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
+    case 2: launch_probe_partial<2>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
+    case 4: launch_probe_partial<4>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
+    case 8: launch_probe_partial<8>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
+    case 16: launch_probe_partial<16>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
+    case 32: launch_probe_partial<32>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
+    default: return -1;
+  }
+  const int entries = nchunk * 8 * NP;
+  hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, partial, sh.Q, sh.Qp, entries,
+                     sh.n_probe, cells);
+  const int n = sh.Q * sh.n_probe;
+  const int np2 = next_pow2(n);
+  hipLaunchKernelGGL(k_cells_unique, dim3((unsigned)sh.B), dim3(256), (size_t)np2 * 4, st, cells, n, np2, ucells, ncells);
+  return 0;
+}
+
+// ============================================================================================
+// subset support (search.rs:494-517, :407-439): subset doc bitmap, allowed-centroid bitmap
+// ============================================================================================
+__global__ void k_subset_prepare(const int64_t* __restrict__ ids, const int64_t* __restrict__ off, int64_t N,
+                                 const int64_t* __restrict__ doc_off, const int32_t* __restrict__ codes,
+                                 uint32_t* __restrict__ subbm, int64_t W, uint32_t* __restrict__ allow, int64_t Cw,
+                                 int32_t* __restrict__ invalid) {
+  const int b = blockIdx.y;
+  const int64_t beg = off[b], end = off[b + 1];
+  for (int64_t i = beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t d = ids[i];
+    if (d < 0 || d >= N) { invalid[b] = 1; continue; }  // index_select out of range -> Err -> empty result
+    atomicOr(&subbm[(int64_t)b * W + (d >> 5)], 1u << (d & 31));
+    for (int64_t t = doc_off[d]; t < doc_off[d + 1]; ++t) {
+      int32_t c = codes[t];
+      atomicOr(&allow[(int64_t)b * Cw + (c >> 5)], 1u << (c & 31));
+    }
+  }
+}
+
+void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off, int B, uint32_t* subbm,
+                        int64_t W, uint32_t* allow, int64_t Cw, int32_t* invalid, hipStream_t st) {
+  hipLaunchKernelGGL(k_subset_prepare, dim3(32, (unsigned)B), dim3(256), 0, st, sub_ids, sub_off, ix.N, ix.doc_off, ix.codes,
+                     subbm, W, allow, Cw, invalid);
+}
+
+// ============================================================================================
+// S3  IVF gather as a per-query document bitmap
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
+                                                  int maxcells, const int64_t* __restrict__ ivf_off,
+                                                  const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
+                                                  int64_t W) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x;
+  if (j >= ncells[b]) return;
+  const int32_t cell = ucells[(int64_t)b * maxcells + j];
+  if (cell < 0 || cell >= P) return;  // centroid without an IVF list
+  const int64_t beg = ivf_off[cell], end = ivf_off[cell + 1];
+  uint32_t* bm = bitmap + (int64_t)b * W;
+  for (int64_t i = beg + (int64_t)blockIdx.z * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.z * 256) {
+    int32_t pid = ivf_pids[i];
+    atomicOr(&bm[pid >> 5], 1u << (pid & 31));
+  }
+}
+
+void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B, uint32_t* bitmap,
+                  int64_t W, hipStream_t st) {
+  hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)maxcells, (unsigned)B, 4), dim3(256), 0, st, ucells, ncells, maxcells, ix.ivf_off,
+                     ix.ivf_pids, ix.P, bitmap, W);
+}
+
+// ---- ordered compaction of the bitmaps ------------------------------------------------------
+#define CAND_WPT 4                           // words per thread
+#define CAND_WPB (256 * CAND_WPT)            // words per block
+__global__ __launch_bounds__(256) void k_cand_count(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
+                                                    const int32_t* __restrict__ invalid, int64_t W, int32_t* __restrict__ blkcnt,
+                                                    int nblk) {
+  const int b = blockIdx.y;
+  int cnt = 0;
+  if (!(invalid && invalid[b])) {
+    const int64_t w0 = (int64_t)blockIdx.x * CAND_WPB + threadIdx.x * CAND_WPT;
+#pragma unroll
+    for (int k = 0; k < CAND_WPT; ++k) {
+      int64_t w = w0 + k;
+      if (w < W) {
+        uint32_t x = bitmap[(int64_t)b * W + w];
+        if (subbm) x &= subbm[(int64_t)b * W + w];
+        cnt += __popc(x);
+      }
+    }
+  }
+  __shared__ int s[256];
+  s[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+}
+
+// exclusive scan of blkcnt per query (in place) + per-query totals; one block per query
+__global__ __launch_bounds__(256) void k_cand_scan(int32_t* __restrict__ blkcnt, int nblk, int32_t* __restrict__ ncand) {
+  const int b = blockIdx.x;
+  __shared__ int s[256];
+  int32_t* v = blkcnt + (int64_t)b * nblk;
+  int base = 0;
+  for (int start = 0; start < nblk; start += 256) {
+    int i = start + threadIdx.x;
+    int x = (i < nblk) ? v[i] : 0;
+    s[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblk) v[i] = base + s[threadIdx.x] - x;
+    int tot = s[255];
+    __syncthreads();
+    base += tot;
+  }
+  if (threadIdx.x == 0) ncand[b] = base;
+}
+
+__global__ void k_cand_offsets(const int32_t* __restrict__ ncand, int B, int64_t* __restrict__ cand_off) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t a = 0;
+    for (int b = 0; b < B; ++b) { cand_off[b] = a; a += ncand[b]; }
+    cand_off[B] = a;
+  }
+}
+
+void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W, int32_t* blkcnt,
+                    int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st) {
+  hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk);
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, ncand, B, cand_off);
+}
+
+__global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
+                                                      const int32_t* __restrict__ invalid, int64_t W,
+                                                      const int32_t* __restrict__ blkoff, int nblk,
+                                                      const int64_t* __restrict__ cand_off, int32_t* __restrict__ cand_pid) {
+  const int b = blockIdx.y;
+  if (invalid && invalid[b]) return;
+  const int64_t w0 = (int64_t)blockIdx.x * CAND_WPB + threadIdx.x * CAND_WPT;
+  uint32_t x[CAND_WPT];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < CAND_WPT; ++k) {
+    int64_t w = w0 + k;
+    x[k] = 0;
+    if (w < W) {
+      x[k] = bitmap[(int64_t)b * W + w];
+      if (subbm) x[k] &= subbm[(int64_t)b * W + w];
+    }
+    cnt += __popc(x[k]);
+  }
+  __shared__ int s[256];
+  s[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t pos = cand_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+#pragma unroll
+  for (int k = 0; k < CAND_WPT; ++k) {
+    uint32_t w = x[k];
+    const int32_t basepid = (int32_t)((w0 + k) * 32);
+    while (w) {
+      int bit = __ffs(w) - 1;
+      cand_pid[pos++] = basepid + bit;
+      w &= w - 1;
+    }
+  }
+}
+
+void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
+                      const int32_t* blkoff, int nblk, const int64_t* cand_off, int32_t* cand_pid, hipStream_t st) {
+  hipLaunchKernelGGL(k_cand_compact, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkoff, nblk,
+                     cand_off, cand_pid);
+}
+
+// ============================================================================================
+// S4  approximate scores.  One wave per candidate document (grid-stride).  Per 32-column
+// chunk of the query: 4 lanes x 16 B cover one 64-byte row S[b][code][chunk*32..+32], so one
+// wave instruction gathers the rows of 16 tokens.  Running max in packed fp16, fp32 sum.
+// ============================================================================================
+__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int B, int Q, int Qp,
+                                                const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
+                                                int64_t M, const int64_t* __restrict__ doc_off, const int32_t* __restrict__ codes,
+                                                float* __restrict__ approx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int tslot = lane >> 2;  // token slot 0..15
+  const int sub = lane & 3;     // 16-byte piece of the 64-byte row
+  const half_t negm = (half_t)NEG_MASK_F;
+  const h2 neg2 = {negm, negm};
+  for (int64_t i = wave0; i < M; i += nwaves) {
+    // query of candidate i: last b with cand_off[b] <= i
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (cand_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    const int32_t pid = cand_pid[i];
+    const int64_t off = doc_off[pid];
+    const int len = (int)(doc_off[pid + 1] - off);
+    const uint16_t* Sb = S + (int64_t)b * C * Qp;
+    float total = 0.f;
+    for (int ch = 0; ch < Qp / 32; ++ch) {
+      h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
+      const uint16_t* Sc = Sb + ch * 32 + sub * 8;
+#pragma unroll 4
+      for (int t = tslot; t < len; t += 16) {
+        const int32_t code = codes[off + t];
+        const uint4 v = *reinterpret_cast<const uint4*>(Sc + (int64_t)code * Qp);
+        m0 = pk_max(m0, u32_as_h2(v.x));
+        m1 = pk_max(m1, u32_as_h2(v.y));
+        m2 = pk_max(m2, u32_as_h2(v.z));
+        m3 = pk_max(m3, u32_as_h2(v.w));
+      }
+#pragma unroll
+      for (int s = 4; s < 64; s <<= 1) {
+        m0 = pk_max(m0, u32_as_h2(shfl_xor_u32(h2_as_u32(m0), s)));
+        m1 = pk_max(m1, u32_as_h2(shfl_xor_u32(h2_as_u32(m1), s)));
+        m2 = pk_max(m2, u32_as_h2(shfl_xor_u32(h2_as_u32(m2), s)));
+        m3 = pk_max(m3, u32_as_h2(shfl_xor_u32(h2_as_u32(m3), s)));
+      }
+      const int q0 = ch * 32 + sub * 8;
+      float s = 0.f;
+      s += (q0 + 0 < Q) ? (float)m0.x : 0.f;
+      s += (q0 + 1 < Q) ? (float)m0.y : 0.f;
+      s += (q0 + 2 < Q) ? (float)m1.x : 0.f;
+      s += (q0 + 3 < Q) ? (float)m1.y : 0.f;
+      s += (q0 + 4 < Q) ? (float)m2.x : 0.f;
+      s += (q0 + 5 < Q) ? (float)m2.y : 0.f;
+      s += (q0 + 6 < Q) ? (float)m3.x : 0.f;
+      s += (q0 + 7 < Q) ? (float)m3.y : 0.f;
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      total += s;
+    }
+    if (lane == 0) approx[i] = total;
+  }
+}
+
+void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
+                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st) {
+  if (M <= 0) return;
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_approx, dim3((unsigned)blocks), dim3(256), 0, st, S, ix.C, sh.B, sh.Q, sh.Qp, cand_off, cand_pid, M,
+                     ix.doc_off, ix.codes, approx);
+}
+
+// ============================================================================================
+// S5  top-R selection by (approx desc, doc id asc): 3-pass radix select (11+11+10 bits) on
+// the monotone key, then one ordered collect pass per query.
+// selstate[b] = {need_select, keep, prefix, k_rem, n, -, -, -}
+// ============================================================================================
+__global__ void k_sel_init(const int64_t* __restrict__ cand_off, int B, int64_t n_full, int64_t R, uint32_t* __restrict__ st,
+                           int32_t* __restrict__ sel_cnt) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t n = cand_off[b + 1] - cand_off[b];
+  int64_t keep = n;
+  if (n_full < keep) keep = n_full;   // search.rs:605-611
+  if (R < keep) keep = R;             // :614-619 (R = max(n_full/4, 1))
+  if (keep < 0) keep = 0;
+  uint32_t* s = st + (int64_t)b * 8;
+  s[0] = (keep < n) ? 1u : 0u;
+  s[1] = (uint32_t)keep;
+  s[2] = 0u;
+  s[3] = (uint32_t)keep;
+  s[4] = (uint32_t)n;
+  sel_cnt[b] = (int32_t)keep;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ approx, const int64_t* __restrict__ cand_off,
+                                                  const uint32_t* __restrict__ st, uint32_t* __restrict__ hist) {
+  constexpr int SHIFT = (PASS == 0) ? 21 : (PASS == 1) ? 10 : 0;
+  constexpr int WIDTH = (PASS == 2) ? 10 : 11;
+  const int b = blockIdx.y;
+  const uint32_t* s = st + (int64_t)b * 8;
+  if (!s[0]) return;
+  __shared__ uint32_t h[FP_SEL_BINS];
+  for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint32_t prefix = s[2];
+  const int64_t beg = cand_off[b], end = cand_off[b + 1];
+  for (int64_t i = beg + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256) {
+    uint32_t k = mono32(approx[i]);
+    bool match = (PASS == 0) ? true : ((k >> (SHIFT + WIDTH)) == prefix);
+    if (match) atomicAdd(&h[(k >> SHIFT) & ((1u << WIDTH) - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t* g = hist + ((int64_t)PASS * gridDim.y + b) * FP_SEL_BINS;
+  for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256)
+    if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sel_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ st, int B) {
+  constexpr int WIDTH = (PASS == 2) ? 10 : 11;
+  constexpr int NB = 1 << WIDTH;
+  constexpr int PER = NB / 256;  // bins per thread (8 or 4)
+  const int b = blockIdx.x;
+  uint32_t* s = st + (int64_t)b * 8;
+  if (!s[0]) return;
+  const uint32_t* g = hist + ((int64_t)PASS * B + b) * FP_SEL_BINS;
+  // thread t owns bins [NB-1 - t*PER - (PER-1), NB-1 - t*PER] walking from the top
+  uint32_t loc[PER];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { loc[j] = g[NB - 1 - (threadIdx.x * PER + j)]; sum += loc[j]; }
+  __shared__ uint32_t sc[256];
+  sc[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    uint32_t t = ((int)threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const uint32_t k_rem = s[3];
+  const uint32_t incl = sc[threadIdx.x], excl = incl - sum;
+  __syncthreads();
+  if (excl < k_rem && incl >= k_rem) {  // exactly one thread
+    uint32_t cum = excl;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (cum + loc[j] >= k_rem) {
+        uint32_t bin = NB - 1 - (threadIdx.x * PER + j);
+        s[2] = (s[2] << WIDTH) | bin;
+        s[3] = k_rem - cum;  // still needed from inside this bin
+        break;
+      }
+      cum += loc[j];
+    }
+  }
+}
+
+// ordered collect: one block per query
+__global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                      const int64_t* __restrict__ cand_off, const uint32_t* __restrict__ st,
+                                                      int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx) {
+  const int b = blockIdx.x;
+  const uint32_t* s = st + (int64_t)b * 8;
+  const bool need = s[0] != 0;
+  const uint32_t kstar = s[2];
+  const uint32_t need_eq = s[3];
+  const uint32_t keep = s[1];
+  const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  if (!need) {
+    for (int64_t i = threadIdx.x; i < n && i < (int64_t)keep; i += 1024) { op[i] = cand_pid[beg + i]; oa[i] = approx[beg + i]; }
+    return;
+  }
+  __shared__ uint32_t wg[16], we[16];
+  __shared__ uint32_t base_g, base_e;
+  if (threadIdx.x == 0) { base_g = 0; base_e = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t start = 0; start < n; start += 1024) {
+    const int64_t i = start + threadIdx.x;
+    float a = 0.f;
+    bool gt = false, eq = false;
+    if (i < n) {
+      a = approx[beg + i];
+      uint32_t k = mono32(a);
+      gt = k > kstar;
+      eq = k == kstar;
+    }
+    const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t rg = __popcll(mg & below), re = __popcll(me & below);
+    if (lane == 0) { wg[wave] = __popcll(mg); we[wave] = __popcll(me); }
+    __syncthreads();
+    uint32_t pg = base_g, pe = base_e;
+    for (int w = 0; w < wave; ++w) { pg += wg[w]; pe += we[w]; }
+    rg += pg;
+    re += pe;
+    if (gt || (eq && re < need_eq)) {
+      uint32_t pos = rg + (re < need_eq ? re : need_eq);
+      if (pos < keep) { op[pos] = cand_pid[beg + i]; oa[pos] = a; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tg = 0, te = 0;
+      for (int w = 0; w < 16; ++w) { tg += wg[w]; te += we[w]; }
+      base_g += tg;
+      base_e += te;
+    }
+    __syncthreads();
+  }
+}
+
+void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
+                uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, hipStream_t st) {
+  const int B = sh.B;
+  (void)hipMemsetAsync(hist, 0, (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t), st);
+  hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, cand_off, B, sh.n_full, sh.R, selstate, sel_cnt);
+  dim3 gh(64, (unsigned)B);
+  hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
+  hipLaunchKernelGGL(k_sel_scan<0>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
+  hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
+  hipLaunchKernelGGL(k_sel_scan<1>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
+  hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
+  hipLaunchKernelGGL(k_sel_scan<2>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
+  hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
+                     sel_approx);
+}
+
+// ============================================================================================
+// S6+S7  fused decompress + exact MaxSim.  One wave per (query, document) pair, 32 tokens per
+// step, everything in registers:
+//   lane (tok = lane&31, h = lane>>5) owns dims [h*D/2, (h+1)*D/2) of token tok:
+//     e   = h(cent[code] + lut[byte])          packed fp16 add  (== fp32 add + round)
+//     n   = h(sqrt(sum_fp32 e^2))              dot2 accumulate, halves combined by one shuffle
+//     e^  = h(float(e) / float(n))             IEEE fp32 divide, one rounding to fp16
+//   and those 8-dim groups ARE the A fragments of v_mfma_f32_32x32x16_f16 (A row = token,
+//   k = 8*h + j  <->  dim h*D/2 + 8*m + j for k-step m); the query B fragments use the same
+//   k <-> dim map, so no LDS staging and no transposes are needed.
+//   sim = h(acc) ; running max over tokens per query column ; fp32 sum over q.
+// ============================================================================================
+template <int D, int NBITS, int NCH>
+__global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
+                                                const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
+                                                const int64_t* __restrict__ doc_off, const uint16_t* __restrict__ qpad, int Q,
+                                                int Qp, int ch_begin, const int32_t* __restrict__ sel_pid,
+                                                const int32_t* __restrict__ sel_cnt, int64_t Rcap, float* __restrict__ exact,
+                                                int accumulate) {
+  constexpr int PR = D * NBITS / 8;   // packed residual bytes per token
+  constexpr int RB = PR / 2;          // bytes per lane
+  constexpr int RW = RB / 4;          // 32-bit words per lane
+  constexpr int PB = 8 / NBITS;       // dims per byte
+  constexpr int KS = D / 16;          // MFMA k-steps
+  constexpr int NE = D / 4;           // half2 registers per lane (D/2 dims)
+  __shared__ uint32_t lut[256 * PB / 2];  // byte -> PB halfs
+  for (int i = threadIdx.x; i < 256 * PB / 2; i += 256) lut[i] = reinterpret_cast<const uint32_t*>(lut_g)[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= sel_cnt[b]) return;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int32_t pid = sel_pid[(int64_t)b * Rcap + r];
+  const int64_t off = doc_off[pid];
+  const int len = (int)(doc_off[pid + 1] - off);
+
+  // query B fragments for NCH chunks
+  h8 qf[NCH][KS];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = ch_begin + c;
+    const bool chv = ch * 32 < Qp;
+    const uint16_t* qrow = qpad + ((int64_t)b * Qp + (chv ? ch * 32 : 0) + l31) * D + hi * (D / 2);
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+      uint4 v = *reinterpret_cast<const uint4*>(qrow + 8 * m);
+      if (!chv) v = make_uint4(0, 0, 0, 0);
+      qf[c][m] = __builtin_bit_cast(h8, v);
+    }
+  }
+  const half_t negm = (half_t)NEG_MASK_F;
+  h2 mx[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) mx[c] = h2{negm, negm};  // .x only is used at the end; both track
+
+  for (int t0 = 0; t0 < len; t0 += 32) {
+    int tok = t0 + l31;
+    if (tok >= len) tok = len - 1;  // clamp: loads stay in bounds, rows masked below
+    const int32_t code = codes[off + tok];
+    const uint8_t* rp = resid + (off + tok) * (int64_t)PR + hi * RB;
+    uint32_t rw[RW];
+    if constexpr (RW >= 4) {
+#pragma unroll
+      for (int i = 0; i < RW / 4; ++i) {
+        uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
+        rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
+      }
+    } else {
+      uint2 v = *reinterpret_cast<const uint2*>(rp);
+      rw[0] = v.x; rw[1] = v.y;
+    }
+    const uint16_t* cp = cent + (int64_t)code * D + hi * (D / 2);
+    uint32_t e[NE];
+#pragma unroll
+    for (int i = 0; i < NE / 4; ++i) {
+      uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
+      e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+    }
+    // e = h(cent + w)
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < RW; ++w) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t byte = (rw[w] >> (8 * k)) & 0xFFu;
+        const int bi = w * 4 + k;  // byte index within the lane -> dims [bi*PB, bi*PB+PB)
+        if constexpr (PB == 2) {
+          h2 v = u32_as_h2(e[bi]) + u32_as_h2(lut[byte]);
+          e[bi] = h2_as_u32(v);
+          ss = __builtin_amdgcn_fdot2(v, v, ss, false);
+        } else {  // PB == 4
+          h2 v0 = u32_as_h2(e[2 * bi]) + u32_as_h2(lut[2 * byte]);
+          h2 v1 = u32_as_h2(e[2 * bi + 1]) + u32_as_h2(lut[2 * byte + 1]);
+          e[2 * bi] = h2_as_u32(v0);
+          e[2 * bi + 1] = h2_as_u32(v1);
+          ss = __builtin_amdgcn_fdot2(v0, v0, ss, false);
+          ss = __builtin_amdgcn_fdot2(v1, v1, ss, false);
+        }
+      }
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float nf = (float)(half_t)__builtin_sqrtf(ss);  // Half norm; clamp_min(1e-12) is a no-op in fp16
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      h2 v = u32_as_h2(e[i]);
+      h2 o;
+      o.x = (half_t)((float)v.x / nf);
+      o.y = (half_t)((float)v.y / nf);
+      e[i] = h2_as_u32(o);
+    }
+    f16v acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+      uint4 av = make_uint4(e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3]);
+      h8 a = __builtin_bit_cast(h8, av);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[c][m], acc[c], 0, 0, 0);
+    }
+    // D[row = token][col = q = lane&31]; this lane's rows: (i&3) + 8*(i>>2) + 4*hi
+    const bool partial = (t0 + 32 > len);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      h2 m = mx[c];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        h2 v;
+        v.x = (half_t)acc[c][i];
+        v.y = (half_t)acc[c][i + 1];
+        if (partial) {
+          const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
+          if (t0 + row0 >= len) v.x = negm;
+          if (t0 + row0 + 1 >= len) v.y = negm;
+        }
+        m = pk_max(m, v);
+      }
+      mx[c] = m;
+    }
+  }
+  float total = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    half_t m = mx[c].x > mx[c].y ? mx[c].x : mx[c].y;
+    uint32_t mu = (uint32_t)__builtin_bit_cast(uint16_t, m);
+    uint32_t ou = shfl_xor_u32(mu, 32);
+    half_t o = __builtin_bit_cast(half_t, (uint16_t)ou);
+    m = o > m ? o : m;
+    const int q = (ch_begin + c) * 32 + l31;
+    float s = (hi == 0 && q < Q) ? (float)m : 0.f;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, 64);
+    total += s;
+  }
+  if (lane == 0) {
+    float* dst = exact + (int64_t)b * Rcap + r;
+    *dst = accumulate ? (*dst + total) : total;
+  }
+}
+
+template <int D, int NBITS>
+static void launch_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid,
+                          const int32_t* sel_cnt, int64_t Rcap, float* exact, hipStream_t st) {
+  dim3 grid((unsigned)((Rcap + 3) / 4), (unsigned)sh.B);
+  const int nch = sh.Qp / 32;
+  int ch = 0;
+  int acc = 0;
+  while (ch < nch) {
+    if (nch - ch >= 2) {
+      hipLaunchKernelGGL((k_maxsim<D, NBITS, 2>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
+                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc);
+      ch += 2;
+    } else {
+      hipLaunchKernelGGL((k_maxsim<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
+                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc);
+      ch += 1;
+    }
+    acc = 1;
+  }
+}
+
+int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
+               int64_t Rcap, float* exact, hipStream_t st) {
+  if (ix.dim == 128 && ix.nbits == 4) launch_maxsim<128, 4>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
+  else if (ix.dim == 128 && ix.nbits == 2) launch_maxsim<128, 2>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
+  else if (ix.dim == 64 && ix.nbits == 4) launch_maxsim<64, 4>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
+  else if (ix.dim == 64 && ix.nbits == 2) launch_maxsim<64, 2>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
+  else return -1;
+  return 0;
+}
+
+// ============================================================================================
+// S8  final ranking: LDS bitonic sort of 64-bit keys (mono32(score) << 32 | ~id), descending.
+// ids must be < 2^32 (global doc ids of a <= 4.29e9-document corpus).
+// ============================================================================================
+__global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ score, const int32_t* __restrict__ pid_local,
+                                                     const int64_t* __restrict__ pid_global, const int32_t* __restrict__ cnt,
+                                                     int64_t stride, int npow2, int64_t top_k, int64_t pid_offset,
+                                                     int64_t* __restrict__ out_pid, float* __restrict__ out_score,
+                                                     int32_t* __restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // all LDS in the dynamic region (a static __shared__ in front would mis-align the 8-byte keys)
+  int* s_validp = reinterpret_cast<int*>(smem);
+  unsigned long long* v = reinterpret_cast<unsigned long long*>(smem + 16);
+  const int b = blockIdx.x;
+  const int n = cnt ? cnt[b] : (int)stride;
+  if (threadIdx.x == 0) *s_validp = 0;
+  __syncthreads();
+  int myvalid = 0;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    unsigned long long key = 0ull;
+    if (i < n) {
+      int64_t id = pid_local ? (int64_t)pid_local[(int64_t)b * stride + i] + pid_offset : pid_global[(int64_t)b * stride + i];
+      float s = score[(int64_t)b * stride + i];
+      if (id >= 0) {  // id < 0 = padding entry of a sharded buffer
+        key = ((unsigned long long)mono32(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+        ++myvalid;
+      }
+    }
+    v[i] = key;
+  }
+  atomicAdd(s_validp, myvalid);
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = v[i], c = v[ixj];
+          bool desc = ((i & k) == 0);
+          if ((a < c) == desc) { v[i] = c; v[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int valid = *s_validp;
+  const int m = (int)(top_k < valid ? top_k : valid);
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    unsigned long long key = v[i];
+    out_pid[(int64_t)b * top_k + i] = (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+    out_score[(int64_t)b * top_k + i] = unmono32((uint32_t)(key >> 32));
+  }
+  if (threadIdx.x == 0) out_cnt[b] = m;
+}
+
+void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
+                    int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
+                    hipStream_t st) {
+  int np2 = next_pow2((int)stride);
+  if (np2 < 2) np2 = 2;
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (gfx950: 160 KiB / workgroup)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_final_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,
+                     top_k, pid_offset, out_pid, out_score, out_cnt);
+}
+
+// ============================================================================================
+// sharded-search helpers
+// ============================================================================================
+__global__ void k_shard_pack(const float* __restrict__ val, const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt,
+                             int64_t R, int64_t pid_offset, float* __restrict__ oval, int64_t* __restrict__ opid, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int b = (int)(i / R);
+  int r = (int)(i % R);
+  if (r < cnt[b]) { oval[i] = val[i]; opid[i] = (int64_t)pid[i] + pid_offset; }
+  else { oval[i] = -__builtin_inff(); opid[i] = -1; }
+}
+
+void fpk_shard_pack_top(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
+                        int64_t pid_offset, float* top_approx, int64_t* top_pid, hipStream_t st) {
+  int64_t total = (int64_t)B * R;
+  hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sel_approx, sel_pid, sel_cnt, R, pid_offset,
+                     top_approx, top_pid, total);
+}
+
+void fpk_shard_pack_scores(const float* exact, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset,
+                           float* loc_score, int64_t* loc_pid, hipStream_t st) {
+  fpk_shard_pack_top(exact, sel_pid, sel_cnt, B, R, pid_offset, loc_score, loc_pid, st);
+}
+
+// [G][B][R] -> [B][G*R]
+__global__ void k_transpose_ranks(const float* __restrict__ in_f, const int64_t* __restrict__ in_p, int G, int B, int64_t R,
+                                  float* __restrict__ out_f, int64_t* __restrict__ out_p) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)G * B * R;
+  if (i >= total) return;
+  int64_t r = i % R;
+  int64_t b = (i / R) % B;
+  int64_t g = i / (R * B);
+  int64_t o = b * (G * R) + g * R + r;
+  out_f[o] = in_f[i];
+  out_p[o] = in_p[i];
+}
+
+void fpk_transpose_ranks(const float* in_f, const int64_t* in_p, int G, int B, int64_t R, float* out_f, int64_t* out_p,
+                         hipStream_t st) {
+  int64_t total = (int64_t)G * B * R;
+  hipLaunchKernelGGL(k_transpose_ranks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in_f, in_p, G, B, R, out_f, out_p);
+}
+
+// global cut: sort the union [B][G*R] by (approx desc, id asc), keep the first R valid, and
+// of those the ones that live on this rank, written as local ids in ascending order.
+__global__ __launch_bounds__(1024) void k_shard_cut(const float* __restrict__ val, const int64_t* __restrict__ pid, int n, int npow2,
+                                                    int64_t R, int64_t pid_lo, int64_t pid_hi, int32_t* __restrict__ sel_pid,
+                                                    int32_t* __restrict__ sel_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_cntp = reinterpret_cast<int*>(smem);
+  unsigned long long* v = reinterpret_cast<unsigned long long*>(smem + 16);
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    unsigned long long key = 0ull;
+    if (i < n) {
+      int64_t id = pid[(int64_t)b * n + i];
+      if (id >= 0) key = ((unsigned long long)mono32(val[(int64_t)b * n + i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+    }
+    v[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = v[i], c = v[ixj];
+          bool desc = ((i & k) == 0);
+          if ((a < c) == desc) { v[i] = c; v[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // first R entries (valid ones have key != 0): keep local ids; then sort them ascending.
+  // Reuse LDS: write local ids (or sentinel) into a second region after a barrier.
+  const int lim = (int)(R < npow2 ? R : npow2);
+  unsigned int* ids = reinterpret_cast<unsigned int*>(smem + 16 + (size_t)npow2 * 8);  // [rpow2]
+  int rpow2 = 2;
+  while (rpow2 < lim) rpow2 <<= 1;
+  if (threadIdx.x == 0) *s_cntp = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < rpow2; i += blockDim.x) {
+    unsigned int x = 0xFFFFFFFFu;
+    if (i < lim) {
+      unsigned long long key = v[i];
+      if (key) {
+        int64_t id = (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+        if (id >= pid_lo && id < pid_hi) { x = (unsigned int)(id - pid_lo); atomicAdd(s_cntp, 1); }
+      }
+    }
+    ids[i] = x;
+  }
+  __syncthreads();
+  for (int k = 2; k <= rpow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < rpow2; i += blockDim.x) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned int a = ids[i], c = ids[ixj];
+          bool up = ((i & k) == 0);
+          if ((a > c) == up) { ids[i] = c; ids[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int cnt = *s_cntp;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) sel_pid[(int64_t)b * R + i] = (int32_t)ids[i];
+  if (threadIdx.x == 0) sel_cnt[b] = cnt;
+}
+
+void fpk_shard_global_cut(const float* all_approx, const int64_t* all_pid, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
+                          int32_t* sel_pid, int32_t* sel_cnt, hipStream_t st) {
+  // all_* already transposed to [B][G*R]
+  const int n = (int)(G * R);
+  const int np2 = next_pow2(n < 2 ? 2 : n);
+  int rp2 = next_pow2((int)(R < 2 ? 2 : R));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_shard_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_shard_cut, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + (size_t)rp2 * 4 + 16, st, all_approx, all_pid, n, np2, R,
+                     pid_lo, pid_hi, sel_pid, sel_cnt);
+}
+
+// ============================================================================================
+// misc
+// ============================================================================================
+__global__ void k_narrow(const int64_t* __restrict__ in, int32_t* __restrict__ out, int64_t n, int64_t add) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)(in[i] + add);
+}
+void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n, add);
+}
+
+// reconstruct_embeddings (embeddings.rs:12-69): decompress rows to fp32.  One 64-thread
+// block per token; the fp32 sum of squares is taken in ascending-dim order by one lane so
+// the result is bit-identical to the CPU reference order.
+__global__ __launch_bounds__(64) void k_reconstruct(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut,
+                                                    const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid, int D,
+                                                    int nbits, const int64_t* __restrict__ tok_idx, float* __restrict__ out) {
+  __shared__ float e[512];
+  __shared__ float nrm;
+  const int64_t t = tok_idx[blockIdx.x];
+  const int pb = 8 / nbits, pr = D * nbits / 8;
+  const int32_t code = codes[t];
+  for (int d = threadIdx.x; d < D; d += 64) {
+    const int byte = resid[t * pr + d / pb];
+    const half_t w = __builtin_bit_cast(half_t, lut[byte * pb + d % pb]);
+    const half_t c = __builtin_bit_cast(half_t, cent[(int64_t)code * D + d]);
+    e[d] = (float)(half_t)((float)w + (float)c);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ss = 0.f;
+    for (int d = 0; d < D; ++d) ss += e[d] * e[d];
+    nrm = (float)(half_t)__builtin_sqrtf(ss);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 64) out[(int64_t)blockIdx.x * D + d] = (float)(half_t)(e[d] / nrm);
+}
+
+void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, float* out, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_reconstruct, dim3((unsigned)n), dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.dim, ix.nbits,
+                     tok_idx, out);
+}

@@ -1,0 +1,183 @@
+// Device-side synthetic corpus generator (benchmark / full-size property tests) and IVF
+// builder.  Bit-identical to the numpy twin in fast-plaid_amd/synth.py: every integer is a
+// pure function of (seed, stream, counter) through the splitmix64 finaliser.
+#include <hipcub/hipcub.hpp>
+
+#include "fp_internal.h"
+
+#define S_DOCLEN 1ull
+#define S_TOPIC 2ull
+#define S_TOKEN 3ull
+#define S_RESID 4ull
+#define TOPIC_SIZE 8
+#define P_TOPIC_256 205ull
+
+__host__ __device__ static inline uint64_t mix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ static inline uint64_t stream_key(uint64_t seed, uint64_t stream) {
+  return mix64(seed * 0xD1342543DE82EF95ull + stream);
+}
+__host__ __device__ static inline int synth_doc_len(uint64_t key_len, int doc_len, int variable, uint64_t pid) {
+  if (!variable) return doc_len;
+  int lo = doc_len / 4 > 1 ? doc_len / 4 : 1;
+  uint64_t span = (uint64_t)(doc_len - lo + 1);
+  return lo + (int)(mix64(key_len + pid) % span);
+}
+
+int64_t fps_doc_offsets_host(const FpSynthParams& p, int64_t* doc_off_host, int* max_len) {
+  // doc_off_host: [n_local + 2]; the extra last slot returns tok_base (tokens before doc_begin)
+  const uint64_t kl = stream_key(p.seed, S_DOCLEN);
+  int64_t tok_base = 0;
+  if (p.variable_len) {
+    for (int64_t d = 0; d < p.doc_begin; ++d) tok_base += synth_doc_len(kl, p.doc_len, 1, (uint64_t)d);
+  } else {
+    tok_base = p.doc_begin * (int64_t)p.doc_len;
+  }
+  int64_t n = p.doc_end - p.doc_begin, a = 0;
+  int mx = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    doc_off_host[i] = a;
+    int l = synth_doc_len(kl, p.doc_len, p.variable_len, (uint64_t)(p.doc_begin + i));
+    if (l > mx) mx = l;
+    a += l;
+  }
+  doc_off_host[n] = a;
+  doc_off_host[n + 1] = tok_base;
+  *max_len = mx;
+  return a;
+}
+
+__device__ static inline uint32_t zipf_centroid(uint64_t r, int lgC, uint64_t Cmask) {
+  uint64_t e = r % (uint64_t)lgC;
+  uint64_t m = (1ull << e) - 1ull;
+  uint64_t rank = m + ((r >> 8) & m);
+  return (uint32_t)((rank * 0x9E3779B1ull + 12345ull) & Cmask);
+}
+
+// one wave per document
+__global__ __launch_bounds__(256) void k_synth_generate(FpSynthParams p, const int64_t* __restrict__ doc_off, int64_t n_docs,
+                                                        int64_t tok_base, int32_t* __restrict__ codes,
+                                                        uint8_t* __restrict__ residuals) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (d >= n_docs) return;
+  const uint64_t pid = (uint64_t)(p.doc_begin + d);
+  const uint64_t k_topic = stream_key(p.seed, S_TOPIC), k_tok = stream_key(p.seed, S_TOKEN), k_res = stream_key(p.seed, S_RESID);
+  const uint64_t Cmask = (uint64_t)p.C - 1ull;
+  uint32_t topics[TOPIC_SIZE];
+#pragma unroll
+  for (int j = 0; j < TOPIC_SIZE; ++j) topics[j] = zipf_centroid(mix64(k_topic + pid * TOPIC_SIZE + j), p.lgC, Cmask);
+  const int64_t off = doc_off[d];
+  const int len = (int)(doc_off[d + 1] - off);
+  const int words = (p.pr + 7) / 8;
+  for (int t = lane; t < len; t += 64) {
+    const uint64_t tg = (uint64_t)(tok_base + off + t);
+    const uint64_t r = mix64(k_tok + tg);
+    uint32_t code;
+    if ((r & 0xFFull) < P_TOPIC_256) {
+      const int slot = (int)((r >> 8) & (TOPIC_SIZE - 1));
+      code = topics[0];
+#pragma unroll
+      for (int j = 1; j < TOPIC_SIZE; ++j) code = (slot == j) ? topics[j] : code;
+    } else {
+      code = (uint32_t)((r >> 16) & Cmask);
+    }
+    codes[off + t] = (int32_t)code;
+    uint8_t* rp = residuals + (off + t) * (int64_t)p.pr;
+    for (int w = 0; w < words; ++w) {
+      const uint64_t v = mix64(k_res + tg * (uint64_t)words + (uint64_t)w);
+      if ((w + 1) * 8 <= p.pr) {
+        *reinterpret_cast<uint64_t*>(rp + 8 * w) = v;  // little-endian, pr % 8 == 0 on supported shapes
+      } else {
+        for (int k = 0; 8 * w + k < p.pr; ++k) rp[8 * w + k] = (uint8_t)(v >> (8 * k));
+      }
+    }
+  }
+}
+
+void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t tok_base, int32_t* codes,
+                  uint8_t* residuals, hipStream_t st) {
+  (void)T;
+  if (n_docs <= 0) return;
+  const int64_t blocks = (n_docs + 3) / 4;
+  hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)blocks), dim3(256), 0, st, p, doc_off_dev, n_docs, tok_base, codes, residuals);
+}
+
+// ---- IVF: per-cell ascending unique local doc ids ----------------------------------------------
+__global__ __launch_bounds__(256) void k_make_keys(const int32_t* __restrict__ codes, const int64_t* __restrict__ doc_off,
+                                                   int64_t n_docs, unsigned long long* __restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (d >= n_docs) return;
+  const int64_t off = doc_off[d], end = doc_off[d + 1];
+  for (int64_t t = off + lane; t < end; t += 64)
+    keys[t] = ((unsigned long long)(uint32_t)codes[t] << 32) | (unsigned long long)(uint32_t)d;
+}
+
+__global__ void k_ivf_pids(const unsigned long long* __restrict__ uniq, int64_t U, int32_t* __restrict__ pids) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < U) pids[i] = (int32_t)(uint32_t)uniq[i];
+}
+
+__global__ void k_ivf_offsets(const unsigned long long* __restrict__ uniq, int64_t U, int64_t P, int64_t* __restrict__ ivf_off) {
+  int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > P) return;
+  const unsigned long long target = (unsigned long long)c << 32;  // first key of cell c
+  int64_t lo = 0, hi = U;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (uniq[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  ivf_off[c] = lo;
+}
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto fail; } } while (0)
+
+int fps_build_ivf(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t P, int32_t** ivf_pids,
+                  int64_t* ivf_total, int64_t* ivf_off_dev, hipStream_t st) {
+  int rc = 0;
+  unsigned long long *ka = nullptr, *kb = nullptr;
+  void* tmp = nullptr;
+  int64_t* d_num = nullptr;
+  int64_t U = 0;
+  size_t tb1 = 0, tb2 = 0, tb = 0;
+  int end_bit = 32;
+  *ivf_pids = nullptr;
+  *ivf_total = 0;
+  if (T <= 0 || T > 0x7FFFFFFFll) {
+    if (T == 0) {
+      HCHK(hipMemsetAsync(ivf_off_dev, 0, (size_t)(P + 1) * sizeof(int64_t), st));
+      HCHK(hipMalloc((void**)ivf_pids, 16));
+      return 0;
+    }
+    return -1;
+  }
+  while ((1ll << (end_bit - 32)) < P) ++end_bit;
+  HCHK(hipMalloc((void**)&ka, (size_t)T * 8));
+  HCHK(hipMalloc((void**)&kb, (size_t)T * 8));
+  HCHK(hipMalloc((void**)&d_num, 8));
+  hipLaunchKernelGGL(k_make_keys, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, codes, doc_off_dev, n_docs, ka);
+  HCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, ka, kb, (int)T, 0, end_bit, st));
+  HCHK(hipcub::DeviceSelect::Unique(nullptr, tb2, kb, ka, d_num, (int)T, st));
+  tb = tb1 > tb2 ? tb1 : tb2;
+  HCHK(hipMalloc(&tmp, tb ? tb : 16));
+  HCHK(hipcub::DeviceRadixSort::SortKeys(tmp, tb1, ka, kb, (int)T, 0, end_bit, st));
+  HCHK(hipcub::DeviceSelect::Unique(tmp, tb2, kb, ka, d_num, (int)T, st));
+  HCHK(hipMemcpyAsync(&U, d_num, 8, hipMemcpyDeviceToHost, st));
+  HCHK(hipStreamSynchronize(st));
+  HCHK(hipMalloc((void**)ivf_pids, (size_t)(U > 0 ? U : 4) * sizeof(int32_t)));
+  if (U > 0) hipLaunchKernelGGL(k_ivf_pids, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, ka, U, *ivf_pids);
+  hipLaunchKernelGGL(k_ivf_offsets, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, st, ka, U, P, ivf_off_dev);
+  HCHK(hipStreamSynchronize(st));
+  *ivf_total = U;
+fail:
+  if (ka) (void)hipFree(ka);
+  if (kb) (void)hipFree(kb);
+  if (tmp) (void)hipFree(tmp);
+  if (d_num) (void)hipFree(d_num);
+  return rc;
+}

@@ -1,0 +1,312 @@
+"""Mirror of the reference's native module ``fast_plaid.fast_plaid_rust`` (rust/lib.rs:366-383)
+for the search path, on top of the C ABI in include/fastplaid.h.
+
+Same names, argument meaning and error behaviour as the PyO3 functions:
+  SearchParameters, QueryResult          rust/search/search.rs:114-200
+  construct_index(...) -> PyLoadedIndex  rust/search/load.rs:124-186
+  pysearch(...) -> list[QueryResult]     rust/lib.rs:195-223
+  reconstruct_embeddings(...)            rust/utils/embeddings.rs:12-69
+  initialize_torch(...)                  rust/lib.rs:100-104 (no libtorch here: a no-op)
+Index maintenance entry points (create / update / delete, lib.rs:132-165, :302-364) are outside
+the search hot path and raise NotImplementedError.
+
+Tensors may be torch CPU tensors or numpy arrays; nothing here needs torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def _np(x, dtype):
+    if x is None:
+        return None
+    if hasattr(x, "detach") and hasattr(x, "cpu"):  # torch tensor
+        x = x.detach().cpu()
+        if str(x.dtype) == "torch.bfloat16":
+            x = x.float()
+        x = x.numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=dtype)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _device_id(device: str) -> int:
+    """rust/search/load.rs:16-37 get_device ("cuda" is how ROCm devices are named in torch)."""
+    d = str(device).lower()
+    if d in ("cuda", "hip"):
+        return 0
+    if d.startswith("cuda:") or d.startswith("hip:"):
+        parts = d.split(":")
+        if len(parts) == 2:
+            try:
+                return int(parts[1])
+            except ValueError:
+                raise ValueError(f"Invalid CUDA device index: '{parts[1]}'")
+        raise ValueError("Invalid CUDA device format. Expected 'cuda:N'.")
+    if d == "cpu":
+        raise ValueError("This build is MI355X-only: device 'cpu' is not available (no CPU fallback).")
+    raise ValueError(f"Unsupported device string: '{device}'")
+
+
+class SearchParameters:
+    """rust/search/search.rs:171-200."""
+
+    def __init__(self, batch_size: int, n_full_scores: int, top_k: int, n_ivf_probe: int):
+        self.batch_size = int(batch_size)
+        self.n_full_scores = int(n_full_scores)
+        self.top_k = int(top_k)
+        self.n_ivf_probe = int(n_ivf_probe)
+
+    def _c(self) -> N.FpSearchParams:
+        return N.FpSearchParams(self.batch_size, self.n_full_scores, self.top_k, self.n_ivf_probe)
+
+
+class QueryResult:
+    """rust/search/search.rs:114-126."""
+
+    __slots__ = ("query_id", "passage_ids", "scores")
+
+    def __init__(self, query_id, passage_ids, scores):
+        self.query_id = query_id
+        self.passage_ids = passage_ids
+        self.scores = scores
+
+
+class PyLoadedIndex:
+    """Opaque handle (rust/search/load.rs:61-69); frees device memory when dropped."""
+
+    def __init__(self, handle, device_id: int, keepalive=()):
+        self._h = handle
+        self.device_id = device_id
+        self._keep = keepalive
+
+    @property
+    def n_docs(self):
+        return int(N.lib().fp_index_num_docs(self._h))
+
+    @property
+    def n_tokens(self):
+        return int(N.lib().fp_index_num_tokens(self._h))
+
+    @property
+    def n_centroids(self):
+        return int(N.lib().fp_index_num_centroids(self._h))
+
+    @property
+    def dim(self):
+        return int(N.lib().fp_index_dim(self._h))
+
+    @property
+    def nbits(self):
+        return int(N.lib().fp_index_nbits(self._h))
+
+    @property
+    def device_bytes(self):
+        return int(N.lib().fp_index_device_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().fp_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def initialize_torch(torch_path: str | None = None) -> None:  # lib.rs:100-104
+    return None
+
+
+def construct_index(nbits, centroids, avg_residual, bucket_cutoffs, bucket_weights, ivf, ivf_lengths, doc_codes,
+                    doc_residuals, doc_lengths, device: str, low_memory: bool = False, pid_offset: int = 0) -> PyLoadedIndex:
+    """rust/search/load.rs:124-186.  `low_memory` (keep document tensors on the host) has no
+    MI355X counterpart -- 288 GB of HBM holds the whole index -- and is accepted and ignored."""
+    del low_memory
+    dev = _device_id(device)
+    cent = _np(centroids, np.float16)
+    if cent.ndim != 2:
+        raise ValueError("centroids must be [n_centroids, dim]")
+    bw = _np(bucket_weights, np.float16)
+    if bw.shape[0] != (1 << int(nbits)):
+        raise ValueError("bucket_weights must have 2^nbits entries")
+    ivf_a = _np(ivf, np.int64)
+    ivfl = _np(ivf_lengths, np.int32)
+    codes = _np(doc_codes, np.int64)
+    res = _np(doc_residuals, np.uint8)
+    lens = _np(doc_lengths, np.int64)
+    dim = int(cent.shape[1])
+    T = int(lens.sum()) if lens.size else 0
+    if codes.shape[0] < T or res.shape[0] < T:
+        raise ValueError("doc_codes / doc_residuals hold fewer rows than sum(doc_lengths)")
+    if res.ndim != 2 or res.shape[1] != dim * int(nbits) // 8:
+        raise ValueError("doc_residuals must be [n_tokens, dim*nbits/8]")
+    if ivf_a is not None and ivfl is not None and int(ivfl.sum()) > ivf_a.shape[0]:
+        raise ValueError("ivf shorter than sum(ivf_lengths)")
+    if T and (codes[:T].min() < 0 or codes[:T].max() >= cent.shape[0]):
+        raise ValueError("doc_codes out of range of the centroid table")
+    if ivf_a is not None and ivf_a.size and (ivf_a.min() < 0 or ivf_a.max() >= lens.shape[0]):
+        raise ValueError("ivf holds document ids out of range")
+    d = N.FpIndexDesc(
+        int(nbits), dim, int(cent.shape[0]), _ptr(cent), None, None, _ptr(bw), _ptr(ivf_a), _ptr(ivfl),
+        0 if ivfl is None else int(ivfl.shape[0]), _ptr(codes), _ptr(res), _ptr(lens), int(lens.shape[0]), int(pid_offset))
+    h = C.c_void_p()
+    N.check(N.lib().fp_index_create(C.byref(d), dev, C.byref(h)))
+    return PyLoadedIndex(h, dev)
+
+
+def construct_synthetic_index(spec, device: str, doc_begin: int = 0, doc_end: int | None = None,
+                              centroids=None, bucket_weights=None) -> PyLoadedIndex:
+    """Device-generated corpus (include/fastplaid.h fp_index_create_synthetic); `spec` is a
+    synth.SynthSpec.  Not part of the reference API: benchmark / property-test plumbing."""
+    from . import synth
+    dev = _device_id(device)
+    cent = _np(synth.centroids(spec) if centroids is None else centroids, np.float16)
+    bw = _np(synth.bucket_weights(spec) if bucket_weights is None else bucket_weights, np.float16)
+    end = spec.n_docs if doc_end is None else int(doc_end)
+    d = N.FpSynthDesc(spec.nbits, spec.dim, spec.n_centroids, _ptr(cent), _ptr(bw), spec.n_docs, int(doc_begin), end,
+                      spec.doc_len, 1 if spec.variable_len else 0, spec.seed)
+    h = C.c_void_p()
+    N.check(N.lib().fp_index_create_synthetic(C.byref(d), dev, C.byref(h)))
+    return PyLoadedIndex(h, dev)
+
+
+def _flatten_subset(subset, n_queries):
+    if subset is None:
+        return None, None
+    if len(subset) != n_queries:
+        raise ValueError("Subset length must match number of queries.")
+    off = np.zeros(n_queries + 1, dtype=np.int64)
+    for i, s in enumerate(subset):
+        off[i + 1] = off[i] + len(s)
+    ids = np.zeros(max(int(off[-1]), 1), dtype=np.int64)
+    for i, s in enumerate(subset):
+        if len(s):
+            ids[off[i]: off[i + 1]] = np.asarray(s, dtype=np.int64)
+    return ids, off
+
+
+def search_arrays(index: PyLoadedIndex, queries_f16: np.ndarray, params: SearchParameters, subset=None):
+    """Array-level pysearch: returns (pids [B,top_k] i64, scores [B,top_k] f32, counts [B] i32)."""
+    q = _np(queries_f16, np.float16)
+    if q.ndim != 3:
+        raise ValueError(f"Expected a 3D tensor for queries, but got shape {list(q.shape)}")
+    B, Q, D = q.shape
+    k = max(params.top_k, 0)
+    pids = np.full((B, max(k, 1)), -1, dtype=np.int64)
+    scores = np.zeros((B, max(k, 1)), dtype=np.float32)
+    counts = np.zeros(max(B, 1), dtype=np.int32)
+    ids, off = _flatten_subset(subset, B)
+    p = params._c()
+    N.check(N.lib().fp_search(index._h, _ptr(q), B, Q, D, C.byref(p), _ptr(ids), _ptr(off), _ptr(pids), _ptr(scores), _ptr(counts)))
+    return pids[:, :k] if k else pids[:, :0], scores[:, :k] if k else scores[:, :0], counts[:B]
+
+
+def pysearch(index: PyLoadedIndex, device: str, queries_embeddings, search_parameters: SearchParameters,
+             show_progress: bool = False, subset=None) -> list[QueryResult]:
+    """rust/lib.rs:195-223.  `device` must name the device the index lives on."""
+    del show_progress
+    if _device_id(device) != index.device_id:
+        raise ValueError(f"index lives on device {index.device_id}, search requested on '{device}'")
+    pids, scores, counts = search_arrays(index, queries_embeddings, search_parameters, subset)
+    return [QueryResult(b, pids[b, : counts[b]].tolist(), scores[b, : counts[b]].tolist()) for b in range(pids.shape[0])]
+
+
+def search_trace(index: PyLoadedIndex, query_f16, params: SearchParameters, subset=None) -> dict:
+    """One query with every stage output (tests / profiling); see fp_search_trace."""
+    q = _np(query_f16, np.float16)
+    Q, D = q.shape
+    Cn, Nd = index.n_centroids, index.n_docs
+    R = max(params.n_full_scores // 4, 1)
+    k = max(params.top_k, 1)
+    S = np.zeros((Cn, Q), np.float16)
+    cells = np.zeros(max(Q * max(params.n_ivf_probe, 1), 1), np.int64)
+    cand = np.zeros(max(Nd, 1), np.int64)
+    approx = np.zeros(max(Nd, 1), np.float32)
+    rer = np.zeros(R, np.int64)
+    exact = np.zeros(R, np.float32)
+    counts = np.zeros(3, np.int64)
+    pids = np.zeros(k, np.int64)
+    scores = np.zeros(k, np.float32)
+    cnt = np.zeros(1, np.int32)
+    sub = None if subset is None else np.ascontiguousarray(np.asarray(subset, dtype=np.int64).reshape(-1))
+    if sub is not None and sub.size == 0:
+        sub = np.zeros(1, np.int64)[:0]
+    p = params._c()
+    N.check(N.lib().fp_search_trace(
+        index._h, _ptr(q), Q, D, C.byref(p), _ptr(sub) if sub is not None and sub.size else None,
+        0 if sub is None else int(sub.shape[0]), 0 if sub is None else 1, _ptr(pids), _ptr(scores), _ptr(cnt), _ptr(S),
+        _ptr(cells), _ptr(cand), _ptr(approx), _ptr(rer), _ptr(exact), _ptr(counts)))
+    nc, ncand, nr = (int(x) for x in counts)
+    n = int(cnt[0])
+    return dict(S=S, cells=cells[:nc].copy(), cand=cand[:ncand].copy(), approx=approx[:ncand].copy(),
+                rerank=rer[:nr].copy(), exact=exact[:nr].copy(), pids=pids[:n].copy(), scores=scores[:n].copy())
+
+
+def last_search_timings() -> dict:
+    names = (C.c_char_p * 16)()
+    ms = (C.c_float * 16)()
+    n = N.lib().fp_last_search_timings(C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), 16)
+    return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+
+def reconstruct_embeddings(index: PyLoadedIndex, subset, device: str = "cuda"):
+    """rust/utils/embeddings.rs:12-69 -> list of [doc_len, dim] float32 arrays."""
+    del device
+    ids = np.ascontiguousarray(np.asarray(subset, dtype=np.int64))
+    n = int(ids.shape[0])
+    lens = np.zeros(max(n, 1), np.int64)
+    cap = index.n_tokens if n else 0
+    # upper bound on rows: sum of requested doc lengths is unknown before the call -> two-step
+    out = np.zeros((max(min(cap, 1 << 22), 1), index.dim), np.float32)
+    rc = N.lib().fp_reconstruct_embeddings(index._h, _ptr(ids), n, _ptr(out), out.shape[0], _ptr(lens))
+    if rc != 0 and "capacity" in N.last_error():
+        out = np.zeros((max(cap, 1), index.dim), np.float32)
+        rc = N.lib().fp_reconstruct_embeddings(index._h, _ptr(ids), n, _ptr(out), out.shape[0], _ptr(lens))
+    N.check(rc)
+    res, o = [], 0
+    for i in range(n):
+        res.append(out[o: o + int(lens[i])].copy())
+        o += int(lens[i])
+    return res
+
+
+def read_doc(index: PyLoadedIndex, local_doc: int, capacity: int = 4096):
+    codes = np.zeros(capacity, np.int64)
+    res = np.zeros((capacity, index.dim * index.nbits // 8), np.uint8)
+    n = N.lib().fp_index_read_doc(index._h, int(local_doc), _ptr(codes), _ptr(res), capacity)
+    if n < 0:
+        raise ValueError(N.last_error())
+    return codes[:n].copy(), res[:n].copy()
+
+
+def read_ivf(index: PyLoadedIndex, cell: int, capacity: int = 1 << 22):
+    pids = np.zeros(capacity, np.int64)
+    n = N.lib().fp_index_read_ivf(index._h, int(cell), _ptr(pids), capacity)
+    if n < 0:
+        raise ValueError(N.last_error())
+    return pids[:n].copy()
+
+
+def create(*args, **kwargs):  # lib.rs:132-165
+    raise NotImplementedError("index creation is outside the MI355X search hot path (SURVEY.md section 8, row f1)")
+
+
+def update(*args, **kwargs):  # lib.rs:302-328
+    raise NotImplementedError("index update is outside the MI355X search hot path")
+
+
+def delete(*args, **kwargs):  # lib.rs:348-364
+    raise NotImplementedError("index delete is outside the MI355X search hot path")
+
+
+def pysearch_with_token_scores(*args, **kwargs):  # lib.rs:248-275
+    raise NotImplementedError("token-score matrices are a 'next' row (SURVEY.md section 8, f4)")

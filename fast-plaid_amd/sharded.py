@@ -1,0 +1,146 @@
+"""Document-sharded PLAID search: one process per GPU, collectives over torch.distributed
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU protocol tests).
+
+New relative to the reference, whose multi-GPU mode is full replicas + query split
+(python/fast_plaid/search/fast_plaid.py:893-928).  Every rank holds the full centroid table
+and a contiguous, token-balanced range of documents.  Per batch of queries:
+
+  stage1  (local)   S1..S4 on the shard, local top-R candidates by approximate score
+  all-gather        [B,R] f32 approx + [B,R] i64 global ids      (R = max(n_full/4, 1))
+  stage2  (local)   global top-R cut == search.rs:605-619 applied to the union, exact
+                    MaxSim of the survivors that live here
+  all-gather        [B,R] f32 scores + [B,R] i64 ids
+  stage3  (local)   global (score desc, id asc) sort, top_k
+
+Both messages are B*R*12 bytes per rank (3 MB at B=256, R=1024): latency-bound on xGMI, so
+they are issued as two fixed-size all_gather_into_tensor calls on device buffers -- no host
+staging, no variable-length exchange.  The result is identical to the unsharded search on
+the concatenated corpus (tests/test_hip_parity.py::test_sharded_equals_unsharded).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from . import fast_plaid_rust as native
+
+
+def plan_shards(doc_lengths, world_size: int) -> list[tuple[int, int]]:
+    """Contiguous doc ranges with (nearly) equal token mass. `doc_lengths` may be an int
+    (uniform lengths: n_docs) or an array."""
+    if isinstance(doc_lengths, (int, np.integer)):
+        n = int(doc_lengths)
+        cuts = [round(i * n / world_size) for i in range(world_size + 1)]
+    else:
+        lens = np.asarray(doc_lengths, dtype=np.int64)
+        n = int(lens.shape[0])
+        cum = np.concatenate([[0], np.cumsum(lens)])
+        total = int(cum[-1])
+        cuts = [0]
+        for i in range(1, world_size):
+            cuts.append(int(np.searchsorted(cum, i * total / world_size, side="left")))
+        cuts.append(n)
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[i], cuts[i + 1]) for i in range(world_size)]
+
+
+def shard_arrays(arrays: dict, begin: int, end: int) -> dict:
+    """Slice a construct_index argument set to documents [begin, end): codes/residuals rows
+    of those docs, IVF restricted (and re-based) to them."""
+    lens = np.asarray(arrays["doc_lengths"], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    t0, t1 = int(offs[begin]), int(offs[end])
+    out = dict(arrays)
+    out["doc_lengths"] = lens[begin:end].copy()
+    out["doc_codes"] = np.asarray(arrays["doc_codes"])[t0:t1].copy()
+    out["doc_residuals"] = np.asarray(arrays["doc_residuals"])[t0:t1].copy()
+    if arrays.get("ivf") is not None:
+        ivf = np.asarray(arrays["ivf"], dtype=np.int64)
+        il = np.asarray(arrays["ivf_lengths"], dtype=np.int64)
+        cell = np.repeat(np.arange(il.shape[0]), il)
+        keep = (ivf >= begin) & (ivf < end)
+        out["ivf"] = (ivf[keep] - begin).astype(np.int64)
+        out["ivf_lengths"] = np.bincount(cell[keep], minlength=il.shape[0]).astype(np.int32)
+    return out
+
+
+class HipShardEngine:
+    """Per-rank engine over the C ABI's fp_shard_* entry points.  Device buffers are torch
+    tensors so that torch.distributed (RCCL) can move them without host staging."""
+
+    def __init__(self, index: native.PyLoadedIndex, device):
+        import torch
+        self.torch = torch
+        self.index = index
+        self.device = torch.device(device)
+
+    def begin(self, queries_f16: np.ndarray, params: native.SearchParameters):
+        q = np.ascontiguousarray(queries_f16, dtype=np.float16)
+        B, Q, D = q.shape
+        ctx = C.c_void_p()
+        p = params._c()
+        N.check(N.lib().fp_shard_begin(self.index._h, q.ctypes.data_as(C.c_void_p), B, Q, D, C.byref(p), C.byref(ctx)))
+        R = int(N.lib().fp_shard_R(ctx))
+        return dict(ctx=ctx, B=B, R=R, top_k=params.top_k)
+
+    def stage1(self, st):
+        t = self.torch
+        a = t.empty((st["B"], st["R"]), dtype=t.float32, device=self.device)
+        p = t.empty((st["B"], st["R"]), dtype=t.int64, device=self.device)
+        N.check(N.lib().fp_shard_stage1(st["ctx"], a.data_ptr(), p.data_ptr()))
+        return a, p
+
+    def stage2(self, st, all_a, all_p, world):
+        t = self.torch
+        s = t.empty((st["B"], st["R"]), dtype=t.float32, device=self.device)
+        p = t.empty((st["B"], st["R"]), dtype=t.int64, device=self.device)
+        N.check(N.lib().fp_shard_stage2(st["ctx"], all_a.data_ptr(), all_p.data_ptr(), world, s.data_ptr(), p.data_ptr()))
+        return s, p
+
+    def stage3(self, st, all_s, all_p, world):
+        B, k = st["B"], max(st["top_k"], 1)
+        pids = np.full((B, k), -1, np.int64)
+        scores = np.zeros((B, k), np.float32)
+        counts = np.zeros(B, np.int32)
+        N.check(N.lib().fp_shard_stage3(st["ctx"], all_s.data_ptr(), all_p.data_ptr(), world,
+                                        pids.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p),
+                                        counts.ctypes.data_as(C.c_void_p)))
+        return pids[:, : st["top_k"]], scores[:, : st["top_k"]], counts
+
+    def end(self, st):
+        N.lib().fp_shard_end(st["ctx"])
+
+
+def _all_gather(torch, dist, x, world, group):
+    """[B,R] per rank -> [G,B,R] on every rank."""
+    if world == 1 or dist is None:
+        return x.unsqueeze(0).contiguous()
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)  # concatenation along dim 0 == [G][B][R]
+    return out.view((world,) + tuple(x.shape))
+
+
+def sharded_search(engine, queries_f16, params, dist=None, group=None):
+    """Runs one batch through the three stages with the two all-gathers in between.
+    `engine` implements begin/stage1/stage2/stage3/end (HipShardEngine in production).
+    Returns (pids [B,top_k], scores, counts) -- identical on every rank."""
+    import torch
+    world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+    st = engine.begin(queries_f16, params)
+    try:
+        a, p = engine.stage1(st)
+        all_a = _all_gather(torch, dist, a, world, group)
+        all_p = _all_gather(torch, dist, p, world, group)
+        if all_a.is_cuda:
+            torch.cuda.current_stream().synchronize()  # library kernels run on their own stream
+        s, sp = engine.stage2(st, all_a, all_p, world)
+        all_s = _all_gather(torch, dist, s, world, group)
+        all_sp = _all_gather(torch, dist, sp, world, group)
+        if all_s.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return engine.stage3(st, all_s, all_sp, world)
+    finally:
+        engine.end(st)

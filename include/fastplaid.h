@@ -1,0 +1,175 @@
+/*
+ * fastplaid.h -- C ABI of the MI355X-native PLAID search engine (libfastplaid_hip.so).
+ *
+ * This is the drop-in boundary for the fast-plaid *search* hot path.  Every entry point
+ * names the reference interface it replaces (paths relative to the lightonai/fast-plaid
+ * tree, v1.4.6).  Plain pointers and sizes only: no torch / tch / PyO3 types.  A Rust
+ * `extern "C"` block, a ctypes stub or a cgo import can bind this header unchanged
+ * (INTEGRATION.md shows the Rust and ctypes bindings).
+ *
+ * Conventions
+ *   - All functions return 0 on success, a negative FP_E* code on failure; the message
+ *     is available from fp_last_error() (thread-local), mirroring anyhow_to_pyerr
+ *     (rust/utils/errors.rs:5-7).
+ *   - "host" pointers are ordinary CPU memory owned by the caller; the library copies
+ *     what it needs.  "dev" pointers are HIP device memory on the index's device.
+ *   - fp16 values travel as uint16_t bit patterns (IEEE binary16).
+ *   - fp_search* are re-entrant on a shared fp_index (rust/search/load.rs:58-59
+ *     `unsafe impl Send/Sync for LoadedIndex`): the index is immutable after creation,
+ *     per-call scratch comes from an internal pool.
+ */
+#ifndef FASTPLAID_H
+#define FASTPLAID_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP_OK 0
+#define FP_EINVAL (-1)        /* bad argument (shape, dtype contract, device string)   */
+#define FP_ECOMPRESS_ONLY (-2) /* index has no IVF: search.rs:227-232                   */
+#define FP_EHIP (-3)          /* HIP runtime failure                                   */
+#define FP_EUNSUPPORTED (-4)  /* dim / nbits / size outside what the kernels are built for */
+#define FP_ENOMEM (-5)
+
+typedef struct fp_index fp_index;       /* replaces PyLoadedIndex / LoadedIndex, load.rs:46-69 */
+typedef struct fp_shard_ctx fp_shard_ctx; /* one in-flight sharded search (multi-GPU path)   */
+
+/* Argument set of `construct_index` (rust/search/load.rs:124-138), as host arrays.
+ * Trailing padding rows on doc_codes/doc_residuals (python load.py:298-320) are ignored:
+ * only the first sum(doc_lengths) rows are read. */
+typedef struct fp_index_desc {
+  int32_t nbits;                  /* 2 or 4 (8 % nbits == 0; dim*nbits % 8 == 0)          */
+  int32_t dim;                    /* embedding dimension (64 or 128)                      */
+  int64_t n_centroids;            /* rows of `centroids`                                  */
+  const uint16_t* centroids;      /* [n_centroids, dim] f16                               */
+  const uint16_t* avg_residual;   /* [dim] f16 -- accepted, unused by search (may be NULL) */
+  const uint16_t* bucket_cutoffs; /* [2^nbits-1] f16 -- accepted, unused (may be NULL)    */
+  const uint16_t* bucket_weights; /* [2^nbits] f16                                        */
+  const int64_t* ivf;             /* concatenated IVF lists (doc ids); NULL = compress_only */
+  const int32_t* ivf_lengths;     /* [n_ivf_lists]; NULL = compress_only                  */
+  int64_t n_ivf_lists;            /* may exceed n_centroids (surplus lists are empty)     */
+  const int64_t* doc_codes;       /* [>= n_tokens] centroid id per token                  */
+  const uint8_t* doc_residuals;   /* [>= n_tokens, dim*nbits/8] packed residuals          */
+  const int64_t* doc_lengths;     /* [n_docs] tokens per document                         */
+  int64_t n_docs;
+  int64_t pid_offset;             /* added to every returned doc id (0 for a whole index; */
+                                  /* first global id of this shard for a document shard)  */
+} fp_index_desc;
+
+/* SearchParameters pyclass (rust/search/search.rs:171-200). batch_size is accepted for
+ * API compatibility; it only chunks work in the reference and has no effect here. */
+typedef struct fp_search_params {
+  int64_t batch_size;
+  int64_t n_full_scores;
+  int64_t top_k;
+  int64_t n_ivf_probe;
+} fp_search_params;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* fp_last_error(void);        /* errors.rs:5-7 */
+const char* fp_version(void);
+int fp_device_count(void);
+
+/* ---- index lifetime ----------------------------------------------------------------- */
+/* construct_index (load.rs:124-186): uploads and re-lays-out the arrays on device
+ * `device_id`.  The caller keeps ownership of the host buffers. */
+int fp_index_create(const fp_index_desc* desc, int device_id, fp_index** out);
+/* Drop of PyLoadedIndex (load.rs:61-69) / FastPlaid.close() (fast_plaid.py:387-396). */
+void fp_index_destroy(fp_index* index);
+/* Introspection (sizes the caller needs to allocate outputs). */
+int64_t fp_index_num_docs(const fp_index* index);
+int64_t fp_index_num_tokens(const fp_index* index);
+int64_t fp_index_num_centroids(const fp_index* index);
+int32_t fp_index_dim(const fp_index* index);
+int32_t fp_index_nbits(const fp_index* index);
+int64_t fp_index_device_bytes(const fp_index* index);
+
+/* ---- search: `pysearch` (rust/lib.rs:195-223) -> search_many (search.rs:219-288) ----- */
+/* queries: host [n_queries, q_len, dim] f16.  subset_offsets NULL = no subset; otherwise
+ * [n_queries+1] offsets into subset_ids (per-query doc-id lists, lib.rs:202).
+ * Outputs (host, caller-allocated): out_pids/out_scores [n_queries, top_k] row-major,
+ * out_counts [n_queries] = results per query = min(top_k, max(n_full/4,1), candidates)
+ * (search.rs:614, :666); rows are sorted by descending score.  A query whose per-query
+ * search fails in the reference (search.rs:268 `.unwrap_or_default()`) gets count 0. */
+int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
+              const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets,
+              int64_t* out_pids, float* out_scores, int32_t* out_counts);
+
+/* Same search with every stage output copied back (parity tests / profiling only).
+ * One query.  Any output pointer may be NULL.  Capacities: S [n_centroids*q_len] f16 as
+ * [c][q]; cells [q_len*n_ivf_probe]; cand/approx [n_docs]; rerank/exact [max(n_full/4,1)].
+ * counts[3] = {n_cells, n_cand, n_rerank}.  rerank is in ascending doc-id order. */
+int fp_search_trace(const fp_index* index, const uint16_t* query, int32_t q_len, int32_t dim,
+                    const fp_search_params* params, const int64_t* subset_ids, int64_t n_subset, int32_t has_subset,
+                    int64_t* out_pids, float* out_scores, int32_t* out_count, uint16_t* S, int64_t* cells,
+                    int64_t* cand, float* approx, int64_t* rerank, float* exact, int64_t* counts);
+
+/* Per-stage device time of the most recent fp_search on this thread, in milliseconds
+ * (HIP events on the search stream).  names[i] are static strings.  Returns the number
+ * of stages written (<= cap). */
+int fp_last_search_timings(const char** names, float* ms, int cap);
+
+/* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */
+/* Decompresses whole documents to fp32 rows. out: host [sum(len(doc)) , dim] f32 in the
+ * order of doc_ids; out_lengths [n]. `out_capacity_rows` guards the buffer. */
+int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int64_t n, float* out,
+                              int64_t out_capacity_rows, int64_t* out_lengths);
+
+/* ---- document-sharded search (one process per GPU; collectives stay with the caller) -
+ * New relative to the reference, which only runs full replicas per device
+ * (fast_plaid.py:893-928).  Every rank holds the full centroid table and a disjoint
+ * document shard (fp_index_desc.pid_offset = first global id).  The three stages are
+ * separated exactly where data must cross ranks; the caller moves the fixed-size device
+ * buffers with RCCL all-gather (torch.distributed "nccl" on ROCm) between stages:
+ *
+ *   stage1: S1-S4 on the local shard + local top-R candidates by approximate score
+ *           -> dev top_approx [B,R] f32 (-inf padded), top_pid [B,R] i64 global (-1 padded)
+ *   (all-gather both to [G,B,R])
+ *   stage2: global top-R cut (reproduces search.rs:605-619 on the union), exact MaxSim of
+ *           the survivors that live on this rank
+ *           -> dev loc_score [B,R] f32 (-inf padded), loc_pid [B,R] i64 (-1 padded)
+ *   (all-gather both to [G,B,R])
+ *   stage3: global sort + top_k -> host outputs as fp_search.
+ * R = max(n_full_scores/4, 1).  With G == 1 the result is identical to fp_search. */
+int fp_shard_begin(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                   const fp_search_params* params, fp_shard_ctx** out);
+int64_t fp_shard_R(const fp_shard_ctx* ctx);
+int fp_shard_stage1(fp_shard_ctx* ctx, float* dev_top_approx, int64_t* dev_top_pid);
+int fp_shard_stage2(fp_shard_ctx* ctx, const float* dev_all_approx, const int64_t* dev_all_pid, int32_t n_ranks,
+                    float* dev_loc_score, int64_t* dev_loc_pid);
+int fp_shard_stage3(fp_shard_ctx* ctx, const float* dev_all_score, const int64_t* dev_all_pid, int32_t n_ranks,
+                    int64_t* out_pids, float* out_scores, int32_t* out_counts);
+void fp_shard_end(fp_shard_ctx* ctx);
+
+/* ---- synthetic corpora generated in HBM (benchmark + full-size property tests) ------- */
+/* Builds an index whose codes / residual bytes / lengths / IVF are generated on the
+ * device from the counter hash documented in fast-plaid_amd/synth.py (bit-identical to
+ * that numpy twin).  Centroids and bucket weights come from the host.  Documents
+ * [doc_begin, doc_end) of the virtual corpus are materialised (a shard); pid_offset is
+ * doc_begin. */
+typedef struct fp_synth_desc {
+  int32_t nbits, dim;
+  int64_t n_centroids;          /* power of two */
+  const uint16_t* centroids;    /* host [n_centroids, dim] f16 */
+  const uint16_t* bucket_weights; /* host [2^nbits] f16 */
+  int64_t n_docs_total;         /* size of the virtual corpus */
+  int64_t doc_begin, doc_end;   /* shard of it held by this index */
+  int32_t doc_len;              /* tokens per doc (max when variable_len) */
+  int32_t variable_len;         /* lengths ~ U[doc_len/4, doc_len] */
+  uint64_t seed;
+} fp_synth_desc;
+int fp_index_create_synthetic(const fp_synth_desc* desc, int device_id, fp_index** out);
+/* Copies a document's compressed arrays back to the host (tests): codes [len] i64,
+ * residuals [len, dim*nbits/8] u8. Returns the length, or a negative error. */
+int64_t fp_index_read_doc(const fp_index* index, int64_t local_doc, int64_t* codes, uint8_t* residuals,
+                          int64_t capacity_tokens);
+/* Copies the IVF list of one cell back (tests). Returns its length. */
+int64_t fp_index_read_ivf(const fp_index* index, int64_t cell, int64_t* pids, int64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTPLAID_H */

@@ -1,0 +1,105 @@
+"""One rank of the world_size-2 gloo protocol test (spawned by tests/test_host_cpu.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fast_plaid_amd as fp  # noqa: E402
+import plaid_oracle as OC  # noqa: E402
+from fast_plaid_amd import sharded  # noqa: E402
+
+
+class OracleShardEngine:
+    """Stand-in for HipShardEngine built on the CPU oracle (TEST ONLY): same stage contract
+    as include/fastplaid.h fp_shard_stage1/2/3."""
+
+    def __init__(self, arr, begin, end):
+        self.begin_, self.end_ = begin, end
+        sh = sharded.shard_arrays(arr, begin, end)
+        self.idx = OC.OracleIndex(nbits=sh["nbits"], centroids=sh["centroids"], bucket_weights=sh["bucket_weights"], ivf=sh["ivf"],
+                                  ivf_lengths=sh["ivf_lengths"], doc_codes=sh["doc_codes"], doc_residuals=sh["doc_residuals"],
+                                  doc_lengths=sh["doc_lengths"])
+
+    def begin(self, q, params):
+        return dict(q=np.ascontiguousarray(q, np.float16), B=q.shape[0], R=max(params.n_full_scores // 4, 1), p=params,
+                    top_k=params.top_k)
+
+    def stage1(self, st):
+        B, R, p = st["B"], st["R"], st["p"]
+        a = torch.full((B, R), float("-inf"))
+        pid = torch.full((B, R), -1, dtype=torch.int64)
+        for b in range(B):
+            t = self.idx.search_trace(st["q"][b], p.top_k, p.n_full_scores, p.n_ivf_probe)
+            amap = dict(zip(t["cand"].tolist(), t["approx"].tolist()))
+            for i, d in enumerate(t["rerank"].tolist()):
+                a[b, i] = amap[d]
+                pid[b, i] = d + self.begin_
+        return a, pid
+
+    def stage2(self, st, all_a, all_p, world):
+        B, R = st["B"], st["R"]
+        s = torch.full((B, R), float("-inf"))
+        sp = torch.full((B, R), -1, dtype=torch.int64)
+        for b in range(B):
+            a = all_a[:, b, :].reshape(-1).numpy()
+            p = all_p[:, b, :].reshape(-1).numpy()
+            ok = p >= 0
+            a, p = a[ok], p[ok]
+            order = np.lexsort((p, -a))[:R]  # (approx desc, id asc)
+            mine = np.sort(p[order][(p[order] >= self.begin_) & (p[order] < self.end_)])
+            if len(mine):
+                ex = self.idx.exact_scores(st["q"][b], mine - self.begin_)
+                s[b, : len(mine)] = torch.from_numpy(ex)
+                sp[b, : len(mine)] = torch.from_numpy(mine)
+        return s, sp
+
+    def stage3(self, st, all_s, all_p, world):
+        B, k = st["B"], st["top_k"]
+        pids = np.full((B, k), -1, np.int64)
+        scores = np.zeros((B, k), np.float32)
+        counts = np.zeros(B, np.int32)
+        for b in range(B):
+            s = all_s[:, b, :].reshape(-1).numpy()
+            p = all_p[:, b, :].reshape(-1).numpy()
+            ok = p >= 0
+            s, p = s[ok], p[ok]
+            order = np.lexsort((p, -s))[:k]
+            counts[b] = len(order)
+            pids[b, : len(order)] = p[order]
+            scores[b, : len(order)] = s[order]
+        return pids, scores, counts
+
+    def end(self, st):
+        pass
+
+
+def main():
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    spec = fp.synth.SynthSpec(n_docs=600, doc_len=40, n_centroids=256, variable_len=True, seed=11)
+    arr = fp.synth.host_index_arrays(spec)
+    q = fp.synth.make_queries(spec, arr["centroids"], 5, 16)
+    params = fp.fast_plaid_rust.SearchParameters(2000, 128, 20, 4)
+    b, e = sharded.plan_shards(arr["doc_lengths"], world)[rank]
+    eng = OracleShardEngine(arr, b, e)
+    pids, scores, counts = sharded.sharded_search(eng, q, params, dist=dist)
+    whole = OC.OracleIndex(nbits=arr["nbits"], centroids=arr["centroids"], bucket_weights=arr["bucket_weights"], ivf=arr["ivf"],
+                           ivf_lengths=arr["ivf_lengths"], doc_codes=arr["doc_codes"], doc_residuals=arr["doc_residuals"],
+                           doc_lengths=arr["doc_lengths"])
+    ref = whole.search(q, 20, 128, 4)
+    for i in range(5):
+        assert counts[i] == len(ref[i][0]), (counts[i], len(ref[i][0]))
+        assert np.array_equal(pids[i, : counts[i]], ref[i][0]), (rank, i, pids[i], ref[i][0])
+        assert np.array_equal(scores[i, : counts[i]], ref[i][1])
+    dist.barrier()
+    print("SHARDED_OK rank", rank)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
