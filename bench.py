@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X PLAID search hot path (contract: see the task's bench.py section).
+
+A "step" = one fp_search call over one batch of synthetic queries against a synthetic,
+HBM-resident compressed corpus.  Default workload = BASELINE.json configs[1]:
+1M docs x 128 tok x dim128 (nbits 4, 2^17 centroids), batch 64 queries x 32 tok, top_k=1000,
+n_full_scores=4096 (R=1024 exact-scored docs / query), n_ivf_probe=8.
+
+    python bench.py                               # N=1, finishes in a few minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N         # document-sharded over N GPUs (RCCL)
+
+N>1: the SAME corpus and the SAME query batch, documents split into N contiguous
+token-balanced shards (one process per GPU), two fixed-size RCCL all-gathers per batch
+(fast-plaid_amd/sharded.py) -> "scaling": "strong".
+
+One JSON line on rank 0.  `roofline` is the fused decompress+MaxSim kernel (the kernel
+BASELINE.json's north star puts the HBM-roofline target on); `stages_ms` + `roofline_by_kernel`
+give every other stage, so the time-dominant kernel is visible too.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_F16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--doc-len", type=int, default=128)
+    ap.add_argument("--centroids", type=int, default=0, help="0 = 2^floor(log2(16*sqrt(tokens)))")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--qlen", type=int, default=32)
+    ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--nfull", type=int, default=4096)
+    ap.add_argument("--nprobe", type=int, default=8)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--nbits", type=int, default=4)
+    ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
+    ap.add_argument("--workload", type=str, default="", help="label override")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        a.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import fast_plaid_amd as fp
+    from fast_plaid_amd import sharded
+    R = fp.fast_plaid_rust
+
+    n_tokens = a.docs * a.doc_len
+    C = a.centroids or fp.synth.default_num_centroids(n_tokens)
+    spec = fp.synth.SynthSpec(n_docs=a.docs, doc_len=a.doc_len, n_centroids=C, dim=a.dim, nbits=a.nbits, seed=42)
+    cent = fp.synth.centroids(spec)
+    bw = fp.synth.bucket_weights(spec)
+    dev = f"cuda:{local_rank}"
+    lo, hi = sharded.plan_shards(a.docs, world)[rank]
+    t0 = time.time()
+    index = R.construct_synthetic_index(spec, dev, doc_begin=lo, doc_end=hi, centroids=cent, bucket_weights=bw)
+    t_build = time.time() - t0
+    params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
+    n_batches = min(a.steps + a.warmup, 12)
+    batches = [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i) for i in range(n_batches)]
+    engine = sharded.HipShardEngine(index, dev) if world > 1 else None
+
+    def step(i):
+        q = batches[i % n_batches]
+        if world > 1:
+            return sharded.sharded_search(engine, q, params, dist=dist)
+        return R.search_arrays(index, q, params)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    stage_acc: dict[str, float] = {}
+    lat = []
+    cand_total = 0
+    sync()
+    t_start = time.perf_counter()
+    for i in range(a.steps):
+        ts = time.perf_counter()
+        pids, scores, counts = step(a.warmup + i)
+        lat.append(time.perf_counter() - ts)
+        if world == 1:
+            for k, v in R.last_search_timings().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
+            cand_total += R.last_search_counts()["candidates"]
+    sync()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    qps = a.batch * a.steps / elapsed
+
+    out = {
+        "metric": "queries/sec @ top_k=%d (batch=%d, dim=%d); p50 search latency" % (a.topk, a.batch, a.dim),
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {
+            "workload": a.workload or ("BASELINE cfg2: %d docs x %d tok x dim%d, nbits=%d, %d centroids, batch=%d x %d tok, "
+                                       "top_k=%d, n_full_scores=%d, n_ivf_probe=%d" % (
+                                           a.docs, a.doc_len, a.dim, a.nbits, C, a.batch, a.qlen, a.topk, a.nfull, a.nprobe)),
+            "parallelism": "1 GPU" if world == 1 else "document-sharded x%d, 2 RCCL all-gathers/batch" % world,
+            "index_bytes_per_gpu": index.device_bytes, "index_build_s": round(t_build, 2),
+        },
+        "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
+    }
+    if world == 1 and rank == 0:
+        stages = {k: v / a.steps for k, v in stage_acc.items()}
+        out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        Rr = max(a.nfull // 4, 1)
+        rer_docs = a.batch * min(Rr, a.docs)
+        pr = a.dim * a.nbits // 8
+        # per exact-scored token D*nbits/8 + 4 B, per (query,doc) 20 B, centroid table + query tile once per batch
+        bytes_maxsim = rer_docs * (a.doc_len * (pr + 4) + 20) + C * a.dim * 2 + a.batch * a.qlen * a.dim * 2
+        t_ms = stages.get("S6+S7 maxsim", 0.0)
+        ach = bytes_maxsim / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        out["roofline"] = {"kernel": "k_maxsim (fused decompress + exact MaxSim)", "bound": "hbm", "achieved": ach,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": bytes_maxsim, "avg_launch_ms": t_ms,
+                           "mfma_tflops": 2.0 * a.dim * a.qlen * rer_docs * a.doc_len / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0}
+        cand_per_step = cand_total / a.steps
+        t_ap = stages.get("S4 approx", 0.0)
+        b_ap = cand_per_step * a.doc_len * 4
+        t_s1 = stages.get("S1 centroid_gemm", 0.0)
+        fl_s1 = 2.0 * C * a.dim * a.batch * a.qlen
+        out["roofline_by_kernel"] = {
+            "k_approx": {"bound": "hbm", "algorithmic_bytes_per_launch": b_ap, "avg_launch_ms": t_ap,
+                         "achieved": b_ap / (t_ap * 1e-3) / 1e9 if t_ap > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (b_ap / (t_ap * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ap > 0 else 0.0,
+                         "candidate_docs_per_batch": cand_per_step,
+                         "gather_bytes_per_launch_L2side": cand_per_step * a.doc_len * 2 * ((a.qlen + 31) // 32 * 32)},
+            "k_centroid_scores": {"bound": "mfma", "flops_per_launch": fl_s1, "avg_launch_ms": t_s1,
+                                  "achieved": fl_s1 / (t_s1 * 1e-3) / 1e12 if t_s1 > 0 else 0.0, "peak": MFMA_F16_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s",
+                                  "frac": (fl_s1 / (t_s1 * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS) if t_s1 > 0 else 0.0},
+        }
+        # ---- CPU baseline: the plain-C oracle ("port"), all host cores, same corpus, bounded sample
+        ncpu = a.cpu_queries
+        if ncpu != 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import plaid_oracle as OC
+            cores = OC.num_procs()
+            if ncpu < 0:
+                ncpu = min(a.batch, max(cores, 1))
+            arr = R.export_index_arrays(index, centroids=cent, bucket_weights=bw)
+            orc = OC.OracleIndex(nbits=spec.nbits, centroids=cent, bucket_weights=bw, ivf=arr["ivf"], ivf_lengths=arr["ivf_lengths"],
+                                 doc_codes=arr["doc_codes"], doc_residuals=arr["doc_residuals"], doc_lengths=arr["doc_lengths"])
+            qs = batches[0][:ncpu]
+            tc = time.perf_counter()
+            ref = orc.search(qs, a.topk, a.nfull, a.nprobe, nthreads=cores)
+            tcpu = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": ncpu / tcpu, "unit": "queries/s", "cores": cores, "kind": "port",
+                                   "sample": "%d queries of the same batch/corpus, plain-C restatement of the reference (oracle/plaid_oracle.c), "
+                                             "OpenMP across queries like the reference's joblib threads path; %.1f s wall" % (ncpu, tcpu)}
+            # parity spot check on the benchmark corpus itself (ids modulo near-ties, scores within 1e-3)
+            gp, gs, gc = R.search_arrays(index, qs, params)
+            ident = sum(int(np.array_equal(gp[b, : gc[b]], ref[b][0])) for b in range(ncpu))
+            overlap = float(np.mean([len(set(gp[b, : gc[b]].tolist()) & set(ref[b][0].tolist())) / max(len(ref[b][0]), 1) for b in range(ncpu)]))
+            md = 0.0
+            for b in range(ncpu):
+                rm = dict(zip(ref[b][0].tolist(), ref[b][1].tolist()))
+                for p, s in zip(gp[b, : gc[b]].tolist(), gs[b, : gc[b]].tolist()):
+                    if p in rm:
+                        md = max(md, abs(rm[p] - s))
+            out["parity_vs_cpu"] = {"queries": ncpu, "identical_id_lists": ident, "mean_id_overlap": overlap, "max_abs_score_diff": md}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,7 @@ struct fp_index {
 
 static thread_local float g_last_ms[ST_N];
 static thread_local bool g_have_ms = false;
+static thread_local int64_t g_last_counts[4];  // candidates, exact-scored docs, exact-scored tokens, sub-batches
 
 static Scratch* acquire(fp_index* ix) {
   {
@@ -529,6 +530,9 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       sids = subset_ids + subset_off[b0];
     }
     if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
+    if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
+    g_last_counts[0] += P.M;
+    g_last_counts[3] += 1;
     // S6+S7
     const int64_t R = P.sh.R;
     HIPCHK(s->exact.ensure((size_t)B * R * 4));
@@ -615,6 +619,12 @@ extern "C" int fp_search_trace(const fp_index* index, const uint16_t* query, int
   int64_t off[2] = {0, n_subset};
   return search_impl(const_cast<fp_index*>(index), query, 1, q_len, params, subset_ids, has_subset ? off : nullptr, out_pids, out_scores,
                      out_count, &tr);
+}
+
+extern "C" int fp_last_search_counts(int64_t* out, int cap) {
+  int n = std::min(cap, 4);
+  for (int i = 0; i < n; ++i) out[i] = g_last_counts[i];
+  return n;
 }
 
 extern "C" int fp_last_search_timings(const char** names, float* ms, int cap) {
@@ -774,5 +784,68 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const in
   HIPCHK(hipMemcpyAsync(out_scores, s->out_score.p, (size_t)B * K * 4, hipMemcpyDeviceToHost, s->st));
   HIPCHK(hipMemcpyAsync(out_counts, s->out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, s->st));
   HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exhaustive arithmetic self-test (see fp_kernels.hip k_selftest_arith)
+// ------------------------------------------------------------------------------------------
+extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[2]*/) {
+  if (!out_mismatches) return fail(FP_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(device_id));
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 16));
+  HIPCHK(hipMemset(d, 0, 16));
+  fpk_selftest_arith(d, nullptr);
+  hipError_t e = hipMemcpy(out_mismatches, d, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(FP_EHIP, hipGetErrorString(e));
+  return FP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// export the index arrays back to the host in the reference's construct_index layout
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t fp_index_ivf_total(const fp_index* ix) {
+  if (!ix || !ix->has_ivf) return 0;
+  (void)hipSetDevice(ix->device);
+  int64_t tot = 0;
+  if (hipMemcpy(&tot, ix->d.ivf_off + ix->d.P, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(FP_EHIP, "memcpy");
+  return tot;
+}
+
+extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* doc_residuals, int64_t* doc_lengths, int64_t* ivf,
+                               int32_t* ivf_lengths) {
+  if (!ix) return fail(FP_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(ix->device));
+  const FpIndexDev& D = ix->d;
+  if (doc_lengths)
+    for (int64_t i = 0; i < D.N; ++i) doc_lengths[i] = ix->h_doc_off[i + 1] - ix->h_doc_off[i];
+  const int64_t chunk = 64ll << 20;
+  std::vector<int32_t> tmp;
+  if (doc_codes) {
+    tmp.resize((size_t)std::min<int64_t>(chunk, std::max<int64_t>(D.T, 1)));
+    for (int64_t s = 0; s < D.T; s += chunk) {
+      const int64_t m = std::min(chunk, D.T - s);
+      HIPCHK(hipMemcpy(tmp.data(), D.codes + s, (size_t)m * 4, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; ++i) doc_codes[s + i] = tmp[i];
+    }
+  }
+  if (doc_residuals && D.T > 0) HIPCHK(hipMemcpy(doc_residuals, D.residuals, (size_t)D.T * D.pr, hipMemcpyDeviceToHost));
+  if (ix->has_ivf && (ivf || ivf_lengths)) {
+    std::vector<int64_t> off((size_t)D.P + 1);
+    HIPCHK(hipMemcpy(off.data(), D.ivf_off, off.size() * 8, hipMemcpyDeviceToHost));
+    if (ivf_lengths)
+      for (int64_t i = 0; i < D.P; ++i) ivf_lengths[i] = (int32_t)(off[i + 1] - off[i]);
+    if (ivf) {
+      const int64_t tot = off[D.P];
+      tmp.resize((size_t)std::min<int64_t>(chunk, std::max<int64_t>(tot, 1)));
+      for (int64_t s = 0; s < tot; s += chunk) {
+        const int64_t m = std::min(chunk, tot - s);
+        HIPCHK(hipMemcpy(tmp.data(), D.ivf_pids + s, (size_t)m * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < m; ++i) ivf[s + i] = tmp[i];
+      }
+    }
+  }
   return FP_OK;
 }

@@ -90,6 +90,8 @@ void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add,
 void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx /*[n] global token rows*/, int64_t n, float* out,
                      hipStream_t st);
 
+void fpk_selftest_arith(unsigned long long* out_dev /*[2], zeroed*/, hipStream_t st);
+
 // ---- fp_synth.hip ----------------------------------------------------------------------------
 struct FpSynthParams {
   int nbits, dim, pr;

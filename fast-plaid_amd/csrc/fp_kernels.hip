@@ -800,8 +800,8 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
       uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
       e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
     }
-    // e = h(cent + w)
-    float ss = 0.f;
+    // e = h(cent + w)   (packed fp16 add == fp32 add + one rounding, verified exhaustively by
+    // fp_selftest_arith)
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
 #pragma unroll
@@ -809,27 +809,43 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
         const uint32_t byte = (rw[w] >> (8 * k)) & 0xFFu;
         const int bi = w * 4 + k;  // byte index within the lane -> dims [bi*PB, bi*PB+PB)
         if constexpr (PB == 2) {
-          h2 v = u32_as_h2(e[bi]) + u32_as_h2(lut[byte]);
-          e[bi] = h2_as_u32(v);
-          ss = __builtin_amdgcn_fdot2(v, v, ss, false);
+          e[bi] = h2_as_u32(u32_as_h2(e[bi]) + u32_as_h2(lut[byte]));
         } else {  // PB == 4
-          h2 v0 = u32_as_h2(e[2 * bi]) + u32_as_h2(lut[2 * byte]);
-          h2 v1 = u32_as_h2(e[2 * bi + 1]) + u32_as_h2(lut[2 * byte + 1]);
-          e[2 * bi] = h2_as_u32(v0);
-          e[2 * bi + 1] = h2_as_u32(v1);
-          ss = __builtin_amdgcn_fdot2(v0, v0, ss, false);
-          ss = __builtin_amdgcn_fdot2(v1, v1, ss, false);
+          e[2 * bi] = h2_as_u32(u32_as_h2(e[2 * bi]) + u32_as_h2(lut[2 * byte]));
+          e[2 * bi + 1] = h2_as_u32(u32_as_h2(e[2 * bi + 1]) + u32_as_h2(lut[2 * byte + 1]));
         }
       }
     }
-    ss += __shfl_xor(ss, 32, 64);
-    const float nf = (float)(half_t)__builtin_sqrtf(ss);  // Half norm; clamp_min(1e-12) is a no-op in fp16
+    // n = h(sqrt(sum_k e_k^2)) with the fp32 sum taken in ASCENDING-k order, exactly like the
+    // CPU reference (a different order flips n by one fp16 ulp on ~0.1% of tokens, which then
+    // moves every similarity of that token the same way: measured 2e-3 on Q=50 documents).
+    // Lane (tok,0) holds dims [0,D/2), lane (tok,1) dims [D/2,D): chain 1 from 0, chain 2
+    // continues from lane (tok,0)'s partial; only lane (tok,1)'s second chain is meaningful.
+    float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-      h2 v = u32_as_h2(e[i]);
+      const h2 v = u32_as_h2(e[i]);
+      ss = __builtin_fmaf((float)v.x, (float)v.x, ss);
+      ss = __builtin_fmaf((float)v.y, (float)v.y, ss);
+    }
+    float s2 = __shfl(ss, l31, 64);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const h2 v = u32_as_h2(e[i]);
+      s2 = __builtin_fmaf((float)v.x, (float)v.x, s2);
+      s2 = __builtin_fmaf((float)v.y, (float)v.y, s2);
+    }
+    const float tot = __shfl(s2, l31 + 32, 64);
+    const float nf = (float)(half_t)__builtin_sqrtf(tot);  // Half norm; clamp_min(1e-12) is a no-op in fp16
+    // e^ = h(fl32(e / n)) computed as h(fl32(e * fl32(1/n))): identical for every fp16 pair
+    // (fp_selftest_arith checks all 2^32 pairs on the device)
+    const float rn = 1.0f / nf;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const h2 v = u32_as_h2(e[i]);
       h2 o;
-      o.x = (half_t)((float)v.x / nf);
-      o.y = (half_t)((float)v.y / nf);
+      o.x = (half_t)((float)v.x * rn);
+      o.y = (half_t)((float)v.y * rn);
       e[i] = h2_as_u32(o);
     }
     f16v acc[NCH];
@@ -1156,4 +1172,40 @@ void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, fl
   if (n <= 0) return;
   hipLaunchKernelGGL(k_reconstruct, dim3((unsigned)n), dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.dim, ix.nbits,
                      tok_idx, out);
+}
+
+// ============================================================================================
+// arithmetic self-test: the two shortcuts the MaxSim kernel takes must equal the reference
+// formulation (fp32 op + one rounding to fp16) for EVERY pair of fp16 bit patterns.
+//   out[0]: pairs where h(fl32(e * fl32(1/n))) != h(fl32(e / n))
+//   out[1]: pairs where (packed fp16 add)(a, b)  != h(fl32(a + b))
+// NaN results compare equal to NaN.
+// ============================================================================================
+__device__ __forceinline__ bool same_h(half_t a, half_t b) {
+  uint16_t x = __builtin_bit_cast(uint16_t, a), y = __builtin_bit_cast(uint16_t, b);
+  bool nx = (x & 0x7FFF) > 0x7C00, ny = (y & 0x7FFF) > 0x7C00;
+  return (nx && ny) || x == y;
+}
+__global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __restrict__ out) {
+  const uint16_t nb = (uint16_t)blockIdx.x;
+  const half_t n = __builtin_bit_cast(half_t, nb);
+  const float nf = (float)n;
+  const float rn = 1.0f / nf;
+  unsigned long long bad_div = 0, bad_add = 0;
+  for (uint32_t eb = threadIdx.x * 2; eb < 65536u; eb += 512u) {
+    const h2 e = u32_as_h2(eb | ((eb + 1u) << 16));
+    const half_t q0 = (half_t)((float)e.x * rn), q1 = (half_t)((float)e.y * rn);
+    const half_t d0 = (half_t)((float)e.x / nf), d1 = (half_t)((float)e.y / nf);
+    bad_div += !same_h(q0, d0);
+    bad_div += !same_h(q1, d1);
+    const h2 nn = {n, n};
+    const h2 sum = e + nn;
+    bad_add += !same_h(sum.x, (half_t)((float)e.x + nf));
+    bad_add += !same_h(sum.y, (half_t)((float)e.y + nf));
+  }
+  if (bad_div) atomicAdd(&out[0], bad_div);
+  if (bad_add) atomicAdd(&out[1], bad_add);
+}
+void fpk_selftest_arith(unsigned long long* out_dev, hipStream_t st) {
+  hipLaunchKernelGGL(k_selftest_arith, dim3(65536), dim3(256), 0, st, out_dev);
 }

@@ -258,6 +258,27 @@ def last_search_timings() -> dict:
     return {names[i].decode(): float(ms[i]) for i in range(n)}
 
 
+def last_search_counts() -> dict:
+    out = (C.c_int64 * 4)()
+    N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 4)
+    return dict(candidates=int(out[0]), sub_batches=int(out[3]))
+
+
+def export_index_arrays(index: PyLoadedIndex, centroids=None, bucket_weights=None) -> dict:
+    """construct_index argument set copied back from the device (fp_index_export)."""
+    T, Nd, Cn = index.n_tokens, index.n_docs, index.n_centroids
+    pr = index.dim * index.nbits // 8
+    codes = np.zeros(max(T, 1), np.int64)[:T]
+    res = np.zeros((max(T, 1), pr), np.uint8)[:T]
+    lens = np.zeros(max(Nd, 1), np.int64)[:Nd]
+    tot = int(N.lib().fp_index_ivf_total(index._h))
+    ivf = np.zeros(max(tot, 1), np.int64)[:tot]
+    ivfl = np.zeros(Cn, np.int32)
+    N.check(N.lib().fp_index_export(index._h, _ptr(codes), _ptr(res), _ptr(lens), _ptr(ivf), _ptr(ivfl)))
+    return dict(nbits=index.nbits, centroids=centroids, bucket_weights=bucket_weights, ivf=ivf, ivf_lengths=ivfl,
+                doc_codes=codes, doc_residuals=res, doc_lengths=lens)
+
+
 def reconstruct_embeddings(index: PyLoadedIndex, subset, device: str = "cuda"):
     """rust/utils/embeddings.rs:12-69 -> list of [doc_len, dim] float32 arrays."""
     del device

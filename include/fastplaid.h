@@ -112,6 +112,10 @@ int fp_search_trace(const fp_index* index, const uint16_t* query, int32_t q_len,
  * of stages written (<= cap). */
 int fp_last_search_timings(const char** names, float* ms, int cap);
 
+/* Work counters of the most recent fp_search on this thread: out[0] = candidate documents
+ * summed over queries (S3 output), out[3] = sub-batches.  Returns entries written. */
+int fp_last_search_counts(int64_t* out, int cap);
+
 /* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */
 /* Decompresses whole documents to fp32 rows. out: host [sum(len(doc)) , dim] f32 in the
  * order of doc_ids; out_lengths [n]. `out_capacity_rows` guards the buffer. */
@@ -168,6 +172,22 @@ int64_t fp_index_read_doc(const fp_index* index, int64_t local_doc, int64_t* cod
                           int64_t capacity_tokens);
 /* Copies the IVF list of one cell back (tests). Returns its length. */
 int64_t fp_index_read_ivf(const fp_index* index, int64_t cell, int64_t* pids, int64_t capacity);
+
+/* Copies the index arrays back to the host in the construct_index layout (any pointer may
+ * be NULL): doc_codes [n_tokens] i64, doc_residuals [n_tokens, dim*nbits/8], doc_lengths
+ * [n_docs], ivf [fp_index_ivf_total] i64 (local doc ids), ivf_lengths [n_centroids] i32.
+ * Lets a device-generated or device-built index be handed to the reference
+ * (search/index_io.py writes the reference's directory format) or to the CPU oracle. */
+int64_t fp_index_ivf_total(const fp_index* index);
+int fp_index_export(const fp_index* index, int64_t* doc_codes, uint8_t* doc_residuals, int64_t* doc_lengths, int64_t* ivf,
+                    int32_t* ivf_lengths);
+
+/* ---- self-test --------------------------------------------------------------------------- */
+/* Exhaustive (all 2^32 fp16 pairs) device check that the two arithmetic shortcuts of the
+ * MaxSim kernel equal the reference formulation "fp32 op + one rounding to fp16":
+ * out[0] = mismatches of h(e * (1/n)) vs h(e / n), out[1] = mismatches of the packed fp16
+ * add vs h(fp32 add).  Both must be 0. */
+int fp_selftest_arith(int device_id, uint64_t* out_mismatches);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,16 @@ def _hip_index(fp, arr, **kw):
                              arr["doc_residuals"], arr["doc_lengths"], "cuda:0", False, **kw)
 
 
+def test_arithmetic_shortcuts_exhaustive(fp):
+    """all 2^32 fp16 pairs: e*(1/n) and the packed fp16 add equal fp32-op-then-round."""
+    import ctypes
+    from fast_plaid_amd import _native
+    out = (ctypes.c_uint64 * 2)()
+    _native.check(_native.lib().fp_selftest_arith(0, ctypes.cast(out, ctypes.c_void_p)))
+    assert out[0] == 0, f"{out[0]} (e, n) pairs where h(e*(1/n)) != h(e/n)"
+    assert out[1] == 0, f"{out[1]} pairs where packed fp16 add != h(fp32 add)"
+
+
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", golden_cases())
 def test_golden_stagewise(fp, name):
