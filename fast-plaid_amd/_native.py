@@ -66,11 +66,15 @@ SYMBOLS = {
 }
 
 _lib = None
+TORCH_LOADED_FIRST = False
 
 
 def lib():
-    global _lib
+    global _lib, TORCH_LOADED_FIRST
     if _lib is None:
+        import sys
+        # whichever libamdhip64.so.7 is loaded first serves the whole process (see sharded.py)
+        TORCH_LOADED_FIRST = "torch" in sys.modules
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or "

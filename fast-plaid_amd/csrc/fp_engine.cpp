@@ -231,6 +231,15 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   if (int rc = upload_narrow(d->doc_codes, codes, D.T, st)) { (void)hipStreamDestroy(st); return bail(rc); }
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   if (D.T > 0) ICHK(hipMemcpy(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice));
+  {
+    int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
+    ICHK(dev_alloc(ix, &uoff, (size_t)D.N + 1));
+    int urc = fps_build_ucodes(codes, doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
+    if (urc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")")); }
+    ix->owned.push_back(ucodes);
+    ix->bytes += U * 4;
+    D.ucodes = ucodes; D.uoff = uoff; D.U = U;
+  }
   ix->has_ivf = d->ivf != nullptr && d->ivf_lengths != nullptr;
   D.P = ix->has_ivf ? d->n_ivf_lists : 0;
   {
@@ -320,9 +329,18 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   fps_generate(p, doc_off, D.N, D.T, tok_base, codes, res, st);
   ICHK(hipStreamSynchronize(st));
+  {
+    int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
+    ICHK(dev_alloc(ix, &uoff, (size_t)D.N + 1));
+    int urc = fps_build_ucodes(codes, doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
+    if (urc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")")); }
+    ix->owned.push_back(ucodes);
+    ix->bytes += U * 4;
+    D.ucodes = ucodes; D.uoff = uoff; D.U = U;
+  }
   ICHK(dev_alloc(ix, &ivf_off, (size_t)D.P + 1));
   int64_t tot = 0;
-  int rc = fps_build_ivf(codes, doc_off, D.N, D.T, D.P, &ivf_pids, &tot, ivf_off, st);
+  int rc = fps_build_ivf(D.ucodes, D.uoff, D.N, D.U, D.P, &ivf_pids, &tot, ivf_off, st);
   if (rc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "IVF build failed (hip/hipcub error " + std::to_string(rc) + ")")); }
   ix->owned.push_back(ivf_pids);
   ix->bytes += tot * 4;
@@ -447,9 +465,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(hipEventRecord(s->ev[ST_IVF], st));
   // S3
   HIPCHK(s->bitmap.ensure((size_t)B * P.W * 4));
-  HIPCHK(hipMemsetAsync(s->bitmap.p, 0, (size_t)B * P.W * 4, st));
-  if (sh.n_probe >= 1)
-    fpk_ivf_mark(D, s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), sh.Q * np, B, s->bitmap.as<uint32_t>(), P.W, st);
+  // k_ivf_mark writes every word of the bitmap (tiles are built in LDS): no memset needed
+  fpk_ivf_mark(D, s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), sh.Q * np, B, s->bitmap.as<uint32_t>(), P.W, st);
   P.nblk = (int)((P.W + 1023) / 1024);
   HIPCHK(s->blkcnt.ensure((size_t)B * P.nblk * 4));
   HIPCHK(s->ncand.ensure((size_t)B * 4));
@@ -790,14 +807,14 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const in
 // ------------------------------------------------------------------------------------------
 // exhaustive arithmetic self-test (see fp_kernels.hip k_selftest_arith)
 // ------------------------------------------------------------------------------------------
-extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[2]*/) {
+extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[3]*/) {
   if (!out_mismatches) return fail(FP_EINVAL, "null argument");
   HIPCHK(hipSetDevice(device_id));
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, 16));
-  HIPCHK(hipMemset(d, 0, 16));
+  HIPCHK(hipMalloc((void**)&d, 24));
+  HIPCHK(hipMemset(d, 0, 24));
   fpk_selftest_arith(d, nullptr);
-  hipError_t e = hipMemcpy(out_mismatches, d, 16, hipMemcpyDeviceToHost);
+  hipError_t e = hipMemcpy(out_mismatches, d, 24, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(FP_EHIP, hipGetErrorString(e));
   return FP_OK;

@@ -19,6 +19,8 @@
 //   codes      [T]         i32   (narrowed from the reference's i64: C < 2^31)
 //   residuals  [T][PR]     u8    PR = D*nbits/8
 //   doc_off    [N+1]       i64   (tensor.rs:221-224 cumulative lengths)
+//   ucodes     [U] i32 + uoff [N+1] i64: per-document ascending UNIQUE codes.  The approximate
+//              score only depends on the set of codes of a document, so S4 walks this list.
 struct FpIndexDev {
   int nbits, dim, pr;
   int64_t C, P, N, T;
@@ -30,6 +32,9 @@ struct FpIndexDev {
   const int32_t* codes;
   const uint8_t* residuals;
   const int64_t* doc_off;
+  const int32_t* ucodes;   // [U]   per-document ascending unique codes (dedup of `codes`)
+  const int64_t* uoff;     // [N+1]
+  int64_t U;
   int max_doc_len;
 };
 
@@ -108,7 +113,10 @@ int64_t fps_doc_offsets_host(const FpSynthParams& p, int64_t* doc_off_host, int*
 // shard's first token.
 void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t tok_base,
                   int32_t* codes, uint8_t* residuals, hipStream_t st);
-// Builds the IVF (per-cell ascending unique local doc ids) from device codes.  Allocates
-// *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
-int fps_build_ivf(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t P,
-                  int32_t** ivf_pids, int64_t* ivf_total, int64_t* ivf_off_dev, hipStream_t st);
+// Per-document sorted unique codes (allocates *ucodes, fills uoff_dev [N+1]).
+int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int max_len, int32_t** ucodes, int64_t* U,
+                     int64_t* uoff_dev, hipStream_t st);
+// Builds the IVF (per-cell ascending unique local doc ids) from the per-document unique codes.
+// Allocates *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
+int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t U, int64_t P, int32_t** ivf_pids,
+                  int64_t* ivf_total, int64_t* ivf_off_dev, hipStream_t st);

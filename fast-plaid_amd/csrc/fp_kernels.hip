@@ -41,6 +41,15 @@ __device__ __forceinline__ float unmono32(uint32_t k) {
   return __uint_as_float(b);
 }
 
+// two-term reciprocal: r_hi + r_lo = 1/n to ~2^-47; specials (n = 0, inf, nan) keep IEEE semantics
+__device__ __forceinline__ void recip2(float n, float& r_hi, float& r_lo) {
+  r_hi = 1.0f / n;
+  const float t = __builtin_fmaf(-n, r_hi, 1.0f) * r_hi;
+  const bool ok = (r_hi != 0.0f) && (__builtin_fabsf(r_hi) < __builtin_inff());  // false for nan too
+  r_lo = ok ? t : 0.0f;
+}
+__device__ __forceinline__ float quot2(float e, float r_hi, float r_lo) { return __builtin_fmaf(e, r_hi, e * r_lo); }
+
 // ============================================================================================
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
 // ============================================================================================
@@ -339,34 +348,124 @@ __global__ void k_subset_prepare(const int64_t* __restrict__ ids, const int64_t*
 
 void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off, int B, uint32_t* subbm,
                         int64_t W, uint32_t* allow, int64_t Cw, int32_t* invalid, hipStream_t st) {
-  hipLaunchKernelGGL(k_subset_prepare, dim3(32, (unsigned)B), dim3(256), 0, st, sub_ids, sub_off, ix.N, ix.doc_off, ix.codes,
+  hipLaunchKernelGGL(k_subset_prepare, dim3(32, (unsigned)B), dim3(256), 0, st, sub_ids, sub_off, ix.N, ix.uoff, ix.ucodes,
                      subbm, W, allow, Cw, invalid);
 }
 
 // ============================================================================================
 // S3  IVF gather as a per-query document bitmap
 // ============================================================================================
-__global__ __launch_bounds__(256) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
-                                                  int maxcells, const int64_t* __restrict__ ivf_off,
-                                                  const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
-                                                  int64_t W) {
+// One workgroup per (query, tile of MARK_TILE_DOCS documents): the tile's bitmap lives in LDS
+// (ds_or atomics instead of tens of millions of global atomics), the probed cells' lists are
+// walked as ONE concatenated stream so that skewed (Zipf) list lengths stay balanced, and the
+// finished tile is written out with coalesced 16-byte stores (no memset of the bitmap needed).
+// search == 0: every tile reads every list and filters by range (cheap when there are few
+//              tiles: lists are short and L2-resident);
+// search == 1: each list's sub-range for this tile is found by binary search first (many
+//              tiles / long lists).
+#define MARK_TILE_WORDS 8192
+#define MARK_TILE_DOCS (MARK_TILE_WORDS * 32)
+__global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
+                                                   int maxcells, const int64_t* __restrict__ ivf_off,
+                                                   const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
+                                                   int64_t W, int search) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                              // [MARK_TILE_WORDS]
+  long long* lo_s = reinterpret_cast<long long*>(smem + MARK_TILE_WORDS * 4);      // [maxcells]
+  uint32_t* pre = reinterpret_cast<uint32_t*>(smem + MARK_TILE_WORDS * 4 + (size_t)maxcells * 8);  // [maxcells + 1]
+  __shared__ uint32_t s_scan[1024];
   const int b = blockIdx.y;
-  const int j = blockIdx.x;
-  if (j >= ncells[b]) return;
-  const int32_t cell = ucells[(int64_t)b * maxcells + j];
-  if (cell < 0 || cell >= P) return;  // centroid without an IVF list
-  const int64_t beg = ivf_off[cell], end = ivf_off[cell + 1];
-  uint32_t* bm = bitmap + (int64_t)b * W;
-  for (int64_t i = beg + (int64_t)blockIdx.z * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.z * 256) {
-    int32_t pid = ivf_pids[i];
-    atomicOr(&bm[pid >> 5], 1u << (pid & 31));
+  const int tid = threadIdx.x;
+  const int64_t word0 = (int64_t)blockIdx.x * MARK_TILE_WORDS;
+  const int32_t tile_lo = (int32_t)(word0 * 32);
+  const int64_t tile_hi64 = (word0 + MARK_TILE_WORDS) * 32;
+  const int32_t tile_hi = tile_hi64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tile_hi64;
+  for (int i = tid; i < MARK_TILE_WORDS; i += 1024) tile[i] = 0u;
+  const int nc = ncells[b];
+  // phase 1: per-cell [lo, lo+len) and exclusive prefix of the lengths
+  uint32_t base = 0;
+  for (int start = 0; start < nc; start += 1024) {
+    const int j = start + tid;
+    uint32_t len = 0;
+    long long lo = 0;
+    if (j < nc) {
+      const int32_t cell = ucells[(int64_t)b * maxcells + j];
+      if (cell >= 0 && cell < P) {
+        long long beg = ivf_off[cell], end = ivf_off[cell + 1];
+        if (search) {
+          long long l = beg, h = end;
+          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < tile_lo) l = m + 1; else h = m; }
+          beg = l;
+          h = end;
+          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < tile_hi) l = m + 1; else h = m; }
+          end = l;
+        }
+        lo = beg;
+        len = (uint32_t)(end - beg);
+      }
+      lo_s[j] = lo;
+    }
+    s_scan[tid] = len;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    if (j < nc) pre[j] = base + s_scan[tid] - len;
+    const uint32_t tot = s_scan[1023];
+    __syncthreads();
+    base += tot;
+  }
+  if (tid == 0) pre[nc] = base;
+  __syncthreads();
+  const uint32_t total = base;
+  // phase 2: walk the concatenated stream, 512 elements per wave-chunk
+  const int lane = tid & 63, wave = tid >> 6;
+  for (uint32_t c0 = (uint32_t)wave * 512u; c0 < total; c0 += 16u * 512u) {
+    int cell = 0;
+    {  // last cell with pre[cell] <= c0
+      int l = 0, h = nc;
+      while (h - l > 1) { int m = (l + h) >> 1; if (pre[m] <= c0) l = m; else h = m; }
+      cell = l;
+    }
+    int32_t pid[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t g = c0 + (uint32_t)k * 64u + (uint32_t)lane;
+      pid[k] = -1;
+      if (g < total) {
+        while (g >= pre[cell + 1]) ++cell;
+        pid[k] = ivf_pids[lo_s[cell] + (long long)(g - pre[cell])];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int32_t p = pid[k];
+      if (p >= tile_lo && p < tile_hi) atomicOr(&tile[(p - tile_lo) >> 5], 1u << (p & 31));
+    }
+  }
+  __syncthreads();
+  // phase 3: write the tile (W is a multiple of 64 words; tiles may overhang the end)
+  uint32_t* dst = bitmap + (int64_t)b * W + word0;
+  for (int i = tid * 4; i < MARK_TILE_WORDS; i += 4096) {
+    if (word0 + i < W) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(tile + i);
   }
 }
 
 void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B, uint32_t* bitmap,
                   int64_t W, hipStream_t st) {
-  hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)maxcells, (unsigned)B, 4), dim3(256), 0, st, ucells, ncells, maxcells, ix.ivf_off,
-                     ix.ivf_pids, ix.P, bitmap, W);
+  const int ntile = (int)((W + MARK_TILE_WORDS - 1) / MARK_TILE_WORDS);
+  const size_t lds = (size_t)MARK_TILE_WORDS * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_ivf_mark, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    attr_set = true;
+  }
+  const int search = ntile > 8 ? 1 : 0;
+  hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ix.ivf_off,
+                     ix.ivf_pids, ix.P, bitmap, W, search);
 }
 
 // ---- ordered compaction of the bitmaps ------------------------------------------------------
@@ -557,8 +656,9 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   if (M <= 0) return;
   int64_t blocks = (M + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
+  // walks the per-document UNIQUE code lists (max over a multiset == max over its set)
   hipLaunchKernelGGL(k_approx, dim3((unsigned)blocks), dim3(256), 0, st, S, ix.C, sh.B, sh.Q, sh.Qp, cand_off, cand_pid, M,
-                     ix.doc_off, ix.codes, approx);
+                     ix.uoff, ix.ucodes, approx);
 }
 
 // ============================================================================================
@@ -837,15 +937,18 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
     }
     const float tot = __shfl(s2, l31 + 32, 64);
     const float nf = (float)(half_t)__builtin_sqrtf(tot);  // Half norm; clamp_min(1e-12) is a no-op in fp16
-    // e^ = h(fl32(e / n)) computed as h(fl32(e * fl32(1/n))): identical for every fp16 pair
-    // (fp_selftest_arith checks all 2^32 pairs on the device)
-    const float rn = 1.0f / nf;
+    // e^ = h(fl32(e / n)).  A quotient with relative error < 2^-24 always rounds to the same
+    // fp16 as the exact one (e/n is never closer than ~2^-23 to an fp16 tie), so instead of an
+    // IEEE divide per element: r_hi = fl32(1/n), r_lo = fl32(1/n - r_hi), q = fma(e, r_hi, e*r_lo).
+    // fp_selftest_arith checks all 2^32 (e, n) pairs on the device.
+    float r_hi, r_lo;
+    recip2(nf, r_hi, r_lo);
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const h2 v = u32_as_h2(e[i]);
       h2 o;
-      o.x = (half_t)((float)v.x * rn);
-      o.y = (half_t)((float)v.y * rn);
+      o.x = (half_t)quot2((float)v.x, r_hi, r_lo);
+      o.y = (half_t)quot2((float)v.y, r_hi, r_lo);
       e[i] = h2_as_u32(o);
     }
     f16v acc[NCH];
@@ -1177,7 +1280,8 @@ void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, fl
 // ============================================================================================
 // arithmetic self-test: the two shortcuts the MaxSim kernel takes must equal the reference
 // formulation (fp32 op + one rounding to fp16) for EVERY pair of fp16 bit patterns.
-//   out[0]: pairs where h(fl32(e * fl32(1/n))) != h(fl32(e / n))
+//   out[0]: pairs where h(quot2(e, 1/n as r_hi + r_lo)) != h(fl32(e / n))
+//   out[2]: (informational) the same for the single product h(fl32(e * fl32(1/n)))
 //   out[1]: pairs where (packed fp16 add)(a, b)  != h(fl32(a + b))
 // NaN results compare equal to NaN.
 // ============================================================================================
@@ -1190,14 +1294,17 @@ __global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __re
   const uint16_t nb = (uint16_t)blockIdx.x;
   const half_t n = __builtin_bit_cast(half_t, nb);
   const float nf = (float)n;
-  const float rn = 1.0f / nf;
-  unsigned long long bad_div = 0, bad_add = 0;
+  float r_hi, r_lo;
+  recip2(nf, r_hi, r_lo);
+  unsigned long long bad_div = 0, bad_add = 0, bad_plain = 0;
   for (uint32_t eb = threadIdx.x * 2; eb < 65536u; eb += 512u) {
     const h2 e = u32_as_h2(eb | ((eb + 1u) << 16));
-    const half_t q0 = (half_t)((float)e.x * rn), q1 = (half_t)((float)e.y * rn);
+    const half_t q0 = (half_t)quot2((float)e.x, r_hi, r_lo), q1 = (half_t)quot2((float)e.y, r_hi, r_lo);
     const half_t d0 = (half_t)((float)e.x / nf), d1 = (half_t)((float)e.y / nf);
     bad_div += !same_h(q0, d0);
     bad_div += !same_h(q1, d1);
+    bad_plain += !same_h((half_t)((float)e.x * r_hi), d0);
+    bad_plain += !same_h((half_t)((float)e.y * r_hi), d1);
     const h2 nn = {n, n};
     const h2 sum = e + nn;
     bad_add += !same_h(sum.x, (half_t)((float)e.x + nf));
@@ -1205,6 +1312,7 @@ __global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __re
   }
   if (bad_div) atomicAdd(&out[0], bad_div);
   if (bad_add) atomicAdd(&out[1], bad_add);
+  if (bad_plain) atomicAdd(&out[2], bad_plain);
 }
 void fpk_selftest_arith(unsigned long long* out_dev, hipStream_t st) {
   hipLaunchKernelGGL(k_selftest_arith, dim3(65536), dim3(256), 0, st, out_dev);

@@ -107,15 +107,107 @@ void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_
   hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)blocks), dim3(256), 0, st, p, doc_off_dev, n_docs, tok_base, codes, residuals);
 }
 
-// ---- IVF: per-cell ascending unique local doc ids ----------------------------------------------
-__global__ __launch_bounds__(256) void k_make_keys(const int32_t* __restrict__ codes, const int64_t* __restrict__ doc_off,
+// ---- per-document sorted unique codes ------------------------------------------------------------
+// The approximate score sum_q max_t S[code_t, q] only depends on the SET of codes of a document
+// (max is idempotent), so the index keeps, next to the raw per-token codes the exact stage
+// needs, a deduplicated ascending code list per document: fewer 64-byte score rows to gather
+// in S4 (the stage that dominates the batch time) and exactly the (cell, doc) pairs of the IVF.
+// One wave per document: LDS bitonic sort (padded to a power of two), then ordered unique.
+// Documents longer than UNIQ_MAX_LEN are copied as they are (duplicates are harmless).
+#define UNIQ_MAX_LEN 8192
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_doc_unique(const int32_t* __restrict__ codes, const int64_t* __restrict__ doc_off,
+                                                   int64_t n_docs, int64_t* __restrict__ ulen, const int64_t* __restrict__ uoff,
+                                                   int32_t* __restrict__ ucodes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* v = reinterpret_cast<int32_t*>(smem);
+  const int64_t d = blockIdx.x;
+  if (d >= n_docs) return;
+  const int lane = threadIdx.x;
+  const int64_t off = doc_off[d];
+  const int n = (int)(doc_off[d + 1] - off);
+  if (n > UNIQ_MAX_LEN) {
+    if (WRITE) { for (int i = lane; i < n; i += 64) ucodes[uoff[d] + i] = codes[off + i]; }
+    else if (lane == 0) ulen[d] = n;
+    return;
+  }
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = lane; i < np2; i += 64) v[i] = (i < n) ? codes[off + i] : 0x7FFFFFFF;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < np2; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const int32_t a = v[i], c = v[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { v[i] = c; v[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int base = 0;
+  const int64_t wbase = WRITE ? uoff[d] : 0;
+  for (int start = 0; start < n; start += 64) {
+    const int i = start + lane;
+    const bool flag = (i < n) && (i == 0 || v[i] != v[i - 1]);
+    const unsigned long long m = __ballot(flag);
+    if (WRITE && flag) {
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      ucodes[wbase + base + __popcll(m & below)] = v[i];
+    }
+    base += __popcll(m);
+  }
+  if (!WRITE && lane == 0) ulen[d] = base;
+}
+
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto fail; } } while (0)
+
+int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int max_len, int32_t** ucodes, int64_t* U,
+                     int64_t* uoff_dev, hipStream_t st) {
+  int rc = 0;
+  int64_t* ulen = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  int np2 = 1;
+  size_t lds = 0;
+  *ucodes = nullptr;
+  *U = 0;
+  if (n_docs <= 0) {
+    HCHK(hipMemsetAsync(uoff_dev, 0, 8, st));
+    HCHK(hipMalloc((void**)ucodes, 16));
+    return 0;
+  }
+  while (np2 < max_len && np2 < UNIQ_MAX_LEN) np2 <<= 1;
+  lds = (size_t)np2 * 4;
+  HCHK(hipMalloc((void**)&ulen, (size_t)(n_docs + 1) * 8));
+  HCHK(hipMemsetAsync(ulen, 0, (size_t)(n_docs + 1) * 8, st));
+  hipLaunchKernelGGL(k_doc_unique<false>, dim3((unsigned)n_docs), dim3(64), lds, st, codes, doc_off_dev, n_docs, ulen, nullptr, nullptr);
+  HCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ulen, uoff_dev, (int)(n_docs + 1), st));
+  HCHK(hipMalloc(&tmp, tb ? tb : 16));
+  HCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ulen, uoff_dev, (int)(n_docs + 1), st));
+  HCHK(hipMemcpyAsync(U, uoff_dev + n_docs, 8, hipMemcpyDeviceToHost, st));
+  HCHK(hipStreamSynchronize(st));
+  HCHK(hipMalloc((void**)ucodes, (size_t)(*U > 0 ? *U : 4) * 4 + 64));
+  hipLaunchKernelGGL(k_doc_unique<true>, dim3((unsigned)n_docs), dim3(64), lds, st, codes, doc_off_dev, n_docs, nullptr, uoff_dev, *ucodes);
+  HCHK(hipStreamSynchronize(st));
+fail:
+  if (ulen) (void)hipFree(ulen);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
+}
+
+// ---- IVF: per-cell ascending unique local doc ids, from the per-document unique codes -------------
+__global__ __launch_bounds__(256) void k_make_keys(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff,
                                                    int64_t n_docs, unsigned long long* __restrict__ keys) {
   const int lane = threadIdx.x & 63;
   const int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (d >= n_docs) return;
-  const int64_t off = doc_off[d], end = doc_off[d + 1];
+  const int64_t off = uoff[d], end = uoff[d + 1];
   for (int64_t t = off + lane; t < end; t += 64)
-    keys[t] = ((unsigned long long)(uint32_t)codes[t] << 32) | (unsigned long long)(uint32_t)d;
+    keys[t] = ((unsigned long long)(uint32_t)ucodes[t] << 32) | (unsigned long long)(uint32_t)d;
 }
 
 __global__ void k_ivf_pids(const unsigned long long* __restrict__ uniq, int64_t U, int32_t* __restrict__ pids) {
@@ -135,21 +227,17 @@ __global__ void k_ivf_offsets(const unsigned long long* __restrict__ uniq, int64
   ivf_off[c] = lo;
 }
 
-#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto fail; } } while (0)
-
-int fps_build_ivf(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t P, int32_t** ivf_pids,
+int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t U, int64_t P, int32_t** ivf_pids,
                   int64_t* ivf_total, int64_t* ivf_off_dev, hipStream_t st) {
   int rc = 0;
   unsigned long long *ka = nullptr, *kb = nullptr;
   void* tmp = nullptr;
-  int64_t* d_num = nullptr;
-  int64_t U = 0;
-  size_t tb1 = 0, tb2 = 0, tb = 0;
+  size_t tb = 0;
   int end_bit = 32;
   *ivf_pids = nullptr;
   *ivf_total = 0;
-  if (T <= 0 || T > 0x7FFFFFFFll) {
-    if (T == 0) {
+  if (U <= 0 || U > 0x7FFFFFFFll) {
+    if (U == 0) {
       HCHK(hipMemsetAsync(ivf_off_dev, 0, (size_t)(P + 1) * sizeof(int64_t), st));
       HCHK(hipMalloc((void**)ivf_pids, 16));
       return 0;
@@ -157,27 +245,20 @@ int fps_build_ivf(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_do
     return -1;
   }
   while ((1ll << (end_bit - 32)) < P) ++end_bit;
-  HCHK(hipMalloc((void**)&ka, (size_t)T * 8));
-  HCHK(hipMalloc((void**)&kb, (size_t)T * 8));
-  HCHK(hipMalloc((void**)&d_num, 8));
-  hipLaunchKernelGGL(k_make_keys, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, codes, doc_off_dev, n_docs, ka);
-  HCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, ka, kb, (int)T, 0, end_bit, st));
-  HCHK(hipcub::DeviceSelect::Unique(nullptr, tb2, kb, ka, d_num, (int)T, st));
-  tb = tb1 > tb2 ? tb1 : tb2;
+  HCHK(hipMalloc((void**)&ka, (size_t)U * 8));
+  HCHK(hipMalloc((void**)&kb, (size_t)U * 8));
+  hipLaunchKernelGGL(k_make_keys, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, ka);
+  HCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, ka, kb, (int)U, 0, end_bit, st));
   HCHK(hipMalloc(&tmp, tb ? tb : 16));
-  HCHK(hipcub::DeviceRadixSort::SortKeys(tmp, tb1, ka, kb, (int)T, 0, end_bit, st));
-  HCHK(hipcub::DeviceSelect::Unique(tmp, tb2, kb, ka, d_num, (int)T, st));
-  HCHK(hipMemcpyAsync(&U, d_num, 8, hipMemcpyDeviceToHost, st));
-  HCHK(hipStreamSynchronize(st));
-  HCHK(hipMalloc((void**)ivf_pids, (size_t)(U > 0 ? U : 4) * sizeof(int32_t)));
-  if (U > 0) hipLaunchKernelGGL(k_ivf_pids, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, ka, U, *ivf_pids);
-  hipLaunchKernelGGL(k_ivf_offsets, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, st, ka, U, P, ivf_off_dev);
+  HCHK(hipcub::DeviceRadixSort::SortKeys(tmp, tb, ka, kb, (int)U, 0, end_bit, st));
+  HCHK(hipMalloc((void**)ivf_pids, (size_t)U * sizeof(int32_t) + 64));
+  hipLaunchKernelGGL(k_ivf_pids, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, kb, U, *ivf_pids);
+  hipLaunchKernelGGL(k_ivf_offsets, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, st, kb, U, P, ivf_off_dev);
   HCHK(hipStreamSynchronize(st));
   *ivf_total = U;
 fail:
   if (ka) (void)hipFree(ka);
   if (kb) (void)hipFree(kb);
   if (tmp) (void)hipFree(tmp);
-  if (d_num) (void)hipFree(d_num);
   return rc;
 }

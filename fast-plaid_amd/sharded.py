@@ -73,6 +73,10 @@ class HipShardEngine:
 
     def __init__(self, index: native.PyLoadedIndex, device):
         import torch
+        if not N.TORCH_LOADED_FIRST:
+            raise RuntimeError(
+                "import torch before the first fast_plaid_amd call in a process that uses the sharded path: torch wheels "
+                "bundle their own libamdhip64.so.7 and cannot see the GPU once another HIP runtime has been loaded")
         self.torch = torch
         self.index = index
         self.device = torch.device(device)

@@ -46,9 +46,9 @@ def test_arithmetic_shortcuts_exhaustive(fp):
     """all 2^32 fp16 pairs: e*(1/n) and the packed fp16 add equal fp32-op-then-round."""
     import ctypes
     from fast_plaid_amd import _native
-    out = (ctypes.c_uint64 * 2)()
+    out = (ctypes.c_uint64 * 3)()
     _native.check(_native.lib().fp_selftest_arith(0, ctypes.cast(out, ctypes.c_void_p)))
-    assert out[0] == 0, f"{out[0]} (e, n) pairs where h(e*(1/n)) != h(e/n)"
+    assert out[0] == 0, f"{out[0]} (e, n) pairs where h(fma(e, r_hi, e*r_lo)) != h(e/n)  (plain e*(1/n): {out[2]})"
     assert out[1] == 0, f"{out[1]} pairs where packed fp16 add != h(fp32 add)"
 
 
@@ -226,37 +226,15 @@ def test_synthetic_vs_oracle(fp, cfg):
 
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
-    IDENTICAL (ids and scores) to the unsharded search."""
-    torch = pytest.importorskip("torch")
-    R = fp.fast_plaid_rust
-    from fast_plaid_amd import sharded
-    spec = _synth(fp, n_docs=9000, doc_len=64, n_centroids=2048, variable_len=True, seed=7)
-    arr = fp.synth.host_index_arrays(spec)
-    q = fp.synth.make_queries(spec, arr["centroids"], 12, 32)
-    params = R.SearchParameters(2000, 512, 100, 8)
-    whole = _hip_index(fp, arr)
-    pids, scores, counts = R.search_arrays(whole, q, params)
-    ranges = sharded.plan_shards(arr["doc_lengths"], 3)
-    engines = []
-    for (b, e) in ranges:
-        idx = _hip_index(fp, sharded.shard_arrays(arr, b, e), pid_offset=b)
-        engines.append(sharded.HipShardEngine(idx, "cuda:0"))
-    sts = [en.begin(q, params) for en in engines]
-    s1 = [en.stage1(st) for en, st in zip(engines, sts)]
-    all_a = torch.stack([x[0] for x in s1]).contiguous()
-    all_p = torch.stack([x[1] for x in s1]).contiguous()
-    torch.cuda.synchronize()
-    s2 = [en.stage2(st, all_a, all_p, 3) for en, st in zip(engines, sts)]
-    all_s = torch.stack([x[0] for x in s2]).contiguous()
-    all_sp = torch.stack([x[1] for x in s2]).contiguous()
-    torch.cuda.synchronize()
-    for en, st in zip(engines, sts):
-        p3, s3, c3 = en.stage3(st, all_s, all_sp, 3)
-        assert np.array_equal(c3, counts)
-        for b in range(q.shape[0]):
-            assert np.array_equal(p3[b, : c3[b]], pids[b, : counts[b]])
-            assert np.array_equal(s3[b, : c3[b]], scores[b, : counts[b]])
-        en.end(st)
+    IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
+    torch BEFORE the HIP library: torch wheels bundle their own libamdhip64.so.7, and the first
+    HIP runtime loaded into a process is the one every later library binds to."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_gpu_worker.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "SHARDED_GPU_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_full_size_properties_cfg2(fp):
