@@ -807,14 +807,14 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const in
 // ------------------------------------------------------------------------------------------
 // exhaustive arithmetic self-test (see fp_kernels.hip k_selftest_arith)
 // ------------------------------------------------------------------------------------------
-extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[3]*/) {
+extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[16]*/) {
   if (!out_mismatches) return fail(FP_EINVAL, "null argument");
   HIPCHK(hipSetDevice(device_id));
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, 24));
-  HIPCHK(hipMemset(d, 0, 24));
+  HIPCHK(hipMalloc((void**)&d, 128));
+  HIPCHK(hipMemset(d, 0, 128));
   fpk_selftest_arith(d, nullptr);
-  hipError_t e = hipMemcpy(out_mismatches, d, 24, hipMemcpyDeviceToHost);
+  hipError_t e = hipMemcpy(out_mismatches, d, 128, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(FP_EHIP, hipGetErrorString(e));
   return FP_OK;

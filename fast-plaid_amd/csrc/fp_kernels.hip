@@ -586,52 +586,58 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 }
 
 // ============================================================================================
-// S4  approximate scores.  One wave per candidate document (grid-stride).  Per 32-column
-// chunk of the query: 4 lanes x 16 B cover one 64-byte row S[b][code][chunk*32..+32], so one
-// wave instruction gathers the rows of 16 tokens.  Running max in packed fp16, fp32 sum.
+// S4  approximate scores  approx[d] = sum_q max_{c in codes(d)} S[c, q]   (fp16 max, fp32 sum).
+// The stage is gather-LATENCY bound (candidate -> its code list -> one 64-byte score row per
+// code), so the layout maximises loads in flight rather than lanes per document:
+//   * 4 lanes per candidate (each lane 16 B = 8 query columns of a 32-column chunk), i.e. 16
+//     candidates per wave, 64 per 256-thread block;
+//   * the per-document loop walks the UNIQUE code list, unrolled x8: eight code loads, then
+//     eight independent row gathers per lane in flight;
+//   * grid = (blocks, queries): the query is blockIdx.y, no per-candidate search.
 // ============================================================================================
-__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int B, int Q, int Qp,
+__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
-                                                int64_t M, const int64_t* __restrict__ doc_off, const int32_t* __restrict__ codes,
+                                                const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                 float* __restrict__ approx) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int tslot = lane >> 2;  // token slot 0..15
-  const int sub = lane & 3;     // 16-byte piece of the 64-byte row
+  const int b = blockIdx.y;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
+  const int grp = threadIdx.x >> 2;           // candidate slot within the block (0..63)
   const half_t negm = (half_t)NEG_MASK_F;
   const h2 neg2 = {negm, negm};
-  for (int64_t i = wave0; i < M; i += nwaves) {
-    // query of candidate i: last b with cand_off[b] <= i
-    int lo = 0, hi = B;
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (cand_off[mid] <= i) lo = mid; else hi = mid;
-    }
-    const int b = lo;
-    const int32_t pid = cand_pid[i];
-    const int64_t off = doc_off[pid];
-    const int len = (int)(doc_off[pid + 1] - off);
-    const uint16_t* Sb = S + (int64_t)b * C * Qp;
+  const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
+  for (int64_t i = (int64_t)blockIdx.x * 64 + grp; i < n; i += (int64_t)gridDim.x * 64) {
+    const int32_t pid = cand_pid[beg + i];
+    const int64_t u0 = uoff[pid];
+    const int len = (int)(uoff[pid + 1] - u0);
+    const int32_t* cp = ucodes + u0;
     float total = 0.f;
     for (int ch = 0; ch < Qp / 32; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
-      const uint16_t* Sc = Sb + ch * 32 + sub * 8;
-#pragma unroll 4
-      for (int t = tslot; t < len; t += 16) {
-        const int32_t code = codes[off + t];
-        const uint4 v = *reinterpret_cast<const uint4*>(Sc + (int64_t)code * Qp);
+      const uint16_t* Sc = Sb + ch * 32;
+      int t = 0;
+      for (; t + 8 <= len; t += 8) {
+        int32_t code[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) code[k] = cp[t + k];
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          m0 = pk_max(m0, u32_as_h2(v[k].x));
+          m1 = pk_max(m1, u32_as_h2(v[k].y));
+          m2 = pk_max(m2, u32_as_h2(v[k].z));
+          m3 = pk_max(m3, u32_as_h2(v[k].w));
+        }
+      }
+      for (; t < len; ++t) {
+        const uint4 v = *reinterpret_cast<const uint4*>(Sc + (int64_t)cp[t] * Qp);
         m0 = pk_max(m0, u32_as_h2(v.x));
         m1 = pk_max(m1, u32_as_h2(v.y));
         m2 = pk_max(m2, u32_as_h2(v.z));
         m3 = pk_max(m3, u32_as_h2(v.w));
-      }
-#pragma unroll
-      for (int s = 4; s < 64; s <<= 1) {
-        m0 = pk_max(m0, u32_as_h2(shfl_xor_u32(h2_as_u32(m0), s)));
-        m1 = pk_max(m1, u32_as_h2(shfl_xor_u32(h2_as_u32(m1), s)));
-        m2 = pk_max(m2, u32_as_h2(shfl_xor_u32(h2_as_u32(m2), s)));
-        m3 = pk_max(m3, u32_as_h2(shfl_xor_u32(h2_as_u32(m3), s)));
       }
       const int q0 = ch * 32 + sub * 8;
       float s = 0.f;
@@ -643,21 +649,26 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
       s += (q0 + 5 < Q) ? (float)m2.y : 0.f;
       s += (q0 + 6 < Q) ? (float)m3.x : 0.f;
       s += (q0 + 7 < Q) ? (float)m3.y : 0.f;
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
       total += s;
     }
-    if (lane == 0) approx[i] = total;
+    // the 4 lanes of the group hold disjoint column sums (lanes of one group run the same trip
+    // counts, so the shuffles are convergent within the group; other groups may have exited)
+    total += __shfl_xor(total, 1, 64);
+    total += __shfl_xor(total, 2, 64);
+    if (sub == 0) approx[beg + i] = total;
   }
 }
 
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
                 const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st) {
   if (M <= 0) return;
-  int64_t blocks = (M + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  // enough blocks to cover the largest per-query candidate list a few times over
+  int64_t per_q = (M + sh.B - 1) / sh.B;
+  int64_t bx = (per_q * 2 + 63) / 64;
+  if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
   // walks the per-document UNIQUE code lists (max over a multiset == max over its set)
-  hipLaunchKernelGGL(k_approx, dim3((unsigned)blocks), dim3(256), 0, st, S, ix.C, sh.B, sh.Q, sh.Qp, cand_off, cand_pid, M,
+  hipLaunchKernelGGL(k_approx, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
                      ix.uoff, ix.ucodes, approx);
 }
 
@@ -1280,8 +1291,11 @@ void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, fl
 // ============================================================================================
 // arithmetic self-test: the two shortcuts the MaxSim kernel takes must equal the reference
 // formulation (fp32 op + one rounding to fp16) for EVERY pair of fp16 bit patterns.
-//   out[0]: pairs where h(quot2(e, 1/n as r_hi + r_lo)) != h(fl32(e / n))
+//   out[0]: REACHABLE pairs (n >= 0, |e| <= n(1+2^-9): a component never exceeds its vector's
+//           norm) where h(quot2(e, 1/n as r_hi + r_lo)) != h(fl32(e / n))          -- must be 0
 //   out[2]: (informational) the same for the single product h(fl32(e * fl32(1/n)))
+//   out[3]: (informational) mismatches of quot2 over ALL pairs (unreachable specials such as
+//           e = inf with finite n give inf - inf = NaN instead of inf)
 //   out[1]: pairs where (packed fp16 add)(a, b)  != h(fl32(a + b))
 // NaN results compare equal to NaN.
 // ============================================================================================
@@ -1296,23 +1310,37 @@ __global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __re
   const float nf = (float)n;
   float r_hi, r_lo;
   recip2(nf, r_hi, r_lo);
-  unsigned long long bad_div = 0, bad_add = 0, bad_plain = 0;
+  // reachable domain of the MaxSim kernel: n = h(sqrt(sum e_k^2)) >= 0 and no component can
+  // exceed its own vector's norm by more than the fp16 rounding of n
+  const bool n_ok = !(nb & 0x8000) || (nb & 0x7FFF) > 0x7C00;  // n >= +0, or NaN
+  unsigned long long bad_dom = 0, bad_add = 0, bad_plain = 0, bad_all = 0;
   for (uint32_t eb = threadIdx.x * 2; eb < 65536u; eb += 512u) {
     const h2 e = u32_as_h2(eb | ((eb + 1u) << 16));
     const half_t q0 = (half_t)quot2((float)e.x, r_hi, r_lo), q1 = (half_t)quot2((float)e.y, r_hi, r_lo);
     const half_t d0 = (half_t)((float)e.x / nf), d1 = (half_t)((float)e.y / nf);
-    bad_div += !same_h(q0, d0);
-    bad_div += !same_h(q1, d1);
-    bad_plain += !same_h((half_t)((float)e.x * r_hi), d0);
-    bad_plain += !same_h((half_t)((float)e.y * r_hi), d1);
+    const bool m0 = !same_h(q0, d0), m1 = !same_h(q1, d1);
+    bad_all += m0 + m1;
+    const bool dom0 = n_ok && !(__builtin_fabsf((float)e.x) > nf * 1.001953125f);
+    const bool dom1 = n_ok && !(__builtin_fabsf((float)e.y) > nf * 1.001953125f);
+    if (m0 && dom0) {
+      ++bad_dom;
+      unsigned long long slot = atomicAdd(&out[4], 1ull);
+      if (slot < 11) out[5 + slot] = (unsigned long long)(eb & 0xFFFF) | ((unsigned long long)nb << 16) |
+                                     ((unsigned long long)__builtin_bit_cast(uint16_t, q0) << 32) |
+                                     ((unsigned long long)__builtin_bit_cast(uint16_t, d0) << 48);
+    }
+    bad_dom += (m1 && dom1);
+    bad_plain += (dom0 && !same_h((half_t)((float)e.x * r_hi), d0));
+    bad_plain += (dom1 && !same_h((half_t)((float)e.y * r_hi), d1));
     const h2 nn = {n, n};
     const h2 sum = e + nn;
     bad_add += !same_h(sum.x, (half_t)((float)e.x + nf));
     bad_add += !same_h(sum.y, (half_t)((float)e.y + nf));
   }
-  if (bad_div) atomicAdd(&out[0], bad_div);
+  if (bad_dom) atomicAdd(&out[0], bad_dom);
   if (bad_add) atomicAdd(&out[1], bad_add);
   if (bad_plain) atomicAdd(&out[2], bad_plain);
+  if (bad_all) atomicAdd(&out[3], bad_all);
 }
 void fpk_selftest_arith(unsigned long long* out_dev, hipStream_t st) {
   hipLaunchKernelGGL(k_selftest_arith, dim3(65536), dim3(256), 0, st, out_dev);

@@ -185,10 +185,12 @@ int fp_index_export(const fp_index* index, int64_t* doc_codes, uint8_t* doc_resi
 /* ---- self-test --------------------------------------------------------------------------- */
 /* Exhaustive (all 2^32 fp16 pairs) device check that the two arithmetic shortcuts of the
  * MaxSim kernel equal the reference formulation "fp32 op + one rounding to fp16":
- * out[0] = mismatches of the compensated reciprocal product h(fma(e, r_hi, e*r_lo)) vs
- * h(e / n), out[1] = mismatches of the packed fp16 add vs h(fp32 add): both must be 0.
- * out[2] (informational) = mismatches of the plain single product h(e * fl32(1/n)).
- * out_mismatches has room for 3 values. */
+ * out[0] = mismatches of the compensated reciprocal product h(fma(e, r_hi, e*r_lo)) vs h(e / n)
+ *          over the reachable domain (n >= 0 or NaN, |e| <= n(1+2^-9)),
+ * out[1] = mismatches of the packed fp16 add vs h(fp32 add) over all pairs: both must be 0.
+ * Informational: out[2] = plain single product h(e * fl32(1/n)) on the reachable domain,
+ * out[3] = compensated product over ALL pairs, out[4] = sample count, out[5..15] = samples
+ * packed as e | n<<16 | fast<<32 | reference<<48.  out_mismatches has room for 16 values. */
 int fp_selftest_arith(int device_id, uint64_t* out_mismatches);
 
 #ifdef __cplusplus
