@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--nbits", type=int, default=4)
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
     ap.add_argument("--workload", type=str, default="", help="label override")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -64,10 +65,13 @@ def main():
         a.gpus = world
     dist = None
     torch = None
-    if world > 1:
-        import torch
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        import torch  # BEFORE the HIP library: see fast-plaid_amd/sharded.py
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import fast_plaid_amd as fp
@@ -87,16 +91,16 @@ def main():
     params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
     n_batches = min(a.steps + a.warmup, 12)
     batches = [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i) for i in range(n_batches)]
-    engine = sharded.HipShardEngine(index, dev) if world > 1 else None
+    engine = sharded.HipShardEngine(index, dev) if use_dist else None
 
     def step(i):
         q = batches[i % n_batches]
-        if world > 1:
-            return sharded.sharded_search(engine, q, params, dist=dist)
+        if use_dist:
+            return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
         return R.search_arrays(index, q, params)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -111,13 +115,13 @@ def main():
         ts = time.perf_counter()
         pids, scores, counts = step(a.warmup + i)
         lat.append(time.perf_counter() - ts)
-        if world == 1:
+        if not use_dist:
             for k, v in R.last_search_timings().items():
                 stage_acc[k] = stage_acc.get(k, 0.0) + v
             cand_total += R.last_search_counts()["candidates"]
     sync()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -133,12 +137,12 @@ def main():
             "workload": a.workload or ("BASELINE cfg2: %d docs x %d tok x dim%d, nbits=%d, %d centroids, batch=%d x %d tok, "
                                        "top_k=%d, n_full_scores=%d, n_ivf_probe=%d" % (
                                            a.docs, a.doc_len, a.dim, a.nbits, C, a.batch, a.qlen, a.topk, a.nfull, a.nprobe)),
-            "parallelism": "1 GPU" if world == 1 else "document-sharded x%d, 2 RCCL all-gathers/batch" % world,
+            "parallelism": "1 GPU" if not use_dist else "document-sharded x%d, 2 RCCL all-gathers/batch" % world,
             "index_bytes_per_gpu": index.device_bytes, "index_build_s": round(t_build, 2),
         },
         "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
     }
-    if world == 1 and rank == 0:
+    if not use_dist and rank == 0:
         stages = {k: v / a.steps for k, v in stage_acc.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
         Rr = max(a.nfull // 4, 1)
@@ -199,7 +203,7 @@ def main():
             out["parity_vs_cpu"] = {"queries": ncpu, "identical_id_lists": ident, "mean_id_overlap": overlap, "max_abs_score_diff": md}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

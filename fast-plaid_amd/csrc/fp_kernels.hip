@@ -1302,7 +1302,8 @@ void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, fl
 __device__ __forceinline__ bool same_h(half_t a, half_t b) {
   uint16_t x = __builtin_bit_cast(uint16_t, a), y = __builtin_bit_cast(uint16_t, b);
   bool nx = (x & 0x7FFF) > 0x7C00, ny = (y & 0x7FFF) > 0x7C00;
-  return (nx && ny) || x == y;
+  bool zx = (x & 0x7FFF) == 0, zy = (y & 0x7FFF) == 0;  // +0 == -0 (e = -0 gives +0: same dot products)
+  return (nx && ny) || (zx && zy) || x == y;
 }
 __global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __restrict__ out) {
   const uint16_t nb = (uint16_t)blockIdx.x;

@@ -118,16 +118,16 @@ class HipShardEngine:
         N.lib().fp_shard_end(st["ctx"])
 
 
-def _all_gather(torch, dist, x, world, group):
+def _all_gather(torch, dist, x, world, group, force=False):
     """[B,R] per rank -> [G,B,R] on every rank."""
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not force):
         return x.unsqueeze(0).contiguous()
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x.contiguous(), group=group)  # concatenation along dim 0 == [G][B][R]
     return out.view((world,) + tuple(x.shape))
 
 
-def sharded_search(engine, queries_f16, params, dist=None, group=None):
+def sharded_search(engine, queries_f16, params, dist=None, group=None, force_collectives=False):
     """Runs one batch through the three stages with the two all-gathers in between.
     `engine` implements begin/stage1/stage2/stage3/end (HipShardEngine in production).
     Returns (pids [B,top_k], scores, counts) -- identical on every rank."""
@@ -136,13 +136,13 @@ def sharded_search(engine, queries_f16, params, dist=None, group=None):
     st = engine.begin(queries_f16, params)
     try:
         a, p = engine.stage1(st)
-        all_a = _all_gather(torch, dist, a, world, group)
-        all_p = _all_gather(torch, dist, p, world, group)
+        all_a = _all_gather(torch, dist, a, world, group, force_collectives)
+        all_p = _all_gather(torch, dist, p, world, group, force_collectives)
         if all_a.is_cuda:
             torch.cuda.current_stream().synchronize()  # library kernels run on their own stream
         s, sp = engine.stage2(st, all_a, all_p, world)
-        all_s = _all_gather(torch, dist, s, world, group)
-        all_sp = _all_gather(torch, dist, sp, world, group)
+        all_s = _all_gather(torch, dist, s, world, group, force_collectives)
+        all_sp = _all_gather(torch, dist, sp, world, group, force_collectives)
         if all_s.is_cuda:
             torch.cuda.current_stream().synchronize()
         return engine.stage3(st, all_s, all_sp, world)
