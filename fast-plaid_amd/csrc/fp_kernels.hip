@@ -844,31 +844,60 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
 //   k <-> dim map, so no LDS staging and no transposes are needed.
 //   sim = h(acc) ; running max over tokens per query column ; fp32 sum over q.
 // ============================================================================================
+// Work item = one 32-token chunk of one document.  A wave owns `dpw` consecutive documents of
+// one query and walks their chunks as one stream, software-pipelined three deep:
+//   codes of item i+2, residual bytes + centroid rows of item i+1 (their addresses need the
+//   codes), arithmetic of item i  ->  the two dependent HBM/L2 round trips of a chunk are
+//   always hidden behind the previous chunks' arithmetic (PMC before this change: 64% of the
+//   wave cycles in s_waitcnt).
+// The byte->weights LUT is replicated per LDS bank (32 x 4-byte or 16 x 8-byte copies) so the
+// 32/64 random lookups per lane never conflict (PMC before: 63% of LDS cycles were conflicts).
+struct MsItem {
+  int k;        // document slot within the wave's group, == nd when exhausted
+  int t0;       // first token of the chunk
+  int len;      // tokens of the document
+  int64_t off;  // first token row of the document
+};
+
 template <int D, int NBITS, int NCH>
 __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
                                                 const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
                                                 const int64_t* __restrict__ doc_off, const uint16_t* __restrict__ qpad, int Q,
                                                 int Qp, int ch_begin, const int32_t* __restrict__ sel_pid,
                                                 const int32_t* __restrict__ sel_cnt, int64_t Rcap, float* __restrict__ exact,
-                                                int accumulate) {
+                                                int accumulate, int dpw) {
   constexpr int PR = D * NBITS / 8;   // packed residual bytes per token
   constexpr int RB = PR / 2;          // bytes per lane
   constexpr int RW = RB / 4;          // 32-bit words per lane
   constexpr int PB = 8 / NBITS;       // dims per byte
   constexpr int KS = D / 16;          // MFMA k-steps
   constexpr int NE = D / 4;           // half2 registers per lane (D/2 dims)
-  __shared__ uint32_t lut[256 * PB / 2];  // byte -> PB halfs
-  for (int i = threadIdx.x; i < 256 * PB / 2; i += 256) lut[i] = reinterpret_cast<const uint32_t*>(lut_g)[i];
+  constexpr int COPIES = (PB == 2) ? 32 : 16;
+  constexpr int EW = PB / 2;          // 32-bit words per LUT entry
+  __shared__ __attribute__((aligned(16))) uint32_t lut[256 * EW * COPIES];  // 32 KiB
+  for (int i = threadIdx.x; i < 256 * COPIES; i += 256) {
+    const int entry = i / COPIES, copy = i % COPIES;
+#pragma unroll
+    for (int w = 0; w < EW; ++w) lut[(entry * COPIES + copy) * EW + w] = reinterpret_cast<const uint32_t*>(lut_g)[entry * EW + w];
+  }
   __syncthreads();
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + wave;
-  if (r >= sel_cnt[b]) return;
+  const int cnt = sel_cnt[b];
+  const int r0 = (blockIdx.x * 4 + wave) * dpw;
+  if (r0 >= cnt) return;
+  const int nd = (cnt - r0 < dpw) ? (cnt - r0) : dpw;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int32_t pid = sel_pid[(int64_t)b * Rcap + r];
-  const int64_t off = doc_off[pid];
-  const int len = (int)(doc_off[pid + 1] - off);
+  const uint32_t* mylut = lut + (lane & (COPIES - 1)) * EW;
 
+  // per-document metadata lives in lanes 0..nd-1
+  long long my_off = 0;
+  int my_len = 0;
+  if (lane < nd) {
+    const int32_t pid = sel_pid[(int64_t)b * Rcap + r0 + lane];
+    my_off = doc_off[pid];
+    my_len = (int)(doc_off[pid + 1] - my_off);
+  }
   // query B fragments for NCH chunks
   h8 qf[NCH][KS];
 #pragma unroll
@@ -884,54 +913,77 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
     }
   }
   const half_t negm = (half_t)NEG_MASK_F;
-  h2 mx[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) mx[c] = h2{negm, negm};  // .x only is used at the end; both track
+  int nq = Q - ch_begin * 32;  // valid query columns handled by this launch
+  nq = nq < 0 ? 0 : (nq > NCH * 32 ? NCH * 32 : nq);
 
-  for (int t0 = 0; t0 < len; t0 += 32) {
-    int tok = t0 + l31;
-    if (tok >= len) tok = len - 1;  // clamp: loads stay in bounds, rows masked below
-    const int32_t code = codes[off + tok];
-    const uint8_t* rp = resid + (off + tok) * (int64_t)PR + hi * RB;
-    uint32_t rw[RW];
+  auto fetch_doc = [&](MsItem& it) {  // wave-uniform metadata of document slot it.k
+    const int lo = __shfl((int)(my_off & 0xFFFFFFFFll), it.k, 64);
+    const int hi32 = __shfl((int)(my_off >> 32), it.k, 64);
+    const int ln = __shfl(my_len, it.k, 64);
+    it.off = ((long long)__builtin_amdgcn_readfirstlane(hi32) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane(lo);
+    it.len = __builtin_amdgcn_readfirstlane(ln);
+  };
+  auto advance = [&](MsItem& it) {  // next chunk in the stream; skips empty documents
+    it.t0 += 32;
+    while (it.k < nd && it.t0 >= it.len) {
+      ++it.k;
+      it.t0 = 0;
+      if (it.k < nd) fetch_doc(it);
+    }
+  };
+  auto load_code = [&](const MsItem& it) -> int32_t {
+    int tok = it.t0 + l31;
+    tok = tok < it.len ? tok : it.len - 1;  // clamp: loads stay in bounds, rows masked at the max
+    return codes[it.off + tok];
+  };
+  auto load_data = [&](const MsItem& it, int32_t code, uint32_t (&ce)[NE], uint32_t (&rw)[RW]) {
+    int tok = it.t0 + l31;
+    tok = tok < it.len ? tok : it.len - 1;
+    const uint8_t* rp = resid + (it.off + tok) * (int64_t)PR + hi * RB;
     if constexpr (RW >= 4) {
 #pragma unroll
       for (int i = 0; i < RW / 4; ++i) {
-        uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
+        const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
         rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
       }
     } else {
-      uint2 v = *reinterpret_cast<const uint2*>(rp);
+      const uint2 v = *reinterpret_cast<const uint2*>(rp);
       rw[0] = v.x; rw[1] = v.y;
     }
     const uint16_t* cp = cent + (int64_t)code * D + hi * (D / 2);
-    uint32_t e[NE];
 #pragma unroll
     for (int i = 0; i < NE / 4; ++i) {
-      uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
-      e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+      const uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
+      ce[4 * i] = v.x; ce[4 * i + 1] = v.y; ce[4 * i + 2] = v.z; ce[4 * i + 3] = v.w;
     }
-    // e = h(cent + w)   (packed fp16 add == fp32 add + one rounding, verified exhaustively by
-    // fp_selftest_arith)
+  };
+
+  h2 mx[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) mx[c] = h2{negm, negm};
+
+  auto compute = [&](const MsItem& it, uint32_t (&e)[NE], const uint32_t (&rw)[RW]) {
+    // e = h(cent + w)   (packed fp16 add == fp32 add + one rounding: fp_selftest_arith)
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t byte = (rw[w] >> (8 * k)) & 0xFFu;
-        const int bi = w * 4 + k;  // byte index within the lane -> dims [bi*PB, bi*PB+PB)
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t byte = (rw[w] >> (8 * kk)) & 0xFFu;
+        const int bi = w * 4 + kk;  // byte index within the lane -> dims [bi*PB, bi*PB+PB)
         if constexpr (PB == 2) {
-          e[bi] = h2_as_u32(u32_as_h2(e[bi]) + u32_as_h2(lut[byte]));
-        } else {  // PB == 4
-          e[2 * bi] = h2_as_u32(u32_as_h2(e[2 * bi]) + u32_as_h2(lut[2 * byte]));
-          e[2 * bi + 1] = h2_as_u32(u32_as_h2(e[2 * bi + 1]) + u32_as_h2(lut[2 * byte + 1]));
+          e[bi] = h2_as_u32(u32_as_h2(e[bi]) + u32_as_h2(mylut[byte * COPIES]));
+        } else {
+          const uint2 wv = *reinterpret_cast<const uint2*>(mylut + byte * COPIES * 2);
+          e[2 * bi] = h2_as_u32(u32_as_h2(e[2 * bi]) + u32_as_h2(wv.x));
+          e[2 * bi + 1] = h2_as_u32(u32_as_h2(e[2 * bi + 1]) + u32_as_h2(wv.y));
         }
       }
     }
-    // n = h(sqrt(sum_k e_k^2)) with the fp32 sum taken in ASCENDING-k order, exactly like the
-    // CPU reference (a different order flips n by one fp16 ulp on ~0.1% of tokens, which then
-    // moves every similarity of that token the same way: measured 2e-3 on Q=50 documents).
-    // Lane (tok,0) holds dims [0,D/2), lane (tok,1) dims [D/2,D): chain 1 from 0, chain 2
-    // continues from lane (tok,0)'s partial; only lane (tok,1)'s second chain is meaningful.
+    // n = h(sqrt(sum_k e_k^2)), fp32 sum in ASCENDING-k order exactly like the CPU reference
+    // (any other order flips n by one fp16 ulp on ~0.1% of tokens, which then moves every
+    // similarity of that token the same way: measured 2e-3 on Q=50 documents).  Lane (tok,0)
+    // holds dims [0,D/2), lane (tok,1) dims [D/2,D): chain 1 from 0, chain 2 continues from
+    // lane (tok,0)'s partial; only lane (tok,1)'s second chain is meaningful.
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -948,10 +1000,7 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
     }
     const float tot = __shfl(s2, l31 + 32, 64);
     const float nf = (float)(half_t)__builtin_sqrtf(tot);  // Half norm; clamp_min(1e-12) is a no-op in fp16
-    // e^ = h(fl32(e / n)).  A quotient with relative error < 2^-24 always rounds to the same
-    // fp16 as the exact one (e/n is never closer than ~2^-23 to an fp16 tie), so instead of an
-    // IEEE divide per element: r_hi = fl32(1/n), r_lo = fl32(1/n - r_hi), q = fma(e, r_hi, e*r_lo).
-    // fp_selftest_arith checks all 2^32 (e, n) pairs on the device.
+    // e^ = h(fl32(e / n)) as h(fma(e, r_hi, e*r_lo)) with r_hi + r_lo = 1/n (fp_selftest_arith)
     float r_hi, r_lo;
     recip2(nf, r_hi, r_lo);
 #pragma unroll
@@ -969,66 +1018,122 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
       for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 #pragma unroll
     for (int m = 0; m < KS; ++m) {
-      uint4 av = make_uint4(e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3]);
-      h8 a = __builtin_bit_cast(h8, av);
+      const uint4 av = make_uint4(e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3]);
+      const h8 a = __builtin_bit_cast(h8, av);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[c][m], acc[c], 0, 0, 0);
     }
     // D[row = token][col = q = lane&31]; this lane's rows: (i&3) + 8*(i>>2) + 4*hi
-    const bool partial = (t0 + 32 > len);
+    const bool partial = (it.t0 + 32 > it.len);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       h2 m = mx[c];
+      if (!partial) {
 #pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        h2 v;
-        v.x = (half_t)acc[c][i];
-        v.y = (half_t)acc[c][i + 1];
-        if (partial) {
-          const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
-          if (t0 + row0 >= len) v.x = negm;
-          if (t0 + row0 + 1 >= len) v.y = negm;
+        for (int i = 0; i < 16; i += 2) {
+          h2 v;
+          v.x = (half_t)acc[c][i];
+          v.y = (half_t)acc[c][i + 1];
+          m = pk_max(m, v);
         }
-        m = pk_max(m, v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          h2 v;
+          v.x = (half_t)acc[c][i];
+          v.y = (half_t)acc[c][i + 1];
+          const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
+          if (it.t0 + row0 >= it.len) v.x = negm;
+          if (it.t0 + row0 + 1 >= it.len) v.y = negm;
+          m = pk_max(m, v);
+        }
       }
       mx[c] = m;
     }
-  }
-  float total = 0.f;
+    if (it.t0 + 32 >= it.len) {  // last chunk of the document: reduce and emit
+      float total = 0.f;
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    half_t m = mx[c].x > mx[c].y ? mx[c].x : mx[c].y;
-    uint32_t mu = (uint32_t)__builtin_bit_cast(uint16_t, m);
-    uint32_t ou = shfl_xor_u32(mu, 32);
-    half_t o = __builtin_bit_cast(half_t, (uint16_t)ou);
-    m = o > m ? o : m;
-    const int q = (ch_begin + c) * 32 + l31;
-    float s = (hi == 0 && q < Q) ? (float)m : 0.f;
+      for (int c = 0; c < NCH; ++c) {
+        half_t m = mx[c].x > mx[c].y ? mx[c].x : mx[c].y;
+        const uint32_t mu = (uint32_t)__builtin_bit_cast(uint16_t, m);
+        const uint32_t ou = shfl_xor_u32(mu, 32);
+        const half_t o = __builtin_bit_cast(half_t, (uint16_t)ou);
+        m = o > m ? o : m;
+        const int q = (ch_begin + c) * 32 + l31;
+        float s = (hi == 0 && q < Q) ? (float)m : 0.f;
 #pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, 64);
-    total += s;
+        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, 64);
+        total += s;
+        mx[c] = h2{negm, negm};
+      }
+      if (lane == 0) {
+        float* dst = exact + (int64_t)b * Rcap + r0 + it.k;
+        *dst = accumulate ? (*dst + total) : total;
+      }
+    }
+  };
+
+  // empty documents never enter the stream: sum over the valid columns of -10000
+  if (lane < nd && my_len == 0) {
+    float* dst = exact + (int64_t)b * Rcap + r0 + lane;
+    const float v = (float)nq * NEG_MASK_F;
+    *dst = accumulate ? (*dst + v) : v;
   }
-  if (lane == 0) {
-    float* dst = exact + (int64_t)b * Rcap + r;
-    *dst = accumulate ? (*dst + total) : total;
+
+  MsItem cur{-1, 0, 0, 0};
+  {  // first non-empty document
+    cur.k = 0;
+    cur.t0 = -32;
+    fetch_doc(cur);
+    advance(cur);
+  }
+  if (cur.k >= nd) return;
+  uint32_t ce_cur[NE], rw_cur[RW], ce_nxt[NE], rw_nxt[RW];
+  int32_t code_nxt = 0;
+  {
+    const int32_t c0 = load_code(cur);
+    load_data(cur, c0, ce_cur, rw_cur);
+  }
+  MsItem nxt = cur;
+  advance(nxt);
+  if (nxt.k < nd) code_nxt = load_code(nxt);
+  while (true) {
+    MsItem nn = nxt;
+    int32_t code_nn = 0;
+    if (nxt.k < nd) {
+      load_data(nxt, code_nxt, ce_nxt, rw_nxt);
+      advance(nn);
+      if (nn.k < nd) code_nn = load_code(nn);
+    }
+    compute(cur, ce_cur, rw_cur);
+    if (nxt.k >= nd) break;
+    cur = nxt;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) ce_cur[i] = ce_nxt[i];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) rw_cur[i] = rw_nxt[i];
+    nxt = nn;
+    code_nxt = code_nn;
   }
 }
 
+#define MAXSIM_DPW 4
 template <int D, int NBITS>
 static void launch_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid,
                           const int32_t* sel_cnt, int64_t Rcap, float* exact, hipStream_t st) {
-  dim3 grid((unsigned)((Rcap + 3) / 4), (unsigned)sh.B);
+  const int dpw = MAXSIM_DPW;
+  dim3 grid((unsigned)((Rcap + 4 * dpw - 1) / (4 * dpw)), (unsigned)sh.B);
   const int nch = sh.Qp / 32;
   int ch = 0;
   int acc = 0;
   while (ch < nch) {
     if (nch - ch >= 2) {
       hipLaunchKernelGGL((k_maxsim<D, NBITS, 2>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc);
+                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
       ch += 2;
     } else {
       hipLaunchKernelGGL((k_maxsim<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc);
+                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
       ch += 1;
     }
     acc = 1;
