@@ -13,6 +13,8 @@
 // tensor op = fp32 arithmetic + one round-to-nearest-even to fp16; matmuls accumulate in
 // fp32 and round once.  The MFMA accumulation ORDER differs from the CPU's ascending-k
 // chain, which is the only source of (<= 1 fp16 ulp, rare) differences.
+#include <cstdlib>
+
 #include "fp_internal.h"
 
 typedef _Float16 half_t;
@@ -49,6 +51,28 @@ __device__ __forceinline__ void recip2(float n, float& r_hi, float& r_lo) {
   r_lo = ok ? t : 0.0f;
 }
 __device__ __forceinline__ float quot2(float e, float r_hi, float r_lo) { return __builtin_fmaf(e, r_hi, e * r_lo); }
+// h(fma(e, r_hi, e*r_lo)) for packed fp16 pairs with 2 VALU instructions per element and no
+// separate conversions: v_fma_mix_* take fp16 sources in place.  Two registers are processed per
+// asm block so that every consumer (and every second write to the same destination, which has
+// to preserve the other half) sits at least two instructions after its producer: the
+// mix -> mix dependency needs one wait state and hipcc does not pad inside asm.
+// fp_selftest_arith runs THIS function over all 2^32 (e, n) pairs.
+__device__ __forceinline__ void norm_pair2(uint32_t& a, uint32_t& b, float r_hi, float r_lo) {
+  uint32_t da, db;
+  float t0, t1, t2, t3;
+  asm("v_fma_mix_f32 %2, %6, %9, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %6, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %4, %7, %9, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %5, %7, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %0, %6, %8, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixlo_f16 %1, %7, %8, %4 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %6, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %7, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(da), "=&v"(db), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(a), "v"(b), "v"(r_hi), "v"(r_lo));
+  a = da;
+  b = db;
+}
 
 // ============================================================================================
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
@@ -844,21 +868,17 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
 //   k <-> dim map, so no LDS staging and no transposes are needed.
 //   sim = h(acc) ; running max over tokens per query column ; fp32 sum over q.
 // ============================================================================================
-// Work item = one 32-token chunk of one document.  A wave owns `dpw` consecutive documents of
-// one query and walks their chunks as one stream, software-pipelined three deep:
-//   codes of item i+2, residual bytes + centroid rows of item i+1 (their addresses need the
-//   codes), arithmetic of item i  ->  the two dependent HBM/L2 round trips of a chunk are
-//   always hidden behind the previous chunks' arithmetic (PMC before this change: 64% of the
-//   wave cycles in s_waitcnt).
-// The byte->weights LUT is replicated per LDS bank (32 x 4-byte or 16 x 8-byte copies) so the
-// 32/64 random lookups per lane never conflict (PMC before: 63% of LDS cycles were conflicts).
-struct MsItem {
-  int k;        // document slot within the wave's group, == nd when exhausted
-  int t0;       // first token of the chunk
-  int len;      // tokens of the document
-  int64_t off;  // first token row of the document
-};
-
+// Layout of the MaxSim kernel (v3).  ONE TOKEN PER LANE: a wave carries two independent
+// 32-token streams (lanes 0-31 and 32-63), each walking its own sequence of documents chunk by
+// chunk.  A lane decompresses all D dims of its token (one 128-step ascending norm chain, no
+// work duplicated between lanes), then v_permlane32_swap turns the per-token registers into the
+// two A operands of v_mfma_f32_32x32x16_f16:
+//   regs G0 = dims [16m, 16m+8), G1 = dims [16m+8, 16m+16) of the lane's own token;
+//   swap(vdst=G0, src=G1): lanes 32-63 of G0 <-> lanes 0-31 of G1
+//   => G0 = A operand for the LOWER stream's 32 tokens (rows), G1 = A operand for the UPPER one.
+// The query B fragments are staged once per block in LDS (all 4 waves serve the same query),
+// the byte->weights LUT is replicated per LDS bank.  Next chunk's centroid codes and the next
+// document's (offset, length) are prefetched one step ahead.
 template <int D, int NBITS, int NCH>
 __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
                                                 const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
@@ -867,109 +887,129 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
                                                 const int32_t* __restrict__ sel_cnt, int64_t Rcap, float* __restrict__ exact,
                                                 int accumulate, int dpw) {
   constexpr int PR = D * NBITS / 8;   // packed residual bytes per token
-  constexpr int RB = PR / 2;          // bytes per lane
-  constexpr int RW = RB / 4;          // 32-bit words per lane
+  constexpr int RW = PR / 4;          // 32-bit residual words per token
   constexpr int PB = 8 / NBITS;       // dims per byte
   constexpr int KS = D / 16;          // MFMA k-steps
-  constexpr int NE = D / 4;           // half2 registers per lane (D/2 dims)
+  constexpr int NE = D / 2;           // half2 registers per token
   constexpr int COPIES = (PB == 2) ? 32 : 16;
   constexpr int EW = PB / 2;          // 32-bit words per LUT entry
-  __shared__ __attribute__((aligned(16))) uint32_t lut[256 * EW * COPIES];  // 32 KiB
+  __shared__ __attribute__((aligned(16))) uint32_t lut[256 * EW * COPIES];   // 32 KiB
+  __shared__ __attribute__((aligned(16))) uint4 qs[NCH * KS * 64];           // B fragments, 1 KiB per (chunk, k-step)
+  const int b = blockIdx.y;
   for (int i = threadIdx.x; i < 256 * COPIES; i += 256) {
     const int entry = i / COPIES, copy = i % COPIES;
 #pragma unroll
     for (int w = 0; w < EW; ++w) lut[(entry * COPIES + copy) * EW + w] = reinterpret_cast<const uint32_t*>(lut_g)[entry * EW + w];
   }
+  for (int i = threadIdx.x; i < NCH * KS * 64; i += 256) {
+    const int ln = i & 63, m = (i >> 6) % KS, c = (i >> 6) / KS;
+    const int ch = ch_begin + c;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ch * 32 < Qp)  // B[k = 8*(ln>>5) + j][n = ln&31] = Q[q = ch*32 + (ln&31)][16m + 8*(ln>>5) + j]
+      v = *reinterpret_cast<const uint4*>(qpad + ((int64_t)b * Qp + ch * 32 + (ln & 31)) * D + 16 * m + 8 * (ln >> 5));
+    qs[i] = v;
+  }
   __syncthreads();
-  const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int cnt = sel_cnt[b];
   const int r0 = (blockIdx.x * 4 + wave) * dpw;
   if (r0 >= cnt) return;
-  const int nd = (cnt - r0 < dpw) ? (cnt - r0) : dpw;
+  const int rend = (r0 + dpw < cnt) ? (r0 + dpw) : cnt;
   const int l31 = lane & 31, hi = lane >> 5;
   const uint32_t* mylut = lut + (lane & (COPIES - 1)) * EW;
-
-  // per-document metadata lives in lanes 0..nd-1
-  long long my_off = 0;
-  int my_len = 0;
-  if (lane < nd) {
-    const int32_t pid = sel_pid[(int64_t)b * Rcap + r0 + lane];
-    my_off = doc_off[pid];
-    my_len = (int)(doc_off[pid + 1] - my_off);
-  }
-  // query B fragments for NCH chunks
-  h8 qf[NCH][KS];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int ch = ch_begin + c;
-    const bool chv = ch * 32 < Qp;
-    const uint16_t* qrow = qpad + ((int64_t)b * Qp + (chv ? ch * 32 : 0) + l31) * D + hi * (D / 2);
-#pragma unroll
-    for (int m = 0; m < KS; ++m) {
-      uint4 v = *reinterpret_cast<const uint4*>(qrow + 8 * m);
-      if (!chv) v = make_uint4(0, 0, 0, 0);
-      qf[c][m] = __builtin_bit_cast(h8, v);
-    }
-  }
   const half_t negm = (half_t)NEG_MASK_F;
   int nq = Q - ch_begin * 32;  // valid query columns handled by this launch
   nq = nq < 0 ? 0 : (nq > NCH * 32 ? NCH * 32 : nq);
+  const int32_t* selp = sel_pid + (int64_t)b * Rcap;
+  float* outp = exact + (int64_t)b * Rcap;
 
-  auto fetch_doc = [&](MsItem& it) {  // wave-uniform metadata of document slot it.k
-    const int lo = __shfl((int)(my_off & 0xFFFFFFFFll), it.k, 64);
-    const int hi32 = __shfl((int)(my_off >> 32), it.k, 64);
-    const int ln = __shfl(my_len, it.k, 64);
-    it.off = ((long long)__builtin_amdgcn_readfirstlane(hi32) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane(lo);
-    it.len = __builtin_amdgcn_readfirstlane(ln);
+  // ---- per-stream state (identical in the 32 lanes of a stream) ----
+  int r = r0 + hi;          // document slot of this stream: r0+hi, r0+hi+2, ...
+  int t0 = 0, len = 0;
+  long long off = 0;
+  bool valid = r < rend;
+  long long n_off = 0;      // prefetched metadata of the stream's next document
+  int n_len = 0;
+  auto meta = [&](int rr, long long& o, int& l) {
+    const int32_t pid = selp[rr];
+    o = doc_off[pid];
+    l = (int)(doc_off[pid + 1] - o);
   };
-  auto advance = [&](MsItem& it) {  // next chunk in the stream; skips empty documents
-    it.t0 += 32;
-    while (it.k < nd && it.t0 >= it.len) {
-      ++it.k;
-      it.t0 = 0;
-      if (it.k < nd) fetch_doc(it);
+  if (valid) meta(r, off, len);
+  if (r + 2 < rend) meta(r + 2, n_off, n_len);
+  // skip leading empty documents / advance helper
+  auto next_doc = [&]() {  // move the stream to its next document (may be empty or absent)
+    r += 2;
+    valid = r < rend;
+    off = n_off;
+    len = n_len;
+    t0 = 0;
+    if (r + 2 < rend) meta(r + 2, n_off, n_len);
+  };
+  auto emit_empty = [&]() {
+    if (l31 == 0) {
+      const float v = (float)nq * NEG_MASK_F;  // every column keeps the masked value
+      outp[r] = accumulate ? (outp[r] + v) : v;
     }
   };
-  auto load_code = [&](const MsItem& it) -> int32_t {
-    int tok = it.t0 + l31;
-    tok = tok < it.len ? tok : it.len - 1;  // clamp: loads stay in bounds, rows masked at the max
-    return codes[it.off + tok];
+  while (valid && len == 0) { emit_empty(); next_doc(); }
+
+  auto tok_row = [&]() -> long long {
+    int tok = t0 + l31;
+    tok = tok < len ? tok : len - 1;  // clamp: loads stay in bounds, rows masked at the max
+    return off + tok;
   };
-  auto load_data = [&](const MsItem& it, int32_t code, uint32_t (&ce)[NE], uint32_t (&rw)[RW]) {
-    int tok = it.t0 + l31;
-    tok = tok < it.len ? tok : it.len - 1;
-    const uint8_t* rp = resid + (it.off + tok) * (int64_t)PR + hi * RB;
-    if constexpr (RW >= 4) {
-#pragma unroll
-      for (int i = 0; i < RW / 4; ++i) {
-        const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
-        rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
-      }
-    } else {
-      const uint2 v = *reinterpret_cast<const uint2*>(rp);
-      rw[0] = v.x; rw[1] = v.y;
-    }
-    const uint16_t* cp = cent + (int64_t)code * D + hi * (D / 2);
-#pragma unroll
-    for (int i = 0; i < NE / 4; ++i) {
-      const uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
-      ce[4 * i] = v.x; ce[4 * i + 1] = v.y; ce[4 * i + 2] = v.z; ce[4 * i + 3] = v.w;
-    }
-  };
+  int32_t code = 0;
+  if (valid) code = codes[tok_row()];
 
   h2 mx[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) mx[c] = h2{negm, negm};
 
-  auto compute = [&](const MsItem& it, uint32_t (&e)[NE], const uint32_t (&rw)[RW]) {
-    // e = h(cent + w)   (packed fp16 add == fp32 add + one rounding: fp_selftest_arith)
+  while (__any(valid)) {
+    uint32_t e[NE];
+    uint32_t rw[RW];
+    // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
+    const long long row = valid ? tok_row() : 0;
+    const int32_t ccode = valid ? code : 0;
+    {
+      const uint8_t* rp = resid + row * (long long)PR;
+      if constexpr (RW >= 4) {
+#pragma unroll
+        for (int i = 0; i < RW / 4; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
+          rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
+        }
+      } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(rp);
+        rw[0] = v.x; rw[1] = v.y;
+      }
+      const uint16_t* cp = cent + (long long)ccode * D;
+#pragma unroll
+      for (int i = 0; i < NE / 4; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
+        e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+      }
+    }
+    // ---- this chunk's bookkeeping, then step the stream and prefetch the next code ----
+    const int c_t0 = t0, c_len = len, c_r = r;
+    const bool c_valid = valid;
+    const bool c_last = valid && (t0 + 32 >= len);
+    if (valid) {
+      t0 += 32;
+      if (t0 >= len) {
+        next_doc();
+        while (valid && len == 0) { emit_empty(); next_doc(); }
+      }
+      if (valid) code = codes[tok_row()];
+    }
+    // ---- e = h(cent + w) ----
 #pragma unroll
     for (int w = 0; w < RW; ++w) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const uint32_t byte = (rw[w] >> (8 * kk)) & 0xFFu;
-        const int bi = w * 4 + kk;  // byte index within the lane -> dims [bi*PB, bi*PB+PB)
+        const int bi = w * 4 + kk;  // byte index -> dims [bi*PB, bi*PB+PB)
         if constexpr (PB == 2) {
           e[bi] = h2_as_u32(u32_as_h2(e[bi]) + u32_as_h2(mylut[byte * COPIES]));
         } else {
@@ -979,11 +1019,7 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
         }
       }
     }
-    // n = h(sqrt(sum_k e_k^2)), fp32 sum in ASCENDING-k order exactly like the CPU reference
-    // (any other order flips n by one fp16 ulp on ~0.1% of tokens, which then moves every
-    // similarity of that token the same way: measured 2e-3 on Q=50 documents).  Lane (tok,0)
-    // holds dims [0,D/2), lane (tok,1) dims [D/2,D): chain 1 from 0, chain 2 continues from
-    // lane (tok,0)'s partial; only lane (tok,1)'s second chain is meaningful.
+    // ---- n = h(sqrt(sum_k e_k^2)): fp32, ascending k, exactly the CPU reference's order ----
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -991,151 +1027,105 @@ __global__ __launch_bounds__(256) void k_maxsim(const uint16_t* __restrict__ cen
       ss = __builtin_fmaf((float)v.x, (float)v.x, ss);
       ss = __builtin_fmaf((float)v.y, (float)v.y, ss);
     }
-    float s2 = __shfl(ss, l31, 64);
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const h2 v = u32_as_h2(e[i]);
-      s2 = __builtin_fmaf((float)v.x, (float)v.x, s2);
-      s2 = __builtin_fmaf((float)v.y, (float)v.y, s2);
-    }
-    const float tot = __shfl(s2, l31 + 32, 64);
-    const float nf = (float)(half_t)__builtin_sqrtf(tot);  // Half norm; clamp_min(1e-12) is a no-op in fp16
-    // e^ = h(fl32(e / n)) as h(fma(e, r_hi, e*r_lo)) with r_hi + r_lo = 1/n (fp_selftest_arith)
+    const float nf = (float)(half_t)__builtin_sqrtf(ss);  // clamp_min(1e-12) is a no-op in fp16
     float r_hi, r_lo;
     recip2(nf, r_hi, r_lo);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const h2 v = u32_as_h2(e[i]);
-      h2 o;
-      o.x = (half_t)quot2((float)v.x, r_hi, r_lo);
-      o.y = (half_t)quot2((float)v.y, r_hi, r_lo);
-      e[i] = h2_as_u32(o);
-    }
-    f16v acc[NCH];
+    for (int i = 0; i < NE; i += 2) norm_pair2(e[i], e[i + 1], r_hi, r_lo);
+    // ---- MFMA: acc0 rows = lower stream's tokens, acc1 rows = upper stream's tokens ----
+    f16v acc0[NCH], acc1[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+      for (int i = 0; i < 16; ++i) { acc0[c][i] = 0.f; acc1[c][i] = 0.f; }
 #pragma unroll
     for (int m = 0; m < KS; ++m) {
-      const uint4 av = make_uint4(e[4 * m], e[4 * m + 1], e[4 * m + 2], e[4 * m + 3]);
-      const h8 a = __builtin_bit_cast(h8, av);
+      uint32_t g0[4], g1[4];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[c][m], acc[c], 0, 0, 0);
-    }
-    // D[row = token][col = q = lane&31]; this lane's rows: (i&3) + 8*(i>>2) + 4*hi
-    const bool partial = (it.t0 + 32 > it.len);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      h2 m = mx[c];
-      if (!partial) {
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          h2 v;
-          v.x = (half_t)acc[c][i];
-          v.y = (half_t)acc[c][i + 1];
-          m = pk_max(m, v);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          h2 v;
-          v.x = (half_t)acc[c][i];
-          v.y = (half_t)acc[c][i + 1];
-          const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
-          if (it.t0 + row0 >= it.len) v.x = negm;
-          if (it.t0 + row0 + 1 >= it.len) v.y = negm;
-          m = pk_max(m, v);
-        }
+      for (int j = 0; j < 4; ++j) {
+        auto sw = __builtin_amdgcn_permlane32_swap(e[8 * m + j], e[8 * m + 4 + j], false, false);
+        g0[j] = sw[0];
+        g1[j] = sw[1];
       }
-      mx[c] = m;
+      const h8 a0 = __builtin_bit_cast(h8, make_uint4(g0[0], g0[1], g0[2], g0[3]));
+      const h8 a1 = __builtin_bit_cast(h8, make_uint4(g1[0], g1[1], g1[2], g1[3]));
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const h8 bq = __builtin_bit_cast(h8, qs[(c * KS + m) * 64 + lane]);
+        acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, acc0[c], 0, 0, 0);
+        acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1[c], 0, 0, 0);
+      }
     }
-    if (it.t0 + 32 >= it.len) {  // last chunk of the document: reduce and emit
+    // ---- epilogue.  acc0 belongs to the lower stream (state in lane 0), acc1 to the upper
+    // (lane 32); D[row = token][col = q = lane&31], this lane's rows (i&3) + 8*(i>>2) + 4*hi.
+    // mx[] tracks the running max of the stream THIS lane belongs to, so the two accumulators'
+    // lane-halves are exchanged first: lower-stream lanes need acc0 from both halves. ----
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int s_t0 = __shfl(c_t0, 32 * s, 64), s_len = __shfl(c_len, 32 * s, 64), s_r = __shfl(c_r, 32 * s, 64);
+      const bool s_valid = __shfl((int)c_valid, 32 * s, 64) != 0;
+      const bool s_last = __shfl((int)c_last, 32 * s, 64) != 0;
+      if (!s_valid) continue;
+      const bool partial = (s_t0 + 32 > s_len);
       float total = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        half_t m = mx[c].x > mx[c].y ? mx[c].x : mx[c].y;
-        const uint32_t mu = (uint32_t)__builtin_bit_cast(uint16_t, m);
-        const uint32_t ou = shfl_xor_u32(mu, 32);
+        h2 m = h2{negm, negm};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          h2 v;
+          v.x = (half_t)(s == 0 ? acc0[c][i] : acc1[c][i]);
+          v.y = (half_t)(s == 0 ? acc0[c][i + 1] : acc1[c][i + 1]);
+          if (partial) {
+            const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            if (s_t0 + row0 >= s_len) v.x = negm;
+            if (s_t0 + row0 + 1 >= s_len) v.y = negm;
+          }
+          m = pk_max(m, v);
+        }
+        // this chunk's max over the 32 tokens for column q = lane&31 (both lane halves agree after the exchange)
+        half_t mm = m.x > m.y ? m.x : m.y;
+        const uint32_t ou = shfl_xor_u32((uint32_t)__builtin_bit_cast(uint16_t, mm), 32);
         const half_t o = __builtin_bit_cast(half_t, (uint16_t)ou);
-        m = o > m ? o : m;
-        const int q = (ch_begin + c) * 32 + l31;
-        float s = (hi == 0 && q < Q) ? (float)m : 0.f;
+        mm = o > mm ? o : mm;
+        // running max lives in the lanes of stream s
+        if (hi == s) {
+          const half_t cur = mx[c].x;
+          mx[c].x = mm > cur ? mm : cur;
+        }
+        if (s_last) {
+          const int q = (ch_begin + c) * 32 + l31;
+          float sv = (hi == s && q < Q) ? (float)mx[c].x : 0.f;
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft, 64);
-        total += s;
-        mx[c] = h2{negm, negm};
+          for (int sft = 32; sft > 0; sft >>= 1) sv += __shfl_xor(sv, sft, 64);
+          total += sv;
+          if (hi == s) mx[c] = h2{negm, negm};
+        }
       }
-      if (lane == 0) {
-        float* dst = exact + (int64_t)b * Rcap + r0 + it.k;
-        *dst = accumulate ? (*dst + total) : total;
-      }
+      if (s_last && lane == 0) outp[s_r] = accumulate ? (outp[s_r] + total) : total;
     }
-  };
-
-  // empty documents never enter the stream: sum over the valid columns of -10000
-  if (lane < nd && my_len == 0) {
-    float* dst = exact + (int64_t)b * Rcap + r0 + lane;
-    const float v = (float)nq * NEG_MASK_F;
-    *dst = accumulate ? (*dst + v) : v;
-  }
-
-  MsItem cur{-1, 0, 0, 0};
-  {  // first non-empty document
-    cur.k = 0;
-    cur.t0 = -32;
-    fetch_doc(cur);
-    advance(cur);
-  }
-  if (cur.k >= nd) return;
-  uint32_t ce_cur[NE], rw_cur[RW], ce_nxt[NE], rw_nxt[RW];
-  int32_t code_nxt = 0;
-  {
-    const int32_t c0 = load_code(cur);
-    load_data(cur, c0, ce_cur, rw_cur);
-  }
-  MsItem nxt = cur;
-  advance(nxt);
-  if (nxt.k < nd) code_nxt = load_code(nxt);
-  while (true) {
-    MsItem nn = nxt;
-    int32_t code_nn = 0;
-    if (nxt.k < nd) {
-      load_data(nxt, code_nxt, ce_nxt, rw_nxt);
-      advance(nn);
-      if (nn.k < nd) code_nn = load_code(nn);
-    }
-    compute(cur, ce_cur, rw_cur);
-    if (nxt.k >= nd) break;
-    cur = nxt;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) ce_cur[i] = ce_nxt[i];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) rw_cur[i] = rw_nxt[i];
-    nxt = nn;
-    code_nxt = code_nn;
   }
 }
 
-#define MAXSIM_DPW 4
+#define MAXSIM_DPW 8
 template <int D, int NBITS>
 static void launch_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid,
                           const int32_t* sel_cnt, int64_t Rcap, float* exact, hipStream_t st) {
-  const int dpw = MAXSIM_DPW;
+  static int dpw_env = -1;
+  if (dpw_env < 0) {
+    const char* s = getenv("FP_MAXSIM_DPW");
+    dpw_env = s ? atoi(s) : MAXSIM_DPW;
+    if (dpw_env < 2) dpw_env = 2;
+  }
+  const int dpw = dpw_env;  // documents per wave (two streams x dpw/2)
   dim3 grid((unsigned)((Rcap + 4 * dpw - 1) / (4 * dpw)), (unsigned)sh.B);
   const int nch = sh.Qp / 32;
   int ch = 0;
   int acc = 0;
-  while (ch < nch) {
-    if (nch - ch >= 2) {
-      hipLaunchKernelGGL((k_maxsim<D, NBITS, 2>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
-      ch += 2;
-    } else {
-      hipLaunchKernelGGL((k_maxsim<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
-      ch += 1;
-    }
+  while (ch < nch) {  // one 32-column query chunk per launch (NCH = 1 keeps the register budget at 3 waves/SIMD)
+    hipLaunchKernelGGL((k_maxsim<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
+                       qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
+    ch += 1;
     acc = 1;
   }
 }
@@ -1422,7 +1412,10 @@ __global__ __launch_bounds__(256) void k_selftest_arith(unsigned long long* __re
   unsigned long long bad_dom = 0, bad_add = 0, bad_plain = 0, bad_all = 0;
   for (uint32_t eb = threadIdx.x * 2; eb < 65536u; eb += 512u) {
     const h2 e = u32_as_h2(eb | ((eb + 1u) << 16));
-    const half_t q0 = (half_t)quot2((float)e.x, r_hi, r_lo), q1 = (half_t)quot2((float)e.y, r_hi, r_lo);
+    uint32_t ea = h2_as_u32(e), eb2 = h2_as_u32(e);
+    norm_pair2(ea, eb2, r_hi, r_lo);  // the exact code path of k_maxsim (both registers must agree)
+    const h2 qq = u32_as_h2(ea);
+    const half_t q0 = qq.x, q1 = (ea == eb2) ? qq.y : (half_t)__builtin_nanf("");
     const half_t d0 = (half_t)((float)e.x / nf), d1 = (half_t)((float)e.y / nf);
     const bool m0 = !same_h(q0, d0), m1 = !same_h(q1, d1);
     bad_all += m0 + m1;
