@@ -232,6 +232,13 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   if (D.T > 0) ICHK(hipMemcpy(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice));
   {
+    uint16_t* perm = nullptr;
+    int src = fps_sort_docs(codes, res, doc_off, D.N, D.T, maxlen, D.pr, &perm, st);
+    if (src != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "in-document token sort failed (hip error " + std::to_string(src) + ")")); }
+    if (perm) { ix->owned.push_back(perm); ix->bytes += D.T * 2; }
+    D.perm = perm;
+  }
+  {
     int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
     ICHK(dev_alloc(ix, &uoff, (size_t)D.N + 1));
     int urc = fps_build_ucodes(codes, doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
@@ -330,6 +337,13 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   fps_generate(p, doc_off, D.N, D.T, tok_base, codes, res, st);
   ICHK(hipStreamSynchronize(st));
   {
+    uint16_t* perm = nullptr;
+    int src = fps_sort_docs(codes, res, doc_off, D.N, D.T, maxlen, D.pr, &perm, st);
+    if (src != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "in-document token sort failed (hip error " + std::to_string(src) + ")")); }
+    if (perm) { ix->owned.push_back(perm); ix->bytes += D.T * 2; }
+    D.perm = perm;
+  }
+  {
     int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
     ICHK(dev_alloc(ix, &uoff, (size_t)D.N + 1));
     int urc = fps_build_ucodes(codes, doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
@@ -357,12 +371,20 @@ extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* c
   (void)hipSetDevice(ix->device);
   const int64_t off = ix->h_doc_off[doc], len = ix->h_doc_off[doc + 1] - off;
   if (len > cap) return fail(FP_EINVAL, "capacity too small");
+  const int pr = ix->d.pr;
   std::vector<int32_t> tmp((size_t)len);
+  std::vector<uint8_t> rtmp((size_t)len * pr);
+  std::vector<uint16_t> perm((size_t)len);
   if (len > 0) {
     HIPCHK(hipMemcpy(tmp.data(), ix->d.codes + off, (size_t)len * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(residuals, ix->d.residuals + off * ix->d.pr, (size_t)len * ix->d.pr, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rtmp.data(), ix->d.residuals + off * pr, (size_t)len * pr, hipMemcpyDeviceToHost));
+    if (ix->d.perm) HIPCHK(hipMemcpy(perm.data(), ix->d.perm + off, (size_t)len * 2, hipMemcpyDeviceToHost));
   }
-  for (int64_t i = 0; i < len; ++i) codes[i] = tmp[i];
+  for (int64_t i = 0; i < len; ++i) {  // stored position i holds original token perm[i]
+    const int64_t p = ix->d.perm ? perm[i] : i;
+    codes[p] = tmp[i];
+    memcpy(residuals + p * pr, rtmp.data() + i * pr, (size_t)pr);
+  }
   return len;
 }
 
@@ -666,8 +688,17 @@ extern "C" int fp_reconstruct_embeddings(const fp_index* cix, const int64_t* doc
   for (int64_t i = 0; i < n; ++i) {
     int64_t d = doc_ids[i] - ix->d.pid_offset;
     if (d < 0 || d >= ix->d.N) return fail(FP_EINVAL, "document id out of range");
-    out_lengths[i] = ix->h_doc_off[d + 1] - ix->h_doc_off[d];
-    for (int64_t t = ix->h_doc_off[d]; t < ix->h_doc_off[d + 1]; ++t) tok.push_back(t);
+    const int64_t o = ix->h_doc_off[d], l = ix->h_doc_off[d + 1] - o;
+    out_lengths[i] = l;
+    const size_t base = tok.size();
+    tok.resize(base + (size_t)l);
+    if (ix->d.perm && l > 0) {  // stored row o+j holds original token perm[j]
+      std::vector<uint16_t> pp((size_t)l);
+      HIPCHK(hipMemcpy(pp.data(), ix->d.perm + o, (size_t)l * 2, hipMemcpyDeviceToHost));
+      for (int64_t j = 0; j < l; ++j) tok[base + pp[j]] = o + j;
+    } else {
+      for (int64_t j = 0; j < l; ++j) tok[base + j] = o + j;
+    }
   }
   const int64_t rows = (int64_t)tok.size();
   if (rows > cap_rows) return fail(FP_EINVAL, "output capacity too small");
@@ -840,15 +871,35 @@ extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* 
     for (int64_t i = 0; i < D.N; ++i) doc_lengths[i] = ix->h_doc_off[i + 1] - ix->h_doc_off[i];
   const int64_t chunk = 64ll << 20;
   std::vector<int32_t> tmp;
+  std::vector<uint16_t> hperm;
+  if (D.perm && D.T > 0 && (doc_codes || doc_residuals)) {
+    hperm.resize((size_t)D.T);
+    HIPCHK(hipMemcpy(hperm.data(), D.perm, (size_t)D.T * 2, hipMemcpyDeviceToHost));
+  }
+  // stored token i of document d is original token perm[i]: write it back to its original slot
+  auto orig_row = [&](int64_t doc, int64_t i) { return hperm.empty() ? i : ix->h_doc_off[doc] + hperm[i]; };
   if (doc_codes) {
-    tmp.resize((size_t)std::min<int64_t>(chunk, std::max<int64_t>(D.T, 1)));
-    for (int64_t s = 0; s < D.T; s += chunk) {
-      const int64_t m = std::min(chunk, D.T - s);
-      HIPCHK(hipMemcpy(tmp.data(), D.codes + s, (size_t)m * 4, hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < m; ++i) doc_codes[s + i] = tmp[i];
+    tmp.resize((size_t)std::max<int64_t>(D.T, 1));
+    if (D.T > 0) HIPCHK(hipMemcpy(tmp.data(), D.codes, (size_t)D.T * 4, hipMemcpyDeviceToHost));
+    for (int64_t d0 = 0; d0 < D.N; ++d0)
+      for (int64_t i = ix->h_doc_off[d0]; i < ix->h_doc_off[d0 + 1]; ++i) doc_codes[orig_row(d0, i)] = tmp[i];
+  }
+  if (doc_residuals && D.T > 0) {
+    if (hperm.empty()) {
+      HIPCHK(hipMemcpy(doc_residuals, D.residuals, (size_t)D.T * D.pr, hipMemcpyDeviceToHost));
+    } else {
+      std::vector<uint8_t> rt((size_t)std::min<int64_t>(chunk, D.T) * D.pr);
+      int64_t d0 = 0;
+      for (int64_t s0 = 0; s0 < D.T; s0 += chunk) {
+        const int64_t m = std::min(chunk, D.T - s0);
+        HIPCHK(hipMemcpy(rt.data(), D.residuals + s0 * D.pr, (size_t)m * D.pr, hipMemcpyDeviceToHost));
+        for (int64_t i = s0; i < s0 + m; ++i) {
+          while (ix->h_doc_off[d0 + 1] <= i) ++d0;
+          memcpy(doc_residuals + orig_row(d0, i) * D.pr, rt.data() + (i - s0) * D.pr, (size_t)D.pr);
+        }
+      }
     }
   }
-  if (doc_residuals && D.T > 0) HIPCHK(hipMemcpy(doc_residuals, D.residuals, (size_t)D.T * D.pr, hipMemcpyDeviceToHost));
   if (ix->has_ivf && (ivf || ivf_lengths)) {
     std::vector<int64_t> off((size_t)D.P + 1);
     HIPCHK(hipMemcpy(off.data(), D.ivf_off, off.size() * 8, hipMemcpyDeviceToHost));

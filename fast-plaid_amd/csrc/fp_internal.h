@@ -19,6 +19,10 @@
 //   codes      [T]         i32   (narrowed from the reference's i64: C < 2^31)
 //   residuals  [T][PR]     u8    PR = D*nbits/8
 //   doc_off    [N+1]       i64   (tensor.rs:221-224 cumulative lengths)
+//   Tokens are stored SORTED BY CODE inside each document (MaxSim is order-independent over a
+//   document's tokens): equal codes sit in adjacent lanes of one gather instruction and coalesce
+//   into a single centroid-row fetch.  perm [T] u16 maps stored position -> original position
+//   (used only by reconstruct / export / read_doc, which return the original order).
 //   ucodes     [U] i32 + uoff [N+1] i64: per-document ascending UNIQUE codes.  The approximate
 //              score only depends on the set of codes of a document, so S4 walks this list.
 struct FpIndexDev {
@@ -32,6 +36,8 @@ struct FpIndexDev {
   const int32_t* codes;
   const uint8_t* residuals;
   const int64_t* doc_off;
+  const uint16_t* perm;    // [T]   original in-document position of stored token i (tokens are stored
+                           //       sorted by code inside each document; nullptr = stored in original order)
   const int32_t* ucodes;   // [U]   per-document ascending unique codes (dedup of `codes`)
   const int64_t* uoff;     // [N+1]
   int64_t U;
@@ -113,6 +119,11 @@ int64_t fps_doc_offsets_host(const FpSynthParams& p, int64_t* doc_off_host, int*
 // shard's first token.
 void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t tok_base,
                   int32_t* codes, uint8_t* residuals, hipStream_t st);
+// Sorts the tokens of every document by (code, original position) in place (documents longer
+// than 4096 tokens are left as they are); allocates *perm [T] u16 and a temporary residual
+// copy.  Returns 0 or a hipError.
+int fps_sort_docs(int32_t* codes, uint8_t* residuals, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int max_len, int pr,
+                  uint16_t** perm, hipStream_t st);
 // Per-document sorted unique codes (allocates *ucodes, fills uoff_dev [N+1]).
 int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int max_len, int32_t** ucodes, int64_t* U,
                      int64_t* uoff_dev, hipStream_t st);

@@ -107,6 +107,98 @@ void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_
   hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)blocks), dim3(256), 0, st, p, doc_off_dev, n_docs, tok_base, codes, residuals);
 }
 
+// ---- in-document token sort by centroid code -------------------------------------------------------
+#define SORT_MAX_LEN 4096
+__global__ __launch_bounds__(64) void k_doc_sort(int32_t* __restrict__ codes, const int64_t* __restrict__ doc_off, int64_t n_docs,
+                                                 uint16_t* __restrict__ perm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
+  const int64_t d = blockIdx.x;
+  if (d >= n_docs) return;
+  const int lane = threadIdx.x;
+  const int64_t off = doc_off[d];
+  const int n = (int)(doc_off[d + 1] - off);
+  if (n > SORT_MAX_LEN) {
+    for (int i = lane; i < n; i += 64) perm[off + i] = (uint16_t)(i & 0xFFFF);  // not sorted: identity (only valid for n < 65536)
+    return;
+  }
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int i = lane; i < np2; i += 64)
+    v[i] = (i < n) ? (((unsigned long long)(uint32_t)codes[off + i] << 32) | (unsigned long long)i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < np2; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = v[i], c = v[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { v[i] = c; v[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = lane; i < n; i += 64) {
+    codes[off + i] = (int32_t)(v[i] >> 32);
+    perm[off + i] = (uint16_t)(v[i] & 0xFFFF);
+  }
+}
+
+// new_res[off + i] = old_res[off + perm[i]]; 16 bytes per thread
+__global__ void k_permute_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint16_t* __restrict__ perm,
+                               const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t T, int pr) {
+  const int ppr = pr / 16 > 0 ? pr / 16 : 1;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = g / ppr;
+  const int piece = (int)(g % ppr);
+  if (row >= T) return;
+  // document of `row`: binary search over doc_off
+  int64_t lo = 0, hi = n_docs;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (doc_off[mid] <= row) lo = mid; else hi = mid;
+  }
+  const int64_t off = doc_off[lo];
+  const int64_t srow = off + perm[row];
+  if (pr >= 16) {
+    *reinterpret_cast<uint4*>(dst + row * pr + piece * 16) = *reinterpret_cast<const uint4*>(src + srow * pr + piece * 16);
+  } else {
+    for (int b = 0; b < pr; ++b) dst[row * pr + b] = src[srow * pr + b];
+  }
+}
+
+#define HCHK0(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc0 = (int)e_; goto fail0; } } while (0)
+int fps_sort_docs(int32_t* codes, uint8_t* residuals, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int max_len, int pr,
+                  uint16_t** perm, hipStream_t st) {
+  int rc0 = 0;
+  uint8_t* tmp = nullptr;
+  int np2 = 1;
+  *perm = nullptr;
+  HCHK0(hipMalloc((void**)perm, (size_t)(T > 0 ? T : 1) * 2 + 64));
+  if (n_docs <= 0 || T <= 0) return 0;
+  if (max_len >= 65536) {  // u16 positions cannot describe such documents: keep original order everywhere
+    (void)hipFree(*perm);
+    *perm = nullptr;
+    return 0;
+  }
+  while (np2 < max_len && np2 < SORT_MAX_LEN) np2 <<= 1;
+  hipLaunchKernelGGL(k_doc_sort, dim3((unsigned)n_docs), dim3(64), (size_t)np2 * 8, st, codes, doc_off_dev, n_docs, *perm);
+  HCHK0(hipMalloc((void**)&tmp, (size_t)T * pr + 64));
+  {
+    const int ppr = pr / 16 > 0 ? pr / 16 : 1;
+    const int64_t threads = T * ppr;
+    hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, residuals, tmp, *perm, doc_off_dev, n_docs,
+                       T, pr);
+  }
+  HCHK0(hipMemcpyAsync(residuals, tmp, (size_t)T * pr, hipMemcpyDeviceToDevice, st));
+  HCHK0(hipStreamSynchronize(st));
+fail0:
+  if (tmp) (void)hipFree(tmp);
+  return rc0;
+}
+
 // ---- per-document sorted unique codes ------------------------------------------------------------
 // The approximate score sum_q max_t S[code_t, q] only depends on the SET of codes of a document
 // (max is idempotent), so the index keeps, next to the raw per-token codes the exact stage
