@@ -642,20 +642,36 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
   const half_t negm = (half_t)NEG_MASK_F;
   const h2 neg2 = {negm, negm};
   const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
-  for (int64_t i = (int64_t)blockIdx.x * 64 + grp; i < n; i += (int64_t)gridDim.x * 64) {
+  const int64_t stride = (int64_t)gridDim.x * 64;
+  int64_t i = (int64_t)blockIdx.x * 64 + grp;
+  // metadata of the first document, then always one document ahead (the pid -> offsets -> codes
+  // -> rows chain is four dependent round trips; only the last two stay on the critical path)
+  int64_t u0 = 0;
+  int len = 0;
+  if (i < n) {
     const int32_t pid = cand_pid[beg + i];
-    const int64_t u0 = uoff[pid];
-    const int len = (int)(uoff[pid + 1] - u0);
+    u0 = uoff[pid];
+    len = (int)(uoff[pid + 1] - u0);
+  }
+  for (; i < n; i += stride) {
+    int64_t nu0 = 0;
+    int nlen = 0;
+    if (i + stride < n) {
+      const int32_t npid = cand_pid[beg + i + stride];
+      nu0 = uoff[npid];
+      nlen = (int)(uoff[npid + 1] - nu0);
+    }
     const int32_t* cp = ucodes + u0;
     float total = 0.f;
     for (int ch = 0; ch < Qp / 32; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
       const uint16_t* Sc = Sb + ch * 32;
-      int t = 0;
-      for (; t + 8 <= len; t += 8) {
+      // eight independent gathers per step; the last step re-reads the final code instead of
+      // running a serial tail (max is idempotent)
+      for (int t = 0; t < len; t += 8) {
         int32_t code[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) code[k] = cp[t + k];
+        for (int k = 0; k < 8; ++k) code[k] = cp[(t + k < len) ? (t + k) : (len - 1)];
         uint4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
@@ -666,13 +682,6 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
           m2 = pk_max(m2, u32_as_h2(v[k].z));
           m3 = pk_max(m3, u32_as_h2(v[k].w));
         }
-      }
-      for (; t < len; ++t) {
-        const uint4 v = *reinterpret_cast<const uint4*>(Sc + (int64_t)cp[t] * Qp);
-        m0 = pk_max(m0, u32_as_h2(v.x));
-        m1 = pk_max(m1, u32_as_h2(v.y));
-        m2 = pk_max(m2, u32_as_h2(v.z));
-        m3 = pk_max(m3, u32_as_h2(v.w));
       }
       const int q0 = ch * 32 + sub * 8;
       float s = 0.f;
@@ -691,6 +700,8 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     total += __shfl_xor(total, 1, 64);
     total += __shfl_xor(total, 2, 64);
     if (sub == 0) approx[beg + i] = total;
+    u0 = nu0;
+    len = nlen;
   }
 }
 
