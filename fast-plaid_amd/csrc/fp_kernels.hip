@@ -643,15 +643,25 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
   const h2 neg2 = {negm, negm};
   const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
   const int64_t stride = (int64_t)gridDim.x * 64;
+  const int nch = Qp / 32;
   int64_t i = (int64_t)blockIdx.x * 64 + grp;
-  // metadata of the first document, then always one document ahead (the pid -> offsets -> codes
-  // -> rows chain is four dependent round trips; only the last two stay on the critical path)
+  // Software pipeline over the dependent chain  pid -> offsets -> codes -> rows:
+  //   document metadata is fetched one document ahead, the next 8 codes (of this document, or
+  //   the first 8 of the next one) are fetched while the current 8 row gathers are in flight,
+  //   so only ONE round trip per 8 rows stays on the critical path.
   int64_t u0 = 0;
   int len = 0;
+  int32_t code[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) code[k] = 0;
   if (i < n) {
     const int32_t pid = cand_pid[beg + i];
     u0 = uoff[pid];
     len = (int)(uoff[pid + 1] - u0);
+    if (len > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[u0 + ((k < len) ? k : (len - 1))];
+    }
   }
   for (; i < n; i += stride) {
     int64_t nu0 = 0;
@@ -663,18 +673,25 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     }
     const int32_t* cp = ucodes + u0;
     float total = 0.f;
-    for (int ch = 0; ch < Qp / 32; ++ch) {
+    for (int ch = 0; ch < nch; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
       const uint16_t* Sc = Sb + ch * 32;
-      // eight independent gathers per step; the last step re-reads the final code instead of
-      // running a serial tail (max is idempotent)
-      for (int t = 0; t < len; t += 8) {
-        int32_t code[8];
+      if (ch > 0 && len > 0) {  // further 32-column chunks restart from the document's first codes
 #pragma unroll
-        for (int k = 0; k < 8; ++k) code[k] = cp[(t + k < len) ? (t + k) : (len - 1)];
+        for (int k = 0; k < 8; ++k) code[k] = cp[(k < len) ? k : (len - 1)];
+      }
+      for (int t = 0; t < len; t += 8) {
         uint4 v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
+        // next codes while the rows are in flight (max is idempotent: the tail re-reads the last code)
+        if (t + 8 < len) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) code[k] = cp[(t + 8 + k < len) ? (t + 8 + k) : (len - 1)];
+        } else if (ch == nch - 1 && nlen > 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           m0 = pk_max(m0, u32_as_h2(v[k].x));
@@ -694,6 +711,10 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
       s += (q0 + 6 < Q) ? (float)m3.x : 0.f;
       s += (q0 + 7 < Q) ? (float)m3.y : 0.f;
       total += s;
+    }
+    if (len == 0 && nlen > 0) {  // an empty document never reaches the prefetch slot above
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
     }
     // the 4 lanes of the group hold disjoint column sums (lanes of one group run the same trip
     // counts, so the shuffles are convergent within the group; other groups may have exited)
