@@ -630,11 +630,19 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 //     eight independent row gathers per lane in flight;
 //   * grid = (blocks, queries): the query is blockIdx.y, no per-candidate search.
 // ============================================================================================
-__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
+__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int B, int bx, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                 float* __restrict__ approx) {
-  const int b = blockIdx.y;
+  // XCD-affine work split: blocks are dispatched round-robin over the 8 XCDs (block id % 8), each
+  // with a private 4 MiB L2.  Query b is served only by XCD b % 8, so a query's 8 MiB score table
+  // is pulled through ONE L2 instead of all eight and each L2 holds one query's table at a time.
+  // (placement only affects speed; any block->XCD mapping gives the same result)
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int b = 8 * (slot / bx) + xcd;
+  if (b >= B) return;
+  const int bxi = slot % bx;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
@@ -642,9 +650,9 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
   const half_t negm = (half_t)NEG_MASK_F;
   const h2 neg2 = {negm, negm};
   const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
-  const int64_t stride = (int64_t)gridDim.x * 64;
+  const int64_t stride = (int64_t)bx * 64;
   const int nch = Qp / 32;
-  int64_t i = (int64_t)blockIdx.x * 64 + grp;
+  int64_t i = (int64_t)bxi * 64 + grp;
   // Software pipeline over the dependent chain  pid -> offsets -> codes -> rows:
   //   document metadata is fetched one document ahead, the next 8 codes (of this document, or
   //   the first 8 of the next one) are fetched while the current 8 row gathers are in flight,
@@ -734,8 +742,9 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   int64_t bx = (per_q * 2 + 63) / 64;
   if (bx > 2048) bx = 2048;
   if (bx < 1) bx = 1;
+  const int64_t groups = (sh.B + 7) / 8;
   // walks the per-document UNIQUE code lists (max over a multiset == max over its set)
-  hipLaunchKernelGGL(k_approx, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+  hipLaunchKernelGGL(k_approx, dim3((unsigned)(bx * 8 * groups)), dim3(256), 0, st, S, ix.C, sh.B, (int)bx, sh.Q, sh.Qp, cand_off, cand_pid,
                      ix.uoff, ix.ucodes, approx);
 }
 
