@@ -690,12 +690,22 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
       }
       for (int t = 0; t < len; t += 8) {
         uint4 v[8];
+#if AP_ABL & 1
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = make_uint4(code[k], code[k] * 3, code[k] * 5, code[k] * 7);
+#else
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
+#endif
         // next codes while the rows are in flight (max is idempotent: the tail re-reads the last code)
         if (t + 8 < len) {
+#if AP_ABL & 2
+#pragma unroll
+          for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)(code[k] * 2654435761u + k)) % (uint32_t)C);
+#else
 #pragma unroll
           for (int k = 0; k < 8; ++k) code[k] = cp[(t + 8 + k < len) ? (t + 8 + k) : (len - 1)];
+#endif
         } else if (ch == nch - 1 && nlen > 0) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
@@ -920,6 +930,9 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
 //   k <-> dim map, so no LDS staging and no transposes are needed.
 //   sim = h(acc) ; running max over tokens per query column ; fp32 sum over q.
 // ============================================================================================
+#ifndef AP_ABL
+#define AP_ABL 0  // k_approx ablation bits (timing only): 1 no row gathers, 2 synthetic codes
+#endif
 #ifndef FP_ABL
 #define FP_ABL 0  // ablation bits (timing experiments only): 1 no norm chain, 2 no normalise, 4 no LUT decode
 #endif
