@@ -73,11 +73,11 @@ struct Scratch {
   hipStream_t st = nullptr;
   hipEvent_t ev[ST_N + 1] = {};
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
-      cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
+      cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon;
   void destroy() {
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
-                     &sub_off,  &bitmap,   &blkcnt,   &ncand,   &cand_off, &cand_pid,  &approx,  &hist,     &selstate, &sel_pid,
+                     &sub_off,  &bitmap,   &blkcnt,   &ncand,   &cand_off, &cand_pid,  &approx,  &hist,     &selstate, &sel_pid, &tie_pid,
                      &sel_approx, &sel_cnt, &exact,   &out_pid, &out_score, &out_cnt,  &tmpf,    &tmpp,     &tok_idx, &recon};
     for (DevBuf* b : all) b->release();
     for (auto& e : ev)
@@ -514,8 +514,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->sel_pid.ensure((size_t)B * sh.R * 4));
   HIPCHK(s->sel_approx.ensure((size_t)B * sh.R * 4));
   HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
+  HIPCHK(s->tie_pid.ensure((size_t)B * sh.R * 4));
   fpk_select(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), s->approx.as<float>(), s->hist.as<uint32_t>(),
-             s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(), st);
+             s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
+             s->tie_pid.as<int32_t>(), st);
   HIPCHK(hipEventRecord(s->ev[ST_MAXSIM], st));
   return FP_OK;
 }

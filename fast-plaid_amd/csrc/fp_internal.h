@@ -78,7 +78,7 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
-                float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, hipStream_t st);
+                float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st);
 int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid,
                const int32_t* sel_cnt, int64_t Rcap, float* exact /*[B][Rcap]*/, hipStream_t st);
 // final ranking: sort (score desc, id asc), emit top_k with pid_offset applied

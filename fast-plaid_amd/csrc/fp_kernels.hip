@@ -630,19 +630,13 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 //     eight independent row gathers per lane in flight;
 //   * grid = (blocks, queries): the query is blockIdx.y, no per-candidate search.
 // ============================================================================================
-__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int B, int bx, int Q, int Qp,
+__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                 float* __restrict__ approx) {
-  // XCD-affine work split: blocks are dispatched round-robin over the 8 XCDs (block id % 8), each
-  // with a private 4 MiB L2.  Query b is served only by XCD b % 8, so a query's 8 MiB score table
-  // is pulled through ONE L2 instead of all eight and each L2 holds one query's table at a time.
-  // (placement only affects speed; any block->XCD mapping gives the same result)
-  const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int b = 8 * (slot / bx) + xcd;
-  if (b >= B) return;
-  const int bxi = slot % bx;
+  const int b = blockIdx.y;
+  const int bxi = blockIdx.x;
+  const int bx = gridDim.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
@@ -752,9 +746,9 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   int64_t bx = (per_q * 2 + 63) / 64;
   if (bx > 2048) bx = 2048;
   if (bx < 1) bx = 1;
-  const int64_t groups = (sh.B + 7) / 8;
-  // walks the per-document UNIQUE code lists (max over a multiset == max over its set)
-  hipLaunchKernelGGL(k_approx, dim3((unsigned)(bx * 8 * groups)), dim3(256), 0, st, S, ix.C, sh.B, (int)bx, sh.Q, sh.Qp, cand_off, cand_pid,
+  // walks the per-document UNIQUE code lists (max over a multiset == max over its set).
+  // (an XCD-affine query assignment was measured slower: 8.3 vs 7.6 ms)
+  hipLaunchKernelGGL(k_approx, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
                      ix.uoff, ix.ucodes, approx);
 }
 
@@ -778,6 +772,9 @@ __global__ void k_sel_init(const int64_t* __restrict__ cand_off, int B, int64_t 
   s[2] = 0u;
   s[3] = (uint32_t)keep;
   s[4] = (uint32_t)n;
+  s[5] = 0u;  // elements strictly above the threshold gathered so far
+  s[6] = 0u;  // elements equal to the threshold seen
+  s[7] = 0u;  // tie buffer overflow -> ordered fallback
   sel_cnt[b] = (int32_t)keep;
 }
 
@@ -852,6 +849,7 @@ __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ 
                                                       int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx) {
   const int b = blockIdx.x;
   const uint32_t* s = st + (int64_t)b * 8;
+  if (!s[7]) return;  // fallback only: the tie buffer of k_sel_gather overflowed for this query
   const bool need = s[0] != 0;
   const uint32_t kstar = s[2];
   const uint32_t need_eq = s[3];
@@ -902,8 +900,101 @@ __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ 
   }
 }
 
+// parallel gather: elements above the threshold go straight to the output (any order), elements
+// equal to it into a tie buffer; k_sel_finish then picks the need_eq smallest doc ids among the
+// ties and sorts the selection by doc id (the order every later stage expects).
+__global__ __launch_bounds__(256) void k_sel_gather(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                    const int64_t* __restrict__ cand_off, uint32_t* __restrict__ st, int64_t R,
+                                                    int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
+                                                    int32_t* __restrict__ tie_pid) {
+  const int b = blockIdx.y;
+  uint32_t* s = st + (int64_t)b * 8;
+  const bool need = s[0] != 0;
+  const uint32_t kstar = s[2];
+  const uint32_t keep = s[1];
+  const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  int32_t* tp = tie_pid + (int64_t)b * R;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = approx[beg + i];
+    if (!need) {  // everything is kept, already in ascending doc-id order
+      if (i < (int64_t)keep) { op[i] = cand_pid[beg + i]; oa[i] = a; }
+      continue;
+    }
+    const uint32_t key = mono32(a);
+    if (key > kstar) {
+      const uint32_t pos = atomicAdd(&s[5], 1u);
+      if (pos < keep) { op[pos] = cand_pid[beg + i]; oa[pos] = a; }
+    } else if (key == kstar) {
+      const uint32_t pos = atomicAdd(&s[6], 1u);
+      if (pos < (uint32_t)R) tp[pos] = cand_pid[beg + i]; else s[7] = 1u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, int64_t R, int32_t* __restrict__ sel_pid,
+                                                     float* __restrict__ sel_approx, const int32_t* __restrict__ tie_pid) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  uint32_t* s = st + (int64_t)b * 8;
+  if (!s[0] || s[7]) return;  // nothing selected away, or fallback
+  const uint32_t keep = s[1], need_eq = s[3], n_gt = s[5];
+  const uint32_t n_eq = s[6] < (uint32_t)R ? s[6] : (uint32_t)R;
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  const int32_t* tp = tie_pid + (int64_t)b * R;
+  // 1) ties: ascending doc id, first need_eq of them complete the selection
+  int tp2 = 2;
+  while (tp2 < (int)n_eq) tp2 <<= 1;
+  unsigned int* tv = reinterpret_cast<unsigned int*>(smem);
+  for (int i = threadIdx.x; i < tp2; i += 1024) tv[i] = (i < (int)n_eq) ? (unsigned int)tp[i] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (int k = 2; k <= tp2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < tp2; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned int a = tv[i], c = tv[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { tv[i] = c; tv[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const float kval = unmono32(s[2]);
+  for (int i = threadIdx.x; i < (int)need_eq && n_gt + i < keep; i += 1024) { op[n_gt + i] = (int32_t)tv[i]; oa[n_gt + i] = kval; }
+  __syncthreads();
+  // 2) whole selection ascending by doc id (64-bit keys: id << 32 | approx bits)
+  int kp2 = 2;
+  while (kp2 < (int)keep) kp2 <<= 1;
+  unsigned long long* kv = reinterpret_cast<unsigned long long*>(smem);
+  __syncthreads();
+  for (int i = threadIdx.x; i < kp2; i += 1024)
+    kv[i] = (i < (int)keep) ? (((unsigned long long)(uint32_t)op[i] << 32) | (unsigned long long)__float_as_uint(oa[i])) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= kp2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < kp2; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = kv[i], c = kv[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { kv[i] = c; kv[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < (int)keep; i += 1024) {
+    op[i] = (int32_t)(kv[i] >> 32);
+    oa[i] = __uint_as_float((uint32_t)kv[i]);
+  }
+}
+
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
-                uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, hipStream_t st) {
+                uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st) {
   const int B = sh.B;
   (void)hipMemsetAsync(hist, 0, (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t), st);
   hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, cand_off, B, sh.n_full, sh.R, selstate, sel_cnt);
@@ -914,6 +1005,19 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   hipLaunchKernelGGL(k_sel_scan<1>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
   hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
   hipLaunchKernelGGL(k_sel_scan<2>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
+  hipLaunchKernelGGL(k_sel_gather, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
+                     tie_pid);
+  {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      attr_set = true;
+    }
+    int kp2 = 2;
+    while (kp2 < (int)sh.R) kp2 <<= 1;
+    hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8, st, selstate, sh.R, sel_pid, sel_approx, tie_pid);
+  }
+  // ordered single-block fallback, only for queries whose tie buffer overflowed (e.g. all scores equal)
   hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
                      sel_approx);
 }
