@@ -473,7 +473,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   int NP = 1;
   while (NP < np) NP <<= 1;
   P.nchunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, D.C / 2048));
-  HIPCHK(s->partial.ensure((size_t)B * sh.Qp * P.nchunk * 8 * NP * 8));
+  (void)NP;
+  HIPCHK(s->partial.ensure(fpk_probe_scratch_bytes(D, sh, P.nchunk)));
   HIPCHK(s->cells.ensure((size_t)B * sh.Q * np * 4));
   HIPCHK(s->ucells.ensure((size_t)B * sh.Q * np * 4));
   HIPCHK(s->ncells.ensure((size_t)B * 4));

@@ -62,6 +62,7 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* q_pad, uint16_t* S
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow /*[B][Cw] or null*/,
               unsigned long long* partial, int nchunk, int32_t* cells /*[B][Q][n_probe]*/, int32_t* ucells /*[B][Q*n_probe]*/,
               int32_t* ncells /*[B]*/, hipStream_t st);
+size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);
 void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off /*[B+1] dev*/, int B,
                         uint32_t* subbm /*[B][W]*/, int64_t W, uint32_t* allow /*[B][Cw]*/, int64_t Cw,
                         int32_t* invalid /*[B]*/, hipStream_t st);

@@ -206,8 +206,9 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
 template <int NP>
 __global__ __launch_bounds__(256) void k_probe_partial(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp, int nchunk,
                                                         const uint32_t* __restrict__ allow, int64_t Cw,
-                                                        unsigned long long* __restrict__ partial) {
+                                                        unsigned long long* __restrict__ partial, const int32_t* __restrict__ flag) {
   // grid: x = chunk, y = b * (Qp/32) + colgroup.  thread: col = tid&31, slice = tid>>5 (8 slices)
+  if (flag && !*flag) return;  // fallback path of the threshold probe
   const int groups = Qp / 32;
   const int b = blockIdx.y / groups, g = blockIdx.y % groups;
   const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(256) void k_probe_partial(const uint16_t* __restric
 
 // one wave per (b, q) column: n_probe rounds of "largest key below the previous pick"
 __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __restrict__ partial, int Q, int Qp, int entries,
-                                                    int n_probe, int32_t* __restrict__ cells) {
+                                                    int n_probe, int32_t* __restrict__ cells, const int32_t* __restrict__ flag,
+                                                    int run_if) {
+  if (flag && ((*flag != 0) != (run_if != 0))) return;
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
   const unsigned long long* src = partial + ((int64_t)b * Qp + q) * entries;
@@ -325,11 +328,126 @@ __global__ __launch_bounds__(256) void k_cells_unique(const int32_t* __restrict_
   if (threadIdx.x == 0) ncells[b] = base;
 }
 
+// ---- threshold probe: two streaming passes over S with 16-byte loads ---------------------------------
+// pass A: maxima of 1024-row chunks per query column; tau = the n_probe-th largest chunk maximum
+//         (each chunk maximum IS an element, so at least n_probe elements are >= tau and the true
+//         top-n_probe all are);
+// pass B: append every element >= tau (a handful per column) to a per-column list;
+// then the exact top-n_probe (score desc, id asc) of the list.  A column whose list overflows
+// (e.g. an all-equal zero-padded query column) raises a flag and the register top-k kernel above
+// redoes the batch -- decided on the device, no host round trip.
+#define PROBE_CHUNK 1024
+#define PROBE_CAP 64
+__global__ __launch_bounds__(256) void k_probe_chunkmax(const uint16_t* __restrict__ S, int64_t C, int Qp, int nchunk,
+                                                        const uint32_t* __restrict__ allow, int64_t Cw,
+                                                        uint16_t* __restrict__ cmax /*[B*Qp][nchunk]*/) {
+  const int groups = Qp / 32;
+  const int b = blockIdx.y / groups, g = blockIdx.y % groups;
+  const int chunk = blockIdx.x;
+  const int piece = threadIdx.x & 3, rl = threadIdx.x >> 2;  // 8 columns, row lane 0..63
+  const half_t ninf = __builtin_bit_cast(half_t, (uint16_t)0xFC00);
+  h2 m[4] = {h2{ninf, ninf}, h2{ninf, ninf}, h2{ninf, ninf}, h2{ninf, ninf}};
+  const uint16_t* Sb = S + ((int64_t)b * C) * Qp + g * 32 + piece * 8;
+  const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
+#pragma unroll 4
+  for (int i = 0; i < PROBE_CHUNK / 64; ++i) {
+    const int64_t c = (int64_t)chunk * PROBE_CHUNK + i * 64 + rl;
+    if (c < C && (!al || ((al[c >> 5] >> (c & 31)) & 1u))) {
+      const uint4 v = *reinterpret_cast<const uint4*>(Sb + c * Qp);
+      m[0] = pk_max(m[0], u32_as_h2(v.x)); m[1] = pk_max(m[1], u32_as_h2(v.y));
+      m[2] = pk_max(m[2], u32_as_h2(v.z)); m[3] = pk_max(m[3], u32_as_h2(v.w));
+    }
+  }
+#pragma unroll
+  for (int s = 4; s < 64; s <<= 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = pk_max(m[j], u32_as_h2(shfl_xor_u32(h2_as_u32(m[j]), s)));
+  __shared__ uint32_t red[4][4][4];  // [wave][piece][j]
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][piece][j] = h2_as_u32(m[j]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {  // thread = (piece p, j): two columns
+    const int p = threadIdx.x >> 2, j = threadIdx.x & 3;
+    h2 r = u32_as_h2(red[0][p][j]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) r = pk_max(r, u32_as_h2(red[w][p][j]));
+    const int q = g * 32 + p * 8 + j * 2;
+    cmax[((int64_t)b * Qp + q) * nchunk + chunk] = __builtin_bit_cast(uint16_t, r.x);
+    cmax[((int64_t)b * Qp + q + 1) * nchunk + chunk] = __builtin_bit_cast(uint16_t, r.y);
+  }
+}
+
+// one wave per (b, q): tau = n_probe-th largest chunk maximum (as a mono16 key; 0 = collect everything)
+__global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ cmax, int Q, int Qp, int nchunk, int n_probe,
+                                                  uint32_t* __restrict__ tau /*[B*Qp]*/) {
+  const int b = blockIdx.x / Q, q = blockIdx.x % Q;
+  const int lane = threadIdx.x;
+  const uint16_t* src = cmax + ((int64_t)b * Qp + q) * nchunk;
+  uint32_t bound = 0xFFFFFFFFu, m = 0;
+  if (nchunk < n_probe) {
+    if (lane == 0) tau[(int64_t)b * Qp + q] = 0u;
+    return;
+  }
+  for (int r = 0; r < n_probe; ++r) {  // keys (mono16 << 12 | chunk) are unique; chunks < 4096
+    m = 0;
+    for (int i = lane; i < nchunk; i += 64) {
+      const uint32_t kk = (mono16(src[i]) << 12) | (uint32_t)(nchunk - 1 - i);
+      if (kk < bound && kk > m) m = kk;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const uint32_t o = shfl_xor_u32(m, s);
+      m = o > m ? o : m;
+    }
+    bound = m;
+  }
+  if (lane == 0) tau[(int64_t)b * Qp + q] = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
+}
+
+__global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
+                                                       const uint32_t* __restrict__ allow, int64_t Cw,
+                                                       const uint32_t* __restrict__ tau, uint32_t* __restrict__ cnt /*[B*Qp]*/,
+                                                       unsigned long long* __restrict__ cand /*[B*Qp][PROBE_CAP]*/,
+                                                       int32_t* __restrict__ flag) {
+  const int groups = Qp / 32;
+  const int b = blockIdx.y / groups, g = blockIdx.y % groups;
+  const int chunk = blockIdx.x;
+  const int piece = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int q0 = g * 32 + piece * 8;
+  uint32_t tq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) tq[j] = (q0 + j < Q) ? tau[(int64_t)b * Qp + q0 + j] : 0xFFFFFFFFu;  // pad columns collect nothing
+  const uint16_t* Sb = S + ((int64_t)b * C) * Qp + q0;
+  const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
+  for (int i = 0; i < PROBE_CHUNK / 64; ++i) {
+    const int64_t c = (int64_t)chunk * PROBE_CHUNK + i * 64 + rl;
+    if (c >= C || (al && !((al[c >> 5] >> (c & 31)) & 1u))) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(Sb + c * Qp);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint16_t hv = (uint16_t)(w[j >> 1] >> (16 * (j & 1)));
+      const uint32_t key = mono16(hv);
+      if (key >= tq[j]) {
+        const int64_t col = (int64_t)b * Qp + q0 + j;
+        const uint32_t pos = atomicAdd(&cnt[col], 1u);
+        if (pos < PROBE_CAP)
+          cand[col * PROBE_CAP + pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)c);
+        else
+          *flag = 1;
+      }
+    }
+  }
+}
+
 template <int NP>
 static void launch_probe_partial(const uint16_t* S, const FpIndexDev& ix, const FpSearchShape& sh, int nchunk,
-                                 const uint32_t* allow, int64_t Cw, unsigned long long* partial, hipStream_t st) {
+                                 const uint32_t* allow, int64_t Cw, unsigned long long* partial, const int32_t* flag, hipStream_t st) {
   dim3 grid((unsigned)nchunk, (unsigned)(sh.B * (sh.Qp / 32)));
-  hipLaunchKernelGGL(k_probe_partial<NP>, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, nchunk, allow, Cw, partial);
+  hipLaunchKernelGGL(k_probe_partial<NP>, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, nchunk, allow, Cw, partial, flag);
 }
 
 static int next_pow2(int x) {
@@ -338,23 +456,57 @@ static int next_pow2(int x) {
   return p;
 }
 
+// scratch layout inside `partial` (bytes): [cand B*Qp*CAP*8][fallback partial B*Qp*nchunk*8*NP*8][cmax B*Qp*nch2*2][tau B*Qp*4][cnt B*Qp*4][flag 4]
+size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk) {
+  int NP = 1;
+  while (NP < (sh.n_probe > 1 ? sh.n_probe : 1)) NP <<= 1;
+  const size_t cols = (size_t)sh.B * sh.Qp;
+  const size_t nch2 = (size_t)((ix.C + PROBE_CHUNK - 1) / PROBE_CHUNK);
+  return cols * PROBE_CAP * 8 + cols * nchunk * 8 * NP * 8 + ((cols * nch2 * 2 + 15) & ~(size_t)15) + cols * 4 + cols * 4 + 64;
+}
+
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
               unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells, hipStream_t st) {
   const int64_t Cw = (ix.C + 31) / 32;
   int NP = 1;
   while (NP < sh.n_probe) NP <<= 1;
-  switch (NP) {
-    case 1: launch_probe_partial<1>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
-    case 2: launch_probe_partial<2>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
-    case 4: launch_probe_partial<4>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
-    case 8: launch_probe_partial<8>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
-    case 16: launch_probe_partial<16>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
-    case 32: launch_probe_partial<32>(S, ix, sh, nchunk, allow, Cw, partial, st); break;
-    default: return -1;
+  if (NP > 32) return -1;
+  const size_t cols = (size_t)sh.B * sh.Qp;
+  const int nch2 = (int)((ix.C + PROBE_CHUNK - 1) / PROBE_CHUNK);
+  unsigned char* base = reinterpret_cast<unsigned char*>(partial);
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(base);
+  unsigned long long* fb_partial = reinterpret_cast<unsigned long long*>(base + cols * PROBE_CAP * 8);
+  unsigned char* p2 = base + cols * PROBE_CAP * 8 + cols * nchunk * 8 * NP * 8;
+  uint16_t* cmax = reinterpret_cast<uint16_t*>(p2);
+  p2 += (cols * nch2 * 2 + 15) & ~(size_t)15;
+  uint32_t* tau = reinterpret_cast<uint32_t*>(p2);
+  uint32_t* cnt = tau + cols;
+  int32_t* flag = reinterpret_cast<int32_t*>(cnt + cols);
+  // the chunk index must fit the 12 low bits of the tau keys
+  const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP;
+  if (threshold_ok) {
+    (void)hipMemsetAsync(cand, 0, cols * PROBE_CAP * 8, st);
+    (void)hipMemsetAsync(cnt, 0, cols * 4 + 4, st);  // counters + flag
+    dim3 grid((unsigned)nch2, (unsigned)(sh.B * (sh.Qp / 32)));
+    hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);
+    hipLaunchKernelGGL(k_probe_tau, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cmax, sh.Q, sh.Qp, nch2, sh.n_probe, tau);
+    hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag);
+    hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
+                       flag, 0);
+  } else {
+    (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
   }
-  const int entries = nchunk * 8 * NP;
-  hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, partial, sh.Q, sh.Qp, entries,
-                     sh.n_probe, cells);
+  // fallback (runs only when the flag is set)
+  switch (NP) {
+    case 1: launch_probe_partial<1>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
+    case 2: launch_probe_partial<2>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
+    case 4: launch_probe_partial<4>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
+    case 8: launch_probe_partial<8>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
+    case 16: launch_probe_partial<16>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
+    default: launch_probe_partial<32>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
+  }
+  hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, fb_partial, sh.Q, sh.Qp, nchunk * 8 * NP, sh.n_probe,
+                     cells, flag, 1);
   const int n = sh.Q * sh.n_probe;
   const int np2 = next_pow2(n);
   hipLaunchKernelGGL(k_cells_unique, dim3((unsigned)sh.B), dim3(256), (size_t)np2 * 4, st, cells, n, np2, ucells, ncells);
