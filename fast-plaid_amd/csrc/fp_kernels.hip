@@ -13,7 +13,9 @@
 // tensor op = fp32 arithmetic + one round-to-nearest-even to fp16; matmuls accumulate in
 // fp32 and round once.  The MFMA accumulation ORDER differs from the CPU's ascending-k
 // chain, which is the only source of (<= 1 fp16 ulp, rare) differences.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "fp_internal.h"
 
@@ -375,8 +377,10 @@ __global__ __launch_bounds__(256) void k_probe_chunkmax(const uint16_t* __restri
 #pragma unroll
     for (int w = 1; w < 4; ++w) r = pk_max(r, u32_as_h2(red[w][p][j]));
     const int q = g * 32 + p * 8 + j * 2;
-    cmax[((int64_t)b * Qp + q) * nchunk + chunk] = __builtin_bit_cast(uint16_t, r.x);
-    cmax[((int64_t)b * Qp + q + 1) * nchunk + chunk] = __builtin_bit_cast(uint16_t, r.y);
+    // (explicit integer extraction: `bit_cast<uint16_t>(r.y)` was compiled to a store of the LOW half)
+    const uint32_t ru = h2_as_u32(r);
+    cmax[((int64_t)b * Qp + q) * nchunk + chunk] = (uint16_t)(ru & 0xFFFFu);
+    cmax[((int64_t)b * Qp + q + 1) * nchunk + chunk] = (uint16_t)(ru >> 16);
   }
 }
 
@@ -483,7 +487,9 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
   uint32_t* cnt = tau + cols;
   int32_t* flag = reinterpret_cast<int32_t*>(cnt + cols);
   // the chunk index must fit the 12 low bits of the tau keys
-  const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP;
+  static int force_fb = -1;
+  if (force_fb < 0) force_fb = getenv("FP_PROBE_FALLBACK") ? 1 : 0;
+  const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP && !force_fb;
   if (threshold_ok) {
     (void)hipMemsetAsync(cand, 0, cols * PROBE_CAP * 8, st);
     (void)hipMemsetAsync(cnt, 0, cols * 4 + 4, st);  // counters + flag
@@ -493,6 +499,20 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag);
     hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
                        flag, 0);
+    if (getenv("FP_PROBE_DEBUG")) {
+      (void)hipStreamSynchronize(st);
+      std::vector<uint32_t> ht(cols), hc(cols + 1);
+      std::vector<uint16_t> hm(cols * nch2);
+      (void)hipMemcpy(ht.data(), tau, cols * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hc.data(), cnt, cols * 4 + 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hm.data(), cmax, cols * nch2 * 2, hipMemcpyDeviceToHost);
+      fprintf(stderr, "PROBE_DEBUG flag=%u\n", hc[cols]);
+      for (size_t c = 0; c < cols && c < 64; ++c) {
+        fprintf(stderr, "col %zu tau=%04x cnt=%u cmax:", c, ht[c], hc[c]);
+        for (int j = 0; j < nch2 && j < 8; ++j) fprintf(stderr, " %04x", hm[c * nch2 + j]);
+        fprintf(stderr, "\n");
+      }
+    }
   } else {
     (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
   }
