@@ -802,17 +802,13 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 //     eight independent row gathers per lane in flight;
 //   * grid = (blocks, queries): the query is blockIdx.y, no per-candidate search.
 // ============================================================================================
-// broadcast lane k (0..3) of each quad to the whole quad: one VALU DPP move, no LDS traffic
-template <int K>
-__device__ __forceinline__ int32_t quad_bcast(int32_t v) {
-  return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false);  // quad_perm:[K,K,K,K]
-}
-
 __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                 float* __restrict__ approx) {
   const int b = blockIdx.y;
+  const int bxi = blockIdx.x;
+  const int bx = gridDim.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
@@ -820,29 +816,26 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
   const half_t negm = (half_t)NEG_MASK_F;
   const h2 neg2 = {negm, negm};
   const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
-  const int64_t stride = (int64_t)gridDim.x * 64;
+  const int64_t stride = (int64_t)bx * 64;
   const int nch = Qp / 32;
-  int64_t i = (int64_t)blockIdx.x * 64 + grp;
+  int64_t i = (int64_t)bxi * 64 + grp;
   // Software pipeline over the dependent chain  pid -> offsets -> codes -> rows:
-  //   * document metadata one document ahead;
-  //   * the 8 codes of a step are loaded COOPERATIVELY (lane s of the 4-lane group holds codes
-  //     t+s and t+4+s: 2 loads instead of 8 per lane, 4x fewer L1 tag accesses) and broadcast
-  //     inside the quad with DPP;
-  //   * the next step's codes (or the first codes of the next document) are fetched while the
-  //     current 8 row gathers are in flight, so one round trip per 8 rows stays on the critical path.
+  //   document metadata is fetched one document ahead, the next 8 codes (of this document, or
+  //   the first 8 of the next one) are fetched while the current 8 row gathers are in flight,
+  //   so only ONE round trip per 8 rows stays on the critical path.
   int64_t u0 = 0;
   int len = 0;
-  int32_t c_lo = 0, c_hi = 0;  // codes t+sub and t+4+sub of the upcoming step
-  auto fetch_codes = [&](const int32_t* base, int t, int l) {
-    const int a0 = t + sub, a1 = t + 4 + sub;
-    c_lo = base[a0 < l ? a0 : l - 1];  // max is idempotent: the tail re-reads the last code
-    c_hi = base[a1 < l ? a1 : l - 1];
-  };
+  int32_t code[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) code[k] = 0;
   if (i < n) {
     const int32_t pid = cand_pid[beg + i];
     u0 = uoff[pid];
     len = (int)(uoff[pid + 1] - u0);
-    if (len > 0) fetch_codes(ucodes + u0, 0, len);
+    if (len > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[u0 + ((k < len) ? k : (len - 1))];
+    }
   }
   for (; i < n; i += stride) {
     int64_t nu0 = 0;
@@ -857,11 +850,11 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     for (int ch = 0; ch < nch; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
       const uint16_t* Sc = Sb + ch * 32;
-      if (ch > 0 && len > 0) fetch_codes(cp, 0, len);  // further 32-column chunks restart from the first codes
+      if (ch > 0 && len > 0) {  // further 32-column chunks restart from the document's first codes
+#pragma unroll
+        for (int k = 0; k < 8; ++k) code[k] = cp[(k < len) ? k : (len - 1)];
+      }
       for (int t = 0; t < len; t += 8) {
-        int32_t code[8];
-        code[0] = quad_bcast<0>(c_lo); code[1] = quad_bcast<1>(c_lo); code[2] = quad_bcast<2>(c_lo); code[3] = quad_bcast<3>(c_lo);
-        code[4] = quad_bcast<0>(c_hi); code[5] = quad_bcast<1>(c_hi); code[6] = quad_bcast<2>(c_hi); code[7] = quad_bcast<3>(c_hi);
         uint4 v[8];
 #if AP_ABL & 1
 #pragma unroll
@@ -870,8 +863,19 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
 #endif
-        if (t + 8 < len) fetch_codes(cp, t + 8, len);
-        else if (ch == nch - 1 && nlen > 0) fetch_codes(ucodes + nu0, 0, nlen);
+        // next codes while the rows are in flight (max is idempotent: the tail re-reads the last code)
+        if (t + 8 < len) {
+#if AP_ABL & 2
+#pragma unroll
+          for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)(code[k] * 2654435761u + k)) % (uint32_t)C);
+#else
+#pragma unroll
+          for (int k = 0; k < 8; ++k) code[k] = cp[(t + 8 + k < len) ? (t + 8 + k) : (len - 1)];
+#endif
+        } else if (ch == nch - 1 && nlen > 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           m0 = pk_max(m0, u32_as_h2(v[k].x));
@@ -892,9 +896,12 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
       s += (q0 + 7 < Q) ? (float)m3.y : 0.f;
       total += s;
     }
-    if (len == 0 && nlen > 0) fetch_codes(ucodes + nu0, 0, nlen);  // an empty document never reaches the prefetch slot
-    // the 4 lanes of the group hold disjoint column sums (the lanes of one group run the same trip
-    // counts, so the quad-level operations are convergent within the group)
+    if (len == 0 && nlen > 0) {  // an empty document never reaches the prefetch slot above
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+    }
+    // the 4 lanes of the group hold disjoint column sums (lanes of one group run the same trip
+    // counts, so the shuffles are convergent within the group; other groups may have exited)
     total += __shfl_xor(total, 1, 64);
     total += __shfl_xor(total, 2, 64);
     if (sub == 0) approx[beg + i] = total;
