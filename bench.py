@@ -56,8 +56,32 @@ def parse():
     return ap.parse_args()
 
 
+def _pmc_traffic(kernel_prefix, applicable):
+    """HBM-side read bytes per launch of one kernel, from the newest committed PMC summary
+    (profiles/*_pmc_traffic.json, written by tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE in its own
+    pass, doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC counters cannot be collected from
+    inside this process, so the number is the one measured on the default workload; any other workload
+    reports null."""
+    import glob
+    if not applicable:
+        return None, None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None, None
+    for name, e in ks.items():
+        if name.startswith(kernel_prefix) and "hbm_read_bytes_corrected" in e:
+            return int(e["hbm_read_bytes_corrected"]), "profiles/" + os.path.basename(files[-1])
+    return None, None
+
+
 def main():
     a = parse()
+    default_cfg = (a.docs == 1_000_000 and a.doc_len == 128 and a.centroids == 0 and a.batch == 64 and a.qlen == 32 and
+                   a.topk == 1000 and a.nfull == 4096 and a.nprobe == 8 and a.dim == 128 and a.nbits == 4)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,8 +176,10 @@ def main():
         bytes_maxsim = rer_docs * (a.doc_len * (pr + 4) + 20) + C * a.dim * 2 + a.batch * a.qlen * a.dim * 2
         t_ms = stages.get("S6+S7 maxsim", 0.0)
         ach = bytes_maxsim / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        traffic, traffic_src = _pmc_traffic("k_maxsim", default_cfg)
         out["roofline"] = {"kernel": "k_maxsim (fused decompress + exact MaxSim)", "bound": "hbm", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": bytes_maxsim, "avg_launch_ms": t_ms,
                            "mfma_tflops": 2.0 * a.dim * a.qlen * rer_docs * a.doc_len / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0}
         cand_per_step = cand_total / a.steps

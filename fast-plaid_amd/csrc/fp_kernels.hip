@@ -499,20 +499,6 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag);
     hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
                        flag, 0);
-    if (getenv("FP_PROBE_DEBUG")) {
-      (void)hipStreamSynchronize(st);
-      std::vector<uint32_t> ht(cols), hc(cols + 1);
-      std::vector<uint16_t> hm(cols * nch2);
-      (void)hipMemcpy(ht.data(), tau, cols * 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hc.data(), cnt, cols * 4 + 4, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(hm.data(), cmax, cols * nch2 * 2, hipMemcpyDeviceToHost);
-      fprintf(stderr, "PROBE_DEBUG flag=%u\n", hc[cols]);
-      for (size_t c = 0; c < cols && c < 64; ++c) {
-        fprintf(stderr, "col %zu tau=%04x cnt=%u cmax:", c, ht[c], hc[c]);
-        for (int j = 0; j < nch2 && j < 8; ++j) fprintf(stderr, " %04x", hm[c * nch2 + j]);
-        fprintf(stderr, "\n");
-      }
-    }
   } else {
     (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
   }

@@ -227,6 +227,44 @@ def test_synthetic_vs_oracle(fp, cfg):
     assert identical >= cfg["B"] // 2, f"only {identical}/{cfg['B']} queries returned id lists identical to the oracle"
 
 
+def test_probe_with_massive_ties_takes_device_fallback(fp):
+    """200 identical centroid rows tie exactly at the top of every query column: more than the
+    threshold probe's per-column capacity (64) pass its cut, so the device raises the fallback flag
+    and the register top-k kernels run.  The probed cells must follow the (score desc, id asc)
+    rule exactly like the oracle."""
+    R = fp.fast_plaid_rust
+    spec = _synth(fp, n_docs=3000, doc_len=40, n_centroids=2048, variable_len=True, seed=5)
+    arr = fp.synth.host_index_arrays(spec)
+    cent = arr["centroids"].copy()
+    dup = np.arange(100, 300)
+    cent[dup] = cent[100]
+    arr = dict(arr, centroids=cent)
+    q = fp.synth.make_queries(spec, cent, 4, 32).copy()
+    q[:, :, :] = cent[100]              # every query token points at the duplicated centroid
+    q[1, 5:] = fp.synth.make_queries(spec, cent, 1, 32)[0, 5:]   # one mixed query
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    params = R.SearchParameters(2000, 256, 20, 8)
+    for b in range(q.shape[0]):
+        h = R.search_trace(hip, q[b], params)
+        o = orc.search_trace(q[b], 20, 256, 8)
+        assert np.array_equal(np.sort(h["cells"]), np.sort(o["cells"])), "tie rule of the probe differs from the oracle"
+        assert set(o["cells"].tolist()) >= set(range(100, 108)), "fixture no longer produces the tie it is meant to"
+        check_trace(h, o, 32, 8, 256, 20)
+
+
+def test_probe_fallback_path_forced(fp):
+    """the register top-k probe (the path taken when the threshold probe overflows) forced for
+    every query via FP_PROBE_FALLBACK=1, in a subprocess because the library reads it once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FP_PROBE_FALLBACK="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "probe_fallback_worker.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "PROBE_FALLBACK_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports

@@ -1,0 +1,44 @@
+#!/bin/bash
+# One-shot evidence run for a round: GPU tests, the bench line, the rocprofv3 kernel-trace summary of the
+# same bench command, and the PMC passes for HBM traffic (separate passes; --kernel-trace only).
+# usage (on the GPU box):  bash tools/profile_round.sh r01_b      -> files under gpurun_out/<tag>_*
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd $R
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.log
+timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 20 --warmup 5 --cpu-queries 0"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o run -- $CMD > $OUT/${TAG}_prof.log 2>&1
+python $R/tools/summarize_prof.py $(ls $OUT/${TAG}_prof/*/run_kernel_stats.csv $OUT/${TAG}_prof/run_kernel_stats.csv 2>/dev/null | head -1) \
+    $OUT/${TAG}_kernel_stats.csv "bench.py --steps 20 --warmup 5 (cfg2: 1M docs, 64 queries/batch), MI355X"
+CMD3="python $R/bench.py --steps 3 --warmup 1 --cpu-queries 0"
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_fetch -o run -- $CMD3 > $OUT/${TAG}_pmc.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/${TAG}_pmc_write -o run -- $CMD3 >> $OUT/${TAG}_pmc.log 2>&1
+python - <<PY
+import csv, glob, collections, json, re
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+for p in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/run_counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(p)):
+        k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")[:60]
+        if not k.startswith("k_"): continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+out = {}
+for k, cs in acc.items():
+    d = {c: v / max(n[(k, c)], 1) for c, v in cs.items()}
+    e = {"launches_sampled": max(n[(k, c)] for c in cs)}
+    if "FETCH_SIZE" in d:   # KB per launch; gfx950 rocprofv3 tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section)
+        e["fetch_size_kb_raw"] = round(d["FETCH_SIZE"], 1)
+        e["hbm_read_bytes_corrected"] = int(d["FETCH_SIZE"] * 1024 * 2)
+    if "WRITE_SIZE" in d:
+        e["write_size_kb_raw"] = round(d["WRITE_SIZE"], 1)
+    if "TCC_HIT_sum" in d:
+        e["l2_hit_rate"] = round(d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0.0), 1.0), 4)
+    out[k] = e
+json.dump({"command": "$CMD3", "note": "per-launch averages; FETCH_SIZE doubled per the guide's gfx950 correction; WRITE_SIZE uncalibrated",
+           "kernels": out}, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+for k in sorted(out): print(k, out[k])
+PY
+cat $OUT/${TAG}_gpu_tests.log; cat $OUT/${TAG}_bench.json
