@@ -421,7 +421,7 @@ static int validate_search(const fp_index* ix, int32_t nq, int32_t q_len, int32_
   if ((int64_t)q_len * std::max<int64_t>(p->n_ivf_probe, 1) > FP_MAX_CELLS)
     return fail(FP_EUNSUPPORTED, "q_len * n_ivf_probe > 8192 is not supported");
   const int64_t R = std::max<int64_t>(p->n_full_scores / 4, 1);
-  if (R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_full_scores > 32768 is not supported by the LDS sort");
+  if (R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_full_scores > 65536 is not supported by the LDS sort");
   return FP_OK;
 }
 
@@ -795,7 +795,13 @@ extern "C" int fp_shard_stage2(fp_shard_ctx* c, const float* all_approx, const i
   const FpIndexDev& D = c->ix->d;
   const int64_t R = c->P.sh.R;
   const int B = c->B;
-  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 8192 is not supported");
+  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 16384 is not supported");
+  {  // the global cut sorts G*R keys (8 B) next to an R-entry output list (4 B) in one workgroup's LDS
+    size_t np2 = 2, rp2 = 2;
+    while ((int64_t)np2 < (int64_t)G * R) np2 <<= 1;
+    while ((int64_t)rp2 < R) rp2 <<= 1;
+    if (np2 * 8 + rp2 * 4 + 16 > 160 * 1024) return fail(FP_EUNSUPPORTED, "n_ranks * n_full_scores too large for the LDS cut");
+  }
   HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
   HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
   fpk_transpose_ranks(all_approx, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);
@@ -822,7 +828,7 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const in
   const int64_t K = c->params.top_k;
   for (int i = 0; i < B; ++i) out_counts[i] = 0;
   if (K == 0) return FP_OK;
-  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 8192 is not supported");
+  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 16384 is not supported");
   HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
   HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
   fpk_transpose_ranks(all_score, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);

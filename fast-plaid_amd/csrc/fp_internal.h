@@ -2,12 +2,13 @@
 // host engine (fp_engine.cpp).  Not part of the C ABI (see include/fastplaid.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #define FP_WAVE 64
 #define FP_MAX_PROBE 32          // n_ivf_probe supported by the register top-k kernel
 #define FP_MAX_CELLS 8192        // q_len * n_ivf_probe cap (LDS sort of probed cells)
-#define FP_MAX_SORT 8192         // entries the LDS bitonic sort handles (R, or G*R when sharded)
+#define FP_MAX_SORT 16384        // entries the LDS bitonic sort handles (R, or G*R when sharded): 8 B keys, 128 KiB of LDS
 #define FP_SEL_BINS 2048
 
 // Device-resident index (all pointers are device memory).  Layout in HBM:
@@ -43,6 +44,17 @@ struct FpIndexDev {
   int64_t U;
   int max_doc_len;
 };
+
+// A HIP dispatch carries its grid size in work-items as a 32-bit number: blocks * block_size must
+// stay below 2^32, a larger launch silently wraps (seen at 10 M documents: 5.1e9 work-items).
+// Kernels whose natural grid scales with the index take this cap and walk a grid-stride loop.
+// FP_GRID_CAP=<blocks> (testing) lowers the cap so that small corpora exercise the loops.
+static inline unsigned fp_grid_cap(int64_t blocks, int block_size) {
+  static const int64_t env_cap = getenv("FP_GRID_CAP") ? atoll(getenv("FP_GRID_CAP")) : 0;
+  int64_t cap = 0xFFFFFFFFll / block_size;
+  if (env_cap > 0 && env_cap < cap) cap = env_cap;
+  return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
 
 // ---- launch wrappers implemented in fp_kernels.hip -----------------------------------------
 // All run on `st`; none synchronises.

@@ -1964,7 +1964,7 @@ void fpk_shard_global_cut(const float* all_approx, const int64_t* all_pid, int G
   int rp2 = next_pow2((int)(R < 2 ? 2 : R));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_shard_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_shard_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   hipLaunchKernelGGL(k_shard_cut, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + (size_t)rp2 * 4 + 16, st, all_approx, all_pid, n, np2, R,
@@ -1975,12 +1975,12 @@ void fpk_shard_global_cut(const float* all_approx, const int64_t* all_pid, int G
 // misc
 // ============================================================================================
 __global__ void k_narrow(const int64_t* __restrict__ in, int32_t* __restrict__ out, int64_t n, int64_t add) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (int32_t)(in[i] + add);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int32_t)(in[i] + add);
 }
 void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n, add);
+  hipLaunchKernelGGL(k_narrow, dim3(fp_grid_cap((n + 255) / 256, 256)), dim3(256), 0, st, in, out, n, add);
 }
 
 // reconstruct_embeddings (embeddings.rs:12-69): decompress rows to fp32.  One 64-thread

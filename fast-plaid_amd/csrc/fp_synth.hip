@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void k_synth_generate(FpSynthParams p, const i
                                                         int64_t tok_base, int32_t* __restrict__ codes,
                                                         uint8_t* __restrict__ residuals) {
   const int lane = threadIdx.x & 63;
-  const int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (d >= n_docs) return;
+  const int64_t dstep = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n_docs; d += dstep) {
   const uint64_t pid = (uint64_t)(p.doc_begin + d);
   const uint64_t k_topic = stream_key(p.seed, S_TOPIC), k_tok = stream_key(p.seed, S_TOKEN), k_res = stream_key(p.seed, S_RESID);
   const uint64_t Cmask = (uint64_t)p.C - 1ull;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void k_synth_generate(FpSynthParams p, const i
       }
     }
   }
+  }
 }
 
 void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_docs, int64_t T, int64_t tok_base, int32_t* codes,
@@ -104,7 +105,7 @@ void fps_generate(const FpSynthParams& p, const int64_t* doc_off_dev, int64_t n_
   (void)T;
   if (n_docs <= 0) return;
   const int64_t blocks = (n_docs + 3) / 4;
-  hipLaunchKernelGGL(k_synth_generate, dim3((unsigned)blocks), dim3(256), 0, st, p, doc_off_dev, n_docs, tok_base, codes, residuals);
+  hipLaunchKernelGGL(k_synth_generate, dim3(fp_grid_cap(blocks, 256)), dim3(256), 0, st, p, doc_off_dev, n_docs, tok_base, codes, residuals);
 }
 
 // ---- in-document token sort by centroid code -------------------------------------------------------
@@ -113,14 +114,13 @@ __global__ __launch_bounds__(64) void k_doc_sort(int32_t* __restrict__ codes, co
                                                  uint16_t* __restrict__ perm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
-  const int64_t d = blockIdx.x;
-  if (d >= n_docs) return;
   const int lane = threadIdx.x;
+  for (int64_t d = blockIdx.x; d < n_docs; d += gridDim.x) {
   const int64_t off = doc_off[d];
   const int n = (int)(doc_off[d + 1] - off);
   if (n > SORT_MAX_LEN) {
     for (int i = lane; i < n; i += 64) perm[off + i] = (uint16_t)(i & 0xFFFF);  // not sorted: identity (only valid for n < 65536)
-    return;
+    continue;
   }
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
@@ -144,16 +144,17 @@ __global__ __launch_bounds__(64) void k_doc_sort(int32_t* __restrict__ codes, co
     codes[off + i] = (int32_t)(v[i] >> 32);
     perm[off + i] = (uint16_t)(v[i] & 0xFFFF);
   }
+  __syncthreads();  // the next document reuses the LDS buffer
+  }
 }
 
 // new_res[off + i] = old_res[off + perm[i]]; 16 bytes per thread
 __global__ void k_permute_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint16_t* __restrict__ perm,
                                const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t T, int pr) {
   const int ppr = pr / 16 > 0 ? pr / 16 : 1;
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < T * ppr; g += (int64_t)gridDim.x * blockDim.x) {
   const int64_t row = g / ppr;
   const int piece = (int)(g % ppr);
-  if (row >= T) return;
   // document of `row`: binary search over doc_off
   int64_t lo = 0, hi = n_docs;
   while (hi - lo > 1) {
@@ -166,6 +167,7 @@ __global__ void k_permute_rows(const uint8_t* __restrict__ src, uint8_t* __restr
     *reinterpret_cast<uint4*>(dst + row * pr + piece * 16) = *reinterpret_cast<const uint4*>(src + srow * pr + piece * 16);
   } else {
     for (int b = 0; b < pr; ++b) dst[row * pr + b] = src[srow * pr + b];
+  }
   }
 }
 
@@ -184,12 +186,12 @@ int fps_sort_docs(int32_t* codes, uint8_t* residuals, const int64_t* doc_off_dev
     return 0;
   }
   while (np2 < max_len && np2 < SORT_MAX_LEN) np2 <<= 1;
-  hipLaunchKernelGGL(k_doc_sort, dim3((unsigned)n_docs), dim3(64), (size_t)np2 * 8, st, codes, doc_off_dev, n_docs, *perm);
+  hipLaunchKernelGGL(k_doc_sort, dim3(fp_grid_cap(n_docs, 64)), dim3(64), (size_t)np2 * 8, st, codes, doc_off_dev, n_docs, *perm);
   HCHK0(hipMalloc((void**)&tmp, (size_t)T * pr + 64));
   {
     const int ppr = pr / 16 > 0 ? pr / 16 : 1;
     const int64_t threads = T * ppr;
-    hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, residuals, tmp, *perm, doc_off_dev, n_docs,
+    hipLaunchKernelGGL(k_permute_rows, dim3(fp_grid_cap((threads + 255) / 256, 256)), dim3(256), 0, st, residuals, tmp, *perm, doc_off_dev, n_docs,
                        T, pr);
   }
   HCHK0(hipMemcpyAsync(residuals, tmp, (size_t)T * pr, hipMemcpyDeviceToDevice, st));
@@ -213,15 +215,14 @@ __global__ __launch_bounds__(64) void k_doc_unique(const int32_t* __restrict__ c
                                                    int32_t* __restrict__ ucodes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int32_t* v = reinterpret_cast<int32_t*>(smem);
-  const int64_t d = blockIdx.x;
-  if (d >= n_docs) return;
   const int lane = threadIdx.x;
+  for (int64_t d = blockIdx.x; d < n_docs; d += gridDim.x) {
   const int64_t off = doc_off[d];
   const int n = (int)(doc_off[d + 1] - off);
   if (n > UNIQ_MAX_LEN) {
     if (WRITE) { for (int i = lane; i < n; i += 64) ucodes[uoff[d] + i] = codes[off + i]; }
     else if (lane == 0) ulen[d] = n;
-    return;
+    continue;
   }
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
@@ -253,6 +254,8 @@ __global__ __launch_bounds__(64) void k_doc_unique(const int32_t* __restrict__ c
     base += __popcll(m);
   }
   if (!WRITE && lane == 0) ulen[d] = base;
+  __syncthreads();  // the next document reuses the LDS buffer
+  }
 }
 
 #define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto fail; } } while (0)
@@ -276,14 +279,14 @@ int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n
   lds = (size_t)np2 * 4;
   HCHK(hipMalloc((void**)&ulen, (size_t)(n_docs + 1) * 8));
   HCHK(hipMemsetAsync(ulen, 0, (size_t)(n_docs + 1) * 8, st));
-  hipLaunchKernelGGL(k_doc_unique<false>, dim3((unsigned)n_docs), dim3(64), lds, st, codes, doc_off_dev, n_docs, ulen, nullptr, nullptr);
+  hipLaunchKernelGGL(k_doc_unique<false>, dim3(fp_grid_cap(n_docs, 64)), dim3(64), lds, st, codes, doc_off_dev, n_docs, ulen, nullptr, nullptr);
   HCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ulen, uoff_dev, (int)(n_docs + 1), st));
   HCHK(hipMalloc(&tmp, tb ? tb : 16));
   HCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, ulen, uoff_dev, (int)(n_docs + 1), st));
   HCHK(hipMemcpyAsync(U, uoff_dev + n_docs, 8, hipMemcpyDeviceToHost, st));
   HCHK(hipStreamSynchronize(st));
   HCHK(hipMalloc((void**)ucodes, (size_t)(*U > 0 ? *U : 4) * 4 + 64));
-  hipLaunchKernelGGL(k_doc_unique<true>, dim3((unsigned)n_docs), dim3(64), lds, st, codes, doc_off_dev, n_docs, nullptr, uoff_dev, *ucodes);
+  hipLaunchKernelGGL(k_doc_unique<true>, dim3(fp_grid_cap(n_docs, 64)), dim3(64), lds, st, codes, doc_off_dev, n_docs, nullptr, uoff_dev, *ucodes);
   HCHK(hipStreamSynchronize(st));
 fail:
   if (ulen) (void)hipFree(ulen);
@@ -295,16 +298,17 @@ fail:
 __global__ __launch_bounds__(256) void k_make_keys(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff,
                                                    int64_t n_docs, unsigned long long* __restrict__ keys) {
   const int lane = threadIdx.x & 63;
-  const int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (d >= n_docs) return;
-  const int64_t off = uoff[d], end = uoff[d + 1];
-  for (int64_t t = off + lane; t < end; t += 64)
-    keys[t] = ((unsigned long long)(uint32_t)ucodes[t] << 32) | (unsigned long long)(uint32_t)d;
+  const int64_t dstep = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t d = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; d < n_docs; d += dstep) {
+    const int64_t off = uoff[d], end = uoff[d + 1];
+    for (int64_t t = off + lane; t < end; t += 64)
+      keys[t] = ((unsigned long long)(uint32_t)ucodes[t] << 32) | (unsigned long long)(uint32_t)d;
+  }
 }
 
 __global__ void k_ivf_pids(const unsigned long long* __restrict__ uniq, int64_t U, int32_t* __restrict__ pids) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < U) pids[i] = (int32_t)(uint32_t)uniq[i];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += (int64_t)gridDim.x * blockDim.x)
+    pids[i] = (int32_t)(uint32_t)uniq[i];
 }
 
 __global__ void k_ivf_offsets(const unsigned long long* __restrict__ uniq, int64_t U, int64_t P, int64_t* __restrict__ ivf_off) {
@@ -339,12 +343,12 @@ int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs
   while ((1ll << (end_bit - 32)) < P) ++end_bit;
   HCHK(hipMalloc((void**)&ka, (size_t)U * 8));
   HCHK(hipMalloc((void**)&kb, (size_t)U * 8));
-  hipLaunchKernelGGL(k_make_keys, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, ka);
+  hipLaunchKernelGGL(k_make_keys, dim3(fp_grid_cap((n_docs + 3) / 4, 256)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, ka);
   HCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, ka, kb, (int)U, 0, end_bit, st));
   HCHK(hipMalloc(&tmp, tb ? tb : 16));
   HCHK(hipcub::DeviceRadixSort::SortKeys(tmp, tb, ka, kb, (int)U, 0, end_bit, st));
   HCHK(hipMalloc((void**)ivf_pids, (size_t)U * sizeof(int32_t) + 64));
-  hipLaunchKernelGGL(k_ivf_pids, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, kb, U, *ivf_pids);
+  hipLaunchKernelGGL(k_ivf_pids, dim3(fp_grid_cap((U + 255) / 256, 256)), dim3(256), 0, st, kb, U, *ivf_pids);
   hipLaunchKernelGGL(k_ivf_offsets, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, st, kb, U, P, ivf_off_dev);
   HCHK(hipStreamSynchronize(st));
   *ivf_total = U;

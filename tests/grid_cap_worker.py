@@ -1,0 +1,48 @@
+"""GPU worker for tests/test_hip_parity.py::test_index_build_with_capped_grids: runs with
+FP_GRID_CAP=3 so every index-build kernel whose grid scales with the corpus walks its
+grid-stride loop many times (the path a > 2^32 work-item launch takes at 10 M documents)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import fast_plaid_amd as fp  # noqa: E402
+import plaid_oracle as OC  # noqa: E402
+from parity import check_trace  # noqa: E402
+
+
+def main():
+    assert os.environ.get("FP_GRID_CAP") == "3"
+    R = fp.fast_plaid_rust
+    # device generator + sort + unique + IVF build == numpy twin
+    spec = fp.synth.SynthSpec(n_docs=3000, doc_len=48, n_centroids=512, variable_len=True, seed=42)
+    host = fp.synth.host_index_arrays(spec)
+    dev = R.construct_synthetic_index(spec, "cuda:0", centroids=host["centroids"])
+    offs = np.concatenate([[0], np.cumsum(host["doc_lengths"])])
+    for pid in (0, 1, 777, 2999):
+        codes, res = R.read_doc(dev, pid)
+        assert np.array_equal(codes, host["doc_codes"][offs[pid]: offs[pid + 1]])
+        assert np.array_equal(res, host["doc_residuals"][offs[pid]: offs[pid + 1]])
+    ivf_off = np.concatenate([[0], np.cumsum(host["ivf_lengths"].astype(np.int64))])
+    for cell in (0, 1, 100, 511):
+        assert np.array_equal(R.read_ivf(dev, cell), host["ivf"][ivf_off[cell]: ivf_off[cell + 1]])
+    # uploaded index (narrow + sort + unique) searched against the oracle
+    q = fp.synth.make_queries(spec, host["centroids"], 3, 32)
+    hip = R.construct_index(host["nbits"], host["centroids"], None, None, host["bucket_weights"], host["ivf"], host["ivf_lengths"],
+                            host["doc_codes"], host["doc_residuals"], host["doc_lengths"], "cuda:0", False)
+    orc = OC.OracleIndex(nbits=host["nbits"], centroids=host["centroids"], bucket_weights=host["bucket_weights"], ivf=host["ivf"],
+                         ivf_lengths=host["ivf_lengths"], doc_codes=host["doc_codes"], doc_residuals=host["doc_residuals"],
+                         doc_lengths=host["doc_lengths"])
+    params = R.SearchParameters(2000, 256, 20, 4)
+    for idx in (dev, hip):
+        for b in range(3):
+            check_trace(R.search_trace(idx, q[b], params), orc.search_trace(q[b], 20, 256, 4), 32, 4, 256, 20)
+    print("GRID_CAP_OK")
+
+
+if __name__ == "__main__":
+    main()
