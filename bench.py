@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
     ap.add_argument("--workload", type=str, default="", help="label override")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
+    ap.add_argument("--dist-mode", choices=["auto", "replica", "shard"], default="auto",
+                    help="N>1: replica = full index per GPU, batch split across ranks (the reference's multi-GPU mode); "
+                         "shard = document shards + 2 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
+    ap.add_argument("--no-alt-mode", action="store_true", help="N>1: do not also time the other distribution mode")
     return ap.parse_args()
 
 
@@ -108,49 +112,83 @@ def main():
     cent = fp.synth.centroids(spec)
     bw = fp.synth.bucket_weights(spec)
     dev = f"cuda:{local_rank}"
-    lo, hi = sharded.plan_shards(a.docs, world)[rank]
-    t0 = time.time()
-    index = R.construct_synthetic_index(spec, dev, doc_begin=lo, doc_end=hi, centroids=cent, bucket_weights=bw)
-    t_build = time.time() - t0
     params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
     n_batches = min(a.steps + a.warmup, 12)
     batches = [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i) for i in range(n_batches)]
-    engine = sharded.HipShardEngine(index, dev) if use_dist else None
-
-    def step(i):
-        q = batches[i % n_batches]
-        if use_dist:
-            return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
-        return R.search_arrays(index, q, params)
 
     def sync():
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    stage_acc: dict[str, float] = {}
-    lat = []
-    cand_total = 0
-    sync()
-    t_start = time.perf_counter()
-    for i in range(a.steps):
-        ts = time.perf_counter()
-        pids, scores, counts = step(a.warmup + i)
-        lat.append(time.perf_counter() - ts)
-        if not use_dist:
-            for k, v in R.last_search_timings().items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
-            cand_total += R.last_search_counts()["candidates"]
-    sync()
-    elapsed = time.perf_counter() - t_start
+    def run_mode(mode):
+        """builds the index for `mode`, W warm-up steps, then EXACTLY K timed steps bracketed by
+        barrier + synchronize; returns the max-over-ranks elapsed time and per-step records."""
+        if mode == "shard":
+            lo, hi = sharded.plan_shards(a.docs, world)[rank]
+        else:
+            lo, hi = 0, a.docs
+        t0 = time.time()
+        index = R.construct_synthetic_index(spec, dev, doc_begin=lo, doc_end=hi, centroids=cent, bucket_weights=bw)
+        t_build = time.time() - t0
+        engine = sharded.HipShardEngine(index, dev) if mode == "shard" else None
+
+        def step(i):
+            q = batches[i % n_batches]
+            if mode == "shard":
+                return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
+            if mode == "replica":
+                return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist, device=dev,
+                                                 force_collectives=True)
+            return R.search_arrays(index, q, params)
+
+        for i in range(a.warmup):
+            step(i)
+        stage_acc: dict[str, float] = {}
+        lat = []
+        cand_total = 0
+        sync()
+        t_start = time.perf_counter()
+        for i in range(a.steps):
+            ts = time.perf_counter()
+            step(a.warmup + i)
+            lat.append(time.perf_counter() - ts)
+            if mode == "single":
+                for k, v in R.last_search_timings().items():
+                    stage_acc[k] = stage_acc.get(k, 0.0) + v
+                cand_total += R.last_search_counts()["candidates"]
+        sync()
+        elapsed = time.perf_counter() - t_start
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return dict(index=index, elapsed=elapsed, lat=lat, stage_acc=stage_acc, cand_total=cand_total, t_build=t_build)
+
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        est_bytes = a.docs * a.doc_len * (a.dim * a.nbits // 8 + 4 + 2 + 4) + C * a.dim * 2
+        hbm = torch.cuda.get_device_properties(local_rank).total_memory
+        fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
+        primary = a.dist_mode if a.dist_mode != "auto" else ("replica" if fits else "shard")
+        other = "shard" if primary == "replica" else "replica"
+        run_other = (not a.no_alt_mode) and (other == "shard" or fits)
+    else:
+        primary, run_other = "single", False
+    res = run_mode(primary)
+    index, elapsed, lat, stage_acc, cand_total, t_build = (res[k] for k in ("index", "elapsed", "lat", "stage_acc", "cand_total", "t_build"))
     ms_per_step = elapsed / a.steps * 1e3
     qps = a.batch * a.steps / elapsed
+    index_bytes = index.device_bytes
+    alt = None
+    if run_other:
+        del res
+        index = None   # free the primary mode's index before building the other one
+        r2 = run_mode(other)
+        alt = {"mode": other, "value": a.batch * a.steps / r2["elapsed"], "ms_per_step": r2["elapsed"] / a.steps * 1e3}
+        del r2
+    par = {"single": "1 GPU",
+           "replica": "full index replica per GPU, batch split %d-way, result all-gather over RCCL" % world,
+           "shard": "document-sharded x%d, 2 RCCL all-gathers/batch" % world}[primary]
 
     out = {
         "metric": "queries/sec @ top_k=%d (batch=%d, dim=%d); p50 search latency" % (a.topk, a.batch, a.dim),
@@ -161,11 +199,13 @@ def main():
             "workload": a.workload or ("BASELINE cfg2: %d docs x %d tok x dim%d, nbits=%d, %d centroids, batch=%d x %d tok, "
                                        "top_k=%d, n_full_scores=%d, n_ivf_probe=%d" % (
                                            a.docs, a.doc_len, a.dim, a.nbits, C, a.batch, a.qlen, a.topk, a.nfull, a.nprobe)),
-            "parallelism": "1 GPU" if not use_dist else "document-sharded x%d, 2 RCCL all-gathers/batch" % world,
-            "index_bytes_per_gpu": index.device_bytes, "index_build_s": round(t_build, 2),
+            "parallelism": par,
+            "index_bytes_per_gpu": index_bytes, "index_build_s": round(t_build, 2),
         },
         "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
     }
+    if alt is not None:
+        out["alt_mode"] = alt
     if not use_dist and rank == 0:
         stages = {k: v / a.steps for k, v in stage_acc.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}

@@ -64,6 +64,28 @@ struct DevBuf {
   T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// grow-only pinned host buffer (results come down in ONE async copy instead of three staged ones)
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t need) {
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = need + need / 8 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APPROX, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
 static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
                                         "S3 compact",  "S4 approx",        "S5 select",     "S6+S7 maxsim",
@@ -74,8 +96,12 @@ struct Scratch {
   hipEvent_t ev[ST_N + 1] = {};
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
-      tok_idx, recon;
+      tok_idx, recon, out_all;
+  HostBuf h_out, h_small;
   void destroy() {
+    out_all.release();
+    h_out.release();
+    h_small.release();
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
                      &sub_off,  &bitmap,   &blkcnt,   &ncand,   &cand_off, &cand_pid,  &approx,  &hist,     &selstate, &sel_pid, &tie_pid,
                      &sel_approx, &sel_cnt, &exact,   &out_pid, &out_score, &out_cnt,  &tmpf,    &tmpp,     &tok_idx, &recon};
@@ -101,6 +127,24 @@ struct fp_index {
 static thread_local float g_last_ms[ST_N];
 static thread_local bool g_have_ms = false;
 static thread_local int64_t g_last_counts[4];  // candidates, exact-scored docs, exact-scored tokens, sub-batches
+
+// results of one (sub-)batch in one device block: ids | scores | counts
+struct OutLayout {
+  size_t score_off, cnt_off, total, nk, n;
+  OutLayout(int B, int64_t K) {
+    n = (size_t)B;
+    nk = (size_t)B * (size_t)K;
+    score_off = (nk * 8 + 255) & ~(size_t)255;
+    cnt_off = (score_off + nk * 4 + 255) & ~(size_t)255;
+    total = cnt_off + n * 4;
+  }
+  void scatter(const void* host, int64_t* pids, float* scores, int32_t* counts) const {
+    const char* h = static_cast<const char*>(host);
+    memcpy(pids, h, nk * 8);
+    memcpy(scores, h + score_off, nk * 4);
+    memcpy(counts, h + cnt_off, n * 4);
+  }
+};
 
 static Scratch* acquire(fp_index* ix) {
   {
@@ -496,10 +540,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->cand_off.ensure((size_t)(B + 1) * 8));
   fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                  s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st);
-  int64_t M = 0;
-  HIPCHK(hipMemcpyAsync(&M, s->cand_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(s->h_small.ensure(64));
+  HIPCHK(hipMemcpyAsync(s->h_small.p, s->cand_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(s->ev[ST_COMPACT], st));
   HIPCHK(hipStreamSynchronize(st));  // the one mid-pipeline host sync: candidate total sizes the buffers
+  const int64_t M = *reinterpret_cast<const int64_t*>(s->h_small.p);
   P.M = M;
   HIPCHK(s->cand_pid.ensure((size_t)std::max<int64_t>(M, 1) * 4));
   HIPCHK(s->approx.ensure((size_t)std::max<int64_t>(M, 1) * 4));
@@ -583,16 +628,16 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     HIPCHK(hipEventRecord(s->ev[ST_TOPK], st));
     // S8
     const int64_t K = p->top_k;
-    HIPCHK(s->out_pid.ensure((size_t)B * K * 8));
-    HIPCHK(s->out_score.ensure((size_t)B * K * 4));
-    HIPCHK(s->out_cnt.ensure((size_t)B * 4));
+    OutLayout ol(B, K);
+    HIPCHK(s->out_all.ensure(ol.total));
+    HIPCHK(s->h_out.ensure(ol.total));
+    char* od = s->out_all.as<char>();
     fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
-                   s->out_pid.as<int64_t>(), s->out_score.as<float>(), s->out_cnt.as<int32_t>(), st);
-    HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, s->out_pid.p, (size_t)B * K * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, s->out_score.p, (size_t)B * K * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out_counts + b0, s->out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+                   reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
+    HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(s->ev[ST_N], st));
     HIPCHK(hipStreamSynchronize(st));
+    ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     if (b0 == 0) {
       for (int i = 0; i < ST_N; ++i) {
         float ms = 0.f;
@@ -832,15 +877,15 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const in
   HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
   HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
   fpk_transpose_ranks(all_score, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);
-  HIPCHK(s->out_pid.ensure((size_t)B * K * 8));
-  HIPCHK(s->out_score.ensure((size_t)B * K * 4));
-  HIPCHK(s->out_cnt.ensure((size_t)B * 4));
-  fpk_final_topk(s->tmpf.as<float>(), nullptr, s->tmpp.as<int64_t>(), nullptr, (int64_t)G * R, B, K, 0, s->out_pid.as<int64_t>(),
-                 s->out_score.as<float>(), s->out_cnt.as<int32_t>(), s->st);
-  HIPCHK(hipMemcpyAsync(out_pids, s->out_pid.p, (size_t)B * K * 8, hipMemcpyDeviceToHost, s->st));
-  HIPCHK(hipMemcpyAsync(out_scores, s->out_score.p, (size_t)B * K * 4, hipMemcpyDeviceToHost, s->st));
-  HIPCHK(hipMemcpyAsync(out_counts, s->out_cnt.p, (size_t)B * 4, hipMemcpyDeviceToHost, s->st));
+  OutLayout ol(B, K);
+  HIPCHK(s->out_all.ensure(ol.total));
+  HIPCHK(s->h_out.ensure(ol.total));
+  char* od = s->out_all.as<char>();
+  fpk_final_topk(s->tmpf.as<float>(), nullptr, s->tmpp.as<int64_t>(), nullptr, (int64_t)G * R, B, K, 0, reinterpret_cast<int64_t*>(od),
+                 reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), s->st);
+  HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, s->st));
   HIPCHK(hipStreamSynchronize(s->st));
+  ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);
   return FP_OK;
 }
 

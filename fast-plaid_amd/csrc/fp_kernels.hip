@@ -556,24 +556,23 @@ void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int6
 //              tiles: lists are short and L2-resident);
 // search == 1: each list's sub-range for this tile is found by binary search first (many
 //              tiles / long lists).
-#define MARK_TILE_WORDS 8192
-#define MARK_TILE_DOCS (MARK_TILE_WORDS * 32)
+#define MARK_TILE_WORDS_MAX 8192   // 32 KiB of LDS bitmap = 262144 documents per tile
 __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
                                                    int maxcells, const int64_t* __restrict__ ivf_off,
                                                    const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
-                                                   int64_t W, int search) {
+                                                   int64_t W, int search, int tw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                              // [MARK_TILE_WORDS]
-  long long* lo_s = reinterpret_cast<long long*>(smem + MARK_TILE_WORDS * 4);      // [maxcells]
-  uint32_t* pre = reinterpret_cast<uint32_t*>(smem + MARK_TILE_WORDS * 4 + (size_t)maxcells * 8);  // [maxcells + 1]
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                              // [tw]
+  long long* lo_s = reinterpret_cast<long long*>(smem + (size_t)tw * 4);      // [maxcells]
+  uint32_t* pre = reinterpret_cast<uint32_t*>(smem + (size_t)tw * 4 + (size_t)maxcells * 8);  // [maxcells + 1]
   __shared__ uint32_t s_scan[1024];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
-  const int64_t word0 = (int64_t)blockIdx.x * MARK_TILE_WORDS;
+  const int64_t word0 = (int64_t)blockIdx.x * tw;
   const int32_t tile_lo = (int32_t)(word0 * 32);
-  const int64_t tile_hi64 = (word0 + MARK_TILE_WORDS) * 32;
+  const int64_t tile_hi64 = (word0 + tw) * 32;
   const int32_t tile_hi = tile_hi64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tile_hi64;
-  for (int i = tid; i < MARK_TILE_WORDS; i += 1024) tile[i] = 0u;
+  for (int i = tid; i < tw; i += 1024) tile[i] = 0u;
   const int nc = ncells[b];
   // phase 1: per-cell [lo, lo+len) and exclusive prefix of the lengths
   uint32_t base = 0;
@@ -642,15 +641,20 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   __syncthreads();
   // phase 3: write the tile (W is a multiple of 64 words; tiles may overhang the end)
   uint32_t* dst = bitmap + (int64_t)b * W + word0;
-  for (int i = tid * 4; i < MARK_TILE_WORDS; i += 4096) {
+  for (int i = tid * 4; i < tw; i += 4096) {
     if (word0 + i < W) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(tile + i);
   }
 }
 
 void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B, uint32_t* bitmap,
                   int64_t W, hipStream_t st) {
-  const int ntile = (int)((W + MARK_TILE_WORDS - 1) / MARK_TILE_WORDS);
-  const size_t lds = (size_t)MARK_TILE_WORDS * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
+  // tile size: the largest that still gives the chip ~4 workgroups per CU (measured at cfg2: B=64 -> 2048 words 0.11 ms vs 8192 words 0.26 ms; B=8 -> 512 words 0.04 vs 0.22 ms)
+  static const int tw_env = getenv("FP_MARK_TW") ? atoi(getenv("FP_MARK_TW")) : 0;
+  int tw = MARK_TILE_WORDS_MAX;
+  while (tw > 512 && ((W + tw - 1) / tw) * B < 1024) tw >>= 1;
+  if (tw_env >= 64 && tw_env <= MARK_TILE_WORDS_MAX && (tw_env & (tw_env - 1)) == 0) tw = tw_env;
+  const int ntile = (int)((W + tw - 1) / tw);
+  const size_t lds = (size_t)tw * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_ivf_mark, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
@@ -658,7 +662,7 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
   }
   const int search = ntile > 8 ? 1 : 0;
   hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ix.ivf_off,
-                     ix.ivf_pids, ix.P, bitmap, W, search);
+                     ix.ivf_pids, ix.P, bitmap, W, search, tw);
 }
 
 // ---- ordered compaction of the bitmaps ------------------------------------------------------

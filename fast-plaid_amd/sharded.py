@@ -148,3 +148,54 @@ def sharded_search(engine, queries_f16, params, dist=None, group=None, force_col
         return engine.stage3(st, all_s, all_sp, world)
     finally:
         engine.end(st)
+
+
+# ---- replicated index, batch split across ranks -------------------------------------------------
+# The reference's own multi-GPU mode (python/fast_plaid/search/fast_plaid.py:893-928: one full
+# index per device, the query list cut into one contiguous slice per device).  Every stage of the
+# path is per query, so this mode replicates NO work (the document-sharded mode above replicates
+# S1/S2 and the per-launch latencies on every rank); it is the throughput mode whenever the index
+# fits one GPU (a 288 GB MI355X holds ~30 M documents x 128 tokens at nbits=4).  The only exchange
+# is the result gather: three fixed-size all_gather_into_tensor calls.
+def split_batch(n_queries: int, world_size: int) -> list[tuple[int, int]]:
+    """contiguous, near-equal query ranges, one per rank (the first ranks take the remainder)."""
+    base, rem = divmod(int(n_queries), int(world_size))
+    out, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def replicated_search(search_local, queries_f16, top_k: int, dist=None, group=None, device="cpu", force_collectives=False):
+    """`search_local(q [b,Q,D]) -> (pids [b,top_k] i64, scores [b,top_k] f32, counts [b] i32)` on this
+    rank's full replica.  Returns the whole batch's (pids, scores, counts), identical on every rank."""
+    import torch
+    q = np.ascontiguousarray(queries_f16)
+    B = q.shape[0]
+    live = dist is not None and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    ranges = split_batch(B, world)
+    lo, hi = ranges[rank]
+    mb = max(h - l for l, h in ranges)
+    pids = np.full((mb, top_k), -1, np.int64)
+    scores = np.zeros((mb, top_k), np.float32)
+    counts = np.zeros((mb,), np.int32)
+    if hi > lo:
+        p, s, c = search_local(q[lo:hi])
+        pids[: hi - lo], scores[: hi - lo], counts[: hi - lo] = p, s, c
+    if not live or (world == 1 and not force_collectives):
+        return pids[:B], scores[:B], counts[:B]
+    outs = []
+    for x in (pids, scores, counts):
+        t = torch.from_numpy(x).to(device)
+        g = torch.empty((world * mb,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(g, t.contiguous(), group=group)
+        outs.append(g)
+    outs = [g.cpu().numpy().reshape((world, mb) + g.shape[1:]) for g in outs]
+    P = np.concatenate([outs[0][r, : h - l] for r, (l, h) in enumerate(ranges)], axis=0)
+    S = np.concatenate([outs[1][r, : h - l] for r, (l, h) in enumerate(ranges)], axis=0)
+    Cn = np.concatenate([outs[2][r, : h - l] for r, (l, h) in enumerate(ranges)], axis=0)
+    return P, S, Cn

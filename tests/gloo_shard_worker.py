@@ -96,6 +96,23 @@ def main():
         assert counts[i] == len(ref[i][0]), (counts[i], len(ref[i][0]))
         assert np.array_equal(pids[i, : counts[i]], ref[i][0]), (rank, i, pids[i], ref[i][0])
         assert np.array_equal(scores[i, : counts[i]], ref[i][1])
+    # replicated index, batch split across ranks (uneven: 5 queries over `world` ranks)
+    def search_local(qs):
+        r = whole.search(qs, 20, 128, 4)
+        P = np.full((len(r), 20), -1, np.int64)
+        S = np.zeros((len(r), 20), np.float32)
+        Cn = np.zeros(len(r), np.int32)
+        for i, (pp, ss) in enumerate(r):
+            P[i, : len(pp)], S[i, : len(pp)], Cn[i] = pp, ss, len(pp)
+        return P, S, Cn
+    rp, rs, rc = sharded.replicated_search(search_local, q, 20, dist=dist)
+    assert rp.shape == (5, 20)
+    for i in range(5):
+        assert rc[i] == len(ref[i][0])
+        assert np.array_equal(rp[i, : rc[i]], ref[i][0]) and np.array_equal(rs[i, : rc[i]], ref[i][1])
+    # more ranks than queries: some ranks hold an empty slice
+    rp1, rs1, rc1 = sharded.replicated_search(search_local, q[:1], 20, dist=dist)
+    assert rp1.shape == (1, 20) and np.array_equal(rp1[0, : rc1[0]], ref[0][0])
     dist.barrier()
     print("SHARDED_OK rank", rank)
     dist.destroy_process_group()

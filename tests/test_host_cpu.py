@@ -119,14 +119,16 @@ def _free_port():
     return p
 
 
-def test_sharded_protocol_gloo_world2():
-    """world_size-2 gloo run of fast_plaid_amd.sharded.sharded_search with an oracle-backed
-    engine standing in for the HIP stages (test infrastructure): the protocol (fixed-size
-    all-gathers, global cut, merge) must reproduce the unsharded oracle exactly."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_protocol_gloo(world):
+    """world_size-2/3 gloo runs of fast_plaid_amd.sharded.sharded_search (document shards) and
+    replicated_search (batch split) with an oracle-backed engine standing in for the HIP stages
+    (test infrastructure): the protocols (fixed-size all-gathers, global cut, merge, result
+    gather) must reproduce the unsharded oracle exactly."""
     port = _free_port()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
     procs = []
-    for rank in range(2):
+    for rank in range(world):
         e = dict(env, RANK=str(rank))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "gloo_shard_worker.py")], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
