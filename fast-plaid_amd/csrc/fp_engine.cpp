@@ -96,10 +96,11 @@ struct Scratch {
   hipEvent_t ev[ST_N + 1] = {};
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
-      tok_idx, recon, out_all;
+      tok_idx, recon, out_all, S8, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid;
   HostBuf h_out, h_small;
   void destroy() {
     out_all.release();
+    for (DevBuf* b : {&S8, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid}) b->release();
     h_out.release();
     h_small.release();
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
@@ -477,6 +478,8 @@ struct Pipe {
   int nblk, nchunk;
   bool degenerate;  // reference errs for every query (topk k out of range) -> all results empty
   int64_t M;
+  bool exact_all = false;  // trace mode: exact approximate score of EVERY candidate (no bound-and-refine)
+  bool used_q8 = false;
 };
 
 // stages S1..S5 for one sub-batch whose fp16 queries are already in s->qin
@@ -551,8 +554,35 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   fpk_cand_compact(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                    s->blkcnt.as<int32_t>(), P.nblk, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), st);
   HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
-  // S4
-  fpk_approx(D, s->S.as<uint16_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->approx.as<float>(), st);
+  // S4: bound-and-refine when one query's slice of S overflows L2 and there is something to prune, else exact for all
+  const int64_t* sel_off = s->cand_off.as<int64_t>();
+  const int32_t* sel_src = s->cand_pid.as<int32_t>();
+  static const int q8_env = [] { const char* e = getenv("FP_APPROX_IMPL"); return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : 0)); }();
+  const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R;
+  P.used_q8 = !P.exact_all && sh.Qp == 32 && M > 0 && q8_env >= 0 && (q8_env > 0 || q8_auto);
+  if (P.used_q8) {
+    const int64_t max_n = std::min<int64_t>(D.N, M);
+    const int nblk2 = (int)((max_n + FP_SURV_CHUNK - 1) / FP_SURV_CHUNK);
+    HIPCHK(s->S8.ensure((size_t)B * D.C * 32));
+    HIPCHK(s->kq.ensure((size_t)M * 4));
+    HIPCHK(s->q8hist.ensure((size_t)B * 8192 * 4));
+    HIPCHK(s->cut.ensure((size_t)B * 4));
+    HIPCHK(s->blkcnt2.ensure((size_t)B * nblk2 * 4));
+    HIPCHK(s->nsurv.ensure((size_t)B * 4));
+    HIPCHK(s->surv_off.ensure((size_t)(B + 1) * 8));
+    HIPCHK(s->surv_pid.ensure((size_t)M * 4));
+    fpk_quant_s8(s->S.as<uint16_t>(), s->S8.as<uint8_t>(), (int64_t)B * D.C * 32, st);
+    fpk_approx_q8_filter(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
+                         s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
+                         s->surv_pid.as<int32_t>(), st);
+    sel_off = s->surv_off.as<int64_t>();
+    sel_src = s->surv_pid.as<int32_t>();
+    // survivor total for fp_last_search_counts: lands in pinned memory by the time the caller's final sync returns
+    HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 8, s->surv_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
+    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::max<int64_t>(M / 8, (int64_t)B * sh.R), s->approx.as<float>(), st);
+  } else {
+    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st);
+  }
   HIPCHK(hipEventRecord(s->ev[ST_SELECT], st));
   // S5
   HIPCHK(s->hist.ensure((size_t)3 * B * FP_SEL_BINS * 4));
@@ -561,7 +591,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->sel_approx.ensure((size_t)B * sh.R * 4));
   HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
   HIPCHK(s->tie_pid.ensure((size_t)B * sh.R * 4));
-  fpk_select(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), s->approx.as<float>(), s->hist.as<uint32_t>(),
+  fpk_select(sh, sel_off, sel_src, s->approx.as<float>(), s->hist.as<uint32_t>(),
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st);
   HIPCHK(hipEventRecord(s->ev[ST_MAXSIM], st));
@@ -606,6 +636,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     const int B = std::min(maxB, nq - b0);
     Pipe P{};
     P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
+    P.exact_all = tr != nullptr;   // the trace reports the approximate score of every candidate
     hipStream_t st = s->st;
     HIPCHK(hipEventRecord(s->ev[ST_UPLOAD], st));
     HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
@@ -638,6 +669,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     HIPCHK(hipEventRecord(s->ev[ST_N], st));
     HIPCHK(hipStreamSynchronize(st));
     ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
+    g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : P.M;
     if (b0 == 0) {
       for (int i = 0; i < ST_N; ++i) {
         float ms = 0.f;

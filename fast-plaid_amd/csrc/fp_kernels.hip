@@ -915,6 +915,306 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 }
 
 // ============================================================================================
+// S4, bound-and-refine form.  The flat kernel above is pinned at the gather ceiling of an 8 MB
+// table (tools/probe/row_probe: 100 G rows/s from 8 MB, 171 from 4 MB, 230 from <= 2 MB; the
+// kernel runs at 92 G rows/s).  The selection only needs the exact approximate score of
+// documents near the top-R cut, so:
+//   (1) k_quant_s8: S -> 8-bit bins,  bin(x) = clamp(floor(128 x) + 100, 0, 255).  128 x and the
+//       floor are exact for fp16 x, so bin k means (k-100)/128 <= x < (k-99)/128 with no
+//       rounding caveat, and the map is monotone: the max over a document's codes of the bins
+//       IS the bin of the max.  Rows shrink to 32 B, one query's slice to C*32 B (4 MB at
+//       C = 2^17).
+//   (2) k_approx_q8: per candidate K = sum over the real query columns of the max bin.  The
+//       exact score A then satisfies  K <= 128 A + 100 Q < K + Q.  Columns whose max bin is 0
+//       (x < -0.78) void the lower bound (K_lo = 0), 255 (x >= 1.21) the upper one
+//       (K_hi = 0xFFFF): such documents simply always survive.
+//   (3) k_q8_cut: T = R'-th largest K_lo of the query (R' = min(R, n_full, n)).  R' documents
+//       have 128 A + 100 Q >= T, hence so has the R'-th best exact score, and every document of
+//       the exact top-R' has K_hi + Q > T.  Survivors: K_hi >= T - Q + 1 (ties at the cut included).
+//   (4) survivors are compacted in order and go through the exact fp16 kernel and the same
+//       selection as before -> the selected set and its scores are identical to scoring all
+//       candidates exactly (tests: fp_search == fp_search_trace, which keeps the all-exact path).
+// ============================================================================================
+#define Q8_OFFSET 100
+#define Q8_BINS_SUM 8192   // 32 columns x 255 < 8192
+
+__global__ __launch_bounds__(256) void k_quant_s8(const uint4* __restrict__ S, uint2* __restrict__ S8, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = S[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const h2 p = u32_as_h2(w[t >> 1]);
+      const float x = (float)((t & 1) ? p.y : p.x);
+      int b = (int)floorf(x * 128.0f) + Q8_OFFSET;   // NaN -> 0 after the clamp below (int conversion of NaN is 0 on this target)
+      b = b < 0 ? 0 : (b > 255 ? 255 : b);
+      o[t >> 2] |= (uint32_t)b << (8 * (t & 3));
+    }
+    S8[i] = make_uint2(o[0], o[1]);
+  }
+}
+
+void fpk_quant_s8(const uint16_t* S, uint8_t* S8, int64_t n_elems, hipStream_t st) {
+  const int64_t n8 = n_elems / 8;
+  if (n8 <= 0) return;
+  hipLaunchKernelGGL(k_quant_s8, dim3(fp_grid_cap((n8 + 255) / 256, 256)), dim3(256), 0, st, reinterpret_cast<const uint4*>(S),
+                     reinterpret_cast<uint2*>(S8), n8);
+}
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm volatile("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// 2 lanes per candidate (16 B = 16 query columns each), 32 candidates per wave, same software
+// pipeline as k_approx.  kq[cand] = K_hi << 16 | K_lo.
+__global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S8, int64_t C, int Q,
+                                                   const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
+                                                   const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
+                                                   uint32_t* __restrict__ kq) {
+  const int b = blockIdx.y, bxi = blockIdx.x;
+  const int nbx = gridDim.x;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const int sub = threadIdx.x & 1;
+  const int grp = threadIdx.x >> 1;  // candidate slot within the block (0..127)
+  const uint8_t* Sb = S8 + (int64_t)b * C * 32 + sub * 16;
+  const int64_t stride = (int64_t)nbx * 128;
+  int64_t i = (int64_t)bxi * 128 + grp;
+  int64_t u0 = 0;
+  int len = 0;
+  int32_t code[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) code[k] = 0;
+  if (i < n) {
+    const int32_t pid = cand_pid[beg + i];
+    u0 = uoff[pid];
+    len = (int)(uoff[pid + 1] - u0);
+    if (len > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[u0 + ((k < len) ? k : (len - 1))];
+    }
+  }
+  for (; i < n; i += stride) {
+    int64_t nu0 = 0;
+    int nlen = 0;
+    if (i + stride < n) {
+      const int32_t npid = cand_pid[beg + i + stride];
+      nu0 = uoff[npid];
+      nlen = (int)(uoff[npid + 1] - nu0);
+    }
+    const int32_t* cp = ucodes + u0;
+    uint32_t me[4] = {0u, 0u, 0u, 0u}, mo[4] = {0u, 0u, 0u, 0u};  // running maxima: even / odd bytes as u16 pairs
+    for (int t = 0; t < len; t += 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sb + (int64_t)code[k] * 32);
+      if (t + 8 < len) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) code[k] = cp[(t + 8 + k < len) ? (t + 8 + k) : (len - 1)];
+      } else if (nlen > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          me[j] = pk_max_u16(me[j], w[j] & 0x00FF00FFu);
+          mo[j] = pk_max_u16(mo[j], (w[j] >> 8) & 0x00FF00FFu);
+        }
+      }
+    }
+    if (len == 0 && nlen > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+    }
+    // sum / min / max of this lane's real columns (column = sub*16 + 4*j + byte)
+    uint32_t sum = 0, mn = 255u, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t val = (((t & 1) ? mo[j] : me[j]) >> (16 * (t >> 1))) & 0xFFFFu;
+        const bool real = (sub * 16 + 4 * j + t) < Q;
+        sum += real ? val : 0u;
+        mn = real ? min(mn, val) : mn;
+        mx = real ? max(mx, val) : mx;
+      }
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    mn = min(mn, (uint32_t)__shfl_xor(mn, 1, 64));
+    mx = max(mx, (uint32_t)__shfl_xor(mx, 1, 64));
+    if (sub == 0) {
+      const uint32_t klo = (len == 0 || mn == 0u) ? 0u : sum;       // a bin-0 column (or an empty document) voids the lower bound
+      const uint32_t khi = (mx == 255u) ? 0xFFFFu : sum;            // a bin-255 column voids the upper bound
+      kq[beg + i] = (khi << 16) | klo;
+    }
+    u0 = nu0;
+    len = nlen;
+  }
+}
+
+// histogram of K_lo per query: Q8_HIST_BLOCKS workgroups per query build LDS histograms of their share
+// and flush the non-empty bins into hist [B][Q8_BINS_SUM] (zeroed by the caller)
+#define Q8_HIST_BLOCKS 16
+__global__ __launch_bounds__(1024) void k_q8_hist(const uint32_t* __restrict__ kq, const int64_t* __restrict__ cand_off,
+                                                  uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[Q8_BINS_SUM];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  for (int i = tid; i < Q8_BINS_SUM; i += 1024) h[i] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < n; i += (int64_t)Q8_HIST_BLOCKS * 1024) atomicAdd(&h[kq[beg + i] & 0xFFFFu], 1u);
+  __syncthreads();
+  uint32_t* hg = hist + (int64_t)b * Q8_BINS_SUM;
+  for (int i = tid; i < Q8_BINS_SUM; i += 1024) {
+    const uint32_t v = h[i];
+    if (v) atomicAdd(&hg[i], v);
+  }
+}
+
+// one workgroup per query: T = keep-th largest K_lo from the histogram, cut = max(T - Q + 1, 0)
+__global__ __launch_bounds__(1024) void k_q8_cut(const uint32_t* __restrict__ hist, const int64_t* __restrict__ cand_off, int64_t n_full,
+                                                 int64_t R, int Q, int32_t* __restrict__ cut) {
+  __shared__ uint32_t part[1024];
+  __shared__ int s_T;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t n = cand_off[b + 1] - cand_off[b];
+  int64_t keep = n;
+  if (n_full < keep) keep = n_full;
+  if (R < keep) keep = R;
+  if (keep >= n) {  // nothing is pruned: everything survives
+    if (tid == 0) cut[b] = 0;
+    return;
+  }
+  if (tid == 0) s_T = 0;
+  const uint32_t* hg = hist + (int64_t)b * Q8_BINS_SUM;
+  // thread t owns bins [8t, 8t+8); suffix counts from the top
+  uint32_t own[8];
+  uint32_t loc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { own[k] = hg[tid * 8 + k]; loc += own[k]; }
+  part[tid] = loc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive suffix scan
+    const uint32_t v = (tid + off < 1024) ? part[tid + off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t above = part[tid] - loc;  // candidates in bins above this thread's bins
+  if (above < (uint32_t)keep && part[tid] >= (uint32_t)keep) {
+    uint32_t acc = above;
+    int T = tid * 8;
+    for (int k = 7; k >= 0; --k) {
+      acc += own[k];
+      if (acc >= (uint32_t)keep) { T = tid * 8 + k; break; }
+    }
+    s_T = T;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int c = s_T - Q + 1;
+    cut[b] = (s_T <= 0 || c < 0) ? 0 : c;
+  }
+}
+
+// ordered compaction of the survivors (K_hi >= cut): count per 2048-candidate chunk, then write
+#define SURV_CHUNK 2048
+__global__ __launch_bounds__(256) void k_surv_count(const uint32_t* __restrict__ kq, const int64_t* __restrict__ cand_off,
+                                                    const int32_t* __restrict__ cut, int32_t* __restrict__ blkcnt, int nblk) {
+  const int b = blockIdx.y;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
+  int cnt = 0;
+  if (c0 < n) {
+    const uint32_t ct = (uint32_t)cut[b];
+#pragma unroll
+    for (int k = 0; k < SURV_CHUNK / 256; ++k) {
+      const int64_t i = c0 + threadIdx.x * (SURV_CHUNK / 256) + k;
+      if (i < n) cnt += ((kq[beg + i] >> 16) >= ct) ? 1 : 0;
+    }
+  }
+  __shared__ int s[256];
+  s[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void k_surv_compact(const uint32_t* __restrict__ kq, const int64_t* __restrict__ cand_off,
+                                                      const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
+                                                      const int32_t* __restrict__ blkoff, int nblk,
+                                                      const int64_t* __restrict__ surv_off, int32_t* __restrict__ surv_pid) {
+  const int b = blockIdx.y;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
+  if (c0 >= n) return;
+  const uint32_t ct = (uint32_t)cut[b];
+  constexpr int PER = SURV_CHUNK / 256;
+  bool keep[PER];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t i = c0 + threadIdx.x * PER + k;
+    keep[k] = (i < n) && ((kq[beg + i] >> 16) >= ct);
+    cnt += keep[k] ? 1 : 0;
+  }
+  __shared__ int s[256];
+  s[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t pos = surv_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (keep[k]) surv_pid[pos++] = cand_pid[beg + c0 + threadIdx.x * PER + k];
+  }
+}
+
+// Runs (2)-(4) of the scheme: on return surv_off [B+1] / surv_pid describe the survivors (ordered, on the device).
+void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off,
+                          const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192]*/, uint32_t* kq, int32_t* cut, int32_t* blkcnt,
+                          int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
+  const int B = sh.B;
+  // One candidate per lane pair and ~2048 workgroups per query: measured best (S4 6.05 ms).  Longer-lived
+  // workgroups (2/4/8 candidates per pair: 6.6/8.3/10.3 ms) put several queries' slices in flight at once.
+  static const int dps_env = getenv("FP_Q8_DPS") ? atoi(getenv("FP_Q8_DPS")) : 0;
+  const int dps = dps_env > 0 ? dps_env : 1;
+  int64_t per_q = (M + B - 1) / B;
+  int64_t bx = (per_q + 128 * dps - 1) / (128 * dps);
+  if (bx > 4096) bx = 4096;
+  if (bx < 1) bx = 1;
+  // (an XCD-affine mapping -- one query per XCD so that each L2 holds one 4 MB slice -- measured slower: 6.9 vs 6.05 ms)
+  hipLaunchKernelGGL(k_approx_q8, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff, ix.ucodes,
+                     kq);
+  (void)hipMemsetAsync(q8hist, 0, (size_t)B * Q8_BINS_SUM * 4, st);
+  hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), 0, st, kq, cand_off, q8hist);
+  hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut);
+  hipLaunchKernelGGL(k_surv_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cut, blkcnt, nblk);
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, nsurv);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
+  hipLaunchKernelGGL(k_surv_compact, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cand_pid, cut, blkcnt, nblk, surv_off,
+                     surv_pid);
+}
+
+// ============================================================================================
 // S5  top-R selection by (approx desc, doc id asc): 3-pass radix select (11+11+10 bits) on
 // the monotone key, then one ordered collect pass per query.
 // selstate[b] = {need_select, keep, prefix, k_rem, n, -, -, -}

@@ -113,7 +113,8 @@ int fp_search_trace(const fp_index* index, const uint16_t* query, int32_t q_len,
 int fp_last_search_timings(const char** names, float* ms, int cap);
 
 /* Work counters of the most recent fp_search on this thread: out[0] = candidate documents
- * summed over queries (S3 output), out[3] = sub-batches.  Returns entries written. */
+ * summed over queries (S3 output), out[1] = candidates that reached the exact approximate-score
+ * kernel (== out[0] unless the 8-bit bound stage pruned), out[3] = sub-batches.  Returns entries written. */
 int fp_last_search_counts(int64_t* out, int cap);
 
 /* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */

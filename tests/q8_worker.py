@@ -1,0 +1,80 @@
+"""GPU worker for tests/test_hip_parity.py::test_bound_and_refine_forced: FP_APPROX_IMPL=q8 forces
+the 8-bit bound stage of S4 on small corpora (it is otherwise chosen only for large centroid
+tables).  fp_search (bounded path) must equal fp_search_trace (exact score of every candidate)
+bit for bit, and the oracle within the usual tolerances."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import fast_plaid_amd as fp  # noqa: E402
+import plaid_oracle as OC  # noqa: E402
+from conftest import GOLDEN_DIR, golden_cases  # noqa: E402
+from parity import check_trace  # noqa: E402
+
+R = fp.fast_plaid_rust
+
+
+def mk(a, **kw):
+    return R.construct_index(a["nbits"], a["centroids"], None, None, a["bucket_weights"], a["ivf"], a["ivf_lengths"],
+                             a["doc_codes"], a["doc_residuals"], a["doc_lengths"], "cuda:0", False, **kw)
+
+
+def same_as_trace(idx, q, params, subs=None):
+    pids, scores, counts = R.search_arrays(idx, q, params, subs)
+    c = R.last_search_counts()
+    for b in range(q.shape[0]):
+        h = R.search_trace(idx, q[b], params, None if subs is None else subs[b])
+        assert counts[b] == len(h["pids"]), (b, counts[b], len(h["pids"]))
+        assert np.array_equal(pids[b, : counts[b]], h["pids"]), b
+        assert np.array_equal(scores[b, : counts[b]], h["scores"]), b
+    return c
+
+
+def main():
+    assert os.environ.get("FP_APPROX_IMPL") == "q8"
+    # committed fixtures (subset, empty documents, zero-padded query rows, unnormalised documents, ...)
+    for name in golden_cases():
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        arr = {k: z[k] for k in ("centroids", "bucket_weights", "ivf", "ivf_lengths", "doc_codes", "doc_residuals", "doc_lengths")}
+        arr["nbits"] = int(z["nbits"])
+        n_probe, n_full, top_k, bs = (int(x) for x in z["params"])
+        q = z["queries"]
+        subs = [z[f"subset_{b}"].tolist() for b in range(q.shape[0])] if "subset_0" in z else None
+        same_as_trace(mk(arr), q, R.SearchParameters(bs, n_full, top_k, n_probe), subs)
+    # synthetic corpora where the cut actually prunes (candidates >> R), Q < 32 exercises the column mask
+    pruned = 0
+    for (n_docs, C, Q, n_full, n_probe, seed) in ((20000, 2048, 32, 256, 8, 1), (20000, 2048, 20, 64, 4, 2), (8000, 512, 7, 32, 2, 3),
+                                                  (30000, 4096, 32, 4096, 8, 4)):
+        spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=48, n_centroids=C, variable_len=True, seed=seed)
+        arr = fp.synth.host_index_arrays(spec)
+        q = fp.synth.make_queries(spec, arr["centroids"], 6, Q)
+        idx = mk(arr)
+        params = R.SearchParameters(2000, n_full, 25, n_probe)
+        c = same_as_trace(idx, q, params)
+        assert c["approx_exact"] <= c["candidates"]
+        pruned += int(c["approx_exact"] < c["candidates"])
+        orc = OC.OracleIndex(nbits=arr["nbits"], centroids=arr["centroids"], bucket_weights=arr["bucket_weights"], ivf=arr["ivf"],
+                             ivf_lengths=arr["ivf_lengths"], doc_codes=arr["doc_codes"], doc_residuals=arr["doc_residuals"],
+                             doc_lengths=arr["doc_lengths"])
+        ref = orc.search(q, 25, n_full, n_probe, nthreads=4)
+        pids, scores, counts = R.search_arrays(idx, q, params)
+        ident = sum(int(np.array_equal(pids[b, : counts[b]], ref[b][0])) for b in range(q.shape[0]))
+        assert ident >= q.shape[0] // 2, ident
+    assert pruned >= 3, "the bound stage never pruned: the test does not exercise it"
+    # values outside the bin range: unnormalised queries scaled x3 (S up to 3: bin 255 voids the upper bound) and x(-3)
+    spec = fp.synth.SynthSpec(n_docs=20000, doc_len=48, n_centroids=2048, variable_len=True, seed=9)
+    arr = fp.synth.host_index_arrays(spec)
+    idx = mk(arr)
+    q = fp.synth.make_queries(spec, arr["centroids"], 4, 32).astype(np.float32)
+    for scale in (3.0, -3.0, 0.01):
+        same_as_trace(idx, (q * scale).astype(np.float16), R.SearchParameters(2000, 128, 25, 8))
+    print("Q8_OK")
+
+
+if __name__ == "__main__":
+    main()
