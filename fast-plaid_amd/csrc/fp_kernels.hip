@@ -936,6 +936,9 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 //       candidates exactly (tests: fp_search == fp_search_trace, which keeps the all-exact path).
 // ============================================================================================
 #define Q8_OFFSET 100
+#ifndef Q8_ABL
+#define Q8_ABL 0  // timing-only ablations of k_approx_q8: 1 no byte-max arithmetic, 2 synthetic codes
+#endif
 #define Q8_BINS_SUM 8192   // 32 columns x 255 < 8192
 
 __global__ __launch_bounds__(256) void k_quant_s8(const uint4* __restrict__ S, uint2* __restrict__ S8, int64_t n8) {
@@ -973,8 +976,8 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S8, int64_t C, int Q,
                                                    const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                    const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
-                                                   uint32_t* __restrict__ kq) {
-  const int b = blockIdx.y, bxi = blockIdx.x;
+                                                   uint32_t* __restrict__ kq, int b0) {
+  const int b = b0 + blockIdx.y, bxi = blockIdx.x;
   const int nbx = gridDim.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
@@ -983,6 +986,29 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
   const uint8_t* Sb = S8 + (int64_t)b * C * 32 + sub * 16;
   const int64_t stride = (int64_t)nbx * 128;
   int64_t i = (int64_t)bxi * 128 + grp;
+  // A step's 8 codes are ONE 16-byte load per lane (codes 4*sub .. 4*sub+3 of the group; dword-aligned only,
+  // the list buffer is padded) plus an exchange inside the lane pair: 8 four-byte loads per step cost 1.6 of
+  // the kernel's 5.6 ms (ablation with synthetic codes).  Positions past the end of the list repeat the
+  // group's first code (max is idempotent).
+  auto load_codes = [&](const int32_t* p, int pos, int ln, int32_t (&code)[8]) {
+    int4 mine;
+    __builtin_memcpy(&mine, p + pos + 4 * sub, 16);
+    int4 oth;  // the partner lane's four codes: DPP quad_perm [1,0,3,2]
+    oth.x = __builtin_amdgcn_update_dpp(0, mine.x, 0xB1, 0xF, 0xF, true);
+    oth.y = __builtin_amdgcn_update_dpp(0, mine.y, 0xB1, 0xF, 0xF, true);
+    oth.z = __builtin_amdgcn_update_dpp(0, mine.z, 0xB1, 0xF, 0xF, true);
+    oth.w = __builtin_amdgcn_update_dpp(0, mine.w, 0xB1, 0xF, 0xF, true);
+    const int4 lo = sub ? oth : mine, hi = sub ? mine : oth;
+    const int rem = ln - pos;  // >= 1
+    code[0] = lo.x;
+    code[1] = rem > 1 ? lo.y : lo.x;
+    code[2] = rem > 2 ? lo.z : lo.x;
+    code[3] = rem > 3 ? lo.w : lo.x;
+    code[4] = rem > 4 ? hi.x : lo.x;
+    code[5] = rem > 5 ? hi.y : lo.x;
+    code[6] = rem > 6 ? hi.z : lo.x;
+    code[7] = rem > 7 ? hi.w : lo.x;
+  };
   int64_t u0 = 0;
   int len = 0;
   int32_t code[8];
@@ -992,11 +1018,9 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
     const int32_t pid = cand_pid[beg + i];
     u0 = uoff[pid];
     len = (int)(uoff[pid + 1] - u0);
-    if (len > 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) code[k] = ucodes[u0 + ((k < len) ? k : (len - 1))];
-    }
   }
+  // (the lanes of a pair always agree on len / nlen, so the exchanges inside load_codes are convergent per pair)
+  if (len > 0) load_codes(ucodes + u0, 0, len, code);
   for (; i < n; i += stride) {
     int64_t nu0 = 0;
     int nlen = 0;
@@ -1011,27 +1035,32 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
       uint4 v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sb + (int64_t)code[k] * 32);
+#if Q8_ABL & 2
+#pragma unroll
+      for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)code[k] * 2654435761u + (uint32_t)k) % (uint32_t)C);
+#else
       if (t + 8 < len) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) code[k] = cp[(t + 8 + k < len) ? (t + 8 + k) : (len - 1)];
+        load_codes(cp, t + 8, len, code);
       } else if (nlen > 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+        load_codes(ucodes + nu0, 0, nlen, code);
       }
+#endif
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#if Q8_ABL & 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) me[j] ^= w[j];
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           me[j] = pk_max_u16(me[j], w[j] & 0x00FF00FFu);
           mo[j] = pk_max_u16(mo[j], (w[j] >> 8) & 0x00FF00FFu);
         }
+#endif
       }
     }
-    if (len == 0 && nlen > 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
-    }
+    if (len == 0 && nlen > 0) load_codes(ucodes + nu0, 0, nlen, code);
     // sum / min / max of this lane's real columns (column = sub*16 + 4*j + byte)
     uint32_t sum = 0, mn = 255u, mx = 0u;
 #pragma unroll
@@ -1202,8 +1231,17 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   if (bx > 4096) bx = 4096;
   if (bx < 1) bx = 1;
   // (an XCD-affine mapping -- one query per XCD so that each L2 holds one 4 MB slice -- measured slower: 6.9 vs 6.05 ms)
-  hipLaunchKernelGGL(k_approx_q8, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff, ix.ucodes,
-                     kq);
+  static const int perq_env = getenv("FP_Q8_PERQ") ? atoi(getenv("FP_Q8_PERQ")) : 0;
+  if (perq_env > 0) {   // queries in groups of perq_env per launch: bounds how many slices of S8 are live at once
+    for (int b0 = 0; b0 < B; b0 += perq_env) {
+      const int nb = (B - b0) < perq_env ? (B - b0) : perq_env;
+      hipLaunchKernelGGL(k_approx_q8, dim3((unsigned)bx, (unsigned)nb), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff,
+                         ix.ucodes, kq, b0);
+    }
+  } else {
+    hipLaunchKernelGGL(k_approx_q8, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff, ix.ucodes,
+                       kq, 0);
+  }
   (void)hipMemsetAsync(q8hist, 0, (size_t)B * Q8_BINS_SUM * 4, st);
   hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), 0, st, kq, cand_off, q8hist);
   hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut);
