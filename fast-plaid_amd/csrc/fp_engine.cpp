@@ -558,7 +558,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   const int64_t* sel_off = s->cand_off.as<int64_t>();
   const int32_t* sel_src = s->cand_pid.as<int32_t>();
   static const int q8_env = [] { const char* e = getenv("FP_APPROX_IMPL"); return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : 0)); }();
-  const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R;
+  // bound stage when (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone
+  // fills the chip at 2 lanes per candidate (~1280 resident workgroups x 128 slots); with fewer, longer candidates
+  // (cfg4: 1024-token documents) several queries' slices are in flight and the exact kernel is faster (3.2 vs 4.1 ms)
+  const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 131072;
   P.used_q8 = !P.exact_all && sh.Qp == 32 && M > 0 && q8_env >= 0 && (q8_env > 0 || q8_auto);
   if (P.used_q8) {
     const int64_t max_n = std::min<int64_t>(D.N, M);

@@ -973,6 +973,7 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 
 // 2 lanes per candidate (16 B = 16 query columns each), 32 candidates per wave, same software
 // pipeline as k_approx.  kq[cand] = K_hi << 16 | K_lo.
+// (96 VGPRs = 5 waves/SIMD; forcing 6 changes nothing, 7-8 spill and are slower: the kernel is bound by L2 misses, not latency)
 __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S8, int64_t C, int Q,
                                                    const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                    const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
@@ -1538,7 +1539,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
 #define AP_ABL 0  // k_approx ablation bits (timing only): 1 no row gathers, 2 synthetic codes
 #endif
 #ifndef FP_ABL
-#define FP_ABL 0  // ablation bits (timing experiments only): 1 no norm chain, 2 no normalise, 4 no LUT decode
+#define FP_ABL 0  // ablation bits (timing experiments only): 1 no norm chain, 2 no normalise, 4 no LUT decode, 8 no centroid gather, 16 no residual stream
 #endif
 // Layout of the MaxSim kernel (v3).  ONE TOKEN PER LANE: a wave carries two independent
 // 32-token streams (lanes 0-31 and 32-63), each walking its own sequence of documents chunk by
@@ -1642,8 +1643,8 @@ __global__ __launch_bounds__(256) void k_maxsim_reg(const uint16_t* __restrict__
     uint32_t e[NE];
     uint32_t rw[RW];
     // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
-    const long long row = valid ? tok_row() : 0;
-    const int32_t ccode = valid ? code : 0;
+    const long long row = (valid && !(FP_ABL & 16)) ? tok_row() : 0;   // ablation 16: every lane reads residual row 0
+    const int32_t ccode = (valid && !(FP_ABL & 8)) ? code : 0;          // ablation 8: every lane reads centroid row 0
     {
       const uint8_t* rp = resid + row * (long long)PR;
       if constexpr (RW >= 4) {
