@@ -96,11 +96,11 @@ struct Scratch {
   hipEvent_t ev[ST_N + 1] = {};
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
-      tok_idx, recon, out_all, S8, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid;
+      tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid;
   HostBuf h_out, h_small;
   void destroy() {
     out_all.release();
-    for (DevBuf* b : {&S8, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid}) b->release();
+    for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid}) b->release();
     h_out.release();
     h_small.release();
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
@@ -494,7 +494,16 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st);
   HIPCHK(hipEventRecord(s->ev[ST_CENTROID], st));
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
-  if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, st)) return fail(FP_EUNSUPPORTED, "dim");
+  // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
+  // per-128-centroid column maxima for the threshold probe
+  static const int q8_env = [] { const char* e = getenv("FP_APPROX_IMPL"); return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : 0)); }();
+  const bool want_s8 = !P.exact_all && sh.Qp == 32 && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
+  const int nch128 = (int)((D.C + 127) / 128);
+  if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * 32));
+  HIPCHK(s->cmax128.ensure((size_t)B * sh.Qp * nch128 * 2));
+  if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
+                          s->cmax128.as<uint16_t>(), st))
+    return fail(FP_EUNSUPPORTED, "dim");
   HIPCHK(hipEventRecord(s->ev[ST_PROBE], st));
   // subset bitmaps
   P.W = ((D.N + 31) / 32 + 63) & ~63ll;
@@ -527,7 +536,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->ncells.ensure((size_t)B * 4));
   if (sh.n_probe >= 1) {
     if (fpk_probe(D, s->S.as<uint16_t>(), sh, has_subset ? s->allow.as<uint32_t>() : nullptr, s->partial.as<unsigned long long>(),
-                  P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), st))
+                  P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), s->cmax128.as<uint16_t>(), st))
       return fail(FP_EUNSUPPORTED, "n_ivf_probe");
   } else {
     HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result
@@ -557,16 +566,14 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // S4: bound-and-refine when one query's slice of S overflows L2 and there is something to prune, else exact for all
   const int64_t* sel_off = s->cand_off.as<int64_t>();
   const int32_t* sel_src = s->cand_pid.as<int32_t>();
-  static const int q8_env = [] { const char* e = getenv("FP_APPROX_IMPL"); return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : 0)); }();
   // bound stage when (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone
   // fills the chip at 2 lanes per candidate (~1280 resident workgroups x 128 slots); with fewer, longer candidates
   // (cfg4: 1024-token documents) several queries' slices are in flight and the exact kernel is faster (3.2 vs 4.1 ms)
   const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 131072;
-  P.used_q8 = !P.exact_all && sh.Qp == 32 && M > 0 && q8_env >= 0 && (q8_env > 0 || q8_auto);
+  P.used_q8 = want_s8 && M > 0 && (q8_env > 0 || q8_auto);
   if (P.used_q8) {
     const int64_t max_n = std::min<int64_t>(D.N, M);
     const int nblk2 = (int)((max_n + FP_SURV_CHUNK - 1) / FP_SURV_CHUNK);
-    HIPCHK(s->S8.ensure((size_t)B * D.C * 32));
     HIPCHK(s->kq.ensure((size_t)M * 4));
     HIPCHK(s->q8hist.ensure((size_t)B * 8192 * 4));
     HIPCHK(s->cut.ensure((size_t)B * 4));
@@ -574,7 +581,6 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     HIPCHK(s->nsurv.ensure((size_t)B * 4));
     HIPCHK(s->surv_off.ensure((size_t)(B + 1) * 8));
     HIPCHK(s->surv_pid.ensure((size_t)M * 4));
-    fpk_quant_s8(s->S.as<uint16_t>(), s->S8.as<uint8_t>(), (int64_t)B * D.C * 32, st);
     fpk_approx_q8_filter(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
                          s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
                          s->surv_pid.as<int32_t>(), st);

@@ -69,11 +69,12 @@ struct FpSearchShape {
 
 void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B*Qp,D]*/, int B, int Q, int Qp, int D,
                       hipStream_t st);
-int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* q_pad, uint16_t* S /*[B][C][Qp]*/, int B, int Qp,
+// S8 (nullable; written only when Qp == 32): 8-bit bins [B][C][32]; cmax (nullable): [B*Qp][ceil(C/128)] f16 column maxima per 128-centroid tile
+int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* q_pad, uint16_t* S /*[B][C][Qp]*/, int B, int Qp, uint8_t* S8, uint16_t* cmax,
                         hipStream_t st);
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow /*[B][Cw] or null*/,
               unsigned long long* partial, int nchunk, int32_t* cells /*[B][Q][n_probe]*/, int32_t* ucells /*[B][Q*n_probe]*/,
-              int32_t* ncells /*[B]*/, hipStream_t st);
+              int32_t* ncells /*[B]*/, const uint16_t* cmax128 /*nullable: S1's [B*Qp][ceil(C/128)] column maxima*/, hipStream_t st);
 size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);
 void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off /*[B+1] dev*/, int B,
                         uint32_t* subbm /*[B][W]*/, int64_t W, uint32_t* allow /*[B][Cw]*/, int64_t Cw,
@@ -91,7 +92,6 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
-void fpk_quant_s8(const uint16_t* S, uint8_t* S8, int64_t n_elems, hipStream_t st);
 void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off,
                           const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192] u32*/, uint32_t* kq, int32_t* cut, int32_t* blkcnt,
                           int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st);

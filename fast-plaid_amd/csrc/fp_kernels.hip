@@ -13,6 +13,7 @@
 // tensor op = fp32 arithmetic + one round-to-nearest-even to fp16; matmuls accumulate in
 // fp32 and round once.  The MFMA accumulation ORDER differs from the CPU's ascending-k
 // chain, which is the only source of (<= 1 fp16 ulp, rare) differences.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -110,14 +111,22 @@ void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, i
 
 // ============================================================================================
 // S1  centroid scores: 128(n = b*Qp+q) x 128(c) tile per 256-thread block, K = D in one go.
-// MFMA rows = query columns n, MFMA cols = centroids c, so that each lane ends up with 4
-// consecutive q for one centroid and can store 8 bytes of the [b][c][q] layout at once.
-// LDS tiles are XOR-swizzled at 16-byte granularity (row-major D-halfs rows would put a
-// whole ds_read_b128 lane group on one bank slot).
+// MFMA rows = query columns n, MFMA cols = centroids c.  LDS operand tiles are XOR-swizzled at
+// 16-byte granularity (row-major D-halfs rows would put a whole ds_read_b128 lane group on one
+// bank slot).
+// Epilogue: the fp16 tile is staged through LDS (the operand tiles are dead by then) so that the
+// [b][c][q] layout is written with 16 B per lane, 1 KiB contiguous per wave instruction (the
+// direct 8-byte stores reached 2 TB/s on the 537 MB of S), and two by-products leave with it:
+//   * S8, the 8-bit bins of S4's bound stage (fp_kernels.hip, "bound-and-refine"), Qp == 32 only;
+//   * cmax, the per-column maximum over the tile's 128 centroids: the threshold probe's chunk
+//     maxima at 128-centroid granularity for free.
 // ============================================================================================
+#define S1_TILE 128
 template <int D>
 __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
-                                                         uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp) {
+                                                         uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
+                                                         uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
+                                                         int nch) {
   constexpr int CH = D / 8;              // 16-byte chunks per row
   constexpr int ROWB = D * 2;            // bytes per row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -163,38 +172,108 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
-  // epilogue: D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi
+  __syncthreads();  // operand tiles are dead: the same LDS now stages the output
+  // D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi.
+  // Output tile in LDS: [group g = n/32 (4)][c (128)][32 q] halves = 64 B rows, the 16-byte chunk index
+  // XORed with (c>>2)&3 (lanes = consecutive c at a 64-byte stride would otherwise share banks).
+  unsigned char* Os = smem;                                           // 32 KiB
+  uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [2 (wc)][128 n] column maxima of each wave's 64 centroids
+  const uint32_t ninf2 = 0xFC00FC00u;  // packed fp16 -inf
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    const int64_t nb = n0 + wr * 64 + a * 32;  // first n of this 32-row MFMA tile (32-aligned, Qp%32==0)
-    if (nb >= Ntot) continue;
-    const int64_t bq = nb / Qp;
-    const int q0 = (int)(nb % Qp);
+    const int g = wr * 2 + a;
+    uint32_t cm[8];  // packed column maxima: cm[2*q4 + h] = columns q = 8*q4 + 4*hi + 2*h + {0,1}
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cm[r] = ninf2;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int64_t c = c0 + wc * 64 + b * 32 + l31;
-      if (c >= C) continue;
-      uint16_t* dst = S + (bq * C + c) * Qp + q0 + 4 * hi;
+      const int cl = wc * 64 + b * 32 + l31;       // centroid within the tile
+      const bool cok = (c0 + cl) < C;
+      unsigned char* orow = Os + ((size_t)(g * 128 + cl)) * 64;
+      const int f = (cl >> 2) & 3;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int q4 = 0; q4 < 4; ++q4) {             // q = 8*q4 + 4*hi + 0..3  -> chunk q4, half hi
         h2 lo, hi2;
-        lo.x = (half_t)acc[a][b][4 * g + 0];
-        lo.y = (half_t)acc[a][b][4 * g + 1];
-        hi2.x = (half_t)acc[a][b][4 * g + 2];
-        hi2.y = (half_t)acc[a][b][4 * g + 3];
-        *reinterpret_cast<uint2*>(dst + 8 * g) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
+        lo.x = (half_t)acc[a][b][4 * q4 + 0];
+        lo.y = (half_t)acc[a][b][4 * q4 + 1];
+        hi2.x = (half_t)acc[a][b][4 * q4 + 2];
+        hi2.y = (half_t)acc[a][b][4 * q4 + 3];
+        *reinterpret_cast<uint2*>(orow + ((q4 ^ f) * 16) + hi * 8) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
+        if (cok) {
+          cm[2 * q4] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4]), lo));
+          cm[2 * q4 + 1] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4 + 1]), hi2));
+        }
       }
+    }
+    if (cmax) {  // max over this wave's 64 centroids: DPP inside the 16-lane rows, one cross-row exchange
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint32_t v = cm[r];
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0xB1, 0xF, 0xF, false))));   // quad_perm [1,0,3,2]
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x4E, 0xF, 0xF, false))));   // quad_perm [2,3,0,1]
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x124, 0xF, 0xF, false))));  // row_ror:4
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x128, 0xF, 0xF, false))));  // row_ror:8
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2(shfl_xor_u32(v, 16))));                                                                  // the other row of this half
+        cm[r] = v;
+      }
+      if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int q = 8 * (r >> 1) + 4 * hi + 2 * (r & 1);
+          *reinterpret_cast<uint32_t*>(red + wc * 128 + g * 32 + q) = cm[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // write-out: 2048 16-byte pieces (g, c, chunk), 8 per thread, consecutive threads -> consecutive bytes of S when Qp == 32
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int p = it * 256 + tid;
+    const int g = p >> 9, cl = (p >> 2) & 127, ch = p & 3;
+    const int64_t nb = n0 + g * 32;
+    const int64_t c = c0 + cl;
+    if (nb >= Ntot || c >= C) continue;
+    const int64_t bq = nb / Qp;
+    const int q0 = (int)(nb % Qp);
+    const uint4 v = *reinterpret_cast<const uint4*>(Os + ((size_t)(g * 128 + cl)) * 64 + ((ch ^ ((cl >> 2) & 3)) * 16));
+    *reinterpret_cast<uint4*>(S + (bq * C + c) * Qp + q0 + ch * 8) = v;
+    if (S8) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t o[2] = {0u, 0u};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const h2 pr = u32_as_h2(w[t >> 1]);
+        const float x = (float)((t & 1) ? pr.y : pr.x);
+        int bin = (int)floorf(x * 128.0f) + 100;   // == Q8_OFFSET, see the bound stage of S4
+        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+        o[t >> 2] |= (uint32_t)bin << (8 * (t & 3));
+      }
+      *reinterpret_cast<uint2*>(S8 + (bq * C + c) * 32 + ch * 8) = make_uint2(o[0], o[1]);
+    }
+  }
+  if (cmax && tid < 128) {
+    const int64_t n = n0 + tid;
+    if (n < Ntot) {
+      const uint16_t u0 = red[tid], u1 = red[128 + tid];
+      cmax[n * nch + blockIdx.x] = (mono16(u0) > mono16(u1)) ? u0 : u1;
     }
   }
 }
 
-int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, hipStream_t st) {
+int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
+                        hipStream_t st) {
   const int64_t Ntot = (int64_t)B * Qp;
-  dim3 grid((unsigned)((ix.C + 127) / 128), (unsigned)((Ntot + 127) / 128));
+  const int nch = (int)((ix.C + S1_TILE - 1) / S1_TILE);
+  dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
+  if (Qp != 32) S8 = nullptr;
+  const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
   if (ix.dim == 128) {
-    hipLaunchKernelGGL(k_centroid_scores<128>, grid, dim3(256), 2 * 128 * 256, st, ix.centroids, qpad, S, ix.C, Ntot, Qp);
+    const size_t lds = std::max<size_t>(2 * 128 * 256, out_lds);
+    hipLaunchKernelGGL(k_centroid_scores<128>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch);
   } else if (ix.dim == 64) {
-    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), 2 * 128 * 128, st, ix.centroids, qpad, S, ix.C, Ntot, Qp);
+    const size_t lds = std::max<size_t>(2 * 128 * 128, out_lds);
+    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch);
   } else {
     return -1;
   }
@@ -415,18 +494,35 @@ __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restric
                                                        const uint32_t* __restrict__ allow, int64_t Cw,
                                                        const uint32_t* __restrict__ tau, uint32_t* __restrict__ cnt /*[B*Qp]*/,
                                                        unsigned long long* __restrict__ cand /*[B*Qp][PROBE_CAP]*/,
-                                                       int32_t* __restrict__ flag) {
+                                                       int32_t* __restrict__ flag, const uint16_t* __restrict__ cmax128, int nch128) {
   const int groups = Qp / 32;
   const int b = blockIdx.y / groups, g = blockIdx.y % groups;
   const int chunk = blockIdx.x;
   const int piece = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int q0 = g * 32 + piece * 8;
+  // which of this block's eight 128-row sub-chunks hold a value >= tau in at least one of the 32 columns
+  __shared__ uint32_t s_live;
+  uint32_t live = 0xFFu;
+  if (cmax128) {
+    if (threadIdx.x == 0) s_live = 0u;
+    __syncthreads();
+    const int sc = threadIdx.x >> 5, j = threadIdx.x & 31;       // (sub-chunk, column)
+    const int64_t sci = (int64_t)chunk * (PROBE_CHUNK / 128) + sc;
+    if (sci < nch128 && g * 32 + j < Q) {
+      const int64_t col = (int64_t)b * Qp + g * 32 + j;
+      if (mono16(cmax128[col * nch128 + sci]) >= tau[col]) atomicOr(&s_live, 1u << sc);
+    }
+    __syncthreads();
+    live = s_live;
+    if (live == 0u) return;
+  }
   uint32_t tq[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) tq[j] = (q0 + j < Q) ? tau[(int64_t)b * Qp + q0 + j] : 0xFFFFFFFFu;  // pad columns collect nothing
   const uint16_t* Sb = S + ((int64_t)b * C) * Qp + q0;
   const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
   for (int i = 0; i < PROBE_CHUNK / 64; ++i) {
+    if (!((live >> (i >> 1)) & 1u)) continue;
     const int64_t c = (int64_t)chunk * PROBE_CHUNK + i * 64 + rl;
     if (c >= C || (al && !((al[c >> 5] >> (c & 31)) & 1u))) continue;
     const uint4 v = *reinterpret_cast<const uint4*>(Sb + c * Qp);
@@ -470,7 +566,8 @@ size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, in
 }
 
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
-              unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells, hipStream_t st) {
+              unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells,
+              const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st) {
   const int64_t Cw = (ix.C + 31) / 32;
   int NP = 1;
   while (NP < sh.n_probe) NP <<= 1;
@@ -494,9 +591,19 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     (void)hipMemsetAsync(cand, 0, cols * PROBE_CAP * 8, st);
     (void)hipMemsetAsync(cnt, 0, cols * 4 + 4, st);  // counters + flag
     dim3 grid((unsigned)nch2, (unsigned)(sh.B * (sh.Qp / 32)));
-    hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);
-    hipLaunchKernelGGL(k_probe_tau, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cmax, sh.Q, sh.Qp, nch2, sh.n_probe, tau);
-    hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag);
+    // S1's 128-centroid column maxima serve as the chunk maxima when no subset masks centroids and their index fits 12 bits:
+    // tau is tighter, and the collect pass skips the 128-row sub-chunks that hold nothing >= tau in any of their 32 columns
+    const int nch128 = (int)((ix.C + 127) / 128);
+    const bool fused = cmax128 != nullptr && allow == nullptr && nch128 <= 4096;
+    if (fused) {
+      hipLaunchKernelGGL(k_probe_tau, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cmax128, sh.Q, sh.Qp, nch128, sh.n_probe, tau);
+      hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag, cmax128, nch128);
+    } else {
+      hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);
+      hipLaunchKernelGGL(k_probe_tau, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cmax, sh.Q, sh.Qp, nch2, sh.n_probe, tau);
+      hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag,
+                         (const uint16_t*)nullptr, 0);
+    }
     hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
                        flag, 0);
   } else {
@@ -919,7 +1026,7 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 // table (tools/probe/row_probe: 100 G rows/s from 8 MB, 171 from 4 MB, 230 from <= 2 MB; the
 // kernel runs at 92 G rows/s).  The selection only needs the exact approximate score of
 // documents near the top-R cut, so:
-//   (1) k_quant_s8: S -> 8-bit bins,  bin(x) = clamp(floor(128 x) + 100, 0, 255).  128 x and the
+//   (1) S1's epilogue writes S8: S -> 8-bit bins,  bin(x) = clamp(floor(128 x) + 100, 0, 255).  128 x and the
 //       floor are exact for fp16 x, so bin k means (k-100)/128 <= x < (k-99)/128 with no
 //       rounding caveat, and the map is monotone: the max over a document's codes of the bins
 //       IS the bin of the max.  Rows shrink to 32 B, one query's slice to C*32 B (4 MB at
@@ -940,30 +1047,6 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 #define Q8_ABL 0  // timing-only ablations of k_approx_q8: 1 no byte-max arithmetic, 2 synthetic codes
 #endif
 #define Q8_BINS_SUM 8192   // 32 columns x 255 < 8192
-
-__global__ __launch_bounds__(256) void k_quant_s8(const uint4* __restrict__ S, uint2* __restrict__ S8, int64_t n8) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint4 v = S[i];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t o[2] = {0u, 0u};
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const h2 p = u32_as_h2(w[t >> 1]);
-      const float x = (float)((t & 1) ? p.y : p.x);
-      int b = (int)floorf(x * 128.0f) + Q8_OFFSET;   // NaN -> 0 after the clamp below (int conversion of NaN is 0 on this target)
-      b = b < 0 ? 0 : (b > 255 ? 255 : b);
-      o[t >> 2] |= (uint32_t)b << (8 * (t & 3));
-    }
-    S8[i] = make_uint2(o[0], o[1]);
-  }
-}
-
-void fpk_quant_s8(const uint16_t* S, uint8_t* S8, int64_t n_elems, hipStream_t st) {
-  const int64_t n8 = n_elems / 8;
-  if (n8 <= 0) return;
-  hipLaunchKernelGGL(k_quant_s8, dim3(fp_grid_cap((n8 + 255) / 256, 256)), dim3(256), 0, st, reinterpret_cast<const uint4*>(S),
-                     reinterpret_cast<uint2*>(S8), n8);
-}
 
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   uint32_t r;
