@@ -805,6 +805,53 @@ extern "C" int fp_reconstruct_embeddings(const fp_index* cix, const int64_t* doc
 }
 
 // ------------------------------------------------------------------------------------------
+// token-score matrices of search hits (search.rs:294-363, :668-686)
+// ------------------------------------------------------------------------------------------
+extern "C" int fp_token_scores(const fp_index* cix, const uint16_t* queries, int32_t nq, int32_t Q, int32_t dim, const int64_t* pids,
+                               const int32_t* counts, int64_t stride, int64_t* out_offsets, uint16_t* out, int64_t out_capacity) {
+  fp_index* ix = const_cast<fp_index*>(cix);
+  if (!ix || nq < 0 || (nq > 0 && (!queries || !pids || !counts)) || !out_offsets) return fail(FP_EINVAL, "null argument");
+  if (dim != ix->d.dim) return fail(FP_EINVAL, "query dim does not match the index");
+  if (Q < 1) return fail(FP_EINVAL, "need at least one query token");
+  HIPCHK(hipSetDevice(ix->device));
+  std::vector<int32_t> hq, hp;
+  int64_t off = 0, h = 0;
+  out_offsets[0] = 0;
+  for (int32_t b = 0; b < nq; ++b) {
+    if (counts[b] < 0 || counts[b] > stride) return fail(FP_EINVAL, "bad hit count");
+    for (int32_t i = 0; i < counts[b]; ++i) {
+      const int64_t d = pids[(int64_t)b * stride + i] - ix->d.pid_offset;
+      if (d < 0 || d >= ix->d.N) return fail(FP_EINVAL, "document id out of range");
+      off += (int64_t)Q * (ix->h_doc_off[d + 1] - ix->h_doc_off[d]);
+      out_offsets[++h] = off;
+      hq.push_back(b);
+      hp.push_back((int32_t)d);
+    }
+  }
+  if (!out || h == 0 || off == 0) return FP_OK;   // sizing call, or nothing to compute
+  if (off > out_capacity) return fail(FP_EINVAL, "output capacity too small");
+  Scratch* s = acquire(ix);
+  if (!s) return fail(FP_EHIP, "could not create a HIP stream");
+  struct Rel { fp_index* ix; Scratch* s; ~Rel() { release(ix, s); } } rel{ix, s};
+  const size_t qbytes = (size_t)nq * Q * dim * 2;
+  HIPCHK(s->qin.ensure(qbytes));
+  HIPCHK(s->tok_idx.ensure((size_t)h * 8 + (size_t)h * 8 + 64));   // hit_query | hit_pid (i32 each) + out offsets (i64)
+  HIPCHK(s->tmpp.ensure((size_t)(h + 1) * 8));
+  HIPCHK(s->recon.ensure((size_t)off * 2));
+  int32_t* d_hq = s->tok_idx.as<int32_t>();
+  int32_t* d_hp = d_hq + h;
+  HIPCHK(hipMemcpyAsync(s->qin.p, queries, qbytes, hipMemcpyHostToDevice, s->st));
+  HIPCHK(hipMemcpyAsync(d_hq, hq.data(), (size_t)h * 4, hipMemcpyHostToDevice, s->st));
+  HIPCHK(hipMemcpyAsync(d_hp, hp.data(), (size_t)h * 4, hipMemcpyHostToDevice, s->st));
+  HIPCHK(hipMemcpyAsync(s->tmpp.p, out_offsets, (size_t)(h + 1) * 8, hipMemcpyHostToDevice, s->st));
+  if (fpk_token_scores(ix->d, s->qin.as<uint16_t>(), Q, d_hq, d_hp, h, s->tmpp.as<int64_t>(), s->recon.as<uint16_t>(), s->st))
+    return fail(FP_EUNSUPPORTED, "q_len * dim too large for the token-score kernel");
+  HIPCHK(hipMemcpyAsync(out, s->recon.p, (size_t)off * 2, hipMemcpyDeviceToHost, s->st));
+  HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // document-sharded search (see fastplaid.h)
 // ------------------------------------------------------------------------------------------
 struct fp_shard_ctx {

@@ -117,6 +117,9 @@ void fpk_transpose_ranks(const float* in_f /*[G][B][R]*/, const int64_t* in_p, i
                          float* out_f /*[B][G*R]*/, int64_t* out_p, hipStream_t st);
 // misc
 void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
+// [q_len, doc_len] fp16 similarity matrices of (query, doc) hits; -1 when q_len * dim does not fit LDS
+int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const int32_t* hit_query, const int32_t* hit_pid, int64_t n_hits,
+                     const int64_t* out_off, uint16_t* out, hipStream_t st);
 void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx /*[n] global token rows*/, int64_t n, float* out,
                      hipStream_t st);
 

@@ -2442,6 +2442,74 @@ void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, fl
                      tok_idx, out);
 }
 
+// token-score matrices (search.rs:651-653, :668-686): one 64-thread block per hit.  Per token: decompress exactly like
+// k_reconstruct (ascending fp32 norm chain), then lane j takes query token j (loop for q_len > 64): ascending-k fp32
+// chain, one rounding to fp16 -- the CPU reference's order, so the matrices are bit-identical to the oracle.
+__global__ __launch_bounds__(64) void k_token_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut,
+                                                     const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
+                                                     const int64_t* __restrict__ doc_off, const uint16_t* __restrict__ perm, int D, int nbits,
+                                                     const uint16_t* __restrict__ queries /*[nq][Q][D]*/, int Q,
+                                                     const int32_t* __restrict__ hit_query, const int32_t* __restrict__ hit_pid,
+                                                     const int64_t* __restrict__ out_off, uint16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);          // [Q][D] the hit's query as fp32
+  float* e = qs + (size_t)Q * D;                       // [D]
+  __shared__ float nrm;
+  const int h = blockIdx.x;
+  const int32_t pid = hit_pid[h];
+  const uint16_t* q = queries + (int64_t)hit_query[h] * Q * D;
+  for (int i = threadIdx.x; i < Q * D; i += 64) qs[i] = (float)__builtin_bit_cast(half_t, q[i]);
+  const int64_t t0 = doc_off[pid];
+  const int len = (int)(doc_off[pid + 1] - t0);
+  const int pb = 8 / nbits, pr = D * nbits / 8;
+  uint16_t* o = out + out_off[h];
+  for (int s = 0; s < len; ++s) {
+    const int64_t t = t0 + s;
+    const int32_t code = codes[t];
+    __syncthreads();  // e / nrm of the previous token are no longer read
+    for (int d = threadIdx.x; d < D; d += 64) {
+      const int byte = resid[t * pr + d / pb];
+      const half_t w = __builtin_bit_cast(half_t, lut[byte * pb + d % pb]);
+      const half_t c = __builtin_bit_cast(half_t, cent[(int64_t)code * D + d]);
+      e[d] = (float)(half_t)((float)w + (float)c);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ss = 0.f;
+      for (int d = 0; d < D; ++d) ss += e[d] * e[d];
+      nrm = (float)(half_t)__builtin_sqrtf(ss);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 64) e[d] = (float)(half_t)(e[d] / nrm);
+    __syncthreads();
+    const int torig = perm ? (int)perm[t] : s;
+    for (int j = threadIdx.x; j < Q; j += 64) {
+      const float* qq = qs + (size_t)j * D;
+      float acc = 0.f;
+      for (int d = 0; d < D; ++d) acc += e[d] * qq[d];   // products of two fp16 values are exact in fp32: mul+add == fma
+      o[(int64_t)j * len + torig] = __builtin_bit_cast(uint16_t, (half_t)acc);
+    }
+  }
+}
+
+int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const int32_t* hit_query, const int32_t* hit_pid, int64_t n_hits,
+                     const int64_t* out_off, uint16_t* out, hipStream_t st) {
+  if (n_hits <= 0) return 0;
+  const size_t lds = ((size_t)Q * ix.dim + ix.dim) * sizeof(float);
+  if (lds > 150 * 1024) return -1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_token_scores, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    attr_set = true;
+  }
+  for (int64_t h0 = 0; h0 < n_hits; h0 += 0x7FFFFF00ll / 64) {   // grid.x * 64 threads must stay below 2^32
+    const int64_t nh = std::min<int64_t>(n_hits - h0, 0x7FFFFF00ll / 64);
+    hipLaunchKernelGGL(k_token_scores, dim3((unsigned)nh), dim3(64), lds, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off, ix.perm,
+                       ix.dim, ix.nbits, queries, Q, hit_query + h0, hit_pid + h0, out_off + h0, out);
+  }
+  return 0;
+}
+
 // ============================================================================================
 // arithmetic self-test: the two shortcuts the MaxSim kernel takes must equal the reference
 // formulation (fp32 op + one rounding to fp16) for EVERY pair of fp16 bit patterns.

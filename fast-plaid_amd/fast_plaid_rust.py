@@ -8,7 +8,7 @@ Same names, argument meaning and error behaviour as the PyO3 functions:
   reconstruct_embeddings(...)            rust/utils/embeddings.rs:12-69
   initialize_torch(...)                  rust/lib.rs:100-104 (no libtorch here: a no-op)
 Index maintenance entry points (create / update / delete, lib.rs:132-165, :302-364) are outside
-the search hot path and raise NotImplementedError.
+the search hot path and raise NotImplementedError (create / update / delete).
 
 Tensors may be torch CPU tensors or numpy arrays; nothing here needs torch.
 """
@@ -329,5 +329,52 @@ def delete(*args, **kwargs):  # lib.rs:348-364
     raise NotImplementedError("index delete is outside the MI355X search hot path")
 
 
-def pysearch_with_token_scores(*args, **kwargs):  # lib.rs:248-275
-    raise NotImplementedError("token-score matrices are a 'next' row (SURVEY.md section 8, f4)")
+class QueryResultWithTokenScores:
+    """rust/search/search.rs:128-169: a QueryResult plus, per hit, the [query_tokens, doc_tokens] fp16
+    similarity matrix."""
+
+    __slots__ = ("query_id", "passage_ids", "scores", "token_scores")
+
+    def __init__(self, query_id, passage_ids, scores, token_scores):
+        self.query_id = query_id
+        self.passage_ids = passage_ids
+        self.scores = scores
+        self.token_scores = token_scores
+
+
+def token_score_matrices(index: PyLoadedIndex, queries_embeddings, pids: np.ndarray, counts: np.ndarray) -> list[list[np.ndarray]]:
+    """fp_token_scores: for every hit (query b, rank i < counts[b]) the [Q, doc_len] fp16 matrix."""
+    q = _np(queries_embeddings, np.float16)
+    if q.ndim != 3:
+        raise ValueError(f"Expected a 3D tensor for queries, but got shape {tuple(q.shape)}")
+    B, Q, D = q.shape
+    pids = np.ascontiguousarray(pids, np.int64)
+    counts = np.ascontiguousarray(counts, np.int32)
+    stride = pids.shape[1] if pids.ndim == 2 else 0
+    n_hits = int(counts.sum())
+    offs = np.zeros(n_hits + 1, np.int64)
+    N.check(N.lib().fp_token_scores(index._h, _ptr(q), B, Q, D, _ptr(pids), _ptr(counts), stride, _ptr(offs), None, 0))
+    out = np.zeros(max(int(offs[-1]), 1), np.float16)
+    if n_hits and offs[-1] > 0:
+        N.check(N.lib().fp_token_scores(index._h, _ptr(q), B, Q, D, _ptr(pids), _ptr(counts), stride, _ptr(offs), _ptr(out), int(offs[-1])))
+    res, h = [], 0
+    for b in range(B):
+        row = []
+        for _ in range(int(counts[b])):
+            n = int(offs[h + 1] - offs[h])
+            row.append(out[offs[h]: offs[h + 1]].reshape(Q, n // Q).copy())
+            h += 1
+        res.append(row)
+    return res
+
+
+def pysearch_with_token_scores(index: PyLoadedIndex, device: str, queries_embeddings, search_parameters: SearchParameters,
+                               show_progress: bool = False, subset=None) -> list[QueryResultWithTokenScores]:
+    """rust/lib.rs:243-290 -> search_many_with_token_scores (search.rs:294-363)."""
+    del show_progress
+    if _device_id(device) != index.device_id:
+        raise ValueError(f"index lives on device {index.device_id}, search requested on '{device}'")
+    pids, scores, counts = search_arrays(index, queries_embeddings, search_parameters, subset)
+    mats = token_score_matrices(index, queries_embeddings, pids, counts)
+    return [QueryResultWithTokenScores(b, pids[b, : counts[b]].tolist(), scores[b, : counts[b]].tolist(), mats[b])
+            for b in range(pids.shape[0])]

@@ -162,6 +162,24 @@ class FastPlaid:
             out.extend(j.result())
         return out
 
+    def search_token_scores(self, queries_embeddings, top_k: int = 10, batch_size: int = 2000, n_full_scores: int = 4096,
+                            n_ivf_probe: int = 8, show_progress: bool = True, subset=None, n_processes: int | None = None):
+        """fast_plaid.py:986-1047: like search(), each hit is (doc_id, score, [query_tokens, doc_tokens] fp16 matrix)."""
+        del n_processes
+        q3, subset = self._prepare_search(queries_embeddings, subset)
+        params = native.SearchParameters(batch_size=batch_size, n_full_scores=n_full_scores, top_k=top_k, n_ivf_probe=n_ivf_probe)
+        out = []
+        nq = q3.shape[0]
+        chunk = max(1, math.ceil(nq / len(self.devices))) if nq else 1
+        for i, dev in enumerate(self.devices):  # search_on_device_with_token_scores :256-322
+            s, e = i * chunk, min(nq, (i + 1) * chunk)
+            if s >= e:
+                break
+            res = native.pysearch_with_token_scores(self.indices[dev], dev, q3[s:e], params, show_progress,
+                                                    None if subset is None else subset[s:e])
+            out.extend([[(pid, sc, m) for sc, pid, m in zip(r.scores, r.passage_ids, r.token_scores)] for r in res])
+        return out
+
     def get_embeddings(self, subset: list[int]):
         """fast_plaid.py:1160-1186 -> list of [doc_len, dim] float32 arrays."""
         return native.reconstruct_embeddings(self.indices[self.devices[0]], subset, self.devices[0])

@@ -117,6 +117,18 @@ int fp_last_search_timings(const char** names, float* ms, int cap);
  * kernel (== out[0] unless the 8-bit bound stage pruned), out[3] = sub-batches.  Returns entries written. */
 int fp_last_search_counts(int64_t* out, int cap);
 
+/* ---- `pysearch_with_token_scores` (rust/lib.rs:243-290 -> search_many_with_token_scores,
+ *      rust/search/search.rs:294-363; matrix extraction :668-686) ------------------------------
+ * Token-level similarity matrices of search hits: for hit h = (query b, rank i) the matrix
+ * [q_len, doc_len(pid)] of fp16 values h(sum_fp32 e_hat[t] . q[j]) in the document's ORIGINAL
+ * token order, row-major, at out + out_offsets[h] (hits ordered query-major, then rank).
+ * Call fp_search first and pass its pids / counts.  With out == NULL only out_offsets
+ * [n_hits + 1] (element offsets) is filled, so the caller can size `out`; out_capacity is in
+ * elements.  Ids outside the index give FP_EINVAL. */
+int fp_token_scores(const fp_index* index, const uint16_t* queries_f16, int32_t n_queries, int32_t q_len, int32_t dim,
+                    const int64_t* pids /*[n_queries, stride]*/, const int32_t* counts /*[n_queries]*/, int64_t stride,
+                    int64_t* out_offsets /*[sum(counts) + 1]*/, uint16_t* out /*f16, nullable*/, int64_t out_capacity);
+
 /* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */
 /* Decompresses whole documents to fp32 rows. out: host [sum(len(doc)) , dim] f32 in the
  * order of doc_ids; out_lengths [n]. `out_capacity_rows` guards the buffer. */

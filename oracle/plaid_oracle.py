@@ -40,6 +40,7 @@ def lib():
         L.pl_search_trace.restype = i64
         L.pl_search_trace.argtypes = [vp, vp, i32, i64, i64, i64, vp, i64, i32] + [vp] * 9
         L.pl_exact_scores.argtypes = [vp, vp, i32, vp, i64, vp]
+        L.pl_token_scores.argtypes = [vp, vp, i32, i64, vp]
         L.pl_num_procs.restype = i32
         _lib = L
     return _lib
@@ -138,6 +139,18 @@ class OracleIndex:
         out = np.zeros(p.shape[0], np.float32)
         lib().pl_exact_scores(self._h, _p(q), q.shape[0], _p(p), p.shape[0], _p(out))
         return out
+
+
+def _token_scores(self, query, pid):
+    """[Q, len(doc)] fp16 similarity matrix (search.rs:651-653, :668-686)."""
+    q = np.ascontiguousarray(query, np.float16)
+    ln = int(self.doc_lengths[int(pid)])
+    out = np.zeros((q.shape[0], ln), np.float16)
+    lib().pl_token_scores(self._h, _p(q), q.shape[0], int(pid), _p(out))
+    return out
+
+
+OracleIndex.token_scores = _token_scores
 
 
 def num_procs() -> int:

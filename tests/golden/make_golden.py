@@ -106,7 +106,7 @@ def make_case(cfg, seed):
     out["params"] = np.array([cfg["n_probe"], cfg["n_full"], cfg["top_k"], 2000], dtype=np.int64)
     for b in range(cfg["B"]):
         sub = None if subsets is None else torch.tensor(subsets[b], dtype=torch.int64)
-        tr = OT.search(q[b], idx, cfg["n_probe"], 2000, cfg["n_full"], cfg["top_k"], sub)
+        tr = OT.search(q[b], idx, cfg["n_probe"], 2000, cfg["n_full"], cfg["top_k"], sub, return_token_scores=(b < 2))
         allowed = None
         if sub is not None:
             allowed = torch.unique(idx.doc_codes.lookup(sub)[0])
@@ -134,6 +134,9 @@ def make_case(cfg, seed):
             out[f"exact_{b}"] = np.zeros(0, np.float32)
         out[f"pids_{b}"] = np.asarray(tr.pids, dtype=np.int64)
         out[f"scores_{b}"] = np.asarray(tr.scores, dtype=np.float32)
+        if tr.token_matrices is not None:   # search.rs:668-686: [query_tokens, doc_tokens] fp16 per hit (first 3 hits kept)
+            for i, m in enumerate(tr.token_matrices[:3]):
+                out[f"tokmat_{b}_{i}"] = m.contiguous().numpy()
         if subsets is not None:
             out[f"subset_{b}"] = np.asarray(subsets[b], dtype=np.int64)
     # a decompression sample straight from the ATen op sequence (search.rs:53-107)

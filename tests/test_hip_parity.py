@@ -291,6 +291,48 @@ def test_bound_and_refine_forced(fp):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("name", ["base_d128_nb4", "d64_nb2", "empty_doc", "zero_pad_query", "topk_gt_ndocs"])
+def test_token_score_matrices(fp, name):
+    """fp_token_scores / pysearch_with_token_scores (search.rs:294-363, :668-686): per hit the
+    [query_tokens, doc_tokens] fp16 similarity matrix in the document's ORIGINAL token order.
+    Bit-identical to the oracle (same ascending fp32 order as the CPU reference), and the
+    properties the reference's tests assert: same ids/scores as search(), and the MaxSim of the
+    returned matrix equals the returned score (tests/test.py token-score tests: within 1e-3 / 0.1)."""
+    R = fp.fast_plaid_rust
+    z, arr = _load_golden(name)
+    n_probe, n_full, top_k, bs = (int(x) for x in z["params"])
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    params = R.SearchParameters(bs, n_full, top_k, n_probe)
+    q = z["queries"]
+    subs = [z[f"subset_{b}"].tolist() for b in range(q.shape[0])] if "subset_0" in z else None
+    plain = R.pysearch(hip, "cuda:0", q, params, False, subs)
+    res = R.pysearch_with_token_scores(hip, "cuda:0", q, params, False, subs)
+    assert len(res) == q.shape[0]
+    for b, (r, p) in enumerate(zip(res, plain)):
+        assert r.query_id == b and r.passage_ids == p.passage_ids and r.scores == p.scores
+        assert len(r.token_scores) == len(r.passage_ids)
+        for pid, sc, m in zip(r.passage_ids, r.scores, r.token_scores):
+            ln = int(arr["doc_lengths"][pid])
+            assert m.dtype == np.float16 and m.shape == (q.shape[1], ln)
+            ref = orc.token_scores(q[b], pid)
+            assert np.array_equal(m.view(np.uint16), ref.view(np.uint16)), f"query {b} doc {pid}: token scores differ from the oracle"
+        for i in range(3):   # the ATen-produced matrices committed with the fixture (ids equal modulo near-ties: match by id)
+            key = f"tokmat_{b}_{i}"
+            if key in z and i < len(r.passage_ids) and int(z[f"pids_{b}"][i]) == r.passage_ids[i]:
+                assert np.array_equal(r.token_scores[i].view(np.uint16), z[key].view(np.uint16))
+            if ln > 0:
+                manual = np.float32(m.astype(np.float32).max(axis=1).sum(dtype=np.float32))
+                assert abs(manual - sc) <= SCORE_TOL, (b, pid, manual, sc)
+    # host class mirror: (doc_id, score, matrix) triples
+    from fast_plaid_amd import search
+    with search.FastPlaid.from_arrays(arr, device="cuda:0") as fpi:
+        out = fpi.search_token_scores(q, top_k=top_k, n_full_scores=n_full, n_ivf_probe=n_probe, subset=subs, show_progress=False)
+        assert [[(d, s) for d, s, _ in row] for row in out] == [list(zip(r.passage_ids, r.scores)) for r in res]
+    with pytest.raises(ValueError):
+        R.token_score_matrices(hip, q[:1], np.array([[10 ** 9]], np.int64), np.array([1], np.int32))
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports

@@ -81,3 +81,25 @@ def test_compress_only_index_raises():
                          doc_lengths=z["doc_lengths"])
     with pytest.raises(ValueError, match="compress_only"):
         idx.search(z["queries"], 5)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_token_score_matrices_match_aten_goldens(name):
+    """pl_token_scores == the [query_tokens, doc_tokens] fp16 matrices the ATen restatement returned
+    for the first hits (search.rs:651-653, :668-686), bit for bit."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    orc = OC.OracleIndex(nbits=int(z["nbits"]), centroids=z["centroids"], bucket_weights=z["bucket_weights"], ivf=z["ivf"],
+                         ivf_lengths=z["ivf_lengths"], doc_codes=z["doc_codes"], doc_residuals=z["doc_residuals"],
+                         doc_lengths=z["doc_lengths"])
+    checked = 0
+    for b in range(2):
+        for i in range(3):
+            key = f"tokmat_{b}_{i}"
+            if key not in z:
+                continue
+            pid = int(z[f"pids_{b}"][i])
+            got = orc.token_scores(z["queries"][b], pid)
+            assert got.shape == z[key].shape
+            assert np.array_equal(got.view(np.uint16), z[key].view(np.uint16)), (name, b, i)
+            checked += 1
+    assert checked >= 1
