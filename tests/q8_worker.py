@@ -73,6 +73,19 @@ def main():
     q = fp.synth.make_queries(spec, arr["centroids"], 4, 32).astype(np.float32)
     for scale in (3.0, -3.0, 0.01):
         same_as_trace(idx, (q * scale).astype(np.float16), R.SearchParameters(2000, 128, 25, 8))
+    # the odd-shape random corpora of test_randomized_shapes_vs_oracle (those with Qp == 32)
+    from test_hip_parity import RANDOM_SHAPES, _random_arrays
+    for shape in RANDOM_SHAPES:
+        n_docs, max_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, use_subset = shape
+        if Q > 32:
+            continue
+        rng = np.random.default_rng(hash(shape) & 0xFFFFFFFF)
+        arr = _random_arrays(rng, n_docs, max_len, C, dim, nbits)
+        pick = rng.integers(0, C, (B, Q))
+        q = arr["centroids"][pick].astype(np.float32) + 0.3 * rng.standard_normal((B, Q, dim), dtype=np.float32) / np.sqrt(dim)
+        q /= np.linalg.norm(q, axis=2, keepdims=True)
+        subs = [rng.integers(0, n_docs, 20).tolist() for _ in range(B)] if use_subset else None
+        same_as_trace(mk(arr), q.astype(np.float16), R.SearchParameters(2000, n_full, top_k, n_probe), subs)
     print("Q8_OK")
 
 

@@ -333,6 +333,112 @@ def test_token_score_matrices(fp, name):
         R.token_score_matrices(hip, q[:1], np.array([[10 ** 9]], np.int64), np.array([1], np.int32))
 
 
+def _random_arrays(rng, n_docs, max_len, C, dim, nbits, n_lists=None, empty_frac=0.1):
+    """plain random index arrays (no power-of-two or corpus-model assumptions): any arrays are a valid
+    construct_index argument set, and both sides get the same ones."""
+    from fast_plaid_amd import synth
+    cent = rng.standard_normal((C, dim), dtype=np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    lens = rng.integers(1, max_len + 1, n_docs).astype(np.int64)
+    lens[rng.random(n_docs) < empty_frac] = 0
+    if n_docs >= 1 and lens.sum() == 0:
+        lens[0] = max_len
+    T = int(lens.sum())
+    codes = rng.integers(0, C, T).astype(np.int64)
+    # a few documents made of one repeated code, a few with all-distinct ascending / descending codes
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    for d in range(0, n_docs, 7):
+        if lens[d] > 1:
+            codes[offs[d]: offs[d + 1]] = codes[offs[d]]
+    for d in range(3, n_docs, 11):
+        if 1 < lens[d] <= C:
+            codes[offs[d]: offs[d + 1]] = np.sort(rng.choice(C, int(lens[d]), replace=False))[::-1]
+    res = rng.integers(0, 256, (T, dim * nbits // 8), dtype=np.uint8)
+    bw = np.sort(rng.normal(0.0, 0.05, 1 << nbits)).astype(np.float16)
+    P = n_lists or C
+    ivf, ivf_lengths = synth.build_ivf(codes, lens, P)
+    return dict(nbits=nbits, centroids=cent.astype(np.float16), bucket_weights=bw, ivf=ivf, ivf_lengths=ivf_lengths,
+                doc_codes=codes, doc_residuals=res, doc_lengths=lens)
+
+
+RANDOM_SHAPES = [
+    # n_docs, max_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, subset
+    (1, 5, 37, 128, 4, 2, 3, 1, 4, 10, False),
+    (7, 1, 100, 64, 2, 3, 1, 2, 1, 1, False),
+    (300, 33, 257, 128, 4, 4, 17, 5, 64, 10, False),
+    (300, 130, 1000, 64, 4, 3, 33, 8, 1000, 50, True),
+    (2000, 40, 3001, 128, 2, 5, 32, 8, 256, 5000, False),
+    (2000, 400, 513, 128, 4, 2, 64, 32, 128, 20, False),
+    (1500, 20, 64, 64, 2, 6, 100, 3, 40, 7, True),
+    (900, 70, 2048, 128, 4, 3, 31, 16, 4096, 100, False),
+    (50, 300, 5000, 128, 4, 2, 50, 8, 8, 3, False),
+    (4000, 12, 129, 64, 4, 9, 8, 1, 2000, 1000, True),
+]
+
+
+@pytest.mark.parametrize("shape", RANDOM_SHAPES, ids=[f"r{i}" for i in range(len(RANDOM_SHAPES))])
+def test_randomized_shapes_vs_oracle(fp, shape):
+    """odd sizes on purpose: centroid counts that are not multiples of the 128-row tiles, 1-token
+    documents, empty documents, repeated-code documents, query lengths off the 32 grid, n_probe up to
+    the kernel limit, n_full below / above the candidate count, top_k above everything, subsets."""
+    R = fp.fast_plaid_rust
+    n_docs, max_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, use_subset = shape
+    rng = np.random.default_rng(hash(shape) & 0xFFFFFFFF)
+    arr = _random_arrays(rng, n_docs, max_len, C, dim, nbits)
+    # queries: noisy copies of random centroids, one of them with a zero (padded) tail
+    pick = rng.integers(0, C, (B, Q))
+    q = arr["centroids"][pick].astype(np.float32) + 0.3 * rng.standard_normal((B, Q, dim), dtype=np.float32) / np.sqrt(dim)
+    q /= np.linalg.norm(q, axis=2, keepdims=True)
+    q = q.astype(np.float16)
+    if Q > 2:
+        q[0, Q - 1:] = 0
+    subs = None
+    if use_subset:
+        subs = [rng.integers(0, n_docs, int(rng.integers(1, 40))).tolist() for _ in range(B)]
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    params = R.SearchParameters(2000, n_full, top_k, n_probe)
+    pids, scores, counts = R.search_arrays(hip, q, params, subs)
+    zero_tail = Q > 2
+    for b in range(B):
+        sub = None if subs is None else subs[b]
+        h = R.search_trace(hip, q[b], params, sub)
+        o = orc.search_trace(q[b], top_k, n_full, n_probe, sub)
+        # a zero query token probes arbitrary (all-tied) centroids: only query 0 carries one, compare it loosely
+        check_trace(h, o, Q, n_probe, n_full, top_k, strict_cells=not (zero_tail and b == 0))
+        assert counts[b] == len(h["pids"])
+        assert np.array_equal(pids[b, : counts[b]], h["pids"]) and np.array_equal(scores[b, : counts[b]], h["scores"])
+
+
+def test_concurrent_searches_on_one_index(fp):
+    """fp_search is re-entrant on a shared index (load.rs:58-59 Send+Sync; the reference's thread-per-device and
+    joblib paths share one index object): 6 threads x 5 calls with different batches == the sequential results."""
+    import threading
+    R = fp.fast_plaid_rust
+    spec = _synth(fp, n_docs=20000, doc_len=48, n_centroids=2048, variable_len=True, seed=21)
+    arr = fp.synth.host_index_arrays(spec)
+    hip = _hip_index(fp, arr)
+    params = R.SearchParameters(2000, 512, 50, 8)
+    batches = [fp.synth.make_queries(spec, arr["centroids"], 3 + i, 32, seed=500 + i) for i in range(6)]
+    want = [R.search_arrays(hip, qb, params) for qb in batches]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                p, s, c = R.search_arrays(hip, batches[i], params)
+                assert np.array_equal(p, want[i][0]) and np.array_equal(s, want[i][1]) and np.array_equal(c, want[i][2])
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
