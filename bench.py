@@ -233,7 +233,7 @@ def main():
         t_s1 = stages.get("S1 centroid_gemm", 0.0)
         fl_s1 = 2.0 * C * a.dim * a.batch * a.qlen
         out["roofline_by_kernel"] = {
-            "S4 (k_quant_s8 + k_approx_q8 + cut + exact refine)": {"bound": "hbm", "algorithmic_bytes_per_launch": b_ap, "avg_launch_ms": t_ap,
+            "S4 (k_approx_q8 + cut + exact refine)": {"bound": "hbm", "algorithmic_bytes_per_launch": b_ap, "avg_launch_ms": t_ap,
                          "achieved": b_ap / (t_ap * 1e-3) / 1e9 if t_ap > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (b_ap / (t_ap * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ap > 0 else 0.0,
                          "candidate_docs_per_batch": cand_per_step,
