@@ -566,10 +566,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // S4: bound-and-refine when one query's slice of S overflows L2 and there is something to prune, else exact for all
   const int64_t* sel_off = s->cand_off.as<int64_t>();
   const int32_t* sel_src = s->cand_pid.as<int32_t>();
-  // bound stage when (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone
-  // fills the chip at 2 lanes per candidate (~1280 resident workgroups x 128 slots); with fewer, longer candidates
-  // (cfg4: 1024-token documents) several queries' slices are in flight and the exact kernel is faster (3.2 vs 4.1 ms)
-  const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 131072;
+  // bound stage when (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone can
+  // fill the chip (~1280 resident workgroups x 128 lane pairs; the kernel spreads a candidate over 4 pairs when there are
+  // fewer than 131072 candidates per query, e.g. cfg4's 1024-token documents or a small shard)
+  const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 32768;
   P.used_q8 = want_s8 && M > 0 && (q8_env > 0 || q8_auto);
   if (P.used_q8) {
     const int64_t max_n = std::min<int64_t>(D.N, M);

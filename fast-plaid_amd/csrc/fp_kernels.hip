@@ -1054,22 +1054,29 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   return r;
 }
 
-// 2 lanes per candidate (16 B = 16 query columns each), 32 candidates per wave, same software
-// pipeline as k_approx.  kq[cand] = K_hi << 16 | K_lo.
+// 2 lanes per lane PAIR (16 B = 16 query columns each), PPD pairs per candidate: pair p of a candidate takes the code
+// groups p, p + PPD, ... of its list and the PPD partial maxima are combined at the end (max is associative).
+// PPD = 1: 32 candidates per wave (many short candidates per query); PPD = 4: one query with few or long candidates
+// still fills the chip instead of leaving several queries' slices in flight.  kq[cand] = K_hi << 16 | K_lo.
 // (96 VGPRs = 5 waves/SIMD; forcing 6 changes nothing, 7-8 spill and are slower: the kernel is bound by L2 misses, not latency)
+template <int PPD>
 __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S8, int64_t C, int Q,
                                                    const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                    const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                    uint32_t* __restrict__ kq, int b0) {
+  constexpr int DPB = 128 / PPD;      // candidates per workgroup
+  constexpr int TSTEP = 8 * PPD;      // codes between two groups of one pair
   const int b = b0 + blockIdx.y, bxi = blockIdx.x;
   const int nbx = gridDim.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const int sub = threadIdx.x & 1;
-  const int grp = threadIdx.x >> 1;  // candidate slot within the block (0..127)
+  const int grp = threadIdx.x >> 1;   // lane pair within the block (0..127)
+  const int pp = grp % PPD;           // which pair of the candidate
+  const int tfirst = 8 * pp;
   const uint8_t* Sb = S8 + (int64_t)b * C * 32 + sub * 16;
-  const int64_t stride = (int64_t)nbx * 128;
-  int64_t i = (int64_t)bxi * 128 + grp;
+  const int64_t stride = (int64_t)nbx * DPB;
+  int64_t i = (int64_t)bxi * DPB + grp / PPD;
   // A step's 8 codes are ONE 16-byte load per lane (codes 4*sub .. 4*sub+3 of the group; dword-aligned only,
   // the list buffer is padded) plus an exchange inside the lane pair: 8 four-byte loads per step cost 1.6 of
   // the kernel's 5.6 ms (ablation with synthetic codes).  Positions past the end of the list repeat the
@@ -1104,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
     len = (int)(uoff[pid + 1] - u0);
   }
   // (the lanes of a pair always agree on len / nlen, so the exchanges inside load_codes are convergent per pair)
-  if (len > 0) load_codes(ucodes + u0, 0, len, code);
+  if (tfirst < len) load_codes(ucodes + u0, tfirst, len, code);
   for (; i < n; i += stride) {
     int64_t nu0 = 0;
     int nlen = 0;
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
     }
     const int32_t* cp = ucodes + u0;
     uint32_t me[4] = {0u, 0u, 0u, 0u}, mo[4] = {0u, 0u, 0u, 0u};  // running maxima: even / odd bytes as u16 pairs
-    for (int t = 0; t < len; t += 8) {
+    for (int t = tfirst; t < len; t += TSTEP) {
       uint4 v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sb + (int64_t)code[k] * 32);
@@ -1123,10 +1130,10 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
 #pragma unroll
       for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)code[k] * 2654435761u + (uint32_t)k) % (uint32_t)C);
 #else
-      if (t + 8 < len) {
-        load_codes(cp, t + 8, len, code);
-      } else if (nlen > 0) {
-        load_codes(ucodes + nu0, 0, nlen, code);
+      if (t + TSTEP < len) {
+        load_codes(cp, t + TSTEP, len, code);
+      } else if (tfirst < nlen) {
+        load_codes(ucodes + nu0, tfirst, nlen, code);
       }
 #endif
 #pragma unroll
@@ -1144,7 +1151,17 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
 #endif
       }
     }
-    if (len == 0 && nlen > 0) load_codes(ucodes + nu0, 0, nlen, code);
+    if (tfirst >= len && tfirst < nlen) load_codes(ucodes + nu0, tfirst, nlen, code);  // this pair had no group in this list
+    if constexpr (PPD > 1) {  // combine the pairs of the candidate (its 2*PPD lanes are consecutive and converged here)
+#pragma unroll
+      for (int m = 2; m < 2 * PPD; m <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          me[j] = pk_max_u16(me[j], shfl_xor_u32(me[j], m));
+          mo[j] = pk_max_u16(mo[j], shfl_xor_u32(mo[j], m));
+        }
+      }
+    }
     // sum / min / max of this lane's real columns (column = sub*16 + 4*j + byte)
     uint32_t sum = 0, mn = 255u, mx = 0u;
 #pragma unroll
@@ -1161,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_approx_q8(const uint8_t* __restrict__ S
     sum += __shfl_xor(sum, 1, 64);
     mn = min(mn, (uint32_t)__shfl_xor(mn, 1, 64));
     mx = max(mx, (uint32_t)__shfl_xor(mx, 1, 64));
-    if (sub == 0) {
+    if (sub == 0 && pp == 0) {
       const uint32_t klo = (len == 0 || mn == 0u) ? 0u : sum;       // a bin-0 column (or an empty document) voids the lower bound
       const uint32_t khi = (mx == 255u) ? 0xFFFFu : sum;            // a bin-255 column voids the upper bound
       kq[beg + i] = (khi << 16) | klo;
@@ -1306,26 +1323,35 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
                           const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192]*/, uint32_t* kq, int32_t* cut, int32_t* blkcnt,
                           int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
   const int B = sh.B;
-  // One candidate per lane pair and ~2048 workgroups per query: measured best (S4 6.05 ms).  Longer-lived
-  // workgroups (2/4/8 candidates per pair: 6.6/8.3/10.3 ms) put several queries' slices in flight at once.
-  static const int dps_env = getenv("FP_Q8_DPS") ? atoi(getenv("FP_Q8_DPS")) : 0;
-  const int dps = dps_env > 0 ? dps_env : 1;
-  int64_t per_q = (M + B - 1) / B;
-  int64_t bx = (per_q + 128 * dps - 1) / (128 * dps);
-  if (bx > 4096) bx = 4096;
+  // Lane pairs per candidate: about 2-3 code groups per pair (cfg2, 33 codes = 5 groups: 1/2/4/8 pairs -> S4 5.15/4.34/
+  // 4.53/4.63 ms), more when one query would otherwise not fill the chip (~1280 resident workgroups x 128 pairs; long
+  // documents, small shards).  One workgroup pass per query wherever possible: a grid cap of 2048 costs 0.5 ms, and
+  // longer-lived workgroups (2/4/8 candidates per pair: 6.6/8.3/10.3 ms at 1 pair) put several queries' slices in flight.
+  static const int ppd_env = getenv("FP_Q8_PPD") ? atoi(getenv("FP_Q8_PPD")) : 0;
+  static const int cap_env = getenv("FP_Q8_BXCAP") ? atoi(getenv("FP_Q8_BXCAP")) : 0;
+  const int64_t per_q = (M + B - 1) / B;
+  const int64_t groups = ix.N > 0 ? (ix.U / ix.N + 7) / 8 : 1;   // average code groups per document
+  int ppd = 1;
+  while (ppd < 8 && ppd * 4 <= groups) ppd <<= 1;                // >= 2 groups per pair
+  while (ppd < 8 && per_q * ppd < 131072) ppd <<= 1;             // fill the chip with one query
+  if (ppd_env == 1 || ppd_env == 2 || ppd_env == 4 || ppd_env == 8) ppd = ppd_env;
+  const int dpb = 128 / ppd;
+  int64_t bx = (per_q + dpb - 1) / dpb;
+  const int64_t cap = cap_env > 0 ? cap_env : 16384;
+  if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
-  // (an XCD-affine mapping -- one query per XCD so that each L2 holds one 4 MB slice -- measured slower: 6.9 vs 6.05 ms)
-  static const int perq_env = getenv("FP_Q8_PERQ") ? atoi(getenv("FP_Q8_PERQ")) : 0;
-  if (perq_env > 0) {   // queries in groups of perq_env per launch: bounds how many slices of S8 are live at once
-    for (int b0 = 0; b0 < B; b0 += perq_env) {
-      const int nb = (B - b0) < perq_env ? (B - b0) : perq_env;
-      hipLaunchKernelGGL(k_approx_q8, dim3((unsigned)bx, (unsigned)nb), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff,
-                         ix.ucodes, kq, b0);
-    }
-  } else {
-    hipLaunchKernelGGL(k_approx_q8, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff, ix.ucodes,
-                       kq, 0);
+  // (an XCD-affine mapping -- one query per XCD so that each L2 holds one 4 MB slice -- measured slower: 6.9 vs 6.05 ms;
+  //  one launch per 1/2/4 queries: 6.2/6.0/5.9 vs 5.8 ms)
+#define FP_Q8_LAUNCH(PPD_)                                                                                                        \
+  hipLaunchKernelGGL(k_approx_q8<PPD_>, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff, \
+                     ix.ucodes, kq, 0)
+  switch (ppd) {
+    case 1: FP_Q8_LAUNCH(1); break;
+    case 2: FP_Q8_LAUNCH(2); break;
+    case 8: FP_Q8_LAUNCH(8); break;
+    default: FP_Q8_LAUNCH(4); break;
   }
+#undef FP_Q8_LAUNCH
   (void)hipMemsetAsync(q8hist, 0, (size_t)B * Q8_BINS_SUM * 4, st);
   hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), 0, st, kq, cand_off, q8hist);
   hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut);
