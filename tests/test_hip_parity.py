@@ -278,15 +278,19 @@ def test_index_build_with_capped_grids(fp):
     assert r.returncode == 0 and "GRID_CAP_OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_bound_and_refine_forced(fp):
+@pytest.mark.parametrize("ppd", ["auto", "1", "2", "4", "8"])
+def test_bound_and_refine_forced(fp, ppd):
     """S4's bound-and-refine form (8-bit bins of S -> per-candidate bounds -> exact rescoring of
-    the survivors) forced on small corpora via FP_APPROX_IMPL=q8: fp_search must equal
-    fp_search_trace (which scores every candidate exactly) bit for bit -- fixtures, pruned
-    synthetic corpora, Q < 32, out-of-range score values."""
+    the survivors) forced on small corpora via FP_APPROX_IMPL=q8, for every lane-pairs-per-candidate
+    instantiation of the bound kernel (FP_Q8_PPD): fp_search must equal fp_search_trace (which
+    scores every candidate exactly) bit for bit -- fixtures, pruned synthetic corpora, Q < 32,
+    out-of-range score values, the odd random shapes."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FP_APPROX_IMPL="q8")
+    if ppd != "auto":
+        env["FP_Q8_PPD"] = ppd
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
