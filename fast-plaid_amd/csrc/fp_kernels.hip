@@ -2204,14 +2204,22 @@ static void launch_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSe
   const int dpw = dpw_env;  // documents per wave (two streams x dpw/2)
   dim3 grid((unsigned)((Rcap + 4 * dpw - 1) / (4 * dpw)), (unsigned)sh.B);
   const int nch = sh.Qp / 32;
+  static const int nch2_env = getenv("FP_MAXSIM_NCH2") ? atoi(getenv("FP_MAXSIM_NCH2")) : 1;
   int acc = 0;
-  for (int ch = 0; ch < nch; ++ch) {  // one 32-column query chunk per launch
-    if (impl_env == 1)
+  for (int ch = 0; ch < nch;) {  // 32-column query chunks: two per launch where possible (the tokens are decompressed once per launch)
+    if (impl_env == 1) {
       hipLaunchKernelGGL((k_maxsim_lds<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
                          qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
-    else
+      ch += 1;
+    } else if (nch2_env && nch - ch >= 2) {
+      hipLaunchKernelGGL((k_maxsim_reg<D, NBITS, 2>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
+                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
+      ch += 2;
+    } else {
       hipLaunchKernelGGL((k_maxsim_reg<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
                          qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
+      ch += 1;
+    }
     acc = 1;
   }
 }
