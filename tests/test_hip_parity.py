@@ -443,6 +443,33 @@ def test_concurrent_searches_on_one_index(fp):
     assert not errors, errors
 
 
+def test_reference_loader_arrays_with_padding_rows(fp):
+    """construct_index on the array set exactly as the reference's loader returns it (trailing max_len - last_len
+    padding rows on codes / residuals, load.py:298-320) == construct_index on the unpadded arrays == the oracle."""
+    R = fp.fast_plaid_rust
+    from fast_plaid_amd import search
+    from fast_plaid_amd.search import index_io
+    gdir = os.path.join(GOLDEN_DIR, "refloader")
+    exp = np.load(os.path.join(gdir, "index_dir_expected.npz"))
+    padded = {k: exp[k] for k in exp.files}
+    padded["nbits"] = int(exp["nbits"])
+    plain = index_io.load_index_arrays(os.path.join(gdir, "index_dir"))
+    assert padded["doc_codes"].shape[0] > plain["doc_codes"].shape[0]
+    a, b = _hip_index(fp, padded), _hip_index(fp, plain)
+    orc = _oracle(plain)
+    rng = np.random.default_rng(5)
+    q = plain["centroids"][rng.integers(0, plain["centroids"].shape[0], (4, 12))]
+    params = R.SearchParameters(2000, 64, 10, 4)
+    ra, rb = R.search_arrays(a, q, params), R.search_arrays(b, q, params)
+    assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    for i in range(4):
+        check_trace(R.search_trace(a, q[i], params), orc.search_trace(q[i], 10, 64, 4), 12, 4, 64, 10)
+    # and the directory loads through the host class
+    with search.FastPlaid(index=os.path.join(gdir, "index_dir"), device="cuda:0") as fpi:
+        out = fpi.search(q, top_k=10, n_full_scores=64, n_ivf_probe=4, show_progress=False)
+        assert [[d for d, _ in row] for row in out] == [ra[0][i, : ra[2][i]].tolist() for i in range(4)]
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports

@@ -136,3 +136,28 @@ def test_sharded_protocol_gloo(world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert "SHARDED_OK" in o, o
+
+
+def test_index_directory_matches_the_reference_loader():
+    """tests/golden/refloader/index_dir was written by this repo's writer; index_dir_expected.npz is what the REFERENCE's own
+    python/fast_plaid/search/load.py::_load_index_tensors_cpu returned for it (tests/golden/make_index_dir_golden.py).
+    So (a) the writer emits a directory the reference reads, and (b) our reader returns the same construct_index
+    argument set, bit for bit, up to the max_len - last_len padding rows the reference appends (load.py:298-320),
+    which construct_index ignores."""
+    from fast_plaid_amd.search import index_io
+    gdir = os.path.join(ROOT, "tests", "golden", "refloader")
+    exp = np.load(os.path.join(gdir, "index_dir_expected.npz"))
+    got = index_io.load_index_arrays(os.path.join(gdir, "index_dir"))
+    assert got["nbits"] == int(exp["nbits"])
+    for k in ("centroids", "avg_residual", "bucket_cutoffs", "bucket_weights", "ivf", "ivf_lengths", "doc_lengths"):
+        assert got[k].dtype == exp[k].dtype, k
+        assert np.array_equal(got[k].view(np.uint16) if got[k].dtype == np.float16 else got[k],
+                              exp[k].view(np.uint16) if exp[k].dtype == np.float16 else exp[k]), k
+    T = int(got["doc_lengths"].sum())
+    lens = got["doc_lengths"]
+    pad = int(lens.max() - lens[-1])
+    assert exp["doc_codes"].shape[0] == T + pad and exp["doc_residuals"].shape[0] == T + pad
+    assert got["doc_codes"].shape[0] == T
+    assert np.array_equal(got["doc_codes"], exp["doc_codes"][:T]) and np.array_equal(got["doc_residuals"], exp["doc_residuals"][:T])
+    # the reference's loader leaves nothing behind in the committed directory (it ran on a scratch copy)
+    assert not [f for f in os.listdir(os.path.join(gdir, "index_dir")) if f.startswith("merged_")]
