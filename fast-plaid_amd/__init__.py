@@ -7,8 +7,9 @@ Layout:
                         (rust/lib.rs:366-383): construct_index / pysearch / SearchParameters / QueryResult
   search/               mirror of `fast_plaid.search` (class FastPlaid)
   synth.py              synthetic compressed-domain corpora (numpy twin of csrc/fp_synth.hip)
-  sharded.py            one-process-per-GPU document-sharded search over torch.distributed (RCCL)
+  sharded.py            one-process-per-GPU document-sharded / replicated search over torch.distributed (RCCL)
+  create.py             index creation given centroids: codec training, device compression (fp_compress), IVF, directory
 """
-from . import fast_plaid_rust, search, synth  # noqa: F401
+from . import create, fast_plaid_rust, search, synth  # noqa: F401
 
-__all__ = ["fast_plaid_rust", "search", "synth"]
+__all__ = ["create", "fast_plaid_rust", "search", "synth"]

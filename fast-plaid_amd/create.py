@@ -1,0 +1,112 @@
+"""Index creation, the part the reference does in its native `create` (rust/lib.rs:132-165 ->
+rust/index/create.rs:206-583) -- SURVEY.md section 8, row f1:
+
+  codec training   create.rs:317-377   bucket cutoffs / weights = quantiles of held-out residuals  (host, numpy)
+  compression      create.rs:148-184, :404-428   nearest centroid + quantised packed residuals      (device, fp_compress)
+  IVF              create.rs:528-559 + optimize_ivf :55-132                                         (host, numpy)
+  directory        create.rs:380-397, :476-491, :548-582                                            (search/index_io.py)
+
+K-means is not here: the reference runs it in Python through the external `fastkmeans` package
+(python/fast_plaid/search/kmeans.py), which is not part of this image; centroids are an input.
+The sampling of held-out passages uses numpy's generator instead of Rust's StdRng, so a directory created
+here is a valid index for the same centroids but not byte-identical to one the reference would create from
+the same seed; every deterministic step is bit-identical to the ATen restatement (tests).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _native as N
+from . import synth
+from .fast_plaid_rust import _device_id, _np, _ptr
+
+
+def compress(centroids, bucket_cutoffs, embeddings, nbits: int, device: str = "cuda:0"):
+    """create.rs:404-428 on the device: (codes int64 [T], packed residuals uint8 [T, dim*nbits/8])."""
+    cent = _np(centroids, np.float16)
+    cut = _np(bucket_cutoffs, np.float16)
+    emb = _np(embeddings, np.float16)
+    if emb.ndim != 2 or cent.ndim != 2 or emb.shape[1] != cent.shape[1]:
+        raise ValueError("embeddings [T, dim] and centroids [C, dim] must agree on dim")
+    if cut.shape[0] != (1 << nbits) - 1:
+        raise ValueError("bucket_cutoffs must hold 2^nbits - 1 values")
+    T, dim = emb.shape
+    codes = np.zeros(T, np.int64)
+    res = np.zeros((T, dim * nbits // 8), np.uint8)
+    N.check(N.lib().fp_compress(_device_id(device), _ptr(cent), cent.shape[0], dim, nbits, _ptr(cut), _ptr(emb), T, _ptr(codes), _ptr(res)))
+    return codes, res
+
+
+def _kth(sorted_flat: np.ndarray, k: int) -> np.float32:
+    return sorted_flat[k]
+
+
+def _quantile(sorted_flat: np.ndarray, q: float) -> np.float32:
+    """rust/search/tensor.rs:18-34 scalar_quantile_kthvalue; lerp as ATen computes it in fp32
+    (weight < 0.5 ? a + w (b - a) : b - (b - a)(1 - w))."""
+    n = sorted_flat.shape[0]
+    idx = q * (n - 1)
+    lo, hi = math.floor(idx), math.ceil(idx)
+    a = np.float32(_kth(sorted_flat, lo))
+    if lo == hi:
+        return a
+    b = np.float32(_kth(sorted_flat, hi))
+    w = np.float32(idx - lo)
+    d = np.float32(b - a)
+    return np.float32(a + w * d) if w < np.float32(0.5) else np.float32(b - d * np.float32(np.float32(1.0) - w))
+
+
+def train_codec(heldout, centroids, nbits: int, device: str = "cuda:0"):
+    """create.rs:317-364 -> (bucket_cutoffs f32 [2^nbits-1], bucket_weights f32 [2^nbits], avg_residual f32 [dim])."""
+    held = _np(heldout, np.float16)
+    cent = _np(centroids, np.float16)
+    n_opt = 1 << nbits
+    codes, _ = compress(cent, np.zeros(n_opt - 1, np.float16), held, nbits, device)   # only the assignment is used
+    res = (held - cent[codes]).astype(np.float32)      # fp16 subtraction (fp32 op + one rounding), then widened like .to(Float)
+    flat = np.sort(res.reshape(-1), kind="stable")
+    cut = np.array([_quantile(flat, i / n_opt) for i in range(1, n_opt)], np.float32)
+    wts = np.array([_quantile(flat, (i + 0.5) / n_opt) for i in range(n_opt)], np.float32)
+    avg = np.abs(res).mean(axis=0, dtype=np.float32)
+    return cut, wts, avg
+
+
+def build_index_arrays(docs, centroids, nbits: int, device: str = "cuda:0", heldout=None, num_partitions: int | None = None) -> dict:
+    """The construct_index argument set for a list of [len, dim] document embeddings (the whole corpus is the
+    held-out sample unless one is given), without the reference loader's trailing padding rows."""
+    cent = _np(centroids, np.float16)
+    docs16 = [_np(d, np.float16) for d in docs]
+    lens = np.array([d.shape[0] for d in docs16], np.int64)
+    allemb = np.concatenate(docs16) if docs16 else np.zeros((0, cent.shape[1]), np.float16)
+    cut, wts, avg = train_codec(allemb if heldout is None else heldout, cent, nbits, device)
+    codes, packed = compress(cent, cut.astype(np.float16), allemb, nbits, device)
+    P = num_partitions if num_partitions is not None else max(cent.shape[0], 1)
+    ivf, ivf_lengths = synth.build_ivf(codes, lens, P)
+    return dict(nbits=nbits, centroids=cent, avg_residual=avg.astype(np.float16), bucket_cutoffs=cut.astype(np.float16),
+                bucket_weights=wts.astype(np.float16), ivf=ivf, ivf_lengths=ivf_lengths, doc_codes=codes, doc_residuals=packed,
+                doc_lengths=lens)
+
+
+def create_index(index_path: str, documents_embeddings, centroids, nbits: int = 4, device: str = "cuda:0", seed: int | None = 42,
+                 compress_only: bool = False, chunk_docs: int = 25_000) -> dict:
+    """rust/index/create.rs:206-583 given centroids: sample held-out passages (:222-290: 16*sqrt(120*N) passages, the
+    last 5 % of their tokens capped at 50 000), train the codec, compress every document, build the IVF, write the
+    directory.  Returns the array set it wrote."""
+    from .search import index_io
+    docs16 = [_np(d, np.float16) for d in documents_embeddings]
+    n = len(docs16)
+    if n == 0:
+        raise ValueError("Cannot create an index from zero documents")
+    rng = np.random.default_rng(seed)
+    k = int(min(1.0 + 16.0 * math.sqrt(120.0 * n), n))
+    sample = np.sort(rng.permutation(n)[:k])
+    total = int(sum(docs16[i].shape[0] for i in sample))
+    held_n = int(round(min(0.05 * total, 50_000.0)))
+    held = np.concatenate([docs16[i] for i in sample])[-max(held_n, 1):]
+    arr = build_index_arrays(docs16, centroids, nbits, device, heldout=held)
+    if compress_only:
+        arr["ivf"] = None
+        arr["ivf_lengths"] = None
+    index_io.save_index_arrays(index_path, arr, chunk_docs=chunk_docs)
+    return arr

@@ -852,6 +852,66 @@ extern "C" int fp_token_scores(const fp_index* cix, const uint16_t* queries, int
 }
 
 // ------------------------------------------------------------------------------------------
+// index creation, device part (create.rs:148-184, :404-428)
+// ------------------------------------------------------------------------------------------
+extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, int32_t dim, int32_t nbits, const uint16_t* cutoffs,
+                           const uint16_t* emb, int64_t T, int64_t* out_codes, uint8_t* out_res) {
+  if (!centroids || !cutoffs || C < 1 || T < 0 || (T > 0 && (!emb || !out_codes || !out_res))) return fail(FP_EINVAL, "bad argument");
+  if (!(nbits == 2 || nbits == 4)) return fail(FP_EUNSUPPORTED, "nbits must be 2 or 4");
+  if (!(dim == 64 || dim == 128)) return fail(FP_EUNSUPPORTED, "dim must be 64 or 128");
+  if (C >= 0x7FFFFFFFll) return fail(FP_EUNSUPPORTED, "too many centroids");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FP_EHIP, "no HIP device available (this library has no CPU path)");
+  if (device_id < 0 || device_id >= ndev) return fail(FP_EINVAL, "device index out of range");
+  HIPCHK(hipSetDevice(device_id));
+  if (T == 0) return FP_OK;
+  const int pr = dim * nbits / 8;
+  const int64_t CHUNK = 1ll << 20;   // tokens per pass
+  const int64_t cap = std::min<int64_t>(T, CHUNK);
+  void *d_cent = nullptr, *d_cut = nullptr, *d_emb = nullptr, *d_c32 = nullptr, *d_c64 = nullptr, *d_out = nullptr;
+  hipStream_t st = nullptr;
+  int rc = FP_OK;
+  auto cleanup = [&]() {
+    for (void* p : {d_cent, d_cut, d_emb, d_c32, d_c64, d_out})
+      if (p) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+  };
+#define CCHK(x)                                                                                   \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess) {                                                                       \
+      cleanup();                                                                                  \
+      return fail(FP_EHIP, std::string("HIP error in fp_compress: ") + hipGetErrorString(e_));    \
+    }                                                                                             \
+  } while (0)
+  CCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  CCHK(hipMalloc(&d_cent, (size_t)C * dim * 2));
+  CCHK(hipMalloc(&d_cut, 64));
+  CCHK(hipMalloc(&d_emb, (size_t)cap * dim * 2));
+  CCHK(hipMalloc(&d_c32, (size_t)cap * 4));
+  CCHK(hipMalloc(&d_c64, (size_t)cap * 8));
+  CCHK(hipMalloc(&d_out, (size_t)cap * pr));
+  CCHK(hipMemcpyAsync(d_cent, centroids, (size_t)C * dim * 2, hipMemcpyHostToDevice, st));
+  CCHK(hipMemcpyAsync(d_cut, cutoffs, (size_t)((1 << nbits) - 1) * 2, hipMemcpyHostToDevice, st));
+  for (int64_t t0 = 0; t0 < T && rc == FP_OK; t0 += CHUNK) {
+    const int64_t n = std::min<int64_t>(CHUNK, T - t0);
+    CCHK(hipMemcpyAsync(d_emb, emb + t0 * dim, (size_t)n * dim * 2, hipMemcpyHostToDevice, st));
+    if (fpk_compress(static_cast<const uint16_t*>(d_emb), n, static_cast<const uint16_t*>(d_cent), C, dim, nbits,
+                     static_cast<const uint16_t*>(d_cut), static_cast<int32_t*>(d_c32), static_cast<int64_t*>(d_c64),
+                     static_cast<uint8_t*>(d_out), st)) {
+      cleanup();
+      return fail(FP_EUNSUPPORTED, "dim");
+    }
+    CCHK(hipMemcpyAsync(out_codes + t0, d_c64, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    CCHK(hipMemcpyAsync(out_res + t0 * pr, d_out, (size_t)n * pr, hipMemcpyDeviceToHost, st));
+    CCHK(hipStreamSynchronize(st));
+  }
+#undef CCHK
+  cleanup();
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
 // document-sharded search (see fastplaid.h)
 // ------------------------------------------------------------------------------------------
 struct fp_shard_ctx {

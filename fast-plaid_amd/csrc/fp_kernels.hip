@@ -2546,6 +2546,113 @@ int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const
 }
 
 // ============================================================================================
+// index creation, device part (create.rs:148-184, :404-428)
+// ============================================================================================
+// Nearest centroid, EXACT: the reference takes argmax over h(fp32 dot) of an ATen half matmul, whose fp32 sum runs in
+// ascending k; an MFMA contraction sums in another order, which moves ~0.05 % of the fp16-rounded scores by an ulp and
+// would flip the argmax between near-tied centroids.  Codes are integers and must be identical, so this kernel keeps
+// one ascending-k fp32 chain per (token, centroid): 64 tokens x 64 centroids per tile, 4x4 outputs per thread, operands
+// in LDS as fp32.  Ties go to the lowest centroid index (torch.argmax: first maximal value).
+template <int D>
+__global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict__ emb, int64_t T, const uint16_t* __restrict__ cent,
+                                                      int64_t C, int32_t* __restrict__ codes) {
+  __shared__ float As[64][D + 1];
+  __shared__ float Bs[64][D + 1];
+  __shared__ unsigned long long best_s[64][16];
+  const int tid = threadIdx.x;
+  const int tr = tid >> 4, tc = tid & 15;       // 16 x 16 threads, 4 rows x 4 cols each
+  const int64_t t0 = (int64_t)blockIdx.x * 64;
+  for (int i = tid; i < 64 * D; i += 256) {
+    const int r = i / D, d = i % D;
+    As[r][d] = (t0 + r < T) ? (float)__builtin_bit_cast(half_t, emb[(t0 + r) * D + d]) : 0.f;
+  }
+  unsigned long long best[4] = {0ull, 0ull, 0ull, 0ull};
+  for (int64_t c0 = 0; c0 < C; c0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * D; i += 256) {
+      const int r = i / D, d = i % D;
+      Bs[r][d] = (c0 + r < C) ? (float)__builtin_bit_cast(half_t, cent[(c0 + r) * D + d]) : 0.f;
+    }
+    __syncthreads();
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int kk = 0; kk < D; ++kk) {   // ascending k: each accumulator is the reference's chain (products of fp16 pairs are exact in fp32)
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[tr * 4 + i][kk];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[tc + 16 * j][kk];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t c = c0 + tc + 16 * j;
+        if (c < C) {
+          const uint16_t hv = __builtin_bit_cast(uint16_t, (half_t)acc[i][j]);
+          const unsigned long long key = ((unsigned long long)mono16(hv) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)c);
+          best[i] = key > best[i] ? key : best[i];   // higher score, then lower index
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) best_s[tr * 4 + i][tc] = best[i];
+  __syncthreads();
+  if (tid < 64 && t0 + tid < T) {
+    unsigned long long m = 0ull;
+    for (int j = 0; j < 16; ++j) m = best_s[tid][j] > m ? best_s[tid][j] : m;
+    codes[t0 + tid] = (int32_t)(0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull));
+  }
+}
+
+// residual quantisation + packing: one thread per output byte
+__global__ __launch_bounds__(256) void k_quantize_pack(const uint16_t* __restrict__ emb, const uint16_t* __restrict__ cent,
+                                                       const int32_t* __restrict__ codes, const uint16_t* __restrict__ cutoffs, int D, int nbits,
+                                                       int64_t T, uint8_t* __restrict__ out, int64_t* __restrict__ codes64) {
+  const int pr = D * nbits / 8, per = 8 / nbits, ncut = (1 << nbits) - 1;
+  const int64_t total = T * pr;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = g / pr;
+    const int bi = (int)(g % pr);
+    const int32_t code = codes[t];
+    if (bi == 0) codes64[t] = code;
+    unsigned byte = 0;
+    for (int v = 0; v < per; ++v) {
+      const int d = bi * per + v;
+      const float e = (float)__builtin_bit_cast(half_t, emb[t * D + d]);
+      const float c = (float)__builtin_bit_cast(half_t, cent[(int64_t)code * D + d]);
+      const half_t r = (half_t)(e - c);   // fp16 subtraction == fp32 subtraction rounded once
+      int bucket = 0;
+      for (int i = 0; i < ncut; ++i) bucket += ((float)__builtin_bit_cast(half_t, cutoffs[i]) < (float)r) ? 1 : 0;
+      // bits of `bucket` LSB first, appended to the big-endian bit stream
+      for (int kbit = 0; kbit < nbits; ++kbit) byte = (byte << 1) | ((bucket >> kbit) & 1u);
+    }
+    out[g] = (uint8_t)byte;
+  }
+}
+
+int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, int nbits, const uint16_t* cutoffs, int32_t* codes32,
+                 int64_t* codes64, uint8_t* out, hipStream_t st) {
+  if (T <= 0) return 0;
+  const unsigned blocks = fp_grid_cap((T + 63) / 64, 256);
+  if ((int64_t)blocks * 64 < T) return -2;   // callers chunk far below this
+  if (D == 128) hipLaunchKernelGGL(k_assign_exact<128>, dim3(blocks), dim3(256), 0, st, emb, T, cent, C, codes32);
+  else if (D == 64) hipLaunchKernelGGL(k_assign_exact<64>, dim3(blocks), dim3(256), 0, st, emb, T, cent, C, codes32);
+  else return -1;
+  const int64_t total = T * (D * nbits / 8);
+  hipLaunchKernelGGL(k_quantize_pack, dim3(fp_grid_cap((total + 255) / 256, 256)), dim3(256), 0, st, emb, cent, codes32, cutoffs, D, nbits, T, out,
+                     codes64);
+  return 0;
+}
+
+// ============================================================================================
 // arithmetic self-test: the two shortcuts the MaxSim kernel takes must equal the reference
 // formulation (fp32 op + one rounding to fp16) for EVERY pair of fp16 bit patterns.
 //   out[0]: REACHABLE pairs (n >= 0, |e| <= n(1+2^-9): a component never exceeds its vector's

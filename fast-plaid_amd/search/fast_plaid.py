@@ -184,10 +184,29 @@ class FastPlaid:
         """fast_plaid.py:1160-1186 -> list of [doc_len, dim] float32 arrays."""
         return native.reconstruct_embeddings(self.indices[self.devices[0]], subset, self.devices[0])
 
-    def create(self, *a, **k):
-        raise NotImplementedError("FastPlaid.create is index maintenance, outside the MI355X search hot path "
-                                  "(SURVEY.md section 8 row f1); build with the reference and load the directory, "
-                                  "or use FastPlaid.from_arrays")
+    def create(self, documents_embeddings, kmeans_niters: int = 4, max_points_per_centroid: int = 256, nbits: int = 4,
+               n_samples_kmeans: int | None = None, seed: int = 42, use_triton_kmeans: bool | None = None, metadata=None,
+               compress_only: bool = False, centroids=None):
+        """fast_plaid.py:398-560.  The native part of the reference's create (codec training, compression, IVF,
+        directory; rust/index/create.rs) runs here given `centroids`; the k-means that produces them is the external
+        `fastkmeans` package in the reference (kmeans.py:61-223) and is not part of this build."""
+        del kmeans_niters, max_points_per_centroid, n_samples_kmeans, use_triton_kmeans
+        if metadata is not None:
+            raise NotImplementedError("metadata filtering (fast_plaid.filtering) is outside the MI355X search hot path")
+        if centroids is None:
+            raise NotImplementedError("k-means is not part of this build (the reference uses the external fastkmeans package): "
+                                      "pass centroids=[C, dim]")
+        if self.index is None:
+            raise ValueError("FastPlaid.create needs an index directory")
+        from .. import create as _create
+        _create.create_index(self.index, documents_embeddings, centroids, nbits=nbits, device=self.devices[0], seed=seed,
+                             compress_only=compress_only)
+        self._last_known_mtime = 0.0
+        self._check_and_reload_index()
+        return self
 
-    update = create
-    delete = create
+    def _maintenance(self, *a, **k):
+        raise NotImplementedError("index update / delete are outside the MI355X search hot path (SURVEY.md section 8, row f4)")
+
+    update = _maintenance
+    delete = _maintenance

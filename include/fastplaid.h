@@ -129,6 +129,18 @@ int fp_token_scores(const fp_index* index, const uint16_t* queries_f16, int32_t 
                     const int64_t* pids /*[n_queries, stride]*/, const int32_t* counts /*[n_queries]*/, int64_t stride,
                     int64_t* out_offsets /*[sum(counts) + 1]*/, uint16_t* out /*f16, nullable*/, int64_t out_capacity);
 
+/* ---- index creation, device part -----------------------------------
+ * rust/index/create.rs:148-170 compress_into_codes, :404-428 process_batch, :176-184 packbits:
+ *   codes[t]  = argmax_c h(sum_fp32 emb[t] . cent[c])          (first maximal index, ascending-k fp32 sum)
+ *   r[t][d]   = h(emb[t][d] - cent[codes[t]][d])
+ *   bucket    = #{ i : cutoffs[i] < r }                          (torch.bucketize, right=False)
+ *   bytes     = each bucket as nbits bits LSB first, the bit stream packed 8 per byte big-endian.
+ * Stand-alone (no index handle): host buffers in and out, processed in device-sized chunks.
+ * k-means, codec training (quantiles) and file writing stay on the host (fast-plaid_amd/create.py). */
+int fp_compress(int device_id, const uint16_t* centroids_f16 /*[n_centroids, dim]*/, int64_t n_centroids, int32_t dim, int32_t nbits,
+                const uint16_t* bucket_cutoffs_f16 /*[2^nbits - 1]*/, const uint16_t* embeddings_f16 /*[n_tokens, dim]*/,
+                int64_t n_tokens, int64_t* out_codes /*[n_tokens]*/, uint8_t* out_residuals /*[n_tokens, dim*nbits/8]*/);
+
 /* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */
 /* Decompresses whole documents to fp32 rows. out: host [sum(len(doc)) , dim] f32 in the
  * order of doc_ids; out_lengths [n]. `out_capacity_rows` guards the buffer. */

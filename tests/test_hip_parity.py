@@ -470,6 +470,74 @@ def test_reference_loader_arrays_with_padding_rows(fp):
         assert [[d for d, _ in row] for row in out] == [ra[0][i, : ra[2][i]].tolist() for i in range(4)]
 
 
+@pytest.mark.parametrize("dim,nbits,C,n_docs", [(128, 4, 300, 120), (64, 2, 77, 90), (128, 2, 1030, 60), (64, 4, 5, 40)])
+def test_compress_and_codec_match_the_aten_restatement(fp, dim, nbits, C, n_docs):
+    """fp_compress (nearest centroid with first-index ties, fp16 residual, bucketize, LSB-first bits packed big-endian;
+    create.rs:148-184, :404-428) and the host codec training (create.rs:317-364) against the op-for-op ATen restatement
+    in oracle/plaid_oracle_torch.py: codes, packed bytes, cutoffs and weights must be IDENTICAL -- including duplicated
+    centroids (exact score ties -> lowest index) and near-ties that an MFMA-order sum would flip."""
+    torch = pytest.importorskip("torch")
+    import plaid_oracle_torch as OT
+    from fast_plaid_amd import create as CR
+    g = torch.Generator().manual_seed(1000 + C)
+    cent = torch.nn.functional.normalize(torch.randn(C, dim, generator=g), dim=-1).to(torch.float16)
+    if C > 20:
+        cent[7] = cent[3]          # exact duplicates: every token nearest to them ties
+        cent[C - 1] = cent[3]
+    docs = []
+    for _ in range(n_docs):
+        n = int(torch.randint(1, 50, (1,), generator=g))
+        pick = torch.randint(0, C, (n,), generator=g)
+        pick[torch.rand(n, generator=g) < 0.2] = 3     # plenty of tokens on the duplicated centroid
+        d = cent[pick].float() + 0.25 * torch.randn(n, dim, generator=g) / dim ** 0.5
+        docs.append(torch.nn.functional.normalize(d, dim=-1).to(torch.float16))
+    ref = OT.build_index_arrays(docs, cent, nbits)
+    T = int(ref["doc_lengths"].sum())
+    got = CR.build_index_arrays([d.numpy() for d in docs], cent.numpy(), nbits, "cuda:0")
+    assert np.array_equal(got["doc_codes"], ref["doc_codes"].numpy()[:T]), "nearest-centroid codes differ"
+    assert np.array_equal(got["doc_residuals"], ref["doc_residuals"].numpy()[:T]), "packed residual bytes differ"
+    for k in ("bucket_cutoffs", "bucket_weights"):
+        assert np.array_equal(got[k].view(np.uint16), ref[k].numpy().view(np.uint16)), k
+    assert np.allclose(got["avg_residual"].astype(np.float32), ref["avg_residual"].numpy().astype(np.float32), rtol=2e-3, atol=1e-6)
+    assert np.array_equal(got["ivf"], ref["ivf"].numpy()) and np.array_equal(got["ivf_lengths"], ref["ivf_lengths"].numpy())
+    # and the created arrays search like the reference-built ones
+    R = fp.fast_plaid_rust
+    q = torch.stack([docs[i][:8] if docs[i].shape[0] >= 8 else torch.cat([docs[i], docs[i][:1].expand(8 - docs[i].shape[0], -1)]) for i in range(3)]).numpy()
+    params = R.SearchParameters(2000, 64, 5, min(4, C))
+    a = R.search_arrays(_hip_index(fp, got), q, params)
+    ref_np = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in ref.items()}
+    b = R.search_arrays(_hip_index(fp, ref_np), q, params)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_create_index_directory_roundtrip(fp, tmp_path):
+    """FastPlaid.create(documents, centroids=...) writes the reference's directory format; the directory loads back
+    and the documents it was built from are found first by their own tokens."""
+    from fast_plaid_amd import search
+    rng = np.random.default_rng(3)
+    dim, C = 128, 64
+    cent = rng.standard_normal((C, dim), dtype=np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    docs = []
+    for _ in range(200):
+        n = int(rng.integers(4, 30))
+        d = cent[rng.integers(0, C, n)] + 0.3 * rng.standard_normal((n, dim), dtype=np.float32) / np.sqrt(dim)
+        docs.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float16))
+    path = str(tmp_path / "idx")
+    with search.FastPlaid(index=path, device="cuda:0") as fpi:
+        with pytest.raises(NotImplementedError):
+            fpi.create(docs)                      # no k-means in this build
+        fpi.create(docs, centroids=cent, nbits=4)
+        assert os.path.exists(os.path.join(path, "metadata.json")) and os.path.exists(os.path.join(path, "ivf.npy"))
+        q = np.stack([np.pad(docs[i][:16], ((0, 16 - min(16, docs[i].shape[0])), (0, 0))) for i in (5, 50, 150)])
+        out = fpi.search(q, top_k=3, n_ivf_probe=8, show_progress=False)
+        assert [row[0][0] for row in out] == [5, 50, 150]
+        emb = fpi.get_embeddings([5])[0]
+        assert emb.shape == (docs[5].shape[0], dim)
+        cos = (emb * docs[5].astype(np.float32)).sum(1)
+        assert cos.min() > 0.9                    # 4-bit residuals reconstruct the tokens closely
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
