@@ -8,8 +8,9 @@ Layout:
   search/               mirror of `fast_plaid.search` (class FastPlaid)
   synth.py              synthetic compressed-domain corpora (numpy twin of csrc/fp_synth.hip)
   sharded.py            one-process-per-GPU document-sharded / replicated search over torch.distributed (RCCL)
+  kmeans.py             k-means centroids (sampling protocol of the reference, Lloyd with device assignment)
   create.py             index creation given centroids: codec training, device compression (fp_compress), IVF, directory
 """
-from . import create, fast_plaid_rust, search, synth  # noqa: F401
+from . import create, fast_plaid_rust, kmeans, search, synth  # noqa: F401
 
-__all__ = ["create", "fast_plaid_rust", "search", "synth"]
+__all__ = ["create", "fast_plaid_rust", "kmeans", "search", "synth"]

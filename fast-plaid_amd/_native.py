@@ -51,6 +51,7 @@ SYMBOLS = {
     "fp_last_search_timings": (C.c_int, [_vp, _vp, C.c_int]),
     "fp_reconstruct_embeddings": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "fp_compress": (C.c_int, [C.c_int, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "fp_assign_l2": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "fp_token_scores": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i64]),
     "fp_shard_begin": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(FpSearchParams), C.POINTER(_vp)]),
     "fp_shard_R": (_i64, [_vp]),

@@ -911,6 +911,57 @@ extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, 
   return rc;
 }
 
+extern "C" int fp_assign_l2(int device_id, const uint16_t* centroids, const float* half_sqnorm, int64_t C, int32_t dim, const uint16_t* emb,
+                            int64_t T, int64_t* out_labels) {
+  if (!centroids || !half_sqnorm || C < 1 || T < 0 || (T > 0 && (!emb || !out_labels))) return fail(FP_EINVAL, "bad argument");
+  if (!(dim == 64 || dim == 128)) return fail(FP_EUNSUPPORTED, "dim must be 64 or 128");
+  if (C >= 0x7FFFFFFFll) return fail(FP_EUNSUPPORTED, "too many centroids");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FP_EHIP, "no HIP device available (this library has no CPU path)");
+  if (device_id < 0 || device_id >= ndev) return fail(FP_EINVAL, "device index out of range");
+  HIPCHK(hipSetDevice(device_id));
+  if (T == 0) return FP_OK;
+  const int64_t CHUNK = 1ll << 20;
+  const int64_t cap = std::min<int64_t>(T, CHUNK);
+  void *d_cent = nullptr, *d_hn = nullptr, *d_emb = nullptr, *d_c32 = nullptr, *d_c64 = nullptr;
+  hipStream_t st = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {d_cent, d_hn, d_emb, d_c32, d_c64})
+      if (p) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+  };
+#define ACHK(x)                                                                                   \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess) {                                                                       \
+      cleanup();                                                                                  \
+      return fail(FP_EHIP, std::string("HIP error in fp_assign_l2: ") + hipGetErrorString(e_));   \
+    }                                                                                             \
+  } while (0)
+  ACHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  ACHK(hipMalloc(&d_cent, (size_t)C * dim * 2));
+  ACHK(hipMalloc(&d_hn, (size_t)C * 4));
+  ACHK(hipMalloc(&d_emb, (size_t)cap * dim * 2));
+  ACHK(hipMalloc(&d_c32, (size_t)cap * 4));
+  ACHK(hipMalloc(&d_c64, (size_t)cap * 8));
+  ACHK(hipMemcpyAsync(d_cent, centroids, (size_t)C * dim * 2, hipMemcpyHostToDevice, st));
+  ACHK(hipMemcpyAsync(d_hn, half_sqnorm, (size_t)C * 4, hipMemcpyHostToDevice, st));
+  for (int64_t t0 = 0; t0 < T; t0 += CHUNK) {
+    const int64_t n = std::min<int64_t>(CHUNK, T - t0);
+    ACHK(hipMemcpyAsync(d_emb, emb + t0 * dim, (size_t)n * dim * 2, hipMemcpyHostToDevice, st));
+    if (fpk_assign_l2(static_cast<const uint16_t*>(d_emb), n, static_cast<const uint16_t*>(d_cent), static_cast<const float*>(d_hn), C, dim,
+                      static_cast<int32_t*>(d_c32), static_cast<int64_t*>(d_c64), st)) {
+      cleanup();
+      return fail(FP_EUNSUPPORTED, "dim");
+    }
+    ACHK(hipMemcpyAsync(out_labels + t0, d_c64, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    ACHK(hipStreamSynchronize(st));
+  }
+#undef ACHK
+  cleanup();
+  return FP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // document-sharded search (see fastplaid.h)
 // ------------------------------------------------------------------------------------------

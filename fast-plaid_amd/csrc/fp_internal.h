@@ -121,6 +121,9 @@ void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add,
 // -1 unsupported dim, -2 chunk too large
 int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, int nbits, const uint16_t* cutoffs, int32_t* codes32,
                  int64_t* codes64, uint8_t* out, hipStream_t st);
+// k-means assignment step: argmax_c (dot - half_sqnorm[c]) in fp32, ties -> lowest index
+int fpk_assign_l2(const uint16_t* emb, int64_t T, const uint16_t* cent, const float* half_sqnorm, int64_t C, int D, int32_t* codes32,
+                  int64_t* codes64, hipStream_t st);
 // [q_len, doc_len] fp16 similarity matrices of (query, doc) hits; -1 when q_len * dim does not fit LDS
 int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const int32_t* hit_query, const int32_t* hit_pid, int64_t n_hits,
                      const int64_t* out_off, uint16_t* out, hipStream_t st);

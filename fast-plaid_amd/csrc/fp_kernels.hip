@@ -2553,9 +2553,10 @@ int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const
 // would flip the argmax between near-tied centroids.  Codes are integers and must be identical, so this kernel keeps
 // one ascending-k fp32 chain per (token, centroid): 64 tokens x 64 centroids per tile, 4x4 outputs per thread, operands
 // in LDS as fp32.  Ties go to the lowest centroid index (torch.argmax: first maximal value).
-template <int D>
+// L2 = true (k-means assignment): score = dot - half_sqnorm[c] compared in fp32 instead of the fp16-rounded dot.
+template <int D, bool L2>
 __global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict__ emb, int64_t T, const uint16_t* __restrict__ cent,
-                                                      int64_t C, int32_t* __restrict__ codes) {
+                                                      int64_t C, const float* __restrict__ half_sqnorm, int32_t* __restrict__ codes) {
   __shared__ float As[64][D + 1];
   __shared__ float Bs[64][D + 1];
   __shared__ unsigned long long best_s[64][16];
@@ -2596,8 +2597,14 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict
       for (int j = 0; j < 4; ++j) {
         const int64_t c = c0 + tc + 16 * j;
         if (c < C) {
-          const uint16_t hv = __builtin_bit_cast(uint16_t, (half_t)acc[i][j]);
-          const unsigned long long key = ((unsigned long long)mono16(hv) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)c);
+          uint32_t ord;
+          if constexpr (L2) {
+            const uint32_t fb = __float_as_uint(acc[i][j] - half_sqnorm[c]);
+            ord = fb ^ ((fb >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // order-preserving key of an fp32 value
+          } else {
+            ord = mono16(__builtin_bit_cast(uint16_t, (half_t)acc[i][j]));
+          }
+          const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)c);
           best[i] = key > best[i] ? key : best[i];   // higher score, then lower index
         }
       }
@@ -2643,12 +2650,28 @@ int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C
   if (T <= 0) return 0;
   const unsigned blocks = fp_grid_cap((T + 63) / 64, 256);
   if ((int64_t)blocks * 64 < T) return -2;   // callers chunk far below this
-  if (D == 128) hipLaunchKernelGGL(k_assign_exact<128>, dim3(blocks), dim3(256), 0, st, emb, T, cent, C, codes32);
-  else if (D == 64) hipLaunchKernelGGL(k_assign_exact<64>, dim3(blocks), dim3(256), 0, st, emb, T, cent, C, codes32);
+  if (D == 128) hipLaunchKernelGGL((k_assign_exact<128, false>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
+  else if (D == 64) hipLaunchKernelGGL((k_assign_exact<64, false>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
   else return -1;
   const int64_t total = T * (D * nbits / 8);
   hipLaunchKernelGGL(k_quantize_pack, dim3(fp_grid_cap((total + 255) / 256, 256)), dim3(256), 0, st, emb, cent, codes32, cutoffs, D, nbits, T, out,
                      codes64);
+  return 0;
+}
+
+__global__ void k_widen_i32(const int32_t* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+int fpk_assign_l2(const uint16_t* emb, int64_t T, const uint16_t* cent, const float* half_sqnorm, int64_t C, int D, int32_t* codes32,
+                  int64_t* codes64, hipStream_t st) {
+  if (T <= 0) return 0;
+  const unsigned blocks = fp_grid_cap((T + 63) / 64, 256);
+  if ((int64_t)blocks * 64 < T) return -2;
+  if (D == 128) hipLaunchKernelGGL((k_assign_exact<128, true>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, half_sqnorm, codes32);
+  else if (D == 64) hipLaunchKernelGGL((k_assign_exact<64, true>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, half_sqnorm, codes32);
+  else return -1;
+  hipLaunchKernelGGL(k_widen_i32, dim3(fp_grid_cap((T + 255) / 256, 256)), dim3(256), 0, st, codes32, codes64, T);
   return 0;
 }
 

@@ -187,15 +187,16 @@ class FastPlaid:
     def create(self, documents_embeddings, kmeans_niters: int = 4, max_points_per_centroid: int = 256, nbits: int = 4,
                n_samples_kmeans: int | None = None, seed: int = 42, use_triton_kmeans: bool | None = None, metadata=None,
                compress_only: bool = False, centroids=None):
-        """fast_plaid.py:398-560.  The native part of the reference's create (codec training, compression, IVF,
-        directory; rust/index/create.rs) runs here given `centroids`; the k-means that produces them is the external
-        `fastkmeans` package in the reference (kmeans.py:61-223) and is not part of this build."""
-        del kmeans_niters, max_points_per_centroid, n_samples_kmeans, use_triton_kmeans
+        """fast_plaid.py:398-560: k-means centroids (unless given), then the native part of the reference's create --
+        codec training, compression, IVF, directory (rust/index/create.rs)."""
+        del use_triton_kmeans
         if metadata is not None:
             raise NotImplementedError("metadata filtering (fast_plaid.filtering) is outside the MI355X search hot path")
-        if centroids is None:
-            raise NotImplementedError("k-means is not part of this build (the reference uses the external fastkmeans package): "
-                                      "pass centroids=[C, dim]")
+        if centroids is None:   # fast_plaid.py:71-185 compute_kmeans (functional equivalent, see kmeans.py)
+            from .. import kmeans as _kmeans
+            first = documents_embeddings[0]
+            centroids = _kmeans.compute_kmeans(documents_embeddings, int(first.shape[1]), self.devices[0], kmeans_niters,
+                                               max_points_per_centroid, seed, n_samples_kmeans)
         if self.index is None:
             raise ValueError("FastPlaid.create needs an index directory")
         from .. import create as _create

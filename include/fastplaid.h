@@ -141,6 +141,13 @@ int fp_compress(int device_id, const uint16_t* centroids_f16 /*[n_centroids, dim
                 const uint16_t* bucket_cutoffs_f16 /*[2^nbits - 1]*/, const uint16_t* embeddings_f16 /*[n_tokens, dim]*/,
                 int64_t n_tokens, int64_t* out_codes /*[n_tokens]*/, uint8_t* out_residuals /*[n_tokens, dim*nbits/8]*/);
 
+/* K-means assignment step for the Python k-means driver (python/fast_plaid/search/fast_plaid.py:71-185 calls the
+ * external fastkmeans package; its Lloyd iteration assigns every point to the centroid of least squared L2 distance):
+ * out_labels[t] = argmax_c ( emb[t] . cent[c] - half_sqnorm[c] ), fp32, ties -> lowest index. */
+int fp_assign_l2(int device_id, const uint16_t* centroids_f16 /*[n_centroids, dim]*/, const float* half_sqnorm /*[n_centroids]*/,
+                 int64_t n_centroids, int32_t dim, const uint16_t* embeddings_f16 /*[n_tokens, dim]*/, int64_t n_tokens,
+                 int64_t* out_labels /*[n_tokens]*/);
+
 /* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */
 /* Decompresses whole documents to fp32 rows. out: host [sum(len(doc)) , dim] f32 in the
  * order of doc_ids; out_lengths [n]. `out_capacity_rows` guards the buffer. */

@@ -525,8 +525,6 @@ def test_create_index_directory_roundtrip(fp, tmp_path):
         docs.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float16))
     path = str(tmp_path / "idx")
     with search.FastPlaid(index=path, device="cuda:0") as fpi:
-        with pytest.raises(NotImplementedError):
-            fpi.create(docs)                      # no k-means in this build
         fpi.create(docs, centroids=cent, nbits=4)
         assert os.path.exists(os.path.join(path, "metadata.json")) and os.path.exists(os.path.join(path, "ivf.npy"))
         q = np.stack([np.pad(docs[i][:16], ((0, 16 - min(16, docs[i].shape[0])), (0, 0))) for i in (5, 50, 150)])
@@ -536,6 +534,42 @@ def test_create_index_directory_roundtrip(fp, tmp_path):
         assert emb.shape == (docs[5].shape[0], dim)
         cos = (emb * docs[5].astype(np.float32)).sum(1)
         assert cos.min() > 0.9                    # 4-bit residuals reconstruct the tokens closely
+
+
+def test_kmeans_assignment_and_create_without_centroids(fp, tmp_path):
+    """fp_assign_l2 == numpy argmin of squared L2 distances (fp32); Lloyd recovers well-separated blobs; and
+    FastPlaid.create(documents) -- k-means included -- builds a searchable directory."""
+    from fast_plaid_amd import kmeans, search
+    rng = np.random.default_rng(11)
+    dim = 64
+    cent = (rng.standard_normal((37, dim)) * 0.7).astype(np.float16)
+    data = (rng.standard_normal((5000, dim))).astype(np.float16)
+    lab = kmeans.assign_l2(cent, data)
+    d2 = ((data.astype(np.float32)[:, None, :] - cent.astype(np.float32)[None, :, :]) ** 2).sum(-1)
+    best = d2.min(axis=1)
+    assert np.all(d2[np.arange(5000), lab] <= best * (1 + 1e-5) + 1e-5)      # the chosen centroid is a nearest one
+    assert (lab == d2.argmin(axis=1)).mean() > 0.999                          # (fp32 summation order aside)
+    # blobs
+    centers = rng.standard_normal((8, dim)).astype(np.float32) * 4
+    pts = (centers[rng.integers(0, 8, 4000)] + 0.1 * rng.standard_normal((4000, dim), dtype=np.float32)).astype(np.float16)
+    got = kmeans.lloyd(pts, 8, 10, np.random.default_rng(0), max_points_per_centroid=None)
+    dist = np.linalg.norm(got[:, None, :] - centers[None, :, :], axis=-1)
+    assert (dist.min(axis=0) < 0.5).sum() >= 6       # random-point init may merge a pair of blobs; most are recovered
+    # end to end
+    dim = 128
+    base = rng.standard_normal((40, dim), dtype=np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    docs = []
+    for _ in range(150):
+        n = int(rng.integers(5, 25))
+        d = base[rng.integers(0, 40, n)] + 0.2 * rng.standard_normal((n, dim), dtype=np.float32) / np.sqrt(dim)
+        docs.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float16))
+    path = str(tmp_path / "idx2")
+    with search.FastPlaid(index=path, device="cuda:0") as fpi:
+        fpi.create(docs, kmeans_niters=4, nbits=4, seed=1)
+        q = np.stack([np.pad(docs[i][:12], ((0, 12 - min(12, docs[i].shape[0])), (0, 0))) for i in (3, 77)])
+        out = fpi.search(q, top_k=3, show_progress=False)
+        assert [row[0][0] for row in out] == [3, 77]
 
 
 def test_sharded_equals_unsharded(fp):
