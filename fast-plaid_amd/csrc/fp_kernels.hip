@@ -80,14 +80,6 @@ __device__ __forceinline__ void norm_pair2(uint32_t& a, uint32_t& b, float r_hi,
   b = db;
 }
 
-typedef __attribute__((address_space(1))) const void fp_gvoid;
-typedef __attribute__((address_space(3))) void fp_lvoid;
-// 16 bytes per lane, global -> LDS without a VGPR round trip; LDS destination = wave-uniform
-// base + lane*16 (the per-lane part is in the SOURCE address: swizzles go there).
-__device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((fp_gvoid*)g, (fp_lvoid*)lds_wave_base, 16, 0, 0);
-}
-
 // ============================================================================================
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
 // ============================================================================================
@@ -756,10 +748,8 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
 void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B, uint32_t* bitmap,
                   int64_t W, hipStream_t st) {
   // tile size: the largest that still gives the chip ~4 workgroups per CU (measured at cfg2: B=64 -> 2048 words 0.11 ms vs 8192 words 0.26 ms; B=8 -> 512 words 0.04 vs 0.22 ms)
-  static const int tw_env = getenv("FP_MARK_TW") ? atoi(getenv("FP_MARK_TW")) : 0;
   int tw = MARK_TILE_WORDS_MAX;
   while (tw > 512 && ((W + tw - 1) / tw) * B < 1024) tw >>= 1;
-  if (tw_env >= 64 && tw_env <= MARK_TILE_WORDS_MAX && (tw_env & (tw_env - 1)) == 0) tw = tw_env;
   const int ntile = (int)((W + tw - 1) / tw);
   const size_t lds = (size_t)tw * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
   static bool attr_set = false;
@@ -1328,7 +1318,6 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   // documents, small shards).  One workgroup pass per query wherever possible: a grid cap of 2048 costs 0.5 ms, and
   // longer-lived workgroups (2/4/8 candidates per pair: 6.6/8.3/10.3 ms at 1 pair) put several queries' slices in flight.
   static const int ppd_env = getenv("FP_Q8_PPD") ? atoi(getenv("FP_Q8_PPD")) : 0;
-  static const int cap_env = getenv("FP_Q8_BXCAP") ? atoi(getenv("FP_Q8_BXCAP")) : 0;
   const int64_t per_q = (M + B - 1) / B;
   const int64_t groups = ix.N > 0 ? (ix.U / ix.N + 7) / 8 : 1;   // average code groups per document
   int ppd = 1;
@@ -1338,7 +1327,7 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   const int tpb = 256;   // 64 / 128 / 512 threads per workgroup measured the same (4.34-4.41 ms)
   const int dpb = (tpb / 2) / ppd;
   int64_t bx = (per_q + dpb - 1) / dpb;
-  const int64_t cap = cap_env > 0 ? cap_env : 65535;
+  const int64_t cap = 65535;   // grid.x limit; caps of 2048 / 4096 cost 0.5 / 0.1 ms at cfg2
   if (bx > cap) bx = cap;
   if (bx < 1) bx = 1;
   // (an XCD-affine mapping -- one query per XCD so that each L2 holds one 4 MB slice -- measured slower: 6.9 vs 6.05 ms;
@@ -1899,319 +1888,16 @@ __global__ __launch_bounds__(256) void k_maxsim_reg(const uint16_t* __restrict__
   }
 }
 
-// Layout of the MaxSim kernel (v4).
-//  * ONE TOKEN PER LANE for the arithmetic: a wave carries two independent 32-token streams
-//    (lanes 0-31 / 32-63), each walking its own documents chunk by chunk.  A lane owns all D
-//    dims of its token: one ascending norm chain, no work duplicated between lanes.
-//  * Loads are COOPERATIVE and coalesced, staged through LDS ("doc-token tiles staged through
-//    LDS"): per-lane row fetches touch 64 cache lines per instruction and pinned the kernel to
-//    the L1/TA tag rate (measured 21 cycles/token/CU = 20 loads x 64 lines per 64 tokens).
-//    Instead 4 lanes fetch one token's 64-byte centroid piece / residual row with
-//    global_load_lds (DMA, no VGPRs), 16 lines per instruction, into a wave-private LDS tile;
-//    the tile is XOR-swizzled through the SOURCE address (the DMA destination is lane-linear)
-//    so that each lane then reads its own token's row with conflict-free ds_read_b128.
-//  * The centroid row is consumed in PH = D/32 phases of 32 dims (64 B): the DMA of phase p+1
-//    is in flight while phase p is decoded and its norm-chain segment runs; the next chunk's
-//    residual rows + phase 0 are issued during the last phase and land under the normalise /
-//    MFMA / epilogue tail.
-//  * v_permlane32_swap turns the per-token registers into the two MFMA A operands:
-//    G0 = dims [16m,16m+8), G1 = dims [16m+8,16m+16); swap(vdst=G0, src=G1) exchanges lanes
-//    32-63 of G0 with lanes 0-31 of G1 => G0 = A for the lower stream's tokens, G1 = upper.
-//  * Query B fragments staged once per block in LDS; byte->weights LUT in 8 bank-offset copies.
-template <int D, int NBITS, int NCH>
-__global__ __launch_bounds__(256) void k_maxsim_lds(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
-                                                const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
-                                                const int64_t* __restrict__ doc_off, const uint16_t* __restrict__ qpad, int Q,
-                                                int Qp, int ch_begin, const int32_t* __restrict__ sel_pid,
-                                                const int32_t* __restrict__ sel_cnt, int64_t Rcap, float* __restrict__ exact,
-                                                int accumulate, int dpw) {
-  constexpr int PR = D * NBITS / 8;    // packed residual bytes per token
-  constexpr int PPR = PR / 16;         // 16-byte pieces per residual row (4, 2 or 1)
-  constexpr int RPB = 16 / PPR;        // residual rows per 256-byte LDS bank row
-  constexpr int PB = 8 / NBITS;        // dims per byte
-  constexpr int KS = D / 16;           // MFMA k-steps
-  constexpr int NE = D / 2;            // half2 registers per token
-  constexpr int PH = D / 32;           // phases of 32 dims
-  constexpr int RBP = 32 * NBITS / 8;  // residual bytes per phase per token (16 or 8)
-  constexpr int COPIES = 8;
-  constexpr int EW = PB / 2;           // 32-bit words per LUT entry
-  __shared__ __attribute__((aligned(16))) uint32_t lut[256 * EW * COPIES];   // 8 / 16 KiB
-  __shared__ __attribute__((aligned(16))) uint4 qs[NCH * KS * 64];           // 8 KiB per query chunk
-  __shared__ __attribute__((aligned(16))) unsigned char cbuf_all[4][64 * 64];  // per wave: [64 tokens][64 B]
-  __shared__ __attribute__((aligned(16))) unsigned char rbuf_all[4][64 * PR];  // per wave: [64 tokens][PR]
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < 256 * COPIES; i += 256) {
-    const int entry = i / COPIES, copy = i % COPIES;
-#pragma unroll
-    for (int w = 0; w < EW; ++w) lut[(entry * COPIES + copy) * EW + w] = reinterpret_cast<const uint32_t*>(lut_g)[entry * EW + w];
-  }
-  for (int i = threadIdx.x; i < NCH * KS * 64; i += 256) {
-    const int ln = i & 63, m = (i >> 6) % KS, c = (i >> 6) / KS;
-    const int ch = ch_begin + c;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ch * 32 < Qp)  // B[k = 8*(ln>>5) + j][n = ln&31] = Q[q = ch*32 + (ln&31)][16m + 8*(ln>>5) + j]
-      v = *reinterpret_cast<const uint4*>(qpad + ((int64_t)b * Qp + ch * 32 + (ln & 31)) * D + 16 * m + 8 * (ln >> 5));
-    qs[i] = v;
-  }
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cnt = sel_cnt[b];
-  const int r0 = (blockIdx.x * 4 + wave) * dpw;
-  if (r0 >= cnt) return;
-  const int rend = (r0 + dpw < cnt) ? (r0 + dpw) : cnt;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const uint32_t* mylut = lut + (lane & (COPIES - 1)) * EW;
-  unsigned char* cbuf = cbuf_all[wave];
-  unsigned char* rbuf = rbuf_all[wave];
-  const half_t negm = (half_t)NEG_MASK_F;
-  int nq = Q - ch_begin * 32;  // valid query columns handled by this launch
-  nq = nq < 0 ? 0 : (nq > NCH * 32 ? NCH * 32 : nq);
-  const int32_t* selp = sel_pid + (int64_t)b * Rcap;
-  float* outp = exact + (int64_t)b * Rcap;
-
-  // ---- per-stream state (identical in the 32 lanes of a stream) ----
-  int r = r0 + hi;          // document slot of this stream: r0+hi, r0+hi+2, ...
-  int t0 = 0, len = 0;
-  long long off = 0;
-  bool valid = r < rend;
-  long long n_off = 0;      // prefetched metadata of the stream's next document
-  int n_len = 0;
-  auto meta = [&](int rr, long long& o, int& l) {
-    const int32_t pid = selp[rr];
-    o = doc_off[pid];
-    l = (int)(doc_off[pid + 1] - o);
-  };
-  if (valid) meta(r, off, len);
-  if (r + 2 < rend) meta(r + 2, n_off, n_len);
-  auto next_doc = [&]() {  // move the stream to its next document (may be empty or absent)
-    r += 2;
-    valid = r < rend;
-    off = n_off;
-    len = n_len;
-    t0 = 0;
-    if (r + 2 < rend) meta(r + 2, n_off, n_len);
-  };
-  auto emit_empty = [&]() {
-    if (l31 == 0) {
-      const float v = (float)nq * NEG_MASK_F;  // every column keeps the masked value
-      outp[r] = accumulate ? (outp[r] + v) : v;
-    }
-  };
-  while (valid && len == 0) { emit_empty(); next_doc(); }
-  auto tok_row = [&]() -> long long {  // global token row of this lane's token (0 for an exhausted stream)
-    int tok = t0 + l31;
-    tok = tok < len ? tok : len - 1;  // clamp: loads stay in bounds, rows masked at the max
-    return valid ? off + tok : 0;
-  };
-  // ---- DMA issue helpers (all 64 lanes participate; row/code of other lanes via shuffles) ----
-  auto issue_resid = [&](long long myrow) {
-    const int rlo = (int)(myrow & 0xFFFFFFFFll), rhi = (int)(myrow >> 32);
-#pragma unroll
-    for (int i = 0; i < PPR; ++i) {
-      const int g = i * 64 + lane;          // linear 16-byte piece of the [64][PR] tile
-      const int row = g / PPR, slot = g % PPR;
-      const int piece = slot ^ ((row / RPB) % PPR);
-      const long long grow = ((long long)__shfl(rhi, row, 64) << 32) | (unsigned int)__shfl(rlo, row, 64);
-      dma16(resid + grow * (long long)PR + piece * 16, rbuf + i * 1024);
-    }
-  };
-  auto issue_cent = [&](const int32_t (&rowcode)[4], int p) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 16 * i + (lane >> 2);
-      const int piece = (lane & 3) ^ ((row >> 2) & 3);
-      dma16(cent + (long long)rowcode[i] * D + p * 32 + piece * 8, cbuf + i * 1024);
-    }
-  };
-  auto row_codes = [&](int32_t code, int32_t (&rowcode)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rowcode[i] = __shfl(code, 16 * i + (lane >> 2), 64);
-  };
-
-  h2 mx[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) mx[c] = h2{negm, negm};
-
-  // prologue: first chunk's code, residual rows and centroid phase 0
-  long long myrow = tok_row();
-  int32_t code = codes[myrow];
-  int32_t rowcode[4];
-  row_codes(code, rowcode);
-  issue_resid(myrow);
-  issue_cent(rowcode, 0);
-
-  while (__any(valid)) {
-    // ---- bookkeeping of THIS chunk, then step the stream and prefetch the next chunk's code ----
-    const int c_t0 = t0, c_len = len, c_r = r;
-    const bool c_valid = valid;
-    const bool c_last = valid && (t0 + 32 >= len);
-    if (valid) {
-      t0 += 32;
-      if (t0 >= len) {
-        next_doc();
-        while (valid && len == 0) { emit_empty(); next_doc(); }
-      }
-    }
-    const long long nrow = tok_row();
-    const int32_t ncode = codes[nrow];
-    const bool more = __any(valid);
-
-    uint32_t e[NE];
-    float ss = 0.f;
-#pragma unroll
-    for (int p = 0; p < PH; ++p) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of phase p (and the residual rows) has landed
-      // this lane's token: 64 B of centroid (4 x 16 B, swizzled) + RBP residual bytes
-      uint32_t rb[RBP / 4];
-      {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint4 v = *reinterpret_cast<const uint4*>(cbuf + lane * 64 + ((j ^ ((lane >> 2) & 3)) * 16));
-          e[16 * p + 4 * j] = v.x; e[16 * p + 4 * j + 1] = v.y; e[16 * p + 4 * j + 2] = v.z; e[16 * p + 4 * j + 3] = v.w;
-        }
-        const int rswz = (lane / RPB) % PPR;
-        if constexpr (RBP == 16) {
-          const uint4 v = *reinterpret_cast<const uint4*>(rbuf + lane * PR + ((p ^ rswz) * 16));
-          rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
-        } else {
-          const uint2 v = *reinterpret_cast<const uint2*>(rbuf + lane * PR + (((p >> 1) ^ rswz) * 16) + (p & 1) * 8);
-          rb[0] = v.x; rb[1] = v.y;
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile reads done: the DMA may overwrite it
-      if (p + 1 < PH) {
-        issue_cent(rowcode, p + 1);
-      } else if (more) {  // next chunk: its residual rows + phase 0 land under the tail of this chunk
-        row_codes(ncode, rowcode);
-        issue_resid(nrow);
-        issue_cent(rowcode, 0);
-      }
-      // ---- e = h(cent + w) for dims [32p, 32p+32) ----
-#pragma unroll
-      for (int w = 0; w < RBP / 4; ++w) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const uint32_t byte = (rb[w] >> (8 * kk)) & 0xFFu;
-          const int bi = w * 4 + kk;  // byte index within the phase -> dims [bi*PB, bi*PB+PB)
-          if constexpr (PB == 2) {
-            e[16 * p + bi] = h2_as_u32(u32_as_h2(e[16 * p + bi]) + u32_as_h2(mylut[byte * COPIES]));
-          } else {
-            const uint2 wv = *reinterpret_cast<const uint2*>(mylut + byte * COPIES * 2);
-            e[16 * p + 2 * bi] = h2_as_u32(u32_as_h2(e[16 * p + 2 * bi]) + u32_as_h2(wv.x));
-            e[16 * p + 2 * bi + 1] = h2_as_u32(u32_as_h2(e[16 * p + 2 * bi + 1]) + u32_as_h2(wv.y));
-          }
-        }
-      }
-      // ---- norm chain segment: fp32, ascending k, exactly the CPU reference's order ----
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const h2 v = u32_as_h2(e[16 * p + i]);
-        ss = __builtin_fmaf((float)v.x, (float)v.x, ss);
-        ss = __builtin_fmaf((float)v.y, (float)v.y, ss);
-      }
-    }
-    const float nf = (float)(half_t)__builtin_sqrtf(ss);  // Half norm; clamp_min(1e-12) is a no-op in fp16
-    float r_hi, r_lo;
-    recip2(nf, r_hi, r_lo);
-#pragma unroll
-    for (int i = 0; i < NE; i += 2) norm_pair2(e[i], e[i + 1], r_hi, r_lo);
-    // ---- MFMA: acc0 rows = lower stream's tokens, acc1 rows = upper stream's tokens ----
-    f16v acc0[NCH], acc1[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[c][i] = 0.f; acc1[c][i] = 0.f; }
-#pragma unroll
-    for (int m = 0; m < KS; ++m) {
-      uint32_t g0[4], g1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        auto sw = __builtin_amdgcn_permlane32_swap(e[8 * m + j], e[8 * m + 4 + j], false, false);
-        g0[j] = sw[0];
-        g1[j] = sw[1];
-      }
-      const h8 a0 = __builtin_bit_cast(h8, make_uint4(g0[0], g0[1], g0[2], g0[3]));
-      const h8 a1 = __builtin_bit_cast(h8, make_uint4(g1[0], g1[1], g1[2], g1[3]));
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const h8 bq = __builtin_bit_cast(h8, qs[(c * KS + m) * 64 + lane]);
-        acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, acc0[c], 0, 0, 0);
-        acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1[c], 0, 0, 0);
-      }
-    }
-    // ---- epilogue.  acc0 belongs to the lower stream (state in lane 0), acc1 to the upper
-    // (lane 32); D[row = token][col = q = lane&31], this lane's rows (i&3) + 8*(i>>2) + 4*hi. ----
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int s_t0 = __shfl(c_t0, 32 * s, 64), s_len = __shfl(c_len, 32 * s, 64), s_r = __shfl(c_r, 32 * s, 64);
-      const bool s_valid = __shfl((int)c_valid, 32 * s, 64) != 0;
-      const bool s_last = __shfl((int)c_last, 32 * s, 64) != 0;
-      if (!s_valid) continue;
-      const bool partial = (s_t0 + 32 > s_len);
-      float total = 0.f;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        h2 m = h2{negm, negm};
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          h2 v;
-          v.x = (half_t)(s == 0 ? acc0[c][i] : acc1[c][i]);
-          v.y = (half_t)(s == 0 ? acc0[c][i + 1] : acc1[c][i + 1]);
-          if (partial) {
-            const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
-            if (s_t0 + row0 >= s_len) v.x = negm;
-            if (s_t0 + row0 + 1 >= s_len) v.y = negm;
-          }
-          m = pk_max(m, v);
-        }
-        half_t mm = m.x > m.y ? m.x : m.y;
-        const uint32_t ou = shfl_xor_u32((uint32_t)__builtin_bit_cast(uint16_t, mm), 32);
-        const half_t o = __builtin_bit_cast(half_t, (uint16_t)ou);
-        mm = o > mm ? o : mm;  // max over the chunk's 32 tokens for column q = lane&31
-        if (hi == s) {         // the running max lives in the lanes of stream s
-          const half_t cur = mx[c].x;
-          mx[c].x = mm > cur ? mm : cur;
-        }
-        if (s_last) {
-          const int q = (ch_begin + c) * 32 + l31;
-          float sv = (hi == s && q < Q) ? (float)mx[c].x : 0.f;
-#pragma unroll
-          for (int sft = 32; sft > 0; sft >>= 1) sv += __shfl_xor(sv, sft, 64);
-          total += sv;
-          if (hi == s) mx[c] = h2{negm, negm};
-        }
-      }
-      if (s_last && lane == 0) outp[s_r] = accumulate ? (outp[s_r] + total) : total;
-    }
-    code = ncode;
-    myrow = nrow;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 #define MAXSIM_DPW 8
 template <int D, int NBITS>
 static void launch_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid,
                           const int32_t* sel_cnt, int64_t Rcap, float* exact, hipStream_t st) {
-  static int dpw_env = -1, impl_env = -1;
-  if (dpw_env < 0) {
-    const char* s = getenv("FP_MAXSIM_DPW");
-    dpw_env = s ? atoi(s) : MAXSIM_DPW;
-    if (dpw_env < 2) dpw_env = 2;
-    const char* m = getenv("FP_MAXSIM_IMPL");  // "lds" = LDS-staged DMA tiles, default = per-lane register fetch
-    impl_env = (m && m[0] == 'l') ? 1 : 0;
-  }
-  const int dpw = dpw_env;  // documents per wave (two streams x dpw/2)
+  const int dpw = MAXSIM_DPW;  // documents per wave (two streams x dpw/2); 4 and 16 measured slower
   dim3 grid((unsigned)((Rcap + 4 * dpw - 1) / (4 * dpw)), (unsigned)sh.B);
   const int nch = sh.Qp / 32;
-  static const int nch2_env = getenv("FP_MAXSIM_NCH2") ? atoi(getenv("FP_MAXSIM_NCH2")) : 1;
   int acc = 0;
   for (int ch = 0; ch < nch;) {  // 32-column query chunks: two per launch where possible (the tokens are decompressed once per launch)
-    if (impl_env == 1) {
-      hipLaunchKernelGGL((k_maxsim_lds<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
-      ch += 1;
-    } else if (nch2_env && nch - ch >= 2) {
+    if (nch - ch >= 2) {
       hipLaunchKernelGGL((k_maxsim_reg<D, NBITS, 2>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
                          qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
       ch += 2;

@@ -86,6 +86,12 @@ def main():
         q /= np.linalg.norm(q, axis=2, keepdims=True)
         subs = [rng.integers(0, n_docs, 20).tolist() for _ in range(B)] if use_subset else None
         same_as_trace(mk(arr), q.astype(np.float16), R.SearchParameters(2000, n_full, top_k, n_probe), subs)
+    # 4000 identical documents: every bound and every exact score ties at the cut
+    from test_hip_parity import _tied_copies_arrays
+    arr, q = _tied_copies_arrays(fp, np.random.default_rng(17))
+    idx = mk(arr)
+    for n_full, top_k in ((400, 50), (8, 5)):
+        same_as_trace(idx, q, R.SearchParameters(2000, n_full, top_k, 4))
     print("Q8_OK")
 
 

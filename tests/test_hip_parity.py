@@ -572,6 +572,52 @@ def test_kmeans_assignment_and_create_without_centroids(fp, tmp_path):
         assert [row[0][0] for row in out] == [3, 77]
 
 
+def _tied_copies_arrays(fp_mod, rng):
+    """6000 random documents of which 1000..4999 are copies of one 6-token document, and 3 queries made of the copies'
+    own centroids: approximate and exact scores tie exactly across 4000 documents."""
+    arr = _random_arrays(rng, 6000, 12, 300, 128, 4, empty_frac=0.0)
+    lens = arr["doc_lengths"]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    proto_codes = rng.integers(0, 300, 6)
+    proto_res = rng.integers(0, 256, (6, 64), dtype=np.uint8)
+    codes, res, new_lens = [], [], lens.copy()
+    for d in range(6000):
+        if 1000 <= d < 5000:
+            codes.append(proto_codes)
+            res.append(proto_res)
+            new_lens[d] = 6
+        else:
+            codes.append(arr["doc_codes"][offs[d]: offs[d + 1]])
+            res.append(arr["doc_residuals"][offs[d]: offs[d + 1]])
+    arr["doc_codes"] = np.concatenate(codes).astype(np.int64)
+    arr["doc_residuals"] = np.concatenate(res).astype(np.uint8)
+    arr["doc_lengths"] = new_lens
+    arr["ivf"], arr["ivf_lengths"] = fp_mod.synth.build_ivf(arr["doc_codes"], new_lens, 300)
+    q = arr["centroids"][proto_codes[rng.integers(0, 6, (3, 8))]]
+    return arr, q
+
+
+def test_selection_with_massive_score_ties(fp):
+    """thousands of IDENTICAL documents tie exactly in approximate score at the pruning cut: the selection must keep
+    the lowest ids among the tied ones (rule: approx desc, id asc) -- this overflows the parallel gather's tie
+    buffer and exercises the ordered fallback pass (k_sel_collect).  Exact scores tie as well, so the final
+    ranking's (score desc, id asc) rule is exercised too."""
+    R = fp.fast_plaid_rust
+    arr, q = _tied_copies_arrays(fp, np.random.default_rng(17))
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    for n_full, top_k in ((400, 50), (4096, 1000), (8, 5)):
+        params = R.SearchParameters(2000, n_full, top_k, 4)
+        pids, scores, counts = R.search_arrays(hip, q, params)
+        ref = orc.search(q, top_k, n_full, 4)
+        for b in range(3):
+            h = R.search_trace(hip, q[b], params)
+            o = orc.search_trace(q[b], top_k, n_full, 4)
+            assert np.array_equal(np.sort(h["rerank"]), np.sort(o["rerank"])), "tied pruning cut resolved differently from the oracle"
+            assert np.array_equal(pids[b, : counts[b]], ref[b][0]), "tied final ranking differs from the oracle"
+            assert np.abs(scores[b, : counts[b]] - ref[b][1]).max() <= SCORE_TOL
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
