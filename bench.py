@@ -57,6 +57,9 @@ def parse():
                     help="N>1: replica = full index per GPU, batch split across ranks (the reference's multi-GPU mode); "
                          "shard = document shards + 2 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
     ap.add_argument("--no-alt-mode", action="store_true", help="N>1: do not also time the other distribution mode")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = result gather through CPU tensors, ranks wrapped onto the visible GPUs (testing the multi-process "
+                         "path on a box with fewer GPUs than ranks; replica mode only)")
     return ap.parse_args()
 
 
@@ -97,10 +100,12 @@ def main():
     if use_dist:
         import torch  # BEFORE the HIP library: see fast-plaid_amd/sharded.py
         import torch.distributed as dist
+        if a.dist_backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
 
     import fast_plaid_amd as fp
     from fast_plaid_amd import sharded
@@ -138,8 +143,8 @@ def main():
             if mode == "shard":
                 return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
             if mode == "replica":
-                return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist, device=dev,
-                                                 force_collectives=True)
+                return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist,
+                                                 device=("cpu" if a.dist_backend == "gloo" else dev), force_collectives=True)
             return R.search_arrays(index, q, params)
 
         for i in range(a.warmup):
@@ -163,7 +168,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t_start
         if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if a.dist_backend == "gloo" else dev))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return dict(index=index, elapsed=elapsed, lat=lat, stage_acc=stage_acc, cand_total=cand_total, exact_total=exact_total,
@@ -174,8 +179,10 @@ def main():
         hbm = torch.cuda.get_device_properties(local_rank).total_memory
         fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
         primary = a.dist_mode if a.dist_mode != "auto" else ("replica" if fits else "shard")
+        if a.dist_backend == "gloo":
+            primary = "replica"
         other = "shard" if primary == "replica" else "replica"
-        run_other = (not a.no_alt_mode) and (other == "shard" or fits)
+        run_other = (not a.no_alt_mode) and (other == "shard" or fits) and a.dist_backend != "gloo"
     else:
         primary, run_other = "single", False
     res = run_mode(primary)
@@ -192,7 +199,8 @@ def main():
         alt = {"mode": other, "value": a.batch * a.steps / r2["elapsed"], "ms_per_step": r2["elapsed"] / a.steps * 1e3}
         del r2
     par = {"single": "1 GPU",
-           "replica": "full index replica per GPU, batch split %d-way, result all-gather over RCCL" % world,
+           "replica": "full index replica per GPU, batch split %d-way, result all-gather over %s" % (
+               world, "RCCL" if a.dist_backend == "nccl" else "gloo (test mode: ranks share the visible GPUs)"),
            "shard": "document-sharded x%d, 2 RCCL all-gathers/batch" % world}[primary]
 
     out = {
