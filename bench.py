@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-alt-mode", action="store_true", help="N>1: do not also time the other distribution mode")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = result gather through CPU tensors, ranks wrapped onto the visible GPUs (testing the multi-process "
-                         "path on a box with fewer GPUs than ranks; replica mode only)")
+                         "path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -179,10 +179,8 @@ def main():
         hbm = torch.cuda.get_device_properties(local_rank).total_memory
         fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
         primary = a.dist_mode if a.dist_mode != "auto" else ("replica" if fits else "shard")
-        if a.dist_backend == "gloo":
-            primary = "replica"
         other = "shard" if primary == "replica" else "replica"
-        run_other = (not a.no_alt_mode) and (other == "shard" or fits) and a.dist_backend != "gloo"
+        run_other = (not a.no_alt_mode) and (other == "shard" or fits)
     else:
         primary, run_other = "single", False
     res = run_mode(primary)

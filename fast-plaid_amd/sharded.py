@@ -122,9 +122,12 @@ def _all_gather(torch, dist, x, world, group, force=False):
     """[B,R] per rank -> [G,B,R] on every rank."""
     if dist is None or (world == 1 and not force):
         return x.unsqueeze(0).contiguous()
-    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous(), group=group)  # concatenation along dim 0 == [G][B][R]
-    return out.view((world,) + tuple(x.shape))
+    src = x.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":   # test mode (several ranks on one GPU): stage through the host
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)  # concatenation along dim 0 == [G][B][R]
+    return out.view((world,) + tuple(x.shape)).to(x.device)
 
 
 def sharded_search(engine, queries_f16, params, dist=None, group=None, force_collectives=False):

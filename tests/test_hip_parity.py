@@ -721,6 +721,26 @@ def test_full_size_properties(fp, name):
     assert np.abs(ref - got).max() <= SCORE_TOL
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_and_replicated_multiprocess(fp, world):
+    """real processes (one per rank, all on cuda:0), gloo transport: document-sharded search with the HIP stage
+    engine and the replicated batch split both return exactly the unsharded result on every rank."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "shard_mp_worker.py")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "SHARD_MP_OK" in o, f"rank {r}:\n{o}"
+
+
 def test_full_size_cleanup(fp):
     """drops the cached multi-GB index before later tests allocate."""
     _full_size_cache.clear()
