@@ -9,8 +9,9 @@ Layout:
   synth.py              synthetic compressed-domain corpora (numpy twin of csrc/fp_synth.hip)
   sharded.py            one-process-per-GPU document-sharded / replicated search over torch.distributed (RCCL)
   kmeans.py             k-means centroids (sampling protocol of the reference, Lloyd with device assignment)
+  maintain.py           update (append with the existing codec) / delete, the native part of the reference
   create.py             index creation given centroids: codec training, device compression (fp_compress), IVF, directory
 """
-from . import create, fast_plaid_rust, kmeans, search, synth  # noqa: F401
+from . import create, fast_plaid_rust, kmeans, maintain, search, synth  # noqa: F401
 
-__all__ = ["create", "fast_plaid_rust", "kmeans", "search", "synth"]
+__all__ = ["create", "fast_plaid_rust", "kmeans", "maintain", "search", "synth"]

@@ -8,7 +8,7 @@ Same names, argument meaning and error behaviour as the PyO3 functions:
   reconstruct_embeddings(...)            rust/utils/embeddings.rs:12-69
   initialize_torch(...)                  rust/lib.rs:100-104 (no libtorch here: a no-op)
 Index maintenance entry points (create / update / delete, lib.rs:132-165, :302-364) are outside
-the search hot path and raise NotImplementedError (create / update / delete).
+the search hot path; create / update / delete delegate to create.py / maintain.py (their native part).
 
 Tensors may be torch CPU tensors or numpy arrays; nothing here needs torch.
 """
@@ -317,16 +317,29 @@ def read_ivf(index: PyLoadedIndex, cell: int, capacity: int = 1 << 22):
     return pids[:n].copy()
 
 
-def create(*args, **kwargs):  # lib.rs:132-165
-    raise NotImplementedError("index creation is outside the MI355X search hot path (SURVEY.md section 8, row f1)")
+def create(index: str, torch_path: str, device: str, embedding_dim: int, nbits: int, embeddings, centroids, batch_size: int = 25_000,
+           seed: int | None = None, compress_only: bool = False) -> None:
+    """rust/lib.rs:132-165 (torch_path / batch_size accepted and ignored)."""
+    del torch_path, batch_size
+    from . import create as _create
+    if embeddings and int(_np(embeddings[0], np.float16).shape[1]) != int(embedding_dim):
+        raise ValueError("embedding_dim does not match the embeddings")
+    _create.create_index(index, embeddings, centroids, nbits=nbits, device=device, seed=seed, compress_only=compress_only)
 
 
-def update(*args, **kwargs):  # lib.rs:302-328
-    raise NotImplementedError("index update is outside the MI355X search hot path")
+def update(index_path: str, index, torch_path: str, device: str, embeddings, batch_size: int = 25_000,
+           update_threshold_centroids: bool | None = None) -> None:
+    """rust/lib.rs:292-320 (the loaded index argument only carries the codec in the reference; it is read from the directory here)."""
+    del index, torch_path, batch_size
+    from . import maintain
+    maintain.update_index(index_path, embeddings, device, update_threshold=bool(update_threshold_centroids))
 
 
-def delete(*args, **kwargs):  # lib.rs:348-364
-    raise NotImplementedError("index delete is outside the MI355X search hot path")
+def delete(index: str, torch_path: str, device: str, subset) -> None:
+    """rust/lib.rs:322-340."""
+    del torch_path, device
+    from . import maintain
+    maintain.delete_from_index(index, subset)
 
 
 class QueryResultWithTokenScores:

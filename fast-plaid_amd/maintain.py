@@ -1,0 +1,146 @@
+"""Index maintenance, the native part of the reference:
+
+  update   rust/lib.rs:292-320 -> rust/index/update.rs:30-473   append documents with the EXISTING codec
+  delete   rust/lib.rs:322-340 -> rust/index/delete.rs:26-145   drop documents, renumber, rebuild the IVF
+
+Both are file operations on the index directory around one device step (fp_compress for the new documents).
+The buffering / re-clustering policy the reference wraps around them in Python (python/fast_plaid/search/update.py,
+which needs the external `usearch` package) is not reproduced: FastPlaid.update appends directly.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from . import create as _create
+from . import synth
+from .fast_plaid_rust import _np
+
+_APPEND_TO_LAST_BELOW = 2000      # update.rs:77: a last chunk with fewer documents is extended instead of starting a new one
+_PROC_CHUNK = 25_000              # update.rs:28 DEFAULT_PROC_CHUNK_SIZE
+
+
+def _read_json(p):
+    with open(p) as f:
+        return json.load(f)
+
+
+def _write_json(p, obj, pretty=False):
+    with open(p, "w") as f:
+        json.dump(obj, f, indent=2 if pretty else None)
+
+
+def _rebuild_ivf(index_path: str, n_chunks: int, n_partitions: int):
+    """per-centroid ascending unique document ids over every chunk (create.rs:528-559 / optimize_ivf :55-132;
+    update.rs merges the new ids into the old lists, which yields the same lists)."""
+    codes, lens = [], []
+    for i in range(n_chunks):
+        cp = os.path.join(index_path, f"{i}.codes.npy")
+        if os.path.exists(cp):
+            codes.append(np.load(cp).astype(np.int64))
+            lens.extend(_read_json(os.path.join(index_path, f"doclens.{i}.json")))
+    codes = np.concatenate(codes) if codes else np.zeros(0, np.int64)
+    lens = np.asarray(lens, np.int64)
+    ivf, ivf_lengths = synth.build_ivf(codes, lens, n_partitions)
+    np.save(os.path.join(index_path, "ivf.npy"), ivf.astype(np.int64))
+    np.save(os.path.join(index_path, "ivf_lengths.npy"), ivf_lengths.astype(np.int32))
+    return int(codes.shape[0]), int(lens.shape[0])
+
+
+def update_index(index_path: str, documents_embeddings, device: str = "cuda:0", update_threshold: bool = False) -> None:
+    """update.rs:30-473."""
+    meta_path = os.path.join(index_path, "metadata.json")
+    meta = _read_json(meta_path)
+    n_chunks = int(meta["num_chunks"])
+    nbits = int(meta["nbits"])
+    n_partitions = int(meta["num_partitions"])
+    old_total = int(meta.get("num_embeddings", 0))
+    compress_only = bool(meta.get("compress_only", False))
+    cent = np.load(os.path.join(index_path, "centroids.npy")).astype(np.float16)
+    cut = np.load(os.path.join(index_path, "bucket_cutoffs.npy")).astype(np.float16)
+    docs = [_np(d, np.float16) for d in documents_embeddings]
+    if not docs:
+        return
+    start, append_to_last, emb_off = n_chunks, False, old_total
+    if n_chunks > 0:
+        lm_path = os.path.join(index_path, f"{n_chunks - 1}.metadata.json")
+        if os.path.exists(lm_path):
+            lm = _read_json(lm_path)
+            if int(lm.get("num_documents", 1 << 60)) < _APPEND_TO_LAST_BELOW:
+                start, append_to_last = n_chunks - 1, True
+                emb_off = int(lm["embedding_offset"]) if "embedding_offset" in lm else old_total - int(lm.get("num_embeddings", 0))
+    chunk = min(_PROC_CHUNK, 1 + len(docs))
+    n_new_chunks = -(-len(docs) // chunk)
+    norms = []
+    for i in range(n_new_chunks):
+        part = docs[i * chunk: (i + 1) * chunk]
+        emb = np.concatenate(part)
+        codes, packed = _create.compress(cent, cut, emb, nbits, device)
+        lens = [int(d.shape[0]) for d in part]
+        if update_threshold:
+            res = (emb - cent[codes]).astype(np.float32)
+            norms.append(np.sqrt((res * res).sum(axis=1, dtype=np.float32)))
+        g = start + i
+        if i == 0 and append_to_last and os.path.exists(os.path.join(index_path, f"{g}.codes.npy")):
+            codes = np.concatenate([np.load(os.path.join(index_path, f"{g}.codes.npy")).astype(np.int64), codes])
+            packed = np.concatenate([np.load(os.path.join(index_path, f"{g}.residuals.npy")).astype(np.uint8), packed])
+            lens = list(_read_json(os.path.join(index_path, f"doclens.{g}.json"))) + lens
+        np.save(os.path.join(index_path, f"{g}.codes.npy"), codes.astype(np.int64))
+        np.save(os.path.join(index_path, f"{g}.residuals.npy"), packed.astype(np.uint8))
+        _write_json(os.path.join(index_path, f"doclens.{g}.json"), lens)
+        _write_json(os.path.join(index_path, f"{g}.metadata.json"),
+                    {"num_documents": len(lens), "num_embeddings": int(codes.shape[0]), "embedding_offset": emb_off}, pretty=True)
+        emb_off += int(codes.shape[0])
+    if update_threshold and norms:   # update.rs:283-310: 0.75 quantile of the new residual norms, count-weighted with the old value
+        new = np.sort(np.concatenate(norms))
+        new_thr = float(_create._quantile(new, 0.75))
+        tp = os.path.join(index_path, "cluster_threshold.npy")
+        if os.path.exists(tp):
+            old_thr = float(np.load(tp))
+            new_thr = (old_thr * old_total + new_thr * new.shape[0]) / (old_total + new.shape[0])
+        np.save(tp, np.asarray(new_thr, np.float32))
+    total_chunks = start + n_new_chunks
+    if compress_only:
+        T = sum(int(_read_json(os.path.join(index_path, f"{i}.metadata.json"))["num_embeddings"]) for i in range(total_chunks))
+        N = sum(len(_read_json(os.path.join(index_path, f"doclens.{i}.json"))) for i in range(total_chunks))
+    else:
+        T, N = _rebuild_ivf(index_path, total_chunks, n_partitions)
+    _write_json(meta_path, {"num_chunks": total_chunks, "nbits": nbits, "num_partitions": n_partitions, "num_embeddings": T,
+                            "avg_doclen": (T / N) if N else 0.0, "num_documents": N, "compress_only": compress_only}, pretty=True)
+
+
+def delete_from_index(index_path: str, subset) -> None:
+    """delete.rs:26-145: documents are addressed by position; the survivors are renumbered consecutively."""
+    meta_path = os.path.join(index_path, "metadata.json")
+    meta = _read_json(meta_path)
+    n_chunks, nbits, n_partitions = int(meta["num_chunks"]), int(meta["nbits"]), int(meta["num_partitions"])
+    compress_only = bool(meta.get("compress_only", False))
+    drop = set(int(x) for x in subset)
+    doc0 = 0
+    for i in range(n_chunks):
+        dl_path = os.path.join(index_path, f"doclens.{i}.json")
+        lens = list(_read_json(dl_path))
+        keep_doc = np.array([(doc0 + j) not in drop for j in range(len(lens))], bool)
+        if not keep_doc.all():
+            keep_tok = np.repeat(keep_doc, np.asarray(lens, np.int64))
+            codes = np.load(os.path.join(index_path, f"{i}.codes.npy"))[keep_tok]
+            res = np.load(os.path.join(index_path, f"{i}.residuals.npy"))[keep_tok]
+            new_lens = [ln for ln, k in zip(lens, keep_doc) if k]
+            np.save(os.path.join(index_path, f"{i}.codes.npy"), codes)
+            np.save(os.path.join(index_path, f"{i}.residuals.npy"), res)
+            _write_json(dl_path, new_lens)
+            cm_path = os.path.join(index_path, f"{i}.metadata.json")
+            cm = _read_json(cm_path) if os.path.exists(cm_path) else {}
+            cm["num_documents"] = len(new_lens)
+            cm["num_embeddings"] = int(codes.shape[0])
+            _write_json(cm_path, cm, pretty=True)
+        doc0 += len(lens)
+    if compress_only:
+        T = sum(int(np.load(os.path.join(index_path, f"{i}.codes.npy"), mmap_mode="r").shape[0]) for i in range(n_chunks))
+        N = sum(len(_read_json(os.path.join(index_path, f"doclens.{i}.json"))) for i in range(n_chunks))
+    else:
+        T, N = _rebuild_ivf(index_path, n_chunks, n_partitions)
+    _write_json(meta_path, {"num_chunks": n_chunks, "nbits": nbits, "num_partitions": n_partitions, "num_embeddings": T,
+                            "avg_doclen": (T / N) if N else 0.0, "num_documents": N, "compress_only": compress_only}, pretty=True)

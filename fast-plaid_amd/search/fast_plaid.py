@@ -206,8 +206,28 @@ class FastPlaid:
         self._check_and_reload_index()
         return self
 
-    def _maintenance(self, *a, **k):
-        raise NotImplementedError("index update / delete are outside the MI355X search hot path (SURVEY.md section 8, row f4)")
+    def update(self, documents_embeddings, metadata=None, batch_size: int = 25_000, update_threshold_centroids: bool = False, **kwargs):
+        """fast_plaid.py update -> rust/index/update.rs: append documents with the index's existing codec.  (The reference's
+        Python layer additionally buffers small updates and may re-cluster, which needs the external usearch package;
+        here every call appends directly.)"""
+        del batch_size, kwargs
+        if metadata is not None:
+            raise NotImplementedError("metadata filtering (fast_plaid.filtering) is outside the MI355X search hot path")
+        if self.index is None or not os.path.exists(os.path.join(self.index, "metadata.json")):
+            raise FileNotFoundError("no index to update: create it first")
+        from .. import maintain
+        maintain.update_index(self.index, documents_embeddings, self.devices[0], update_threshold=update_threshold_centroids)
+        self._last_known_mtime = 0.0
+        self._check_and_reload_index()
+        return self
 
-    update = _maintenance
-    delete = _maintenance
+    def delete(self, subset: list[int], **kwargs):
+        """fast_plaid.py:1049-1100 -> rust/index/delete.rs: documents are addressed by position; survivors are renumbered."""
+        del kwargs
+        if self.index is None or not os.path.exists(os.path.join(self.index, "metadata.json")):
+            raise FileNotFoundError("no index to delete from")
+        from .. import maintain
+        maintain.delete_from_index(self.index, subset)
+        self._last_known_mtime = 0.0
+        self._check_and_reload_index()
+        return self

@@ -618,6 +618,63 @@ def test_selection_with_massive_score_ties(fp):
             assert np.abs(scores[b, : counts[b]] - ref[b][1]).max() <= SCORE_TOL
 
 
+def test_update_and_delete_match_one_shot_builds(fp, tmp_path):
+    """FastPlaid.update (rust/index/update.rs: append with the EXISTING codec, extend a small last chunk) and
+    FastPlaid.delete (rust/index/delete.rs): the directory that results loads to exactly the arrays of a one-shot
+    compression of the same documents with the same codec, and searches accordingly."""
+    from fast_plaid_amd import create as CR
+    from fast_plaid_amd import search, synth
+    from fast_plaid_amd.search import index_io
+    rng = np.random.default_rng(23)
+    dim, C = 128, 96
+    cent = rng.standard_normal((C, dim), dtype=np.float32)
+    cent = (cent / np.linalg.norm(cent, axis=1, keepdims=True)).astype(np.float16)
+
+    def mkdocs(n):
+        out = []
+        for _ in range(n):
+            ln = int(rng.integers(3, 40))
+            d = cent[rng.integers(0, C, ln)].astype(np.float32) + 0.25 * rng.standard_normal((ln, dim), dtype=np.float32) / np.sqrt(dim)
+            out.append((d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float16))
+        return out
+
+    A, B1, B2 = mkdocs(300), mkdocs(120), mkdocs(2500)
+    path = str(tmp_path / "idx")
+    with search.FastPlaid(index=path, device="cuda:0") as fpi:
+        fpi.create(A, centroids=cent, nbits=4)
+        codec = index_io.load_index_arrays(path)
+        fpi.update(B1)                      # last chunk has 300 < 2000 documents: extended in place
+        assert __import__("json").load(open(os.path.join(path, "metadata.json")))["num_chunks"] == 1
+        fpi.update(B2, update_threshold_centroids=True)     # 420 < 2000: still extended; now 2920 documents
+        fpi.update(B1)                      # 2920 >= 2000: a new chunk
+        meta = __import__("json").load(open(os.path.join(path, "metadata.json")))
+        assert meta["num_chunks"] == 2 and meta["num_documents"] == 300 + 120 + 2500 + 120
+        assert os.path.exists(os.path.join(path, "cluster_threshold.npy"))
+        got = index_io.load_index_arrays(path)
+        alldocs = A + B1 + B2 + B1
+        codes, packed = CR.compress(codec["centroids"], codec["bucket_cutoffs"], np.concatenate(alldocs), 4)
+        lens = np.array([d.shape[0] for d in alldocs], np.int64)
+        assert np.array_equal(got["doc_lengths"], lens) and np.array_equal(got["doc_codes"], codes) and np.array_equal(got["doc_residuals"], packed)
+        ivf, ivfl = synth.build_ivf(codes, lens, got["ivf_lengths"].shape[0])
+        assert np.array_equal(got["ivf"], ivf) and np.array_equal(got["ivf_lengths"], ivfl)
+        for k in ("centroids", "bucket_cutoffs", "bucket_weights"):
+            assert np.array_equal(got[k], codec[k])          # the codec is untouched by updates
+        # an appended document is found by its own tokens
+        target = 300 + 120 + 17
+        q = np.pad(alldocs[target][:16], ((0, 16 - min(16, alldocs[target].shape[0])), (0, 0)))[None]
+        assert fpi.search(q, top_k=1, show_progress=False)[0][0][0] == target
+        # delete: survivors renumbered by position
+        fpi.delete([0, 5, target])
+        after = index_io.load_index_arrays(path)
+        keep = np.ones(len(alldocs), bool)
+        keep[[0, 5, target]] = False
+        assert np.array_equal(after["doc_lengths"], lens[keep]) and np.array_equal(after["doc_codes"], codes[np.repeat(keep, lens)])
+        assert fpi.search(q, top_k=1, show_progress=False)[0][0][0] != target
+        nxt = target + 1                    # the document after the deleted one moved up by three positions
+        q2 = np.pad(alldocs[nxt][:16], ((0, 16 - min(16, alldocs[nxt].shape[0])), (0, 0)))[None]
+        assert fpi.search(q2, top_k=1, show_progress=False)[0][0][0] == nxt - 3
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports

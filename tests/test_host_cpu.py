@@ -161,3 +161,30 @@ def test_index_directory_matches_the_reference_loader():
     assert np.array_equal(got["doc_codes"], exp["doc_codes"][:T]) and np.array_equal(got["doc_residuals"], exp["doc_residuals"][:T])
     # the reference's loader leaves nothing behind in the committed directory (it ran on a scratch copy)
     assert not [f for f in os.listdir(os.path.join(gdir, "index_dir")) if f.startswith("merged_")]
+
+
+def test_delete_from_index_matches_rebuild(tmp_path):
+    """maintain.delete_from_index (rust/index/delete.rs:26-145) on a copy of the committed directory: what loads back
+    equals the arrays of the surviving documents (renumbered by position), IVF rebuilt; pure host work."""
+    import shutil
+    from fast_plaid_amd import maintain, synth
+    from fast_plaid_amd.search import index_io
+    src = os.path.join(ROOT, "tests", "golden", "refloader", "index_dir")
+    dst = str(tmp_path / "idx")
+    shutil.copytree(src, dst)
+    before = index_io.load_index_arrays(dst)
+    drop = [0, 3, 49, 50, 51, 129, 129, 100000]          # first, a chunk boundary, last, a duplicate, an id that does not exist
+    maintain.delete_from_index(dst, drop)
+    after = index_io.load_index_arrays(dst)
+    keep = np.array([d not in set(drop) for d in range(before["doc_lengths"].shape[0])])
+    lens = before["doc_lengths"]
+    keep_tok = np.repeat(keep, lens)
+    assert np.array_equal(after["doc_lengths"], lens[keep])
+    assert np.array_equal(after["doc_codes"], before["doc_codes"][keep_tok])
+    assert np.array_equal(after["doc_residuals"], before["doc_residuals"][keep_tok])
+    ivf, ivf_lengths = synth.build_ivf(after["doc_codes"], after["doc_lengths"], before["ivf_lengths"].shape[0])
+    assert np.array_equal(after["ivf"], ivf) and np.array_equal(after["ivf_lengths"], ivf_lengths)
+    meta = __import__("json").load(open(os.path.join(dst, "metadata.json")))
+    assert meta["num_documents"] == int(keep.sum()) and meta["num_embeddings"] == int(keep_tok.sum()) and meta["num_chunks"] == 3
+    for k in ("centroids", "bucket_weights", "bucket_cutoffs"):
+        assert np.array_equal(after[k], before[k])
