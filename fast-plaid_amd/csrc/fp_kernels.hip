@@ -14,6 +14,7 @@
 // fp32 and round once.  The MFMA accumulation ORDER differs from the CPU's ascending-k
 // chain, which is the only source of (<= 1 fp16 ulp, rare) differences.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -78,6 +79,18 @@ __device__ __forceinline__ void norm_pair2(uint32_t& a, uint32_t& b, float r_hi,
       : "v"(a), "v"(b), "v"(r_hi), "v"(r_lo));
   a = da;
   b = db;
+}
+
+// More than 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (gfx950: 160 KiB per workgroup); one process
+// may drive several GPUs (FastPlaid(device=[...])), so the "done" flag is a bit per device.
+static void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_relaxed) & bit)) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_relaxed);
+  }
 }
 
 // ============================================================================================
@@ -752,11 +765,8 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
   while (tw > 512 && ((W + tw - 1) / tw) * B < 1024) tw >>= 1;
   const int ntile = (int)((W + tw - 1) / tw);
   const size_t lds = (size_t)tw * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_ivf_mark, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  fp_allow_big_lds((const void*)k_ivf_mark, lds_ok, 144 * 1024);
   const int search = ntile > 8 ? 1 : 0;
   hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ix.ivf_off,
                      ix.ivf_pids, ix.P, bitmap, W, search, tw);
@@ -1608,11 +1618,8 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   hipLaunchKernelGGL(k_sel_gather, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
                      tie_pid);
   {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)k_sel_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    fp_allow_big_lds((const void*)k_sel_finish, lds_ok, 144 * 1024);
     int kp2 = 2;
     while (kp2 < (int)sh.R) kp2 <<= 1;
     hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8, st, selstate, sh.R, sel_pid, sel_approx, tie_pid);
@@ -1980,11 +1987,8 @@ void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t*
                     hipStream_t st) {
   int np2 = next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in (gfx950: 160 KiB / workgroup)
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_final_topk, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  fp_allow_big_lds((const void*)k_final_topk, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,
                      top_k, pid_offset, out_pid, out_score, out_cnt);
 }
@@ -2109,11 +2113,8 @@ void fpk_shard_global_cut(const float* all_approx, const int64_t* all_pid, int G
   const int n = (int)(G * R);
   const int np2 = next_pow2(n < 2 ? 2 : n);
   int rp2 = next_pow2((int)(R < 2 ? 2 : R));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_shard_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  fp_allow_big_lds((const void*)k_shard_cut, lds_ok, 160 * 1024);
   hipLaunchKernelGGL(k_shard_cut, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + (size_t)rp2 * 4 + 16, st, all_approx, all_pid, n, np2, R,
                      pid_lo, pid_hi, sel_pid, sel_cnt);
 }
@@ -2218,11 +2219,8 @@ int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const
   if (n_hits <= 0) return 0;
   const size_t lds = ((size_t)Q * ix.dim + ix.dim) * sizeof(float);
   if (lds > 150 * 1024) return -1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_token_scores, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  fp_allow_big_lds((const void*)k_token_scores, lds_ok, 152 * 1024);
   for (int64_t h0 = 0; h0 < n_hits; h0 += 0x7FFFFF00ll / 64) {   // grid.x * 64 threads must stay below 2^32
     const int64_t nh = std::min<int64_t>(n_hits - h0, 0x7FFFFF00ll / 64);
     hipLaunchKernelGGL(k_token_scores, dim3((unsigned)nh), dim3(64), lds, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off, ix.perm,
