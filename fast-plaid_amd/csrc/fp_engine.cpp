@@ -497,9 +497,9 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
   // per-128-centroid column maxima for the threshold probe
   static const int q8_env = [] { const char* e = getenv("FP_APPROX_IMPL"); return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : 0)); }();
-  const bool want_s8 = !P.exact_all && sh.Qp == 32 && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
+  const bool want_s8 = !P.exact_all && (sh.Qp == 32 || sh.Qp == 64) && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
   const int nch128 = (int)((D.C + 127) / 128);
-  if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * 32));
+  if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
   HIPCHK(s->cmax128.ensure((size_t)B * sh.Qp * nch128 * 2));
   if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
                           s->cmax128.as<uint16_t>(), st))
@@ -574,8 +574,9 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   if (P.used_q8) {
     const int64_t max_n = std::min<int64_t>(D.N, M);
     const int nblk2 = (int)((max_n + FP_SURV_CHUNK - 1) / FP_SURV_CHUNK);
-    HIPCHK(s->kq.ensure((size_t)M * 4));
-    HIPCHK(s->q8hist.ensure((size_t)B * 8192 * 4));
+    const int nch8 = sh.Qp / 32;
+    HIPCHK(s->kq.ensure((size_t)M * 4 * (nch8 > 1 ? 1 + nch8 : 1)));
+    HIPCHK(s->q8hist.ensure((size_t)B * 8192 * nch8 * 4));
     HIPCHK(s->cut.ensure((size_t)B * 4));
     HIPCHK(s->blkcnt2.ensure((size_t)B * nblk2 * 4));
     HIPCHK(s->nsurv.ensure((size_t)B * 4));

@@ -122,7 +122,7 @@ void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, i
 // Epilogue: the fp16 tile is staged through LDS (the operand tiles are dead by then) so that the
 // [b][c][q] layout is written with 16 B per lane, 1 KiB contiguous per wave instruction (the
 // direct 8-byte stores reached 2 TB/s on the 537 MB of S), and two by-products leave with it:
-//   * S8, the 8-bit bins of S4's bound stage (fp_kernels.hip, "bound-and-refine"), Qp == 32 only;
+//   * S8, the 8-bit bins of S4's bound stage (fp_kernels.hip, "bound-and-refine"), Qp <= 64 only;
 //   * cmax, the per-column maximum over the tile's 128 centroids: the threshold probe's chunk
 //     maxima at 128-centroid granularity for free.
 // ============================================================================================
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
         bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
         o[t >> 2] |= (uint32_t)bin << (8 * (t & 3));
       }
-      *reinterpret_cast<uint2*>(S8 + (bq * C + c) * 32 + ch * 8) = make_uint2(o[0], o[1]);
+      // S8 is [b][Qp/32][c][32]: every 32-column chunk of a query is its own contiguous C x 32 B table
+      *reinterpret_cast<uint2*>(S8 + ((bq * (Qp / 32) + q0 / 32) * C + c) * 32 + ch * 8) = make_uint2(o[0], o[1]);
     }
   }
   if (cmax && tid < 128) {
@@ -271,7 +272,7 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   const int64_t Ntot = (int64_t)B * Qp;
   const int nch = (int)((ix.C + S1_TILE - 1) / S1_TILE);
   dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
-  if (Qp != 32) S8 = nullptr;
+  if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
   const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
   if (ix.dim == 128) {
     const size_t lds = std::max<size_t>(2 * 128 * 256, out_lds);
@@ -1063,10 +1064,14 @@ template <int PPD>
 __global__ __launch_bounds__(512) void k_approx_q8(const uint8_t* __restrict__ S8, int64_t C, int Q,
                                                    const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                    const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
-                                                   uint32_t* __restrict__ kq, int b0) {
+                                                   uint32_t* __restrict__ kq, int nch, int64_t M) {
   const int DPB = (int)(blockDim.x >> 1) / PPD;   // candidates per workgroup
   constexpr int TSTEP = 8 * PPD;      // codes between two groups of one pair
-  const int b = b0 + blockIdx.y, bxi = blockIdx.x;
+  // blockIdx.y = query * nch + 32-column chunk; chunk ch writes its partial sums to kq + ch * M (nch == 1: the final ones)
+  const int b = blockIdx.y / nch, chq = blockIdx.y % nch, bxi = blockIdx.x;
+  Q = Q - 32 * chq;
+  Q = Q > 32 ? 32 : Q;
+  kq += (int64_t)chq * M;
   const int nbx = gridDim.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
@@ -1074,7 +1079,7 @@ __global__ __launch_bounds__(512) void k_approx_q8(const uint8_t* __restrict__ S
   const int grp = threadIdx.x >> 1;   // lane pair within the block (0..127)
   const int pp = grp % PPD;           // which pair of the candidate
   const int tfirst = 8 * pp;
-  const uint8_t* Sb = S8 + (int64_t)b * C * 32 + sub * 16;
+  const uint8_t* Sb = S8 + ((int64_t)b * nch + chq) * C * 32 + sub * 16;
   const int64_t stride = (int64_t)nbx * DPB;
   int64_t i = (int64_t)bxi * DPB + grp / PPD;
   // A step's 8 codes are ONE 16-byte load per lane (codes 4*sub .. 4*sub+3 of the group; dword-aligned only,
@@ -1188,22 +1193,41 @@ __global__ __launch_bounds__(512) void k_approx_q8(const uint8_t* __restrict__ S
   }
 }
 
+// two 32-column chunks (32 < q_len <= 64): the candidate's bounds are the sums of the chunks' bounds; a void bound in either
+// chunk voids the sum
+__global__ void k_q8_combine(const uint32_t* __restrict__ part, int nch, int64_t M, uint32_t* __restrict__ kq) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t lo = 0, hi = 0;
+    bool lo_void = false, hi_void = false;
+    for (int c = 0; c < nch; ++c) {
+      const uint32_t v = part[(int64_t)c * M + i];
+      const uint32_t l = v & 0xFFFFu, h = v >> 16;
+      lo_void |= (l == 0u);
+      hi_void |= (h == 0xFFFFu);
+      lo += l;
+      hi += h;
+    }
+    kq[i] = ((hi_void ? 0xFFFFu : hi) << 16) | (lo_void ? 0u : lo);
+  }
+}
+
 // histogram of K_lo per query: Q8_HIST_BLOCKS workgroups per query build LDS histograms of their share
-// and flush the non-empty bins into hist [B][Q8_BINS_SUM] (zeroed by the caller)
+// and flush the non-empty bins into hist [B][bins] (zeroed by the caller); bins = Q8_BINS_SUM * chunks
 #define Q8_HIST_BLOCKS 16
 __global__ __launch_bounds__(1024) void k_q8_hist(const uint32_t* __restrict__ kq, const int64_t* __restrict__ cand_off,
-                                                  uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[Q8_BINS_SUM];
+                                                  uint32_t* __restrict__ hist, int bins) {
+  extern __shared__ uint32_t h_dyn[];
+  uint32_t* h = h_dyn;
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
-  for (int i = tid; i < Q8_BINS_SUM; i += 1024) h[i] = 0u;
+  for (int i = tid; i < bins; i += 1024) h[i] = 0u;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < n; i += (int64_t)Q8_HIST_BLOCKS * 1024) atomicAdd(&h[kq[beg + i] & 0xFFFFu], 1u);
   __syncthreads();
-  uint32_t* hg = hist + (int64_t)b * Q8_BINS_SUM;
-  for (int i = tid; i < Q8_BINS_SUM; i += 1024) {
+  uint32_t* hg = hist + (int64_t)b * bins;
+  for (int i = tid; i < bins; i += 1024) {
     const uint32_t v = h[i];
     if (v) atomicAdd(&hg[i], v);
   }
@@ -1211,7 +1235,7 @@ __global__ __launch_bounds__(1024) void k_q8_hist(const uint32_t* __restrict__ k
 
 // one workgroup per query: T = keep-th largest K_lo from the histogram, cut = max(T - Q + 1, 0)
 __global__ __launch_bounds__(1024) void k_q8_cut(const uint32_t* __restrict__ hist, const int64_t* __restrict__ cand_off, int64_t n_full,
-                                                 int64_t R, int Q, int32_t* __restrict__ cut) {
+                                                 int64_t R, int Q, int32_t* __restrict__ cut, int bins) {
   __shared__ uint32_t part[1024];
   __shared__ int s_T;
   const int b = blockIdx.x;
@@ -1225,12 +1249,16 @@ __global__ __launch_bounds__(1024) void k_q8_cut(const uint32_t* __restrict__ hi
     return;
   }
   if (tid == 0) s_T = 0;
-  const uint32_t* hg = hist + (int64_t)b * Q8_BINS_SUM;
-  // thread t owns bins [8t, 8t+8); suffix counts from the top
-  uint32_t own[8];
+  const uint32_t* hg = hist + (int64_t)b * bins;
+  // thread t owns bins [bpt*t, bpt*(t+1)); suffix counts from the top
+  const int bpt = bins / 1024;   // 8 or 16
+  uint32_t own[16];
   uint32_t loc = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { own[k] = hg[tid * 8 + k]; loc += own[k]; }
+  for (int k = 0; k < 16; ++k) {
+    own[k] = (k < bpt) ? hg[tid * bpt + k] : 0u;
+    loc += own[k];
+  }
   part[tid] = loc;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {  // inclusive suffix scan
@@ -1242,10 +1270,13 @@ __global__ __launch_bounds__(1024) void k_q8_cut(const uint32_t* __restrict__ hi
   const uint32_t above = part[tid] - loc;  // candidates in bins above this thread's bins
   if (above < (uint32_t)keep && part[tid] >= (uint32_t)keep) {
     uint32_t acc = above;
-    int T = tid * 8;
-    for (int k = 7; k >= 0; --k) {
-      acc += own[k];
-      if (acc >= (uint32_t)keep) { T = tid * 8 + k; break; }
+    int T = tid * bpt;
+#pragma unroll
+    for (int k = 15; k >= 0; --k) {
+      if (k < bpt) {
+        acc += own[k];
+        if (acc >= (uint32_t)keep) { T = tid * bpt + k; break; }
+      }
     }
     s_T = T;
   }
@@ -1320,7 +1351,8 @@ __global__ __launch_bounds__(256) void k_surv_compact(const uint32_t* __restrict
 
 // Runs (2)-(4) of the scheme: on return surv_off [B+1] / surv_pid describe the survivors (ordered, on the device).
 void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off,
-                          const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192]*/, uint32_t* kq, int32_t* cut, int32_t* blkcnt,
+                          const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192 * Qp/32]*/, uint32_t* kq /*[M * (1 + (Qp > 32 ? Qp/32 : 0))]*/,
+                          int32_t* cut, int32_t* blkcnt,
                           int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
   const int B = sh.B;
   // Lane pairs per candidate: about 2-3 code groups per pair (cfg2, 33 codes = 5 groups: 1/2/4/8 pairs -> S4 5.15/4.34/
@@ -1334,6 +1366,9 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   while (ppd < 8 && ppd * 4 <= groups) ppd <<= 1;                // >= 2 groups per pair
   while (ppd < 8 && per_q * ppd < 131072) ppd <<= 1;             // fill the chip with one query
   if (ppd_env == 1 || ppd_env == 2 || ppd_env == 4 || ppd_env == 8) ppd = ppd_env;
+  const int nch = sh.Qp / 32;                            // 1 or 2 chunks of 32 query columns
+  uint32_t* kq_part = nch > 1 ? kq + M : kq;             // per-chunk partial sums behind the final ones
+  const int bins = Q8_BINS_SUM * nch;
   const int tpb = 256;   // 64 / 128 / 512 threads per workgroup measured the same (4.34-4.41 ms)
   const int dpb = (tpb / 2) / ppd;
   int64_t bx = (per_q + dpb - 1) / dpb;
@@ -1343,8 +1378,8 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   // (an XCD-affine mapping -- one query per XCD so that each L2 holds one 4 MB slice -- measured slower: 6.9 vs 6.05 ms;
   //  one launch per 1/2/4 queries: 6.2/6.0/5.9 vs 5.8 ms)
 #define FP_Q8_LAUNCH(PPD_)                                                                                                        \
-  hipLaunchKernelGGL(k_approx_q8<PPD_>, dim3((unsigned)bx, (unsigned)B), dim3(tpb), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, ix.uoff, \
-                     ix.ucodes, kq, 0)
+  hipLaunchKernelGGL(k_approx_q8<PPD_>, dim3((unsigned)bx, (unsigned)(B * nch)), dim3(tpb), 0, st, S8, ix.C, sh.Q, cand_off, cand_pid, \
+                     ix.uoff, ix.ucodes, kq_part, nch, M)
   switch (ppd) {
     case 1: FP_Q8_LAUNCH(1); break;
     case 2: FP_Q8_LAUNCH(2); break;
@@ -1352,9 +1387,12 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
     default: FP_Q8_LAUNCH(4); break;
   }
 #undef FP_Q8_LAUNCH
-  (void)hipMemsetAsync(q8hist, 0, (size_t)B * Q8_BINS_SUM * 4, st);
-  hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), 0, st, kq, cand_off, q8hist);
-  hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut);
+  if (nch > 1) hipLaunchKernelGGL(k_q8_combine, dim3(fp_grid_cap((M + 255) / 256, 256)), dim3(256), 0, st, kq_part, nch, M, kq);
+  (void)hipMemsetAsync(q8hist, 0, (size_t)B * bins * 4, st);
+  static std::atomic<uint64_t> lds_ok{0};
+  fp_allow_big_lds((const void*)k_q8_hist, lds_ok, 144 * 1024);
+  hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), (size_t)bins * 4, st, kq, cand_off, q8hist, bins);
+  hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut, bins);
   hipLaunchKernelGGL(k_surv_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cut, blkcnt, nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, nsurv);
   hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);

@@ -49,7 +49,8 @@ def main():
     # synthetic corpora where the cut actually prunes (candidates >> R), Q < 32 exercises the column mask
     pruned = 0
     for (n_docs, C, Q, n_full, n_probe, seed) in ((20000, 2048, 32, 256, 8, 1), (20000, 2048, 20, 64, 4, 2), (8000, 512, 7, 32, 2, 3),
-                                                  (30000, 4096, 32, 4096, 8, 4)):
+                                                  (30000, 4096, 32, 4096, 8, 4), (20000, 2048, 50, 256, 8, 5), (15000, 1024, 64, 128, 4, 6),
+                                                  (15000, 1024, 33, 64, 8, 7)):   # q_len 33..64: two 32-column chunks
         spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=48, n_centroids=C, variable_len=True, seed=seed)
         arr = fp.synth.host_index_arrays(spec)
         q = fp.synth.make_queries(spec, arr["centroids"], 6, Q)
@@ -65,7 +66,7 @@ def main():
         pids, scores, counts = R.search_arrays(idx, q, params)
         ident = sum(int(np.array_equal(pids[b, : counts[b]], ref[b][0])) for b in range(q.shape[0]))
         assert ident >= q.shape[0] // 2, ident
-    assert pruned >= 3, "the bound stage never pruned: the test does not exercise it"
+    assert pruned >= 5, "the bound stage never pruned: the test does not exercise it"
     # values outside the bin range: unnormalised queries scaled x3 (S up to 3: bin 255 voids the upper bound) and x(-3)
     spec = fp.synth.SynthSpec(n_docs=20000, doc_len=48, n_centroids=2048, variable_len=True, seed=9)
     arr = fp.synth.host_index_arrays(spec)
@@ -73,11 +74,11 @@ def main():
     q = fp.synth.make_queries(spec, arr["centroids"], 4, 32).astype(np.float32)
     for scale in (3.0, -3.0, 0.01):
         same_as_trace(idx, (q * scale).astype(np.float16), R.SearchParameters(2000, 128, 25, 8))
-    # the odd-shape random corpora of test_randomized_shapes_vs_oracle (those with Qp == 32)
+    # the odd-shape random corpora of test_randomized_shapes_vs_oracle (those with q_len <= 64)
     from test_hip_parity import RANDOM_SHAPES, _random_arrays
     for shape in RANDOM_SHAPES:
         n_docs, max_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, use_subset = shape
-        if Q > 32:
+        if Q > 64:
             continue
         rng = np.random.default_rng(hash(shape) & 0xFFFFFFFF)
         arr = _random_arrays(rng, n_docs, max_len, C, dim, nbits)

@@ -695,6 +695,7 @@ FULL_SIZE = {
     "cfg5": dict(n_docs=5_000_000, doc_len=128, n_centroids=65536, B=128, Q=32, top_k=1000, n_full=4096, n_probe=8),
     "cfg5_nfull16k": dict(n_docs=5_000_000, doc_len=128, n_centroids=65536, B=16, Q=32, top_k=1000, n_full=16384, n_probe=8),
     "cfg5_nfull64k": dict(n_docs=5_000_000, doc_len=128, n_centroids=65536, B=8, Q=32, top_k=1000, n_full=65536, n_probe=8),
+    "cfg2_q50": dict(n_docs=1_000_000, doc_len=128, n_centroids=131072, B=16, Q=50, top_k=1000, n_full=4096, n_probe=8),
     "cfg3_1gpu": dict(n_docs=10_000_000, doc_len=128, n_centroids=524288, B=256, Q=32, top_k=1000, n_full=4096, n_probe=8),
 }
 _full_size_cache = {}
