@@ -86,10 +86,13 @@ struct HostBuf {
   }
 };
 
-enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APPROX, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
+enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
 static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
-                                        "S3 compact",  "S4 approx",        "S5 select",     "S6+S7 maxsim",
-                                        "S8 topk+download"};
+                                        "S3 compact",  "S4 approx",        "S4 refine",     "S5 select",
+                                        "S6+S7 maxsim", "S8 topk+download"};
+// "S4 approx" is exactly ONE kernel -- k_approx_q8 (bounds of every candidate) when the bound stage runs, else k_approx
+// (exact score of every candidate) -- so that it can be compared with a profiler's per-kernel time; "S4 refine" is
+// the cut, the survivor compaction and their exact rescoring (zero without the bound stage).
 
 struct Scratch {
   hipStream_t st = nullptr;
@@ -582,9 +585,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     HIPCHK(s->nsurv.ensure((size_t)B * 4));
     HIPCHK(s->surv_off.ensure((size_t)(B + 1) * 8));
     HIPCHK(s->surv_pid.ensure((size_t)M * 4));
-    fpk_approx_q8_filter(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
-                         s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
-                         s->surv_pid.as<int32_t>(), st);
+    fpk_approx_q8_bounds(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->kq.as<uint32_t>(), st);
+    HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
+    fpk_approx_q8_cut(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
+                      s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
+                      s->surv_pid.as<int32_t>(), st);
     sel_off = s->surv_off.as<int64_t>();
     sel_src = s->surv_pid.as<int32_t>();
     // survivor total for fp_last_search_counts: lands in pinned memory by the time the caller's final sync returns
@@ -592,6 +597,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::max<int64_t>(M / 8, (int64_t)B * sh.R), s->approx.as<float>(), st);
   } else {
     fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st);
+    HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
   }
   HIPCHK(hipEventRecord(s->ev[ST_SELECT], st));
   // S5

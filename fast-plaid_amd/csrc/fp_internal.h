@@ -92,9 +92,10 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
-void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off,
-                          const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192] u32*/, uint32_t* kq, int32_t* cut, int32_t* blkcnt,
-                          int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
+void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid,
+                          int64_t M, uint32_t* kq, hipStream_t st);
+void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, uint32_t* q8hist, uint32_t* kq,
+                       int32_t* cut, int32_t* blkcnt, int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st);

@@ -1349,11 +1349,9 @@ __global__ __launch_bounds__(256) void k_surv_compact(const uint32_t* __restrict
   }
 }
 
-// Runs (2)-(4) of the scheme: on return surv_off [B+1] / surv_pid describe the survivors (ordered, on the device).
-void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off,
-                          const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192 * Qp/32]*/, uint32_t* kq /*[M * (1 + (Qp > 32 ? Qp/32 : 0))]*/,
-                          int32_t* cut, int32_t* blkcnt,
-                          int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
+// (2) of the scheme: kq [M] (behind it, for two chunks, the per-chunk partial sums) <- bounds of every candidate
+void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid,
+                          int64_t M, uint32_t* kq /*[M * (1 + (Qp > 32 ? Qp/32 : 0))]*/, hipStream_t st) {
   const int B = sh.B;
   // Lane pairs per candidate: about 2-3 code groups per pair (cfg2, 33 codes = 5 groups: 1/2/4/8 pairs -> S4 5.15/4.34/
   // 4.53/4.63 ms), more when one query would otherwise not fill the chip (~1280 resident workgroups x 128 pairs; long
@@ -1368,7 +1366,6 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   if (ppd_env == 1 || ppd_env == 2 || ppd_env == 4 || ppd_env == 8) ppd = ppd_env;
   const int nch = sh.Qp / 32;                            // 1 or 2 chunks of 32 query columns
   uint32_t* kq_part = nch > 1 ? kq + M : kq;             // per-chunk partial sums behind the final ones
-  const int bins = Q8_BINS_SUM * nch;
   const int tpb = 256;   // 64 / 128 / 512 threads per workgroup measured the same (4.34-4.41 ms)
   const int dpb = (tpb / 2) / ppd;
   int64_t bx = (per_q + dpb - 1) / dpb;
@@ -1387,7 +1384,16 @@ void fpk_approx_q8_filter(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
     default: FP_Q8_LAUNCH(4); break;
   }
 #undef FP_Q8_LAUNCH
-  if (nch > 1) hipLaunchKernelGGL(k_q8_combine, dim3(fp_grid_cap((M + 255) / 256, 256)), dim3(256), 0, st, kq_part, nch, M, kq);
+}
+
+// (3)-(4): per-query cut from the histogram of the lower bounds, ordered survivors in surv_off [B+1] / surv_pid
+void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192 * Qp/32]*/,
+                       uint32_t* kq, int32_t* cut, int32_t* blkcnt, int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid,
+                       hipStream_t st) {
+  const int B = sh.B;
+  const int nch = sh.Qp / 32;
+  const int bins = Q8_BINS_SUM * nch;
+  if (nch > 1) hipLaunchKernelGGL(k_q8_combine, dim3(fp_grid_cap((M + 255) / 256, 256)), dim3(256), 0, st, kq + M, nch, M, kq);
   (void)hipMemsetAsync(q8hist, 0, (size_t)B * bins * 4, st);
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_q8_hist, lds_ok, 144 * 1024);

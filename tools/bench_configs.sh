@@ -4,8 +4,10 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 run() { name=$1; shift; timeout 300 python $R/bench.py --steps 5 --warmup 2 --cpu-queries 0 --workload "$name" "$@" 2>$OUT/cfg_$name.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-k=[v for kk,v in d['roofline_by_kernel'].items() if kk.startswith('S4')][0]
-print('$name', 'qps=%.1f ms/batch=%.2f' % (d['value'], d['ms_per_step']), d['stages_ms'], 'maxsim_frac=%.3f' % d['roofline']['frac'], 'cand/batch=%.0f rescored=%.0f' % (k['candidate_docs_per_batch'], k['docs_rescored_exactly_per_batch']))"; }
+allk=[d['roofline']]+list(d['roofline_by_kernel'].values())
+k=[v for v in allk if str(v.get('kernel','')).startswith('k_approx')][0]
+m=[v for v in allk if str(v.get('kernel','')).startswith('k_maxsim')][0]
+print('$name', 'qps=%.1f ms/batch=%.2f' % (d['value'], d['ms_per_step']), d['stages_ms'], 'dominant=%s' % d['roofline']['kernel'].split(' ')[0], 'maxsim_frac=%.3f' % m['frac'], 'cand/batch=%.0f rescored=%.0f' % (k['candidate_docs_per_batch'], k['docs_rescored_exactly_per_batch']))"; }
 run cfg1 --docs 1000 --doc-len 300 --batch 16 --qlen 50 --topk 10
 run cfg4 --docs 100000 --doc-len 1024 --batch 32 --topk 100
 run cfg5 --docs 5000000 --centroids 65536 --batch 128
