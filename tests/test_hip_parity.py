@@ -150,6 +150,41 @@ def test_api_level_behaviour(fp):
     F.close()
 
 
+def test_degenerate_parameters_match_the_oracle(fp):
+    """parameter corners: top_k = 0, n_full_scores = 1 (R = 1), n_ivf_probe = number of centroids and beyond (the
+    reference's topk errs -> empty result, search.rs:268), one-token queries, a batch of one, an empty batch, empty and
+    duplicated subsets, and a corpus of one document."""
+    R = fp.fast_plaid_rust
+    rng = np.random.default_rng(99)
+    arr = _random_arrays(rng, 200, 20, 24, 128, 4)
+    hip, orc = _hip_index(fp, arr), _oracle(arr)
+    q = arr["centroids"][rng.integers(0, 24, (3, 5))]
+
+    def same(params_tuple, queries, subs=None):
+        bs, n_full, top_k, n_probe = params_tuple
+        p, s, c = R.search_arrays(hip, queries, R.SearchParameters(bs, n_full, top_k, n_probe), subs)
+        ref = orc.search(queries, top_k, n_full, n_probe, subset=subs)
+        for b in range(queries.shape[0]):
+            assert c[b] == len(ref[b][0]), (params_tuple, b, c[b], len(ref[b][0]))
+            check_final(p[b, : c[b]], s[b, : c[b]], ref[b][0], ref[b][1], max(top_k, 1), excused=set(range(200)))
+        return c
+
+    assert np.all(same((2000, 4096, 0, 4), q) == 0)                  # top_k = 0
+    assert np.all(same((2000, 1, 10, 4), q) <= 1)                    # R = max(1 // 4, 1) = 1
+    same((2000, 64, 10, 24), q)                                      # probe every centroid
+    assert np.all(same((2000, 64, 10, 25), q) == 0)                  # n_ivf_probe > centroids: every query fails -> empty
+    same((2000, 64, 10, 1), q[:, :1])                                # one-token queries
+    same((2000, 64, 10, 4), q[:1])                                   # batch of one
+    p, s, c = R.search_arrays(hip, q[:0], R.SearchParameters(2000, 64, 10, 4))
+    assert p.shape[0] == 0 and c.shape[0] == 0                       # empty batch
+    same((2000, 64, 10, 4), q, [[], [7, 7, 7, 3], [199]])            # empty / duplicated / single-id subsets
+    one = _random_arrays(rng, 1, 9, 24, 128, 4, empty_frac=0.0)
+    h1, o1 = _hip_index(fp, one), _oracle(one)
+    r1 = R.search_arrays(h1, q, R.SearchParameters(2000, 64, 10, 24))
+    ref1 = o1.search(q, 10, 64, 24)
+    assert [int(x) for x in r1[2]] == [len(ref1[b][0]) for b in range(3)]
+
+
 def test_compress_only_index_raises(fp):
     z, arr = _load_golden("d64_nb2")
     arr = dict(arr)
