@@ -132,25 +132,18 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
                                                          uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
                                                          int nch) {
-  constexpr int CH = D / 8;              // 16-byte chunks per row
-  constexpr int ROWB = D * 2;            // bytes per row
+  // K is consumed in slices of KS dims: the operand tiles take 2 x 128 x KS x 2 B of LDS (32 KiB at KS = 64) instead of
+  // 64 KiB for the whole K = 128, which lifts the kernel from 2 to 3 workgroups per CU (VGPR limit) so that one
+  // workgroup's store phase overlaps another's MFMA phase.
+  constexpr int KS = D < 64 ? D : 64;    // dims per slice
+  constexpr int CH = KS / 8;             // 16-byte chunks per slice row
+  constexpr int ROWB = KS * 2;           // bytes per slice row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem;              // [128][ROWB]
   unsigned char* Cs = smem + 128 * ROWB; // [128][ROWB]
   const int tid = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.y * 128;
   const int64_t c0 = (int64_t)blockIdx.x * 128;
-  // stage both tiles (coalesced 16 B per thread), swizzled
-  for (int i = tid; i < 128 * CH; i += 256) {
-    int row = i / CH, j = i % CH;
-    int js = j ^ (row & (CH - 1));
-    uint4 vq = make_uint4(0, 0, 0, 0), vc = make_uint4(0, 0, 0, 0);
-    if (n0 + row < Ntot) vq = *reinterpret_cast<const uint4*>(qpad + (n0 + row) * D + j * 8);
-    if (c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + j * 8);
-    *reinterpret_cast<uint4*>(Qs + row * ROWB + js * 16) = vq;
-    *reinterpret_cast<uint4*>(Cs + row * ROWB + js * 16) = vc;
-  }
-  __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
   const int l31 = lane & 31, hi = lane >> 5;
@@ -161,21 +154,35 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < D / 16; ++ks) {
-    h8 af[2], bf[2];
-    const int j = ks * 2 + hi;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      int rq = wr * 64 + t * 32 + l31;
-      int rc = wc * 64 + t * 32 + l31;
-      af[t] = *reinterpret_cast<const h8*>(Qs + rq * ROWB + ((j ^ (rq & (CH - 1))) * 16));
-      bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
+  for (int k0 = 0; k0 < D; k0 += KS) {
+    if (k0 > 0) __syncthreads();   // the previous slice is no longer read
+    // stage both tiles (coalesced 16 B per thread), swizzled
+    for (int i = tid; i < 128 * CH; i += 256) {
+      int row = i / CH, j = i % CH;
+      int js = j ^ (row & (CH - 1));
+      uint4 vq = make_uint4(0, 0, 0, 0), vc = make_uint4(0, 0, 0, 0);
+      if (n0 + row < Ntot) vq = *reinterpret_cast<const uint4*>(qpad + (n0 + row) * D + k0 + j * 8);
+      if (c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + k0 + j * 8);
+      *reinterpret_cast<uint4*>(Qs + row * ROWB + js * 16) = vq;
+      *reinterpret_cast<uint4*>(Cs + row * ROWB + js * 16) = vc;
     }
+    __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int ks = 0; ks < KS / 16; ++ks) {
+      h8 af[2], bf[2];
+      const int j = ks * 2 + hi;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) {
+        int rq = wr * 64 + t * 32 + l31;
+        int rc = wc * 64 + t * 32 + l31;
+        af[t] = *reinterpret_cast<const h8*>(Qs + rq * ROWB + ((j ^ (rq & (CH - 1))) * 16));
+        bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
   }
   __syncthreads();  // operand tiles are dead: the same LDS now stages the output
   // D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi.
@@ -275,10 +282,10 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
   const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
   if (ix.dim == 128) {
-    const size_t lds = std::max<size_t>(2 * 128 * 256, out_lds);
+    const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
     hipLaunchKernelGGL(k_centroid_scores<128>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch);
   } else if (ix.dim == 64) {
-    const size_t lds = std::max<size_t>(2 * 128 * 128, out_lds);
+    const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
     hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch);
   } else {
     return -1;
