@@ -594,7 +594,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     sel_src = s->surv_pid.as<int32_t>();
     // survivor total for fp_last_search_counts: lands in pinned memory by the time the caller's final sync returns
     HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 8, s->surv_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
-    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::max<int64_t>(M / 8, (int64_t)B * sh.R), s->approx.as<float>(), st);
+    // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2); the kernel walks a grid-stride loop if there are more
+    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 4 * (int64_t)B * sh.R), s->approx.as<float>(), st);
   } else {
     fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st);
     HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));

@@ -854,6 +854,9 @@ __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict
                                                       const int32_t* __restrict__ invalid, int64_t W,
                                                       const int32_t* __restrict__ blkoff, int nblk,
                                                       const int64_t* __restrict__ cand_off, int32_t* __restrict__ cand_pid) {
+  // a block covers CAND_WPB words = 32768 documents; its ids are expanded into LDS in order and then written out
+  // coalesced (the per-thread `cand_pid[pos++] = ...` stores it replaces ran at 0.85 TB/s: 108 us for 84 MB)
+  __shared__ int32_t stage[CAND_WPB * 32 / 4];   // 8192 ids (32 KiB) per pass
   const int b = blockIdx.y;
   if (invalid && invalid[b]) return;
   const int64_t w0 = (int64_t)blockIdx.x * CAND_WPB + threadIdx.x * CAND_WPT;
@@ -878,16 +881,27 @@ __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict
     s[threadIdx.x] += t;
     __syncthreads();
   }
-  int64_t pos = cand_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+  const int total = s[255];
+  const int mine0 = s[threadIdx.x] - cnt;          // rank of this thread's first id inside the block
+  int32_t* out = cand_pid + cand_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x];
+  constexpr int STAGE = CAND_WPB * 32 / 4;
+  for (int base = 0; base < total; base += STAGE) {   // at most 4 passes (density 100 %)
+    int pos = mine0;
 #pragma unroll
-  for (int k = 0; k < CAND_WPT; ++k) {
-    uint32_t w = x[k];
-    const int32_t basepid = (int32_t)((w0 + k) * 32);
-    while (w) {
-      int bit = __ffs(w) - 1;
-      cand_pid[pos++] = basepid + bit;
-      w &= w - 1;
+    for (int k = 0; k < CAND_WPT; ++k) {
+      uint32_t w = x[k];
+      const int32_t basepid = (int32_t)((w0 + k) * 32);
+      while (w) {
+        const int bit = __ffs(w) - 1;
+        if (pos >= base && pos < base + STAGE) stage[pos - base] = basepid + bit;
+        ++pos;
+        w &= w - 1;
+      }
     }
+    __syncthreads();
+    const int nthis = (total - base) < STAGE ? (total - base) : STAGE;
+    for (int i = threadIdx.x; i < nthis; i += 256) out[base + i] = stage[i];
+    __syncthreads();
   }
 }
 
