@@ -17,6 +17,7 @@ python $R/tools/summarize_prof.py $(ls $OUT/${TAG}_prof/*/run_kernel_stats.csv $
 CMD3="python $R/bench.py --steps 3 --warmup 1 --cpu-queries 0"
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_fetch -o run -- $CMD3 > $OUT/${TAG}_pmc.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/${TAG}_pmc_write -o run -- $CMD3 >> $OUT/${TAG}_pmc.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_mfma -o run -- $CMD3 >> $OUT/${TAG}_pmc.log 2>&1
 python - <<PY
 import csv, glob, collections, json, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
@@ -34,6 +35,12 @@ for k, cs in acc.items():
         e["hbm_read_bytes_corrected"] = int(d["FETCH_SIZE"] * 1024 * 2)
     if "WRITE_SIZE" in d:
         e["write_size_kb_raw"] = round(d["WRITE_SIZE"], 1)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("GRBM_GUI_ACTIVE", 0) > 0:
+        # MFMA-pipe busy cycles summed over the 1024 SIMDs (256 CUs x 4) over the kernel's active cycles; GRBM_GUI_ACTIVE comes
+        # back summed over the 8 XCDs (checked: 8 x kernel duration x clock), SQ_VALU_MFMA_BUSY_CYCLES = 32 per 32x32x16 MFMA
+        e["mfma_busy_cycles"] = int(d["SQ_VALU_MFMA_BUSY_CYCLES"])
+        e["gpu_active_cycles_sum_over_8_xcd"] = int(d["GRBM_GUI_ACTIVE"])
+        e["mfma_util"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
     if "TCC_HIT_sum" in d:
         e["l2_hit_rate"] = round(d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0.0), 1.0), 4)
     out[k] = e
