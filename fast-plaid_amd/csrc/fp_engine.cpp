@@ -876,11 +876,18 @@ extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, 
   const int pr = dim * nbits / 8;
   const int64_t CHUNK = 1ll << 20;   // tokens per pass
   const int64_t cap = std::min<int64_t>(T, CHUNK);
-  void *d_cent = nullptr, *d_cut = nullptr, *d_emb = nullptr, *d_c32 = nullptr, *d_c64 = nullptr, *d_out = nullptr;
+  void *d_cent = nullptr, *d_cut = nullptr, *d_emb = nullptr, *d_c32 = nullptr, *d_c64 = nullptr, *d_out = nullptr, *d_work = nullptr;
   hipStream_t st = nullptr;
   int rc = FP_OK;
+  float cmaxabs = 0.f;   // bounds the MFMA summation error in the assignment (fp16 -> float by hand: no device needed)
+  for (int64_t i = 0; i < C * dim; ++i) {
+    const uint16_t hbits = centroids[i] & 0x7FFF;
+    const int ex = hbits >> 10, ma = hbits & 0x3FF;
+    const float v = ex == 0 ? std::ldexp((float)ma, -24) : (ex == 31 ? INFINITY : std::ldexp((float)(ma | 0x400), ex - 25));
+    if (v > cmaxabs) cmaxabs = v;
+  }
   auto cleanup = [&]() {
-    for (void* p : {d_cent, d_cut, d_emb, d_c32, d_c64, d_out})
+    for (void* p : {d_cent, d_cut, d_emb, d_c32, d_c64, d_out, d_work})
       if (p) (void)hipFree(p);
     if (st) (void)hipStreamDestroy(st);
   };
@@ -899,14 +906,15 @@ extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, 
   CCHK(hipMalloc(&d_c32, (size_t)cap * 4));
   CCHK(hipMalloc(&d_c64, (size_t)cap * 8));
   CCHK(hipMalloc(&d_out, (size_t)cap * pr));
+  CCHK(hipMalloc(&d_work, fpk_compress_work_bytes(cap)));
   CCHK(hipMemcpyAsync(d_cent, centroids, (size_t)C * dim * 2, hipMemcpyHostToDevice, st));
   CCHK(hipMemcpyAsync(d_cut, cutoffs, (size_t)((1 << nbits) - 1) * 2, hipMemcpyHostToDevice, st));
   for (int64_t t0 = 0; t0 < T && rc == FP_OK; t0 += CHUNK) {
     const int64_t n = std::min<int64_t>(CHUNK, T - t0);
     CCHK(hipMemcpyAsync(d_emb, emb + t0 * dim, (size_t)n * dim * 2, hipMemcpyHostToDevice, st));
     if (fpk_compress(static_cast<const uint16_t*>(d_emb), n, static_cast<const uint16_t*>(d_cent), C, dim, nbits,
-                     static_cast<const uint16_t*>(d_cut), static_cast<int32_t*>(d_c32), static_cast<int64_t*>(d_c64),
-                     static_cast<uint8_t*>(d_out), st)) {
+                     static_cast<const uint16_t*>(d_cut), cmaxabs, static_cast<int32_t*>(d_c32), static_cast<int64_t*>(d_c64),
+                     static_cast<uint8_t*>(d_out), d_work, st)) {
       cleanup();
       return fail(FP_EUNSUPPORTED, "dim");
     }

@@ -118,10 +118,13 @@ void fpk_transpose_ranks(const float* in_f /*[G][B][R]*/, const int64_t* in_p, i
                          float* out_f /*[B][G*R]*/, int64_t* out_p, hipStream_t st);
 // misc
 void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
-// create.rs:148-184, :404-428 on device pointers: exact nearest centroid (codes32 scratch, codes64 output) + quantised packed residuals;
-// -1 unsupported dim, -2 chunk too large
-int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, int nbits, const uint16_t* cutoffs, int32_t* codes32,
-                 int64_t* codes64, uint8_t* out, hipStream_t st);
+// create.rs:148-184, :404-428 on device pointers: nearest centroid (MFMA narrowing + exact re-check of the near-ties, or the exact
+// kernel alone; codes32 scratch, codes64 output) + quantised packed residuals.  cmaxabs = max |centroid element| (bounds the MFMA
+// summation error); work = fpk_compress_work_bytes(T) bytes of device scratch (nullptr: exact kernel only).
+// -1 unsupported dim, -2 chunk too large, -3 HIP error
+size_t fpk_compress_work_bytes(int64_t T);
+int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, int nbits, const uint16_t* cutoffs, float cmaxabs,
+                 int32_t* codes32, int64_t* codes64, uint8_t* out, void* work, hipStream_t st);
 // k-means assignment step: argmax_c (dot - half_sqnorm[c]) in fp32, ties -> lowest index
 int fpk_assign_l2(const uint16_t* emb, int64_t T, const uint16_t* cent, const float* half_sqnorm, int64_t C, int D, int32_t* codes32,
                   int64_t* codes64, hipStream_t st);

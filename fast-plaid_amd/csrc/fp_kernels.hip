@@ -2368,6 +2368,156 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict
   }
 }
 
+// ---- MFMA fast path of the nearest-centroid search, still exact -------------------------------------------------------
+// The exact kernel above runs at 30 TFLOP/s.  MFMA sums in another order, so its scores cannot decide near-ties; but they
+// can NARROW the search: pass 1 finds, per token, the maximum MFMA score m; pass 2 collects every centroid whose MFMA score
+// is within one fp16 ulp (plus twice the worst-case summation error) of m -- the true argmax of the fp16-rounded exact
+// scores is always among them (see k_assign_thr) -- and k_assign_recheck evaluates only those (1-2 per token, at most
+// ASSIGN_CAP) with the ascending-k chain and the first-index tie rule.  A token that collects more than ASSIGN_CAP
+// candidates (many near-duplicate centroids) sends the whole chunk back to the exact kernel.
+#define ASSIGN_CAP 8
+template <int D, int PASS>
+__global__ __launch_bounds__(256) void k_assign_mfma(const uint16_t* __restrict__ emb, int64_t T, const uint16_t* __restrict__ cent, int64_t C,
+                                                     float* __restrict__ tmax /*PASS 1 out*/, const float* __restrict__ thr /*PASS 2 in*/,
+                                                     int32_t* __restrict__ ccnt, int32_t* __restrict__ ccand) {
+  constexpr int CH = D / 8;
+  constexpr int ROWB = D * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ts = smem;               // [128 tokens][ROWB]
+  unsigned char* Cs = smem + 128 * ROWB;  // [128 centroids][ROWB]
+  const int tid = threadIdx.x;
+  const int64_t t0 = (int64_t)blockIdx.x * 128;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  for (int i = tid; i < 128 * CH; i += 256) {
+    const int row = i / CH, j = i % CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t0 + row < T) v = *reinterpret_cast<const uint4*>(emb + (t0 + row) * D + j * 8);
+    *reinterpret_cast<uint4*>(Ts + row * ROWB + ((j ^ (row & (CH - 1))) * 16)) = v;
+  }
+  // per-lane state over this lane's centroid columns: running maxima (pass 1) or the thresholds of its 32 token rows (pass 2)
+  float st[2][16];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (PASS == 1) {
+        st[a][r] = -INFINITY;
+      } else {
+        const int64_t t = t0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        st[a][r] = (t < T) ? thr[t] : INFINITY;
+      }
+    }
+  for (int64_t c0 = 0; c0 < C; c0 += 128) {
+    __syncthreads();
+    for (int i = tid; i < 128 * CH; i += 256) {
+      const int row = i / CH, j = i % CH;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (c0 + row < C) v = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + j * 8);
+      *reinterpret_cast<uint4*>(Cs + row * ROWB + ((j ^ (row & (CH - 1))) * 16)) = v;
+    }
+    __syncthreads();
+    f16v acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+      h8 af[2], bf[2];
+      const int j = ks * 2 + hi;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rq = wr * 64 + t * 32 + l31;
+        const int rc = wc * 64 + t * 32 + l31;
+        af[t] = *reinterpret_cast<const h8*>(Ts + rq * ROWB + ((j ^ (rq & (CH - 1))) * 16));
+        bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t c = c0 + wc * 64 + b * 32 + l31;
+      if (c >= C) continue;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[a][b][r];
+          if (PASS == 1) {
+            st[a][r] = fmaxf(st[a][r], v);
+          } else if (v >= st[a][r]) {
+            const int64_t t = t0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int pos = atomicAdd(&ccnt[t], 1);
+            if (pos < ASSIGN_CAP) ccand[t * ASSIGN_CAP + pos] = (int32_t)c;
+          }
+        }
+    }
+  }
+  if (PASS == 1) {
+    __shared__ float red[2][128];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = st[a][r];
+#pragma unroll
+        for (int s = 1; s < 32; s <<= 1) v = fmaxf(v, __shfl_xor(v, s, 64));
+        if (l31 == 0) red[wc][wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi] = v;
+      }
+    __syncthreads();
+    if (tid < 128 && t0 + tid < T) tmax[t0 + tid] = fmaxf(red[0][tid], red[1][tid]);
+  }
+}
+
+// thr[t] = m - (two fp16 ulps at |m| + twice the worst-case fp32 summation error of a D-term dot product of this token).
+// Why the true winner w is collected: h is monotone, so exact_w > exact_c - ulp16 for every c (else h(exact_c) > h(exact_w));
+// with c* = argmax of the MFMA scores and |mfma - exact| <= eps:  mfma_w >= exact_w - eps > exact_c* - ulp16 - eps >= m - ulp16 - 2 eps.
+__global__ void k_assign_thr(const uint16_t* __restrict__ emb, int64_t T, int D, float cmaxabs, const float* __restrict__ tmax,
+                             float* __restrict__ thr, int32_t* __restrict__ ccnt) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+    float l1 = 0.f;
+    for (int d = 0; d < D; ++d) l1 += __builtin_fabsf((float)__builtin_bit_cast(half_t, emb[t * D + d]));
+    const float m = tmax[t];
+    const float ulp2 = __builtin_fmaxf(__builtin_fabsf(m), 6.103515625e-05f) * 0.001953125f;   // 2^-9 |m|  >= 2 ulp16
+    const float eps2 = l1 * cmaxabs * (float)D * 1.1920929e-07f * 2.0f;                          // 2 * D * 2^-23 * sum|x_k| max|c|
+    thr[t] = m - (ulp2 + eps2);
+    ccnt[t] = 0;
+  }
+}
+
+// exact evaluation of the collected candidates; codes[t] = -1 when the candidate list overflowed
+__global__ void k_assign_recheck(const uint16_t* __restrict__ emb, int64_t T, const uint16_t* __restrict__ cent, int D,
+                                 const int32_t* __restrict__ ccnt, const int32_t* __restrict__ ccand, int32_t* __restrict__ codes,
+                                 int32_t* __restrict__ overflow) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+    const int n = ccnt[t];
+    if (n > ASSIGN_CAP || n < 1) {   // n < 1 cannot happen (the maximum itself passes its threshold) unless a score is NaN
+      codes[t] = -1;
+      atomicAdd(overflow, 1);
+      continue;
+    }
+    unsigned long long best = 0ull;
+    for (int i = 0; i < n; ++i) {
+      const int32_t c = ccand[t * ASSIGN_CAP + i];
+      float acc = 0.f;
+      for (int d = 0; d < D; ++d)
+        acc += (float)__builtin_bit_cast(half_t, emb[t * D + d]) * (float)__builtin_bit_cast(half_t, cent[(int64_t)c * D + d]);
+      const uint16_t hv = __builtin_bit_cast(uint16_t, (half_t)acc);
+      const unsigned long long key = ((unsigned long long)mono16(hv) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)c);
+      best = key > best ? key : best;
+    }
+    codes[t] = (int32_t)(0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull));
+  }
+}
+
 // residual quantisation + packing: one thread per output byte
 __global__ __launch_bounds__(256) void k_quantize_pack(const uint16_t* __restrict__ emb, const uint16_t* __restrict__ cent,
                                                        const int32_t* __restrict__ codes, const uint16_t* __restrict__ cutoffs, int D, int nbits,
@@ -2394,14 +2544,56 @@ __global__ __launch_bounds__(256) void k_quantize_pack(const uint16_t* __restric
   }
 }
 
-int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, int nbits, const uint16_t* cutoffs, int32_t* codes32,
-                 int64_t* codes64, uint8_t* out, hipStream_t st) {
+// scratch: tmax / thr f32 [T], ccnt i32 [T], ccand i32 [T * ASSIGN_CAP], overflow i32 [1]  (all inside `work`, see fpk_compress_work_bytes)
+size_t fpk_compress_work_bytes(int64_t T) { return (size_t)T * (4 + 4 + 4 + 4 * ASSIGN_CAP) + 64; }
+
+static int assign_codes(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, float cmaxabs, int32_t* codes32, void* work,
+                        hipStream_t st) {
+  static const int impl_env = [] { const char* e = getenv("FP_ASSIGN_IMPL"); return (e && e[0] == 'e') ? 1 : 0; }();   // "exact": VALU kernel only
+  const unsigned eblocks = fp_grid_cap((T + 63) / 64, 256);
+  if ((int64_t)eblocks * 64 < T) return -2;   // callers chunk far below this
+  auto exact = [&]() {
+    if (D == 128) hipLaunchKernelGGL((k_assign_exact<128, false>), dim3(eblocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
+    else hipLaunchKernelGGL((k_assign_exact<64, false>), dim3(eblocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
+  };
+  if (D != 128 && D != 64) return -1;
+  if (impl_env || !work || C < 256) {   // tiny tables: the exact kernel is as fast
+    exact();
+    return 0;
+  }
+  float* tmax = static_cast<float*>(work);
+  float* thr = tmax + T;
+  int32_t* ccnt = reinterpret_cast<int32_t*>(thr + T);
+  int32_t* ccand = ccnt + T;
+  int32_t* overflow = ccand + T * ASSIGN_CAP;
+  const unsigned mblocks = (unsigned)((T + 127) / 128);
+  const size_t lds = (size_t)2 * 128 * D * 2;
+  (void)hipMemsetAsync(overflow, 0, 4, st);
+  if (D == 128) {
+    static std::atomic<uint64_t> ok1{0}, ok2{0};
+    fp_allow_big_lds((const void*)k_assign_mfma<128, 1>, ok1, 80 * 1024);
+    fp_allow_big_lds((const void*)k_assign_mfma<128, 2>, ok2, 80 * 1024);
+    hipLaunchKernelGGL((k_assign_mfma<128, 1>), dim3(mblocks), dim3(256), lds, st, emb, T, cent, C, tmax, (const float*)nullptr, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_assign_thr, dim3(fp_grid_cap((T + 255) / 256, 256)), dim3(256), 0, st, emb, T, D, cmaxabs, tmax, thr, ccnt);
+    hipLaunchKernelGGL((k_assign_mfma<128, 2>), dim3(mblocks), dim3(256), lds, st, emb, T, cent, C, (float*)nullptr, thr, ccnt, ccand);
+  } else {
+    hipLaunchKernelGGL((k_assign_mfma<64, 1>), dim3(mblocks), dim3(256), lds, st, emb, T, cent, C, tmax, (const float*)nullptr, (int32_t*)nullptr,
+                       (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_assign_thr, dim3(fp_grid_cap((T + 255) / 256, 256)), dim3(256), 0, st, emb, T, D, cmaxabs, tmax, thr, ccnt);
+    hipLaunchKernelGGL((k_assign_mfma<64, 2>), dim3(mblocks), dim3(256), lds, st, emb, T, cent, C, (float*)nullptr, thr, ccnt, ccand);
+  }
+  hipLaunchKernelGGL(k_assign_recheck, dim3(fp_grid_cap((T + 255) / 256, 256)), dim3(256), 0, st, emb, T, cent, D, ccnt, ccand, codes32, overflow);
+  int32_t h_over = 0;
+  if (hipMemcpyAsync(&h_over, overflow, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -3;
+  if (h_over > 0) exact();   // a token met more than ASSIGN_CAP near-tied centroids: the whole chunk goes through the exact kernel
+  return 0;
+}
+
+int fpk_compress(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, int nbits, const uint16_t* cutoffs, float cmaxabs,
+                 int32_t* codes32, int64_t* codes64, uint8_t* out, void* work, hipStream_t st) {
   if (T <= 0) return 0;
-  const unsigned blocks = fp_grid_cap((T + 63) / 64, 256);
-  if ((int64_t)blocks * 64 < T) return -2;   // callers chunk far below this
-  if (D == 128) hipLaunchKernelGGL((k_assign_exact<128, false>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
-  else if (D == 64) hipLaunchKernelGGL((k_assign_exact<64, false>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
-  else return -1;
+  if (int rc = assign_codes(emb, T, cent, C, D, cmaxabs, codes32, work, st)) return rc;
   const int64_t total = T * (D * nbits / 8);
   hipLaunchKernelGGL(k_quantize_pack, dim3(fp_grid_cap((total + 255) / 256, 256)), dim3(256), 0, st, emb, cent, codes32, cutoffs, D, nbits, T, out,
                      codes64);

@@ -505,7 +505,8 @@ def test_reference_loader_arrays_with_padding_rows(fp):
         assert [[d for d, _ in row] for row in out] == [ra[0][i, : ra[2][i]].tolist() for i in range(4)]
 
 
-@pytest.mark.parametrize("dim,nbits,C,n_docs", [(128, 4, 300, 120), (64, 2, 77, 90), (128, 2, 1030, 60), (64, 4, 5, 40)])
+@pytest.mark.parametrize("dim,nbits,C,n_docs", [(128, 4, 300, 120), (64, 2, 77, 90), (128, 2, 1030, 60), (64, 4, 5, 40), (128, 4, 4096, 150),
+                                                (64, 4, 2500, 150)])
 def test_compress_and_codec_match_the_aten_restatement(fp, dim, nbits, C, n_docs):
     """fp_compress (nearest centroid with first-index ties, fp16 residual, bucketize, LSB-first bits packed big-endian;
     create.rs:148-184, :404-428) and the host codec training (create.rs:317-364) against the op-for-op ATen restatement
@@ -519,11 +520,15 @@ def test_compress_and_codec_match_the_aten_restatement(fp, dim, nbits, C, n_docs
     if C > 20:
         cent[7] = cent[3]          # exact duplicates: every token nearest to them ties
         cent[C - 1] = cent[3]
+    if C == 4096:                  # 12 copies of one centroid: more near-ties than the MFMA path's candidate list holds -> exact fallback
+        cent[100:112] = cent[50]
     docs = []
     for _ in range(n_docs):
         n = int(torch.randint(1, 50, (1,), generator=g))
         pick = torch.randint(0, C, (n,), generator=g)
         pick[torch.rand(n, generator=g) < 0.2] = 3     # plenty of tokens on the duplicated centroid
+        if C == 4096:
+            pick[torch.rand(n, generator=g) < 0.1] = 50
         d = cent[pick].float() + 0.25 * torch.randn(n, dim, generator=g) / dim ** 0.5
         docs.append(torch.nn.functional.normalize(d, dim=-1).to(torch.float16))
     ref = OT.build_index_arrays(docs, cent, nbits)
