@@ -911,6 +911,9 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
                      cand_off, cand_pid);
 }
 
+#ifndef AP_ABL
+#define AP_ABL 0  // k_approx ablation bits (timing only): 1 no row gathers, 2 synthetic codes
+#endif
 // ============================================================================================
 // S4  approximate scores  approx[d] = sum_q max_{c in codes(d)} S[c, q]   (fp16 max, fp32 sum).
 // The stage is gather-LATENCY bound (candidate -> its code list -> one 64-byte score row per
@@ -1706,9 +1709,6 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
 //   k <-> dim map, so no LDS staging and no transposes are needed.
 //   sim = h(acc) ; running max over tokens per query column ; fp32 sum over q.
 // ============================================================================================
-#ifndef AP_ABL
-#define AP_ABL 0  // k_approx ablation bits (timing only): 1 no row gathers, 2 synthetic codes
-#endif
 #ifndef FP_ABL
 #define FP_ABL 0  // ablation bits (timing experiments only): 1 no norm chain, 2 no normalise, 4 no LUT decode, 8 no centroid gather, 16 no residual stream
 #endif
