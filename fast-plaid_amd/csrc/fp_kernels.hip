@@ -4,10 +4,13 @@
 //   S1 k_centroid_scores   :491        fp16 MFMA GEMM  S[b][c][q] = h(sum_k cent[c,k]*Q[b,q,k])
 //   S2 k_probe_*           :518-532    per query token top-n_probe centroids -> sorted unique cells
 //   S3 k_ivf_mark/k_cand_* :535-547    IVF gather + sort + unique  == per-query doc bitmap + ordered compaction
-//   S4 k_approx            :553-600    sum_q max_t S[code_t, q]   (fp16 max, fp32 sum)
+//   S4 k_approx_q8/k_approx:553-600    sum_q max_t S[code_t, q]   (fp16 max, fp32 sum): 8-bit bounds for every candidate,
+//                                      exact fp16 for the ones that can reach the top-R cut (or exact for all)
 //   S5 k_sel_*             :602-623    top-R by approx (radix select, ties -> lower doc id)
 //   S6+S7 k_maxsim         :626-656    decompress (search.rs:53-107) fused with the exact MaxSim
 //   S8 k_final_topk        :658-692    sort by (score desc, doc id asc), truncate to top_k
+// Beside the search path: k_token_scores (search.rs:668-686), k_reconstruct (embeddings.rs), k_assign_* / k_quantize_pack
+// (index/create.rs:148-184, :404-428), shard helpers, the exhaustive arithmetic self-test.
 //
 // Numerical contract (measured on ATen 2.10 CPU, see oracle/plaid_oracle.c): every fp16
 // tensor op = fp32 arithmetic + one round-to-nearest-even to fp16; matmuls accumulate in
