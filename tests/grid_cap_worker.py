@@ -41,6 +41,20 @@ def main():
     for idx in (dev, hip):
         for b in range(3):
             check_trace(R.search_trace(idx, q[b], params), orc.search_trace(q[b], 20, 256, 4), 32, 4, 256, 20)
+    # FP_S_BUDGET_KB (set by the test next to FP_GRID_CAP): the batch is cut into sub-batches of the centroid-score table's
+    # budget; results must not depend on the cut
+    if os.environ.get("FP_S_BUDGET_KB"):
+        qb = fp.synth.make_queries(spec, host["centroids"], 23, 32)
+        pids, scores, counts = R.search_arrays(hip, qb, params)
+        assert R.last_search_counts()["sub_batches"] > 1, "the budget did not force sub-batching"
+        for b in range(23):
+            t = R.search_trace(hip, qb[b], params)
+            assert np.array_equal(pids[b, : counts[b]], t["pids"]) and np.array_equal(scores[b, : counts[b]], t["scores"])
+        subs = [[int(x) for x in np.random.default_rng(b).integers(0, 3000, 30)] for b in range(23)]
+        p2, s2, c2 = R.search_arrays(hip, qb, params, subs)       # per-query subsets must follow their queries across the cut
+        for b in range(23):
+            t = R.search_trace(hip, qb[b], params, subs[b])
+            assert np.array_equal(p2[b, : c2[b]], t["pids"])
     print("GRID_CAP_OK")
 
 

@@ -303,11 +303,12 @@ def test_probe_fallback_path_forced(fp):
 def test_index_build_with_capped_grids(fp):
     """HIP dispatches wrap silently beyond 2^32 work-items (hit at 10 M documents); the
     index-build kernels therefore cap their grids and loop.  FP_GRID_CAP=3 forces those loops on
-    a small corpus; results must still equal the numpy twin / the oracle."""
+    a small corpus; results must still equal the numpy twin / the oracle.  The same worker also forces the batch
+    to be cut into sub-batches (FP_S_BUDGET_KB) and checks that results do not depend on the cut."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FP_GRID_CAP="3")
+    env = dict(os.environ, FP_GRID_CAP="3", FP_S_BUDGET_KB="200")   # 512 centroids x 32 x 2 B = 32 KiB per query -> sub-batches of 6
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "grid_cap_worker.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "GRID_CAP_OK" in r.stdout, r.stdout + r.stderr
