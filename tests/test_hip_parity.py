@@ -716,6 +716,26 @@ def test_update_and_delete_match_one_shot_builds(fp, tmp_path):
         assert fpi.search(q2, top_k=1, show_progress=False)[0][0][0] == nxt - 3
 
 
+def test_token_score_matrices_long_query_and_odd_shapes(fp):
+    """token-score matrices where one wave has to loop over the query tokens (q_len 100 > 64), dim 64 / nbits 2,
+    one-token documents, against the oracle bit for bit."""
+    R = fp.fast_plaid_rust
+    rng = np.random.default_rng(31)
+    for (dim, nbits, Q) in ((64, 2, 100), (128, 4, 65), (128, 2, 1)):
+        arr = _random_arrays(rng, 120, 9, 200, dim, nbits, empty_frac=0.0)
+        hip, orc = _hip_index(fp, arr), _oracle(arr)
+        q = arr["centroids"][rng.integers(0, 200, (2, Q))]
+        res = R.pysearch_with_token_scores(hip, "cuda:0", q, R.SearchParameters(2000, 64, 6, 4), False, None)
+        checked = 0
+        for b, r in enumerate(res):
+            for pid, m in zip(r.passage_ids, r.token_scores):
+                ref = orc.token_scores(q[b], pid)
+                assert m.shape == ref.shape == (Q, int(arr["doc_lengths"][pid]))
+                assert np.array_equal(m.view(np.uint16), ref.view(np.uint16))
+                checked += 1
+        assert checked >= 2
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
