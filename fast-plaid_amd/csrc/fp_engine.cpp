@@ -626,12 +626,17 @@ static FpSearchShape make_shape(int B, int Q, const fp_search_params* p) {
   return sh;
 }
 
+// dev_io: `queries` and the three outputs are DEVICE pointers on the index's GPU (fp_search_device); subsets stay host-side.
 static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_t Q, const fp_search_params* p,
                        const int64_t* subset_ids, const int64_t* subset_off, int64_t* out_pids, float* out_scores,
-                       int32_t* out_counts, TraceOut* tr) {
+                       int32_t* out_counts, TraceOut* tr, bool dev_io = false) {
   const FpIndexDev& D = ix->d;
   HIPCHK(hipSetDevice(ix->device));
-  for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+  if (dev_io) {
+    if (nq > 0) HIPCHK(hipMemset(out_counts, 0, (size_t)nq * 4));
+  } else {
+    for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+  }
   if (nq == 0 || p->top_k == 0) return FP_OK;
   const bool has_subset = subset_off != nullptr;
   // reference: topk(k > C) errs inside search() -> per-query empty result (search.rs:268)
@@ -658,7 +663,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     hipStream_t st = s->st;
     HIPCHK(hipEventRecord(s->ev[ST_UPLOAD], st));
     HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
-    HIPCHK(hipMemcpyAsync(s->qin.p, queries + (size_t)b0 * Q * D.dim, (size_t)B * Q * D.dim * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->qin.p, queries + (size_t)b0 * Q * D.dim, (size_t)B * Q * D.dim * 2,
+                          dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     const int64_t* sids = nullptr;
     if (has_subset) {
       sub_off_local.resize((size_t)B + 1);
@@ -683,10 +689,18 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     char* od = s->out_all.as<char>();
     fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
                    reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
-    HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(s->ev[ST_N], st));
-    HIPCHK(hipStreamSynchronize(st));
-    ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
+    if (dev_io) {
+      HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, od, ol.nk * 8, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, od + ol.score_off, ol.nk * 4, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(out_counts + b0, od + ol.cnt_off, ol.n * 4, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipEventRecord(s->ev[ST_N], st));
+      HIPCHK(hipStreamSynchronize(st));   // results are complete in HBM when the call returns
+    } else {
+      HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipEventRecord(s->ev[ST_N], st));
+      HIPCHK(hipStreamSynchronize(st));
+      ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
+    }
     g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : P.M;
     if (b0 == 0) {
       for (int i = 0; i < ST_N; ++i) {
@@ -744,6 +758,40 @@ extern "C" int fp_search(const fp_index* index, const uint16_t* queries, int32_t
     return fail(FP_EINVAL, "null buffer");
   return search_impl(const_cast<fp_index*>(index), queries, n_queries, q_len, params, subset_ids, subset_offsets, out_pids, out_scores,
                      out_counts, nullptr);
+}
+
+extern "C" int fp_dev_alloc(int device_id, size_t bytes, void** out) {
+  if (!out) return fail(FP_EINVAL, "null argument");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+  return FP_OK;
+}
+extern "C" int fp_dev_free(int device_id, void* p) {
+  HIPCHK(hipSetDevice(device_id));
+  if (p) HIPCHK(hipFree(p));
+  return FP_OK;
+}
+extern "C" int fp_dev_upload(int device_id, void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return fail(FP_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return FP_OK;
+}
+extern "C" int fp_dev_download(int device_id, void* dst, const void* src, size_t bytes) {
+  if (bytes && (!dst || !src)) return fail(FP_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return FP_OK;
+}
+
+extern "C" int fp_search_device(const fp_index* index, const uint16_t* dev_queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                                const fp_search_params* params, int64_t* dev_out_pids, float* dev_out_scores, int32_t* dev_out_counts) {
+  if (int rc = validate_search(index, n_queries, q_len, dim, params)) return rc;
+  if (n_queries > 0 && (!dev_queries || !dev_out_counts || (params->top_k > 0 && (!dev_out_pids || !dev_out_scores))))
+    return fail(FP_EINVAL, "null argument");
+  return search_impl(const_cast<fp_index*>(index), dev_queries, n_queries, q_len, params, nullptr, nullptr, dev_out_pids, dev_out_scores,
+                     dev_out_counts, nullptr, true);
 }
 
 extern "C" int fp_search_trace(const fp_index* index, const uint16_t* query, int32_t q_len, int32_t dim, const fp_search_params* params,

@@ -210,6 +210,45 @@ def search_arrays(index: PyLoadedIndex, queries_f16: np.ndarray, params: SearchP
     return pids[:, :k] if k else pids[:, :0], scores[:, :k] if k else scores[:, :0], counts[:B]
 
 
+class DeviceBuffer:
+    """a block of HBM on the index's GPU (fp_dev_alloc); freed when dropped."""
+
+    def __init__(self, device_id: int, nbytes: int):
+        self.device_id, self.nbytes = int(device_id), int(nbytes)
+        p = C.c_void_p()
+        N.check(N.lib().fp_dev_alloc(self.device_id, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(arr)
+        if a.nbytes > self.nbytes:
+            raise ValueError("device buffer too small")
+        N.check(N.lib().fp_dev_upload(self.device_id, self.ptr, _ptr(a), a.nbytes))
+        return self
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.zeros(shape, dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("device buffer too small")
+        N.check(N.lib().fp_dev_download(self.device_id, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None) is not None and self.ptr:
+            N.lib().fp_dev_free(self.device_id, self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
+def search_device(index: PyLoadedIndex, dev_queries: DeviceBuffer, n_queries: int, q_len: int, params: SearchParameters,
+                  dev_pids: DeviceBuffer, dev_scores: DeviceBuffer, dev_counts: DeviceBuffer) -> None:
+    """fp_search_device: queries already in HBM ([n_queries, q_len, dim] f16), results left in HBM
+    ([n_queries, top_k] i64 / f32, [n_queries] i32)."""
+    N.check(N.lib().fp_search_device(index._h, dev_queries.ptr, n_queries, q_len, index.dim, C.byref(params._c()), dev_pids.ptr,
+                                     dev_scores.ptr, dev_counts.ptr))
+
+
 def pysearch(index: PyLoadedIndex, device: str, queries_embeddings, search_parameters: SearchParameters,
              show_progress: bool = False, subset=None) -> list[QueryResult]:
     """rust/lib.rs:195-223.  `device` must name the device the index lives on."""

@@ -98,6 +98,19 @@ int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries,
               const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets,
               int64_t* out_pids, float* out_scores, int32_t* out_counts);
 
+/* Plain device-memory helpers for callers without a HIP binding of their own (bench.py, tests): allocate / free / copy on
+ * the given GPU through the same HIP runtime this library uses. */
+int fp_dev_alloc(int device_id, size_t bytes, void** out_dev_ptr);
+int fp_dev_free(int device_id, void* dev_ptr);
+int fp_dev_upload(int device_id, void* dev_dst, const void* host_src, size_t bytes);
+int fp_dev_download(int device_id, void* host_dst, const void* dev_src, size_t bytes);
+
+/* fp_search with the queries already in HBM and the results left in HBM: every pointer except `params` is a DEVICE
+ * pointer on the index's GPU (no subsets).  Results are complete when the call returns.  This is what `bench.py` times
+ * for `value` (inputs resident in HBM); fp_search adds the host <-> device copies of queries and results. */
+int fp_search_device(const fp_index* index, const uint16_t* dev_queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                     const fp_search_params* params, int64_t* dev_out_pids, float* dev_out_scores, int32_t* dev_out_counts);
+
 /* Same search with every stage output copied back (parity tests / profiling only).
  * One query.  Any output pointer may be NULL.  Capacities: S [n_centroids*q_len] f16 as
  * [c][q]; cells [q_len*n_ivf_probe]; cand/approx [n_docs]; rerank/exact [max(n_full/4,1)].

@@ -736,6 +736,30 @@ def test_token_score_matrices_long_query_and_odd_shapes(fp):
         assert checked >= 2
 
 
+def test_search_device_equals_host_buffer_search(fp):
+    """fp_search_device (queries already in HBM, results left in HBM) == fp_search, including top_k = 0 and a
+    degenerate probe count (device-side zero counts)."""
+    R = fp.fast_plaid_rust
+    spec = _synth(fp, n_docs=5000, doc_len=40, n_centroids=512, variable_len=True, seed=8)
+    arr = fp.synth.host_index_arrays(spec)
+    hip = _hip_index(fp, arr)
+    q = fp.synth.make_queries(spec, arr["centroids"], 9, 32)
+    dq = R.DeviceBuffer(0, q.nbytes).upload(q)
+    for (n_full, top_k, n_probe) in ((256, 20, 8), (64, 0, 4), (64, 5, 32)):
+        params = R.SearchParameters(2000, n_full, top_k, n_probe)
+        k = max(top_k, 1)
+        dp, ds, dc = R.DeviceBuffer(0, 9 * k * 8), R.DeviceBuffer(0, 9 * k * 4), R.DeviceBuffer(0, 9 * 4)
+        dc.upload(np.full(9, 77, np.int32))                   # stale values must be overwritten
+        R.search_device(hip, dq, 9, 32, params, dp, ds, dc)
+        pids, scores, counts = R.search_arrays(hip, q, params)
+        gc = dc.download(np.int32, (9,))
+        assert np.array_equal(gc, counts)
+        if top_k > 0:
+            gp, gs = dp.download(np.int64, (9, k)), ds.download(np.float32, (9, k))
+            for b in range(9):
+                assert np.array_equal(gp[b, : gc[b]], pids[b, : counts[b]]) and np.array_equal(gs[b, : gc[b]], scores[b, : counts[b]])
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
