@@ -6,14 +6,14 @@ New relative to the reference, whose multi-GPU mode is full replicas + query spl
 and a contiguous, token-balanced range of documents.  Per batch of queries:
 
   stage1  (local)   S1..S4 on the shard, local top-R candidates by approximate score
-  all-gather        [B,R] f32 approx + [B,R] i64 global ids      (R = max(n_full/4, 1))
+  all-gather        [B,R] f32 approx + [B,R] i64 global ids, packed into ONE byte tensor  (R = max(n_full/4, 1))
   stage2  (local)   global top-R cut == search.rs:605-619 applied to the union, exact
                     MaxSim of the survivors that live here
-  all-gather        [B,R] f32 scores + [B,R] i64 ids
+  all-gather        [B,R] f32 scores + [B,R] i64 ids, packed likewise
   stage3  (local)   global (score desc, id asc) sort, top_k
 
 Both messages are B*R*12 bytes per rank (3 MB at B=256, R=1024): latency-bound on xGMI, so
-they are issued as two fixed-size all_gather_into_tensor calls on device buffers -- no host
+they are issued as two fixed-size all_gather_into_tensor calls (one per exchange) on device buffers -- no host
 staging, no variable-length exchange.  The result is identical to the unsharded search on
 the concatenated corpus (tests/test_hip_parity.py::test_sharded_equals_unsharded).
 """
@@ -130,6 +130,19 @@ def _all_gather(torch, dist, x, world, group, force=False):
     return out.view((world,) + tuple(x.shape)).to(x.device)
 
 
+def _all_gather_pair(torch, dist, f, i, world, group, force=False):
+    """one exchange for a ([B,R] f32, [B,R] i64) pair: both are viewed as bytes and travel in ONE all-gather
+    (the exchanges are latency-bound: B*R*12 bytes per rank)."""
+    if dist is None or (world == 1 and not force):
+        return f.unsqueeze(0).contiguous(), i.unsqueeze(0).contiguous()
+    B, R = f.shape
+    packed = torch.cat([f.contiguous().view(torch.uint8).reshape(B, R * 4), i.contiguous().view(torch.uint8).reshape(B, R * 8)], dim=1)
+    g = _all_gather(torch, dist, packed, world, group, force)            # [G, B, R*12] bytes
+    gf = g[:, :, : R * 4].contiguous().view(torch.float32).reshape(world, B, R)
+    gi = g[:, :, R * 4:].contiguous().view(torch.int64).reshape(world, B, R)
+    return gf, gi
+
+
 def sharded_search(engine, queries_f16, params, dist=None, group=None, force_collectives=False):
     """Runs one batch through the three stages with the two all-gathers in between.
     `engine` implements begin/stage1/stage2/stage3/end (HipShardEngine in production).
@@ -139,13 +152,11 @@ def sharded_search(engine, queries_f16, params, dist=None, group=None, force_col
     st = engine.begin(queries_f16, params)
     try:
         a, p = engine.stage1(st)
-        all_a = _all_gather(torch, dist, a, world, group, force_collectives)
-        all_p = _all_gather(torch, dist, p, world, group, force_collectives)
+        all_a, all_p = _all_gather_pair(torch, dist, a, p, world, group, force_collectives)
         if all_a.is_cuda:
             torch.cuda.current_stream().synchronize()  # library kernels run on their own stream
         s, sp = engine.stage2(st, all_a, all_p, world)
-        all_s = _all_gather(torch, dist, s, world, group, force_collectives)
-        all_sp = _all_gather(torch, dist, sp, world, group, force_collectives)
+        all_s, all_sp = _all_gather_pair(torch, dist, s, sp, world, group, force_collectives)
         if all_s.is_cuda:
             torch.cuda.current_stream().synchronize()
         return engine.stage3(st, all_s, all_sp, world)
@@ -159,7 +170,7 @@ def sharded_search(engine, queries_f16, params, dist=None, group=None, force_col
 # path is per query, so this mode replicates NO work (the document-sharded mode above replicates
 # S1/S2 and the per-launch latencies on every rank); it is the throughput mode whenever the index
 # fits one GPU (a 288 GB MI355X holds ~30 M documents x 128 tokens at nbits=4).  The only exchange
-# is the result gather: three fixed-size all_gather_into_tensor calls.
+# is the result gather: one fixed-size all_gather_into_tensor call.
 def split_batch(n_queries: int, world_size: int) -> list[tuple[int, int]]:
     """contiguous, near-equal query ranges, one per rank (the first ranks take the remainder)."""
     base, rem = divmod(int(n_queries), int(world_size))
@@ -191,14 +202,19 @@ def replicated_search(search_local, queries_f16, top_k: int, dist=None, group=No
         pids[: hi - lo], scores[: hi - lo], counts[: hi - lo] = p, s, c
     if not live or (world == 1 and not force_collectives):
         return pids[:B], scores[:B], counts[:B]
-    outs = []
-    for x in (pids, scores, counts):
-        t = torch.from_numpy(x).to(device)
-        g = torch.empty((world * mb,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(g, t.contiguous(), group=group)
-        outs.append(g)
-    outs = [g.cpu().numpy().reshape((world, mb) + g.shape[1:]) for g in outs]
-    P = np.concatenate([outs[0][r, : h - l] for r, (l, h) in enumerate(ranges)], axis=0)
-    S = np.concatenate([outs[1][r, : h - l] for r, (l, h) in enumerate(ranges)], axis=0)
-    Cn = np.concatenate([outs[2][r, : h - l] for r, (l, h) in enumerate(ranges)], axis=0)
+    # ONE exchange per batch: ids | scores | counts packed row-wise into a byte tensor (three separate small all-gathers cost
+    # three collective latencies, which is what a rank's 8-query slice of a 64-query batch is measured in)
+    row = top_k * 12 + 4
+    packed = np.empty((mb, row), np.uint8)
+    packed[:, : top_k * 8] = pids.view(np.uint8).reshape(mb, top_k * 8)
+    packed[:, top_k * 8: top_k * 12] = scores.view(np.uint8).reshape(mb, top_k * 4)
+    packed[:, top_k * 12:] = counts.view(np.uint8).reshape(mb, 4)
+    t = torch.from_numpy(packed).to(device)
+    g = torch.empty((world * mb, row), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(g, t, group=group)
+    allp = g.cpu().numpy().reshape(world, mb, row)
+    P = np.concatenate([np.ascontiguousarray(allp[r, : h - l, : top_k * 8]).view(np.int64).reshape(h - l, top_k) for r, (l, h) in enumerate(ranges)], axis=0)
+    S = np.concatenate([np.ascontiguousarray(allp[r, : h - l, top_k * 8: top_k * 12]).view(np.float32).reshape(h - l, top_k)
+                        for r, (l, h) in enumerate(ranges)], axis=0)
+    Cn = np.concatenate([np.ascontiguousarray(allp[r, : h - l, top_k * 12:]).view(np.int32).reshape(h - l) for r, (l, h) in enumerate(ranges)], axis=0)
     return P, S, Cn
