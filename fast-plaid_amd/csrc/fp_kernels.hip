@@ -479,23 +479,30 @@ __global__ __launch_bounds__(256) void k_probe_chunkmax(const uint16_t* __restri
   }
 }
 
-// one wave per (b, q): tau = n_probe-th largest chunk maximum (as a mono16 key; 0 = collect everything)
+// one wave per (b, q): tau = n_probe-th largest chunk maximum (as a mono16 key; 0 = collect everything).
+// The chunk maxima of the column are read ONCE into registers (KPL keys per lane); the n_probe selection rounds then run
+// on registers (re-reading global memory every round cost 24 us at cfg2).
+template <int KPL>
 __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ cmax, int Q, int Qp, int nchunk, int n_probe,
                                                   uint32_t* __restrict__ tau /*[B*Qp]*/) {
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
   const uint16_t* src = cmax + ((int64_t)b * Qp + q) * nchunk;
-  uint32_t bound = 0xFFFFFFFFu, m = 0;
   if (nchunk < n_probe) {
     if (lane == 0) tau[(int64_t)b * Qp + q] = 0u;
     return;
   }
-  for (int r = 0; r < n_probe; ++r) {  // keys (mono16 << 12 | chunk) are unique; chunks < 4096
+  uint32_t key[KPL];   // (mono16 << 12 | reversed chunk index): unique, chunks < 4096; 0 = no chunk
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) {
+    const int i = lane + 64 * j;
+    key[j] = (i < nchunk) ? ((mono16(src[i]) << 12) | (uint32_t)(nchunk - 1 - i)) : 0u;
+  }
+  uint32_t bound = 0xFFFFFFFFu, m = 0;
+  for (int r = 0; r < n_probe; ++r) {
     m = 0;
-    for (int i = lane; i < nchunk; i += 64) {
-      const uint32_t kk = (mono16(src[i]) << 12) | (uint32_t)(nchunk - 1 - i);
-      if (kk < bound && kk > m) m = kk;
-    }
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) m = (key[j] < bound && key[j] > m) ? key[j] : m;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) {
       const uint32_t o = shfl_xor_u32(m, s);
@@ -504,6 +511,13 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     bound = m;
   }
   if (lane == 0) tau[(int64_t)b * Qp + q] = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
+}
+
+static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st) {
+  const dim3 grid((unsigned)(sh.B * sh.Q));
+  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau);
+  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau);
+  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau);   // nchunk <= 4096
 }
 
 __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
@@ -612,11 +626,11 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     const int nch128 = (int)((ix.C + 127) / 128);
     const bool fused = cmax128 != nullptr && allow == nullptr && nch128 <= 4096;
     if (fused) {
-      hipLaunchKernelGGL(k_probe_tau, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cmax128, sh.Q, sh.Qp, nch128, sh.n_probe, tau);
+      launch_probe_tau(cmax128, sh, nch128, tau, st);
       hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag, cmax128, nch128);
     } else {
       hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);
-      hipLaunchKernelGGL(k_probe_tau, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cmax, sh.Q, sh.Qp, nch2, sh.n_probe, tau);
+      launch_probe_tau(cmax, sh, nch2, tau, st);
       hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag,
                          (const uint16_t*)nullptr, 0);
     }
