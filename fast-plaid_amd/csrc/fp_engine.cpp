@@ -760,6 +760,14 @@ extern "C" int fp_search(const fp_index* index, const uint16_t* queries, int32_t
                      out_counts, nullptr);
 }
 
+static int64_t mem_info(int device_id, bool want_free) {
+  size_t f = 0, t = 0;
+  if (hipSetDevice(device_id) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return -1;
+  return (int64_t)(want_free ? f : t);
+}
+extern "C" int64_t fp_device_free_bytes(int device_id) { return mem_info(device_id, true); }
+extern "C" int64_t fp_device_total_bytes(int device_id) { return mem_info(device_id, false); }
+
 extern "C" int fp_dev_alloc(int device_id, size_t bytes, void** out) {
   if (!out) return fail(FP_EINVAL, "null argument");
   *out = nullptr;

@@ -72,6 +72,9 @@ typedef struct fp_search_params {
 const char* fp_last_error(void);        /* errors.rs:5-7 */
 const char* fp_version(void);
 int fp_device_count(void);
+/* free / total HBM of a device in bytes (hipMemGetInfo); negative on error */
+int64_t fp_device_free_bytes(int device_id);
+int64_t fp_device_total_bytes(int device_id);
 
 /* ---- index lifetime ----------------------------------------------------------------- */
 /* construct_index (load.rs:124-186): uploads and re-lays-out the arrays on device

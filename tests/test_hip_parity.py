@@ -760,6 +760,37 @@ def test_search_device_equals_host_buffer_search(fp):
                 assert np.array_equal(gp[b, : gc[b]], pids[b, : counts[b]]) and np.array_equal(gs[b, : gc[b]], scores[b, : counts[b]])
 
 
+def test_device_memory_is_returned(fp):
+    """create -> search (all scratch pools grown) -> token scores -> close, ten times: the device's free memory comes back
+    (an index, its scratch pools, pinned staging buffers and the fp_compress / DeviceBuffer helpers release what they took)."""
+    import gc
+    from fast_plaid_amd import _native
+    R = fp.fast_plaid_rust
+    L = _native.lib()
+    spec = _synth(fp, n_docs=200_000, doc_len=64, n_centroids=8192, seed=4)
+    cent = fp.synth.centroids(spec)
+    q = fp.synth.make_queries(spec, cent, 16, 32)
+    params = R.SearchParameters(2000, 1024, 50, 8)
+
+    def cycle():
+        idx = R.construct_synthetic_index(spec, "cuda:0", centroids=cent)
+        p, s, c = R.search_arrays(idx, q, params)
+        R.token_score_matrices(idx, q[:2], p[:2, :3], np.minimum(c[:2], 3))
+        d = R.DeviceBuffer(0, 1 << 20)
+        d.close()
+        idx.close()
+        del idx
+        gc.collect()
+
+    cycle()                                   # the first cycle loads code objects and HIP-internal pools
+    before = L.fp_device_free_bytes(0)
+    for _ in range(10):
+        cycle()
+    after = L.fp_device_free_bytes(0)
+    assert before > 0 and after > 0
+    assert before - after < (64 << 20), f"device memory shrank by {(before - after) >> 20} MiB over 10 create/search/close cycles"
+
+
 def test_sharded_equals_unsharded(fp):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
