@@ -14,9 +14,12 @@ N>1: the SAME corpus and the SAME query batch, documents split into N contiguous
 token-balanced shards (one process per GPU), two fixed-size RCCL all-gathers per batch
 (fast-plaid_amd/sharded.py) -> "scaling": "strong".
 
-One JSON line on rank 0.  `roofline` is the fused decompress+MaxSim kernel (the kernel
-BASELINE.json's north star puts the HBM-roofline target on); `stages_ms` + `roofline_by_kernel`
-give every other stage, so the time-dominant kernel is visible too.
+One JSON line on rank 0.  `value` is timed on the boundary call fp_search (host query buffer in, host
+results out -- what the reference's pysearch hands over, rust/lib.rs:195-223); the same steps with queries and
+results resident in HBM (fp_search_device) are reported as `value_device_io`.  Every step uses its own query
+batch.  `roofline` describes the DOMINANT kernel of the step (S4's per-candidate kernel on the default workload);
+the fused decompress+MaxSim kernel -- the kernel BASELINE.json's north star puts the HBM-roofline target on -- and
+S1 are under `roofline_by_kernel`; `stages_ms` gives every stage.
 """
 from __future__ import annotations
 
@@ -118,7 +121,7 @@ def main():
     bw = fp.synth.bucket_weights(spec)
     dev = f"cuda:{local_rank}"
     params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
-    n_batches = min(a.steps + a.warmup, 12)
+    n_batches = a.steps + a.warmup   # a distinct query batch for every step (no cache-warm repeats)
     batches = [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i) for i in range(n_batches)]
 
     def sync():
@@ -138,16 +141,9 @@ def main():
         t_build = time.time() - t0
         engine = sharded.HipShardEngine(index, dev) if mode == "shard" else None
 
-        # single-GPU mode: the timed path is fp_search_device -- query batches are uploaded to HBM before the timed region and the
-        # results stay in HBM ("inputs already resident in HBM when the timed region starts"); the host-buffer call
-        # (fp_search: + 512 KB up, 768 KB down per batch over PCIe) is timed separately below.
-        dq = dp = dsc = dc = None
-        if mode == "single":
-            devid = index.device_id
-            dq = [R.DeviceBuffer(devid, q.nbytes).upload(q) for q in batches]
-            dp = R.DeviceBuffer(devid, a.batch * max(a.topk, 1) * 8)
-            dsc = R.DeviceBuffer(devid, a.batch * max(a.topk, 1) * 4)
-            dc = R.DeviceBuffer(devid, a.batch * 4)
+        # single-GPU mode: the timed path is the boundary call fp_search -- host query buffer in, host results out (the index is
+        # resident in HBM; + 512 KB up, 768 KB down per batch over PCIe); fp_search_device (queries / results resident in HBM) is
+        # timed separately below and reported beside it.
 
         def step(i):
             q = batches[i % n_batches]
@@ -156,7 +152,7 @@ def main():
             if mode == "replica":
                 return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist,
                                                  device=("cpu" if a.dist_backend == "gloo" else dev), force_collectives=True)
-            return R.search_device(index, dq[i % n_batches], a.batch, a.qlen, params, dp, dsc, dc)
+            return R.search_arrays(index, q, params)
 
         for i in range(a.warmup):
             step(i)
@@ -182,16 +178,22 @@ def main():
             tt = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if a.dist_backend == "gloo" else dev))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        host_elapsed = None
-        if mode == "single":   # the same K steps through the host-buffer entry point (PCIe-inclusive)
+        dev_elapsed = None
+        if mode == "single":   # the same K steps with queries uploaded beforehand and results left in HBM
+            devid = index.device_id
+            dq = [R.DeviceBuffer(devid, q.nbytes).upload(q) for q in batches]
+            dp = R.DeviceBuffer(devid, a.batch * max(a.topk, 1) * 8)
+            dsc = R.DeviceBuffer(devid, a.batch * max(a.topk, 1) * 4)
+            dc = R.DeviceBuffer(devid, a.batch * 4)
             for i in range(min(a.warmup, 2)):
-                R.search_arrays(index, batches[i % n_batches], params)
+                R.search_device(index, dq[i], a.batch, a.qlen, params, dp, dsc, dc)
             t1 = time.perf_counter()
             for i in range(a.steps):
-                R.search_arrays(index, batches[(a.warmup + i) % n_batches], params)
-            host_elapsed = time.perf_counter() - t1
+                R.search_device(index, dq[a.warmup + i], a.batch, a.qlen, params, dp, dsc, dc)
+            dev_elapsed = time.perf_counter() - t1
+            del dq, dp, dsc, dc
         return dict(index=index, elapsed=elapsed, lat=lat, stage_acc=stage_acc, cand_total=cand_total, exact_total=exact_total,
-                    t_build=t_build, host_elapsed=host_elapsed)
+                    t_build=t_build, dev_elapsed=dev_elapsed)
 
     if use_dist:
         est_bytes = a.docs * a.doc_len * (a.dim * a.nbits // 8 + 4 + 2 + 4) + C * a.dim * 2
@@ -205,7 +207,7 @@ def main():
     res = run_mode(primary)
     index, elapsed, lat, stage_acc, cand_total, t_build = (res[k] for k in ("index", "elapsed", "lat", "stage_acc", "cand_total", "t_build"))
     exact_total = res["exact_total"]
-    host_elapsed = res["host_elapsed"]
+    dev_elapsed = res["dev_elapsed"]
     ms_per_step = elapsed / a.steps * 1e3
     qps = a.batch * a.steps / elapsed
     index_bytes = index.device_bytes
@@ -237,11 +239,11 @@ def main():
     }
     if alt is not None:
         out["alt_mode"] = alt
-    if host_elapsed:
-        out["io"] = "queries and results resident in HBM (fp_search_device)"
-        out["value_host_buffers"] = {"value": a.batch * a.steps / host_elapsed, "ms_per_step": host_elapsed / a.steps * 1e3,
-                                     "note": "fp_search with host buffers: + %d KB up and %d KB down per batch over PCIe" % (
-                                         a.batch * a.qlen * a.dim * 2 // 1024, a.batch * a.topk * 12 // 1024)}
+    if dev_elapsed:
+        out["io"] = "fp_search: host query buffer in, host results out (index resident in HBM); %d KB up and %d KB down per batch" % (
+            a.batch * a.qlen * a.dim * 2 // 1024, a.batch * a.topk * 12 // 1024)
+        out["value_device_io"] = {"value": a.batch * a.steps / dev_elapsed, "ms_per_step": dev_elapsed / a.steps * 1e3,
+                                  "note": "fp_search_device: queries uploaded before the timed region, results left in HBM"}
     if not use_dist and rank == 0:
         stages = {k: v / a.steps for k, v in stage_acc.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
@@ -261,14 +263,25 @@ def main():
         t_ap = stages.get("S4 approx", 0.0)
         b_ap = cand_per_step * a.doc_len * 4
         used_bounds = exact_total < cand_total
-        ap_name = "k_approx_q8" if used_bounds else "k_approx"
+        l0 = stages.get("S4 prepare", 0.0) > 0.0
+        ap_name = "k_l0_scan" if l0 else ("k_approx_q8" if used_bounds else "k_approx")
+        ap_what = {"k_l0_scan": " (S4 level 0: upper bound of every candidate from its code list and a per-centroid byte table in LDS)",
+                   "k_approx_q8": " (S4: 8-bit bounds of every candidate)", "k_approx": " (S4: exact approximate score of every candidate)"}[ap_name]
         ap_traffic, ap_src = _pmc_traffic(ap_name, default_cfg)
-        r_ap = {"kernel": ap_name + (" (S4: 8-bit bounds of every candidate)" if used_bounds else " (S4: exact approximate score of every candidate)"),
+        # bytes the kernel's own layout makes compulsory: the per-document UNIQUE code list (4 B each) + 4 B id + 16 B offsets + 2 B out
+        ucodes_per_doc = index.n_unique_codes / max(index.n_docs, 1)
+        b_layout = cand_per_step * (ucodes_per_doc * 4 + 22)
+        r_ap = {"kernel": ap_name + ap_what,
                 "bound": "hbm", "achieved": b_ap / (t_ap * 1e-3) / 1e9 if t_ap > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (b_ap / (t_ap * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ap > 0 else 0.0, "traffic": ap_traffic, "traffic_source": ap_src,
-                "algorithmic_bytes_per_launch": b_ap, "avg_launch_ms": t_ap, "share_of_step": t_ap / ms_per_step if ms_per_step > 0 else 0.0,
+                "algorithmic_bytes_per_launch": b_ap,
+                "algorithmic_bytes_note": "SURVEY 8d accounting: 4 B (int32 code) per candidate document token",
+                "layout_bytes_per_launch": b_layout,
+                "frac_on_layout_bytes": (b_layout / (t_ap * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ap > 0 else 0.0,
+                "layout_bytes_note": "what this index layout reads per candidate: %.1f unique codes x 4 B + 22 B of id / offsets / output" % ucodes_per_doc,
+                "avg_launch_ms": t_ap, "share_of_step": t_ap / ms_per_step if ms_per_step > 0 else 0.0,
                 "candidate_docs_per_batch": cand_per_step, "docs_rescored_exactly_per_batch": exact_total / a.steps,
-                "refine_ms": stages.get("S4 refine", 0.0)}
+                "prepare_ms": stages.get("S4 prepare", 0.0), "refine_ms": stages.get("S4 refine", 0.0)}
         traffic, traffic_src = _pmc_traffic("k_maxsim", default_cfg)
         t_ms = stages.get("S6+S7 maxsim", 0.0)
         ach = bytes_maxsim / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
@@ -294,18 +307,22 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import plaid_oracle as OC
             cores = OC.num_procs()
-            if ncpu < 0:
-                ncpu = min(a.batch, max(cores, 1))
+            if ncpu < 0:   # one query per host core (OpenMP over queries, dynamic schedule), at least one batch
+                ncpu = min(max(a.batch, cores), a.batch * n_batches, 512)
             arr = R.export_index_arrays(index, centroids=cent, bucket_weights=bw)
             orc = OC.OracleIndex(nbits=spec.nbits, centroids=cent, bucket_weights=bw, ivf=arr["ivf"], ivf_lengths=arr["ivf_lengths"],
                                  doc_codes=arr["doc_codes"], doc_residuals=arr["doc_residuals"], doc_lengths=arr["doc_lengths"])
-            qs = batches[0][:ncpu]
+            qs_all = np.concatenate(batches[: (ncpu + a.batch - 1) // a.batch], axis=0)[:ncpu]
+            threads = min(cores, ncpu)
             tc = time.perf_counter()
-            ref = orc.search(qs, a.topk, a.nfull, a.nprobe, nthreads=cores)
+            ref = orc.search(qs_all, a.topk, a.nfull, a.nprobe, nthreads=threads)
             tcpu = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": ncpu / tcpu, "unit": "queries/s", "cores": cores, "kind": "port",
-                                   "sample": "%d queries of the same batch/corpus, plain-C restatement of the reference (oracle/plaid_oracle.c), "
-                                             "OpenMP across queries like the reference's joblib threads path; %.1f s wall" % (ncpu, tcpu)}
+            out["cpu_baseline"] = {"value": ncpu / tcpu, "unit": "queries/s", "cores": threads, "host_cores": cores, "kind": "port",
+                                   "sample": "%d queries (%d batches of the timed workload) on the same corpus, plain-C restatement of the reference "
+                                             "(oracle/plaid_oracle.c), one query per OpenMP thread, %d threads busy on %d host cores; %.1f s wall" % (
+                                                 ncpu, (ncpu + a.batch - 1) // a.batch, threads, cores, tcpu)}
+            ncpu = min(ncpu, a.batch)
+            qs = qs_all[:ncpu]
             # parity spot check on the benchmark corpus itself (ids modulo near-ties, scores within 1e-3)
             gp, gs, gc = R.search_arrays(index, qs, params)
             ident = sum(int(np.array_equal(gp[b, : gc[b]], ref[b][0])) for b in range(ncpu))

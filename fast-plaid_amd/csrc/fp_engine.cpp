@@ -86,24 +86,28 @@ struct HostBuf {
   }
 };
 
-enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
+enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APREP, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
 static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
-                                        "S3 compact",  "S4 approx",        "S4 refine",     "S5 select",
-                                        "S6+S7 maxsim", "S8 topk+download"};
-// "S4 approx" is exactly ONE kernel -- k_approx_q8 (bounds of every candidate) when the bound stage runs, else k_approx
-// (exact score of every candidate) -- so that it can be compared with a profiler's per-kernel time; "S4 refine" is
-// the cut, the survivor compaction and their exact rescoring (zero without the bound stage).
+                                        "S3 compact",  "S4 prepare",       "S4 approx",     "S4 refine",
+                                        "S5 select",   "S6+S7 maxsim",     "S8 topk+download"};
+// "S4 approx" is exactly ONE kernel -- k_l0_scan (level-0 bound of every candidate), k_approx_q8 (8-bit bounds of every
+// candidate) or k_approx (exact score of every candidate), whichever form of S4 runs -- so that it can be compared with a
+// profiler's per-kernel time; "S4 prepare" = level 0's floors + excess table (zero otherwise); "S4 refine" = the cut, the
+// survivor compaction and their exact rescoring (zero when every candidate is scored exactly).
 
 struct Scratch {
   hipStream_t st = nullptr;
   hipEvent_t ev[ST_N + 1] = {};
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
-      tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid;
+      tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
+      l0_hist, l0_npilot, l0_pilot_off, l0_pilot_pid, l0_pilot_approx;
   HostBuf h_out, h_small;
   void destroy() {
     out_all.release();
-    for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid}) b->release();
+    for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
+                      &l0_hist, &l0_npilot, &l0_pilot_off, &l0_pilot_pid, &l0_pilot_approx})
+      b->release();
     h_out.release();
     h_small.release();
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
@@ -334,6 +338,7 @@ extern "C" int64_t fp_index_num_centroids(const fp_index* ix) { return ix ? ix->
 extern "C" int32_t fp_index_dim(const fp_index* ix) { return ix ? ix->d.dim : 0; }
 extern "C" int32_t fp_index_nbits(const fp_index* ix) { return ix ? ix->d.nbits : 0; }
 extern "C" int64_t fp_index_device_bytes(const fp_index* ix) { return ix ? ix->bytes : 0; }
+extern "C" int64_t fp_index_num_unique_codes(const fp_index* ix) { return ix ? ix->d.U : 0; }
 
 // ------------------------------------------------------------------------------------------
 // synthetic device-resident corpora
@@ -482,7 +487,8 @@ struct Pipe {
   bool degenerate;  // reference errs for every query (topk k out of range) -> all results empty
   int64_t M;
   bool exact_all = false;  // trace mode: exact approximate score of EVERY candidate (no bound-and-refine)
-  bool used_q8 = false;
+  bool used_q8 = false;   // a bound stage pruned the candidates (8-bit bounds or level 0)
+  int approx_impl = 0;    // 0 exact for all, 1 8-bit bounds, 2 level 0
 };
 
 // stages S1..S5 for one sub-batch whose fp16 queries are already in s->qin
@@ -499,7 +505,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
   // per-128-centroid column maxima for the threshold probe
-  static const int q8_env = [] { const char* e = getenv("FP_APPROX_IMPL"); return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : 0)); }();
+  // FP_APPROX_IMPL: exact | q8 | l0 force a form of S4 (tests); otherwise chosen below from the table size and the candidate count
+  static const int q8_env = [] {
+    const char* e = getenv("FP_APPROX_IMPL");
+    return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : (e[0] == 'l' ? 2 : 0)));
+  }();
   const bool want_s8 = !P.exact_all && (sh.Qp == 32 || sh.Qp == 64) && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
   const int nch128 = (int)((D.C + 127) / 128);
   if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
@@ -565,38 +575,79 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->approx.ensure((size_t)std::max<int64_t>(M, 1) * 4));
   fpk_cand_compact(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                    s->blkcnt.as<int32_t>(), P.nblk, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), st);
-  HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
-  // S4: bound-and-refine when one query's slice of S overflows L2 and there is something to prune, else exact for all
+  HIPCHK(hipEventRecord(s->ev[ST_APREP], st));
+  // S4.  Three forms, all giving the selection of "score every candidate exactly":
+  //   level 0  (k_l0_scan): a scalar bound per centroid in LDS prunes ~99 % of the candidates without touching S -- when the
+  //            byte table of C entries fits LDS and there is something to prune;
+  //   8-bit bounds (k_approx_q8): when one query's slice of S overflows L2 (and level 0 does not apply);
+  //   exact for all (k_approx).
   const int64_t* sel_off = s->cand_off.as<int64_t>();
   const int32_t* sel_src = s->cand_pid.as<int32_t>();
-  // bound stage when (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone can
+  const bool l0_ok = want_s8 && M > 0 && fpk_l0_fits(D);
+  const bool l0_auto = l0_ok && M > 16 * (int64_t)B * sh.R;
+  // 8-bit bounds: (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone can
   // fill the chip (~1280 resident workgroups x 128 lane pairs; the kernel spreads a candidate over 4 pairs when there are
   // fewer than 131072 candidates per query, e.g. cfg4's 1024-token documents or a small shard)
   const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 32768;
-  P.used_q8 = want_s8 && M > 0 && (q8_env > 0 || q8_auto);
-  if (P.used_q8) {
+  P.approx_impl = 0;
+  if (want_s8 && M > 0) {
+    if (q8_env == 2) P.approx_impl = l0_ok ? 2 : 0;
+    else if (q8_env == 1) P.approx_impl = 1;
+    else P.approx_impl = l0_auto ? 2 : (q8_auto ? 1 : 0);
+  }
+  P.used_q8 = P.approx_impl != 0;
+  if (P.approx_impl != 0) {
     const int64_t max_n = std::min<int64_t>(D.N, M);
     const int nblk2 = (int)((max_n + FP_SURV_CHUNK - 1) / FP_SURV_CHUNK);
-    const int nch8 = sh.Qp / 32;
-    HIPCHK(s->kq.ensure((size_t)M * 4 * (nch8 > 1 ? 1 + nch8 : 1)));
-    HIPCHK(s->q8hist.ensure((size_t)B * 8192 * nch8 * 4));
     HIPCHK(s->cut.ensure((size_t)B * 4));
     HIPCHK(s->blkcnt2.ensure((size_t)B * nblk2 * 4));
     HIPCHK(s->nsurv.ensure((size_t)B * 4));
     HIPCHK(s->surv_off.ensure((size_t)(B + 1) * 8));
     HIPCHK(s->surv_pid.ensure((size_t)M * 4));
-    fpk_approx_q8_bounds(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->kq.as<uint32_t>(), st);
-    HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
-    fpk_approx_q8_cut(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
-                      s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
-                      s->surv_pid.as<int32_t>(), st);
+    if (P.approx_impl == 2) {
+      const int64_t Cpad = (D.C + 15) & ~15ll;
+      HIPCHK(s->l0_floors.ensure((size_t)B * sh.Qp));
+      HIPCHK(s->l0_F.ensure((size_t)B * 4));
+      HIPCHK(s->l0_e8.ensure((size_t)B * Cpad));
+      HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
+      HIPCHK(s->l0_ub.ensure((size_t)M * 2));
+      HIPCHK(s->l0_hist.ensure((size_t)B * 16384 * 4));
+      HIPCHK(s->l0_npilot.ensure((size_t)B * 4));
+      HIPCHK(s->l0_pilot_off.ensure((size_t)(B + 1) * 8));
+      HIPCHK(s->l0_pilot_pid.ensure((size_t)M * 4));
+      HIPCHK(s->l0_pilot_approx.ensure((size_t)M * 4));
+      FpL0Scratch w{s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(),
+                    s->l0_ub.as<uint16_t>(), s->l0_hist.as<uint32_t>(), s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2,
+                    s->l0_npilot.as<int32_t>(), s->l0_pilot_off.as<int64_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>()};
+      fpk_l0_prepare(D, s->S8.as<uint8_t>(), sh, w, st);
+      HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
+      fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
+      HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
+      fpk_l0_pilot(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, st);
+      // exact scores of the pilot group (<= FP_L0_PILOT x keep documents per query unless UB0 ties inflate it)
+      fpk_approx(D, s->S.as<uint16_t>(), sh, w.pilot_off, w.pilot_pid, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), w.pilot_approx, st);
+      fpk_l0_survivors(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
+                       s->surv_pid.as<int32_t>(), st);
+    } else {
+      const int nch8 = sh.Qp / 32;
+      HIPCHK(s->kq.ensure((size_t)M * 4 * (nch8 > 1 ? 1 + nch8 : 1)));
+      HIPCHK(s->q8hist.ensure((size_t)B * 8192 * nch8 * 4));
+      HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
+      fpk_approx_q8_bounds(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->kq.as<uint32_t>(), st);
+      HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
+      fpk_approx_q8_cut(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
+                        s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
+                        s->surv_pid.as<int32_t>(), st);
+    }
     sel_off = s->surv_off.as<int64_t>();
     sel_src = s->surv_pid.as<int32_t>();
     // survivor total for fp_last_search_counts: lands in pinned memory by the time the caller's final sync returns
     HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 8, s->surv_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
-    // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2); the kernel walks a grid-stride loop if there are more
-    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 4 * (int64_t)B * sh.R), s->approx.as<float>(), st);
+    // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2 after the 8-bit bounds, ~4 x R after level 0); the
+    // kernel walks a grid-stride loop if there are more
+    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), s->approx.as<float>(), st);
   } else {
+    HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
     fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st);
     HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
   }

@@ -96,6 +96,29 @@ void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
                           int64_t M, uint32_t* kq, hipStream_t st);
 void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, uint32_t* q8hist, uint32_t* kq,
                        int32_t* cut, int32_t* blkcnt, int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
+// level 0 of S4 (see fp_kernels.hip): scalar excess bound per centroid in LDS, pilot group, survivors
+struct FpL0Scratch {
+  uint8_t* floors;      // [B][Qp]
+  uint32_t* Fsum;       // [B]
+  uint8_t* e8;          // [B][Cpad]
+  uint32_t* esc;        // [B][64]
+  uint16_t* ub;         // [M]
+  uint32_t* hist;       // [B][16384]
+  int32_t* cut;         // [B]
+  int32_t* blkcnt;      // [B][nblk]
+  int nblk;             // ceil(max candidates per query / FP_SURV_CHUNK)
+  int32_t* npilot;      // [B]
+  int64_t* pilot_off;   // [B+1]
+  int32_t* pilot_pid;   // [M]
+  float* pilot_approx;  // [M]
+};
+bool fpk_l0_fits(const FpIndexDev& ix);
+void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st);
+void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w,
+                 hipStream_t st);
+void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, hipStream_t st);
+void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
+                      int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st);

@@ -1448,6 +1448,443 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 }
 
 // ============================================================================================
+// S4, level 0: one scalar per centroid, held in LDS.  The bound stage above still gathers one 32-byte row per (candidate,
+// unique code) from a table that overflows an XCD's L2; this stage needs NO row gathers at all.
+//   f_q      = a per-column floor (bin units), here the (1 - tail)-quantile of column q over a sample of the centroids
+//   e(c)     = sum_q max(0, S8[c][q] - f_q)                        "excess" of centroid c over the floors
+//   UB0(d)   = F + sum_{c in codes(d)} e(c),  F = sum_q f_q
+// Since max_c S8[c][q] <= f_q + sum_c max(0, S8[c][q] - f_q), UB0(d) >= K(d) = sum_q max_c S8[c][q] for every document, and
+// with 128 A + 100 Q < K + Q (see above; a bin-255 entry makes e(c) infinite) a document can only reach an exact
+// approximate score A >= A_T if UB0(d) > 128 A_T + 99 Q.  e(c) is a BYTE table of C entries (128 KiB at C = 2^17) that
+// every workgroup copies into LDS; a candidate then costs its code list (a coalesced stream) and one LDS byte per code.
+// Values 0..191 are stored as they are, 192..254 name one of 63 escape slots (u32 values in LDS), 255 = infinite.
+//   A_T: the top-R' documents by UB0 (R' = 4 R) are scored exactly; A_T = the keep-th largest of THEIR exact scores, which
+//        is <= the keep-th largest exact score overall.  Survivors = { UB0 >= floor(128 A_T + 99 Q) + 1 }: they contain
+//        every document with A >= A_T, hence the exact top-keep with all its ties -> the selection that follows is
+//        identical to scoring every candidate exactly.  On the benchmark corpus 0.5-1.5 % of the candidates survive
+//        (tools/sim_s4_bounds.py reproduces the bound on the CPU).
+// ============================================================================================
+#define L0_ESC_BASE 192
+#define L0_ESC_SLOTS 63
+#define L0_INF 0xFFFFu
+#define L0_HIST_BINS 16384      // histogram of min(UB0 - F, 16383)
+#define L0_SAMPLE 8192          // centroids sampled for the column quantiles
+
+// floors[b][Qp] u8 (pad columns 0), Fsum[b]; one workgroup per query
+__global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S8, int64_t C, int Q, int nch, float tail,
+                                                   uint8_t* __restrict__ floors, uint32_t* __restrict__ Fsum) {
+  extern __shared__ uint32_t l0h[];   // [nch*32][256]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ncol = nch * 32;
+  for (int i = tid; i < ncol * 256; i += 1024) l0h[i] = 0u;
+  __syncthreads();
+  const int64_t stride = C > L0_SAMPLE ? C / L0_SAMPLE : 1;
+  const int64_t ns = (C + stride - 1) / stride;
+  for (int64_t i = tid; i < ns * nch * 2; i += 1024) {   // (sample, chunk, 16-byte half)
+    const int half = (int)(i & 1);
+    const int ch = (int)((i >> 1) % nch);
+    const int64_t c = ((i >> 1) / nch) * stride;
+    const uint4 v = *reinterpret_cast<const uint4*>(S8 + (((int64_t)b * nch + ch) * C + c) * 32 + half * 16);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) atomicAdd(&l0h[(ch * 32 + half * 16 + j) * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu)], 1u);
+  }
+  __syncthreads();
+  __shared__ uint32_t fl[64];
+  if (tid < ncol) {
+    uint32_t f = 0;
+    if (tid < Q) {   // smallest bin f such that at most tail * ns samples lie above it
+      const uint32_t lim = (uint32_t)(tail * (float)ns);
+      uint32_t above = 0;
+      int k = 255;
+      for (; k > 0; --k) {
+        above += l0h[tid * 256 + k];
+        if (above > lim) break;
+      }
+      f = (uint32_t)k;
+    }
+    fl[tid] = f;
+    floors[(int64_t)b * ncol + tid] = (uint8_t)f;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t s = 0;
+    for (int i = 0; i < ncol; ++i) s += fl[i];
+    Fsum[b] = s;
+  }
+}
+
+// e8[b][c]; esc[b][64]: [0..62] escape values, [63] = slots handed out
+__global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8, int64_t C, int64_t Cpad, int Q, int nch,
+                                                  const uint8_t* __restrict__ floors, uint8_t* __restrict__ e8, uint32_t* __restrict__ esc) {
+  const int b = blockIdx.y;
+  __shared__ uint8_t fl[64];
+  if (threadIdx.x < nch * 32) fl[threadIdx.x] = floors[(int64_t)b * nch * 32 + threadIdx.x];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cpad) return;
+  uint32_t out = 0;
+  if (c < C) {
+    uint32_t e = 0;
+    bool inf = false;
+    for (int ch = 0; ch < nch; ++ch) {
+      const uint4* row = reinterpret_cast<const uint4*>(S8 + (((int64_t)b * nch + ch) * C + c) * 32);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint4 v = row[h];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int q = ch * 32 + h * 16 + j;
+          const uint32_t x = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+          if (q < Q) {
+            inf |= (x == 255u);   // clamped bin: no upper bound on the score behind it
+            const uint32_t f = fl[q];
+            e += x > f ? x - f : 0u;
+          }
+        }
+      }
+    }
+    if (inf) {
+      out = 255u;
+    } else if (e < L0_ESC_BASE) {
+      out = e;
+    } else {
+      const uint32_t slot = atomicAdd(&esc[(int64_t)b * 64 + 63], 1u);
+      if (slot < L0_ESC_SLOTS) {
+        esc[(int64_t)b * 64 + slot] = e;
+        out = L0_ESC_BASE + slot;
+      } else {
+        out = 255u;
+      }
+    }
+  }
+  e8[(int64_t)b * Cpad + c] = (uint8_t)out;
+}
+
+// ub[cand] = min(F + sum e(c), 0xFFFE), or 0xFFFF when some code has an infinite excess.  8 lanes per candidate, each
+// lane one 16-byte piece (4 codes) of the candidate's unique-code list per step.
+__global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, const uint32_t* __restrict__ esc,
+                                                  const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
+                                                  const int32_t* __restrict__ cand_pid, const int64_t* __restrict__ uoff,
+                                                  const int32_t* __restrict__ ucodes, uint16_t* __restrict__ ub) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
+  uint8_t* tab = l0s;                                             // [Cpad]
+  uint32_t* es = reinterpret_cast<uint32_t*>(l0s + Cpad);         // [64]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  if ((int64_t)blockIdx.x * 128 >= n) return;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad);
+    uint4* dst = reinterpret_cast<uint4*>(tab);
+    for (int64_t i = tid; i < Cpad / 16; i += 1024) dst[i] = src[i];
+    if (tid < 64) es[tid] = esc[(int64_t)b * 64 + tid];
+  }
+  __syncthreads();
+  const uint32_t F = Fsum[b];
+  const int sub = tid & 7;
+  const int64_t stride = (int64_t)gridDim.x * 128;
+  int64_t i = (int64_t)blockIdx.x * 128 + (tid >> 3);
+  // metadata one candidate ahead
+  int64_t u0 = 0;
+  int len = 0;
+  if (i < n) {
+    const int32_t pid = cand_pid[beg + i];
+    u0 = uoff[pid];
+    len = (int)(uoff[pid + 1] - u0);
+  }
+  for (; i < n; i += stride) {
+    int64_t nu0 = 0;
+    int nlen = 0;
+    if (i + stride < n) {
+      const int32_t npid = cand_pid[beg + i + stride];
+      nu0 = uoff[npid];
+      nlen = (int)(uoff[npid + 1] - nu0);
+    }
+    uint32_t sum = 0;
+    bool inf = false;
+    const int32_t* cp = ucodes + u0;
+    for (int t = sub * 4; t < len; t += 32) {
+      int4 cd;
+      __builtin_memcpy(&cd, cp + t, 16);    // dword-aligned only; the list buffer is padded past its end
+      const int32_t c4[4] = {cd.x, cd.y, cd.z, cd.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (t + k < len) {
+          uint32_t v = tab[c4[k]];
+          if (v >= L0_ESC_BASE) {
+            inf |= (v == 255u);
+            v = es[(v - L0_ESC_BASE) & 63];
+          }
+          sum += v;
+        }
+      }
+    }
+    uint32_t infu = inf ? 1u : 0u;
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      sum += shfl_xor_u32(sum, m);
+      infu |= shfl_xor_u32(infu, m);
+    }
+    if (sub == 0) {
+      uint32_t v = F + sum;
+      v = v > 0xFFFEu ? 0xFFFEu : v;
+      ub[beg + i] = (uint16_t)(infu ? L0_INF : v);
+    }
+    u0 = nu0;
+    len = nlen;
+  }
+}
+
+// histogram of min(ub - F, L0_HIST_BINS - 1) per query (hist zeroed by the caller)
+__global__ __launch_bounds__(1024) void k_l0_hist(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
+                                                  const uint32_t* __restrict__ Fsum, uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t l0hh[];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  if ((int64_t)blockIdx.x * 1024 >= n) return;
+  for (int i = tid; i < L0_HIST_BINS; i += 1024) l0hh[i] = 0u;
+  __syncthreads();
+  const uint32_t F = Fsum[b];
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < n; i += (int64_t)gridDim.x * 1024) {
+    const uint32_t v = ub[beg + i];
+    uint32_t k = v >= F ? v - F : 0u;
+    k = k > L0_HIST_BINS - 1 ? L0_HIST_BINS - 1 : k;
+    atomicAdd(&l0hh[k], 1u);
+  }
+  __syncthreads();
+  uint32_t* hg = hist + (int64_t)b * L0_HIST_BINS;
+  for (int i = tid; i < L0_HIST_BINS; i += 1024) {
+    const uint32_t v = l0hh[i];
+    if (v) atomicAdd(&hg[i], v);
+  }
+}
+
+// cut[b] = the largest u with #{ub >= u} >= want (want = min(mult * keep, n)); 0 when nothing is pruned
+__global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__ hist, const int64_t* __restrict__ cand_off, int64_t n_full,
+                                                    int64_t R, int mult, const uint32_t* __restrict__ Fsum, int32_t* __restrict__ cut) {
+  __shared__ uint32_t part[1024];
+  __shared__ int s_k;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t n = cand_off[b + 1] - cand_off[b];
+  int64_t keep = n;
+  if (n_full < keep) keep = n_full;
+  if (R < keep) keep = R;
+  int64_t want = keep * mult;
+  if (want >= n) {
+    if (tid == 0) cut[b] = 0;
+    return;
+  }
+  if (tid == 0) s_k = 0;
+  const uint32_t* hg = hist + (int64_t)b * L0_HIST_BINS;
+  constexpr int BPT = L0_HIST_BINS / 1024;
+  uint32_t own[BPT];
+  uint32_t loc = 0;
+#pragma unroll
+  for (int k = 0; k < BPT; ++k) {
+    own[k] = hg[tid * BPT + k];
+    loc += own[k];
+  }
+  part[tid] = loc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive suffix scan
+    const uint32_t v = (tid + off < 1024) ? part[tid + off] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t above = part[tid] - loc;
+  if (above < (uint32_t)want && part[tid] >= (uint32_t)want) {
+    uint32_t acc = above;
+    int kk = tid * BPT;
+#pragma unroll
+    for (int k = BPT - 1; k >= 0; --k) {
+      acc += own[k];
+      if (acc >= (uint32_t)want) { kk = tid * BPT + k; break; }
+    }
+    s_k = kk;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // bin L0_HIST_BINS-1 collects everything above it (and the infinite ones): cutting there keeps exactly that bin
+    cut[b] = s_k <= 0 ? 0 : (int32_t)(Fsum[b] + (uint32_t)s_k);
+  }
+}
+
+// A_T = keep-th largest exact score of the pilot group -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).
+// One workgroup per query; the pilot scores are sorted in LDS (at most L0_PILOT_MAX of them, else nothing is pruned).
+#define L0_PILOT_MAX 32768
+__global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int64_t* __restrict__ pilot_off,
+                                                 const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
+                                                 int32_t* __restrict__ cut) {
+  extern __shared__ uint32_t l0k[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t n = cand_off[b + 1] - cand_off[b];
+  const int64_t pb = pilot_off[b];
+  const int64_t np = pilot_off[b + 1] - pb;
+  int64_t keep = n;
+  if (n_full < keep) keep = n_full;
+  if (R < keep) keep = R;
+  if (keep >= n || np < keep || np > L0_PILOT_MAX || keep < 1) {
+    if (tid == 0) cut[b] = 0;
+    return;
+  }
+  int np2 = 2;
+  while (np2 < (int)np) np2 <<= 1;
+  for (int i = tid; i < np2; i += 1024) l0k[i] = (i < (int)np) ? mono32(pilot[pb + i]) : 0u;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t a = l0k[i], c = l0k[ixj];
+          const bool desc = ((i & k) == 0);
+          if ((a < c) == desc) { l0k[i] = c; l0k[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    const float at = unmono32(l0k[keep - 1]);
+    int32_t c = 0;
+    if (at == at) {   // NaN scores: prune nothing
+      const double t = floor(128.0 * (double)at + 99.0 * (double)Q) + 1.0;
+      c = t <= 0.0 ? 0 : (t >= 65535.0 ? 65535 : (int32_t)t);   // 65535 keeps only the infinite bounds
+    }
+    cut[b] = c;
+  }
+}
+
+// ordered compaction of { ub >= cut[b] } (same scheme as k_surv_count / k_surv_compact)
+__global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
+                                                  const int32_t* __restrict__ cut, int32_t* __restrict__ blkcnt, int nblk) {
+  const int b = blockIdx.y;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
+  int cnt = 0;
+  if (c0 < n) {
+    const uint32_t ct = (uint32_t)cut[b];
+#pragma unroll
+    for (int k = 0; k < SURV_CHUNK / 256; ++k) {
+      const int64_t i = c0 + threadIdx.x * (SURV_CHUNK / 256) + k;
+      if (i < n) cnt += ((uint32_t)ub[beg + i] >= ct) ? 1 : 0;
+    }
+  }
+  __shared__ int s[256];
+  s[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
+                                                    const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
+                                                    const int32_t* __restrict__ blkoff, int nblk, const int64_t* __restrict__ surv_off,
+                                                    int32_t* __restrict__ surv_pid) {
+  const int b = blockIdx.y;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
+  if (c0 >= n) return;
+  const uint32_t ct = (uint32_t)cut[b];
+  constexpr int PER = SURV_CHUNK / 256;
+  bool keep[PER];
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t i = c0 + threadIdx.x * PER + k;
+    keep[k] = (i < n) && ((uint32_t)ub[beg + i] >= ct);
+    cnt += keep[k] ? 1 : 0;
+  }
+  __shared__ int s[256];
+  s[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int64_t pos = surv_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (keep[k]) surv_pid[pos++] = cand_pid[beg + c0 + threadIdx.x * PER + k];
+  }
+}
+
+size_t fpk_l0_lds_bytes(const FpIndexDev& ix) { return (size_t)((ix.C + 15) & ~(int64_t)15) + 256; }
+bool fpk_l0_fits(const FpIndexDev& ix) { return fpk_l0_lds_bytes(ix) <= 158 * 1024; }
+
+// level 0 in three launch groups so that the scan kernel can be timed alone:
+//   prepare: floors + excess table;  scan: UB0 of every candidate;  pilot: the top mult*keep documents by UB0, compacted
+void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st) {
+  const int B = sh.B;
+  const int nch = sh.Qp / 32;
+  const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
+  static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
+  static std::atomic<uint64_t> ok1{0};
+  fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
+  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum);
+  (void)hipMemsetAsync(w.esc, 0, (size_t)B * 64 * 4, st);
+  hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,
+                     w.esc);
+}
+
+void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w,
+                 hipStream_t st) {
+  const int B = sh.B;
+  const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
+  static std::atomic<uint64_t> ok2{0};
+  fp_allow_big_lds((const void*)k_l0_scan, ok2, 160 * 1024);
+  const int64_t per_q = (M + B - 1) / B;
+  // each workgroup copies the table (Cpad bytes) into LDS first: give it at least ~8 rounds of 128 candidates
+  static const int cpw = [] { const char* e = getenv("FP_L0_CPW"); const int v = e ? atoi(e) : 1024; return v >= 128 ? v : 1024; }();
+  int64_t bx = (per_q + cpw - 1) / cpw;
+  if (bx > 8192) bx = 8192;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, w.esc, w.Fsum, cand_off,
+                     cand_pid, ix.uoff, ix.ucodes, w.ub);
+}
+
+void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, hipStream_t st) {
+  const int B = sh.B;
+  static const int mult = [] { const char* e = getenv("FP_L0_PILOT"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
+  static std::atomic<uint64_t> ok3{0};
+  fp_allow_big_lds((const void*)k_l0_hist, ok3, 72 * 1024);
+  (void)hipMemsetAsync(w.hist, 0, (size_t)B * L0_HIST_BINS * 4, st);
+  hipLaunchKernelGGL(k_l0_hist, dim3(16, (unsigned)B), dim3(1024), (size_t)L0_HIST_BINS * 4, st, w.ub, cand_off, w.Fsum, w.hist);
+  hipLaunchKernelGGL(k_l0_topcut, dim3((unsigned)B), dim3(1024), 0, st, w.hist, cand_off, sh.n_full, sh.R, mult, w.Fsum, w.cut);
+  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.cut, w.blkcnt, w.nblk);
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, w.npilot);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, w.npilot, B, w.pilot_off);
+  hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.blkcnt, w.nblk,
+                     w.pilot_off, w.pilot_pid);
+}
+
+// level 0, second half (the pilot group's exact scores are in w.pilot_approx): threshold, ordered survivors
+void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
+                      int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
+  const int B = sh.B;
+  static std::atomic<uint64_t> ok{0};
+  fp_allow_big_lds((const void*)k_l0_thr, ok, 136 * 1024);
+  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), (size_t)L0_PILOT_MAX * 4, st, w.pilot_approx, w.pilot_off, cand_off, sh.n_full, sh.R,
+                     sh.Q, w.cut);
+  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.cut, w.blkcnt, w.nblk);
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
+  hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.blkcnt, w.nblk, surv_off,
+                     surv_pid);
+}
+
+// ============================================================================================
 // S5  top-R selection by (approx desc, doc id asc): 3-pass radix select (11+11+10 bits) on
 // the monotone key, then one ordered collect pass per query.
 // selstate[b] = {need_select, keep, prefix, k_rem, n, -, -, -}
@@ -2060,6 +2497,10 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
     unsigned long long key = v[i];
     out_pid[(int64_t)b * top_k + i] = (int64_t)(0xFFFFFFFFu - (uint32_t)key);
     out_score[(int64_t)b * top_k + i] = unmono32((uint32_t)(key >> 32));
+  }
+  for (int64_t i = m + threadIdx.x; i < top_k; i += blockDim.x) {   // padding contract (fastplaid.h): id -1, score 0 beyond the count
+    out_pid[(int64_t)b * top_k + i] = -1;
+    out_score[(int64_t)b * top_k + i] = 0.f;
   }
   if (threadIdx.x == 0) out_cnt[b] = m;
 }

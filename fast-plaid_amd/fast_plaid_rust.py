@@ -110,6 +110,10 @@ class PyLoadedIndex:
     def device_bytes(self):
         return int(N.lib().fp_index_device_bytes(self._h))
 
+    @property
+    def n_unique_codes(self):
+        return int(N.lib().fp_index_num_unique_codes(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib().fp_index_destroy(self._h)

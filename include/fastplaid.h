@@ -89,14 +89,17 @@ int64_t fp_index_num_centroids(const fp_index* index);
 int32_t fp_index_dim(const fp_index* index);
 int32_t fp_index_nbits(const fp_index* index);
 int64_t fp_index_device_bytes(const fp_index* index);
+/* Entries of the per-document unique-code lists (the approximate stage walks these instead of the per-token codes). */
+int64_t fp_index_num_unique_codes(const fp_index* index);
 
 /* ---- search: `pysearch` (rust/lib.rs:195-223) -> search_many (search.rs:219-288) ----- */
 /* queries: host [n_queries, q_len, dim] f16.  subset_offsets NULL = no subset; otherwise
  * [n_queries+1] offsets into subset_ids (per-query doc-id lists, lib.rs:202).
  * Outputs (host, caller-allocated): out_pids/out_scores [n_queries, top_k] row-major,
  * out_counts [n_queries] = results per query = min(top_k, max(n_full/4,1), candidates)
- * (search.rs:614, :666); rows are sorted by descending score.  A query whose per-query
- * search fails in the reference (search.rs:268 `.unwrap_or_default()`) gets count 0. */
+ * (search.rs:614, :666); rows are sorted by descending score; the slots [count, top_k) of
+ * a row hold id -1 and score 0.  A query whose per-query search fails in the reference
+ * (search.rs:268 `.unwrap_or_default()`) gets count 0 (its row is left untouched). */
 int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
               const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets,
               int64_t* out_pids, float* out_scores, int32_t* out_counts);

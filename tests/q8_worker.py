@@ -1,7 +1,8 @@
-"""GPU worker for tests/test_hip_parity.py::test_bound_and_refine_forced: FP_APPROX_IMPL=q8 forces
-the 8-bit bound stage of S4 on small corpora (it is otherwise chosen only for large centroid
-tables).  fp_search (bounded path) must equal fp_search_trace (exact score of every candidate)
-bit for bit, and the oracle within the usual tolerances."""
+"""GPU worker for tests/test_hip_parity.py::test_bound_and_refine_forced / test_level0_forced:
+FP_APPROX_IMPL=q8 forces the 8-bit bound stage of S4 on small corpora, FP_APPROX_IMPL=l0 the level-0
+stage (scalar excess bound per centroid in LDS); both are otherwise chosen only for large centroid
+tables / candidate sets.  fp_search (pruned path) must equal fp_search_trace (exact score of every
+candidate) bit for bit, and the oracle within the usual tolerances."""
 import os
 import sys
 
@@ -36,7 +37,7 @@ def same_as_trace(idx, q, params, subs=None):
 
 
 def main():
-    assert os.environ.get("FP_APPROX_IMPL") == "q8"
+    assert os.environ.get("FP_APPROX_IMPL") in ("q8", "l0")
     # committed fixtures (subset, empty documents, zero-padded query rows, unnormalised documents, ...)
     for name in golden_cases():
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))

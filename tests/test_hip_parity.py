@@ -331,6 +331,20 @@ def test_bound_and_refine_forced(fp, ppd):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("tail,pilot", [("0.025", "4"), ("0.3", "1"), ("0.002", "2"), ("0.1", "16")])
+def test_level0_forced(fp, tail, pilot):
+    """S4's level-0 form (per-centroid excess table in LDS -> upper bound of every candidate from its code list alone ->
+    pilot group scored exactly -> threshold -> survivors scored exactly) forced on small corpora via FP_APPROX_IMPL=l0, for
+    several floor quantiles (FP_L0_TAIL) and pilot-group sizes (FP_L0_PILOT): fp_search must equal fp_search_trace (which
+    scores every candidate exactly) bit for bit on the same inputs as the 8-bit bound stage's test."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FP_APPROX_IMPL="l0", FP_L0_TAIL=tail, FP_L0_PILOT=pilot)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("name", ["base_d128_nb4", "d64_nb2", "empty_doc", "zero_pad_query", "topk_gt_ndocs"])
 def test_token_score_matrices(fp, name):
     """fp_token_scores / pysearch_with_token_scores (search.rs:294-363, :668-686): per hit the

@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""CPU simulation (numpy) of S4 pruning bounds on the cfg2 synthetic corpus: how many candidates survive a cheap
+first-level upper bound?  Design aid for the level-0 stage (no GPU needed).
+
+UB_b(d) = sum_q f_q + sum_{c in codes(d)} e(c),   e(c) = sum_q max(0, S8[c,q] - f_q)     (scalar per centroid)
+UB_a(d) = sum_q max(f_q, max_{c in codes(d), c hot} S8[c,q])                                (rows of hot centroids)
+survivor rule: UB + Q > T, T = R-th largest exact K among the candidates (best possible threshold).
+"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fast_plaid_amd as fp
+S = fp.synth
+
+N = int(os.environ.get("SIM_DOCS", 1_000_000)); L = 128; Q = 32; NPROBE = 8; R = 1024
+spec = S.SynthSpec(n_docs=N, doc_len=L, n_centroids=S.default_num_centroids(N * L), seed=42)
+C = spec.n_centroids
+cache = f"/tmp/sim/codes_{N}.npy"
+t0 = time.time()
+if os.path.exists(cache):
+    codes = np.load(cache)
+else:
+    codes = np.empty((N, L), np.int32)
+    step = 8192
+    for d0 in range(0, N, step):
+        d1 = min(N, d0 + step)
+        pids = np.repeat(np.arange(d0, d1, dtype=np.int64), L)
+        tok = np.arange(d0 * L, d1 * L, dtype=np.uint64)
+        codes[d0:d1] = S.token_codes(spec, pids, tok).reshape(d1 - d0, L)
+    codes.sort(axis=1)
+    np.save(cache, codes)
+print("codes", codes.shape, "C", C, "%.1fs" % (time.time() - t0), flush=True)
+uniq = np.ones(codes.shape, bool); uniq[:, 1:] = codes[:, 1:] != codes[:, :-1]
+print("unique codes/doc %.2f" % uniq.sum(1).mean())
+cent = S.centroids(spec)
+cent32 = cent.astype(np.float32)
+nq = int(os.environ.get("SIM_QUERIES", 4))
+qs = S.make_queries(spec, cent, nq, Q, seed=1000)
+for b in range(nq):
+    q = qs[b].astype(np.float32)
+    Sc = (cent32 @ q.T).astype(np.float16)                       # [C, Q]
+    S8 = np.clip(np.floor(Sc.astype(np.float32) * 128.0) + 100, 0, 255).astype(np.int32)
+    # probed cells
+    cells = np.unique(np.argpartition(-Sc.astype(np.float32), NPROBE, axis=0)[:NPROBE].ravel())
+    iscell = np.zeros(C, bool); iscell[cells] = True
+    cand = np.nonzero((iscell[codes]).any(1))[0]
+    cc = codes[cand]; um = uniq[cand]
+    # exact K (8-bit): per column max over codes
+    K = np.zeros(len(cand), np.int64)
+    colmax = np.zeros((len(cand), Q), np.int32)
+    for j in range(L):
+        np.maximum(colmax, S8[cc[:, j]], out=colmax)
+    K = colmax.sum(1)
+    n = len(cand)
+    T = np.sort(K)[-R] if n > R else 0
+    print(f"q{b}: cells {len(cells)} cand {n} ({n/N:.3f})  K: median {np.median(K):.0f} p99 {np.percentile(K,99):.0f} T(R-th) {T} max {K.max()}", flush=True)
+    for pct in (90.0, 95.0, 97.5, 99.0, 99.5):
+        f = np.percentile(S8, pct, axis=0).astype(np.int32)       # per-column floor
+        F = int(f.sum())
+        exc = np.maximum(S8 - f[None, :], 0)
+        e = exc.sum(1)                                           # [C]
+        hot = e > 0
+        ub_b = F + (e[cc] * um).sum(1)
+        # UB_a
+        S8c = np.maximum(S8, f[None, :])
+        cm = np.broadcast_to(f, (n, Q)).copy()
+        for j in range(L):
+            np.maximum(cm, S8c[cc[:, j]], out=cm)
+        ub_a = cm.sum(1)
+        assert (ub_b >= K).all() and (ub_a >= K).all() and (ub_b >= ub_a).all()
+        sb = int((ub_b + Q > T).sum()); sa = int((ub_a + Q > T).sum())
+        # threshold from exactly scoring only the top-4R by UB_b
+        top = np.argsort(-ub_b)[: 4 * R]
+        T4 = np.sort(K[top])[-R] if n > R else 0
+        sb4 = int((ub_b + Q > T4).sum())
+        hot_pairs = float((hot[cc] * um).sum()) / max(um.sum(), 1)
+        e255 = float((e > 254).mean())
+        print(f"   floor p{pct}: F {F} hot centroids {hot.mean():.3f} hot (doc,code) pairs {hot_pairs:.3f} e>254 {e255:.4f} | survivors UB_b {sb} ({sb/n:.4f})  "
+              f"UB_b with T from top-4R {sb4} ({sb4/n:.4f}) T4 {T4} | UB_a {sa} ({sa/n:.4f})", flush=True)
