@@ -1,0 +1,84 @@
+// Device-side helpers shared by the HIP translation units (fp_kernels.hip, fp_maxsim.hip).  gfx950 only.
+#pragma once
+#include <atomic>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define NEG_MASK_F (-10000.0f)  // masked_fill(-9999.0) stored in fp16 (search.rs:395)
+
+__device__ __forceinline__ uint32_t h2_as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ h2 u32_as_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ h2 pk_max(h2 a, h2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+
+// order-preserving maps (larger float <-> larger unsigned)
+__device__ __forceinline__ uint32_t mono16(uint16_t h) {
+  if ((h & 0x7FFF) == 0) h = 0;  // -0 == +0
+  return (h & 0x8000) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000);
+}
+__device__ __forceinline__ uint32_t mono32(float f) {
+  uint32_t b = __float_as_uint(f + 0.0f);  // -0 -> +0
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unmono32(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(b);
+}
+
+// two-term reciprocal: r_hi + r_lo = 1/n to ~2^-47; specials (n = 0, inf, nan) keep IEEE semantics
+__device__ __forceinline__ void recip2(float n, float& r_hi, float& r_lo) {
+  r_hi = 1.0f / n;
+  const float t = __builtin_fmaf(-n, r_hi, 1.0f) * r_hi;
+  const bool ok = (r_hi != 0.0f) && (__builtin_fabsf(r_hi) < __builtin_inff());  // false for nan too
+  r_lo = ok ? t : 0.0f;
+}
+__device__ __forceinline__ float quot2(float e, float r_hi, float r_lo) { return __builtin_fmaf(e, r_hi, e * r_lo); }
+// h(fl32(fma(e, r_hi, e*r_lo))) for two packed fp16 pairs in 10 VALU instructions (2.5 per
+// element, no separate fp16->fp32 conversions: v_fma_mix_f32 takes fp16 sources in place).
+// The result is rounded to fp32 FIRST and then to fp16 by v_cvt_pk_f16_f32, exactly like the
+// reference's h(fl32(e/n)); v_fma_mixlo/hi_f16 would round once and disagree on exact
+// subnormal ties (measured: 5,626 of 2^32 pairs).  Every consumer sits >= 2 instructions after
+// its producer (mix -> dependent op needs one wait state; hipcc does not pad inside asm).
+// fp_selftest_arith runs THIS function over all 2^32 (e, n) pairs.
+__device__ __forceinline__ void norm_pair2(uint32_t& a, uint32_t& b, float r_hi, float r_lo) {
+  uint32_t da, db;
+  float t0, t1, t2, t3;
+  asm("v_fma_mix_f32 %2, %6, %9, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %6, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %4, %7, %9, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %5, %7, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %2, %6, %8, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %6, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %4, %7, %8, %4 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %5, %7, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_cvt_pk_f16_f32 %1, %4, %5"
+      : "=&v"(da), "=&v"(db), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(a), "v"(b), "v"(r_hi), "v"(r_lo));
+  a = da;
+  b = db;
+}
+
+// More than 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (gfx950: 160 KiB per workgroup); one process
+// may drive several GPUs (FastPlaid(device=[...])), so the "done" flag is a bit per device.
+static inline void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_relaxed) & bit)) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_relaxed);
+  }
+}
+
+
+static inline int fp_next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}

@@ -101,12 +101,13 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_off, l0_pilot_pid, l0_pilot_approx;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark;
   HostBuf h_out, h_small;
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
-                      &l0_hist, &l0_npilot, &l0_pilot_off, &l0_pilot_pid, &l0_pilot_approx})
+                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
+                      &ms_nmark})
       b->release();
     h_out.release();
     h_small.release();
@@ -230,10 +231,54 @@ static int upload_narrow(const int64_t* host, int32_t* dev, int64_t n, hipStream
   return FP_OK;
 }
 
+// residual_codec.rs:83-140 / search.rs:53-107 are generic in nbits (a divisor of 8) and dim; the centroid GEMM stages K in
+// 8-dim (16-byte) pieces, hence dim % 8.  MFMA MaxSim kernels exist for dim 48/64/96/128 x nbits 2/4; every other shape runs
+// the generic (exact, slower) MaxSim kernel.
 static int check_shape(int nbits, int dim) {
-  if (!(nbits == 2 || nbits == 4))
-    return fail(FP_EUNSUPPORTED, "nbits must be 2 or 4 (kernels are instantiated for these)");
-  if (!(dim == 64 || dim == 128)) return fail(FP_EUNSUPPORTED, "dim must be 64 or 128 (kernels are instantiated for these)");
+  if (!(nbits == 1 || nbits == 2 || nbits == 4 || nbits == 8)) return fail(FP_EINVAL, "nbits must divide 8 (1, 2, 4 or 8)");
+  if (dim < 8 || dim % 8 != 0 || dim > 1024) return fail(FP_EUNSUPPORTED, "dim must be a multiple of 8 in [8, 1024]");
+  return FP_OK;
+}
+
+struct StreamGuard {   // destroys the construction stream on every exit path
+  hipStream_t st = nullptr;
+  ~StreamGuard() { if (st) (void)hipStreamDestroy(st); }
+};
+
+// common tail of index construction: tokens sorted by code inside each document, per-token norms, per-document unique codes.
+// ix->d.{centroids, lut, codes, residuals, doc_off} are set.  Every device buffer is registered in ix->owned before its
+// producer's return code is looked at, so a failing build frees it with the index.
+static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
+  FpIndexDev& D = ix->d;
+  {
+    uint16_t* perm = nullptr;
+    const int src = fps_sort_docs(const_cast<int32_t*>(D.codes), const_cast<uint8_t*>(D.residuals), D.doc_off, D.N, D.T, maxlen, D.pr, &perm, st);
+    if (perm) { ix->owned.push_back(perm); ix->bytes += D.T * 2; }
+    if (src != 0) return fail(FP_EHIP, "in-document token sort failed (hip error " + std::to_string(src) + ")");
+    D.perm = perm;
+  }
+  {
+    uint16_t* norms = nullptr;
+    hipError_t e = hipMalloc((void**)&norms, (size_t)std::max<int64_t>(D.T, 1) * 2 + 64);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token norms)");
+    ix->owned.push_back(norms);
+    ix->bytes += D.T * 2;
+    fpk_token_norms(D, norms, st);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token norms)");
+    D.norms = norms;
+  }
+  {
+    int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
+    hipError_t e = hipMalloc((void**)&uoff, ((size_t)D.N + 1) * 8 + 64);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (unique-code offsets)");
+    ix->owned.push_back(uoff);
+    ix->bytes += (D.N + 1) * 8;
+    const int urc = fps_build_ucodes(D.codes, D.doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
+    if (ucodes) { ix->owned.push_back(ucodes); ix->bytes += U * 4; }
+    if (urc != 0) return fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")");
+    D.ucodes = ucodes; D.uoff = uoff; D.U = U;
+  }
   return FP_OK;
 }
 
@@ -252,7 +297,8 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
     fp_index_destroy(ix);
     return rc;
   };
-  hipStream_t st = nullptr;
+  StreamGuard sg;
+  hipStream_t& st = sg.st;
   FpIndexDev& D = ix->d;
   D.nbits = d->nbits; D.dim = d->dim; D.pr = d->dim * d->nbits / 8;
   D.C = d->n_centroids; D.N = d->n_docs; D.pid_offset = d->pid_offset;
@@ -280,31 +326,17 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   ICHK(dev_alloc(ix, &doc_off, (size_t)D.N + 1));
   ICHK(hipMemcpy(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice));
   ICHK(dev_alloc(ix, &codes, (size_t)D.T));
-  if (int rc = upload_narrow(d->doc_codes, codes, D.T, st)) { (void)hipStreamDestroy(st); return bail(rc); }
+  if (int rc = upload_narrow(d->doc_codes, codes, D.T, st)) return bail(rc);
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   if (D.T > 0) ICHK(hipMemcpy(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice));
-  {
-    uint16_t* perm = nullptr;
-    int src = fps_sort_docs(codes, res, doc_off, D.N, D.T, maxlen, D.pr, &perm, st);
-    if (src != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "in-document token sort failed (hip error " + std::to_string(src) + ")")); }
-    if (perm) { ix->owned.push_back(perm); ix->bytes += D.T * 2; }
-    D.perm = perm;
-  }
-  {
-    int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
-    ICHK(dev_alloc(ix, &uoff, (size_t)D.N + 1));
-    int urc = fps_build_ucodes(codes, doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
-    if (urc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")")); }
-    ix->owned.push_back(ucodes);
-    ix->bytes += U * 4;
-    D.ucodes = ucodes; D.uoff = uoff; D.U = U;
-  }
+  D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res;
+  if (int rc = finish_layout(ix, maxlen, st)) return bail(rc);
   ix->has_ivf = d->ivf != nullptr && d->ivf_lengths != nullptr;
   D.P = ix->has_ivf ? d->n_ivf_lists : 0;
   {
     std::vector<int64_t> hoff((size_t)D.P + 1, 0);
     for (int64_t i = 0; i < D.P; ++i) {
-      if (d->ivf_lengths[i] < 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EINVAL, "negative ivf length")); }
+      if (d->ivf_lengths[i] < 0) return bail(fail(FP_EINVAL, "negative ivf length"));
       hoff[i + 1] = hoff[i] + d->ivf_lengths[i];
     }
     ICHK(dev_alloc(ix, &ivf_off, hoff.size()));
@@ -312,11 +344,11 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
     const int64_t tot = hoff[D.P];
     ICHK(dev_alloc(ix, &ivf_pids, (size_t)tot));
     if (tot > 0)
-      if (int rc = upload_narrow(d->ivf, ivf_pids, tot, st)) { (void)hipStreamDestroy(st); return bail(rc); }
+      if (int rc = upload_narrow(d->ivf, ivf_pids, tot, st)) return bail(rc);
   }
-  ICHK(hipStreamDestroy(st));
+  ICHK(hipStreamSynchronize(st));
 #undef ICHK
-  D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res; D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
+  D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
   *out = ix;
   return FP_OK;
 }
@@ -375,7 +407,8 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x)); } while (0)
   uint16_t* cent = nullptr; uint16_t* lut = nullptr; int64_t* doc_off = nullptr; int32_t* codes = nullptr; uint8_t* res = nullptr;
   int64_t* ivf_off = nullptr; int32_t* ivf_pids = nullptr;
-  hipStream_t st = nullptr;
+  StreamGuard sg;
+  hipStream_t& st = sg.st;
   ICHK(hipStreamCreate(&st));
   ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
   ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
@@ -389,32 +422,17 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   fps_generate(p, doc_off, D.N, D.T, tok_base, codes, res, st);
   ICHK(hipStreamSynchronize(st));
-  {
-    uint16_t* perm = nullptr;
-    int src = fps_sort_docs(codes, res, doc_off, D.N, D.T, maxlen, D.pr, &perm, st);
-    if (src != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "in-document token sort failed (hip error " + std::to_string(src) + ")")); }
-    if (perm) { ix->owned.push_back(perm); ix->bytes += D.T * 2; }
-    D.perm = perm;
-  }
-  {
-    int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
-    ICHK(dev_alloc(ix, &uoff, (size_t)D.N + 1));
-    int urc = fps_build_ucodes(codes, doc_off, D.N, maxlen, &ucodes, &U, uoff, st);
-    if (urc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")")); }
-    ix->owned.push_back(ucodes);
-    ix->bytes += U * 4;
-    D.ucodes = ucodes; D.uoff = uoff; D.U = U;
-  }
+  D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res;
+  if (int rc = finish_layout(ix, maxlen, st)) return bail(rc);
   ICHK(dev_alloc(ix, &ivf_off, (size_t)D.P + 1));
   int64_t tot = 0;
   int rc = fps_build_ivf(D.ucodes, D.uoff, D.N, D.U, D.P, &ivf_pids, &tot, ivf_off, st);
-  if (rc != 0) { (void)hipStreamDestroy(st); return bail(fail(FP_EHIP, "IVF build failed (hip/hipcub error " + std::to_string(rc) + ")")); }
-  ix->owned.push_back(ivf_pids);
-  ix->bytes += tot * 4;
-  ICHK(hipStreamDestroy(st));
+  if (ivf_pids) { ix->owned.push_back(ivf_pids); ix->bytes += tot * 4; }
+  if (rc != 0) return bail(fail(FP_EHIP, "IVF build failed (hip/hipcub error " + std::to_string(rc) + ")"));
+  ICHK(hipStreamSynchronize(st));
 #undef ICHK
   ix->has_ivf = true;
-  D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res; D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
+  D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
   *out = ix;
   return FP_OK;
 }
@@ -611,21 +629,21 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       HIPCHK(s->l0_e8.ensure((size_t)B * Cpad));
       HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
       HIPCHK(s->l0_ub.ensure((size_t)M * 2));
-      HIPCHK(s->l0_hist.ensure((size_t)B * 16384 * 4));
+      const int64_t pcap = fpk_l0_pilot_cap();
+      HIPCHK(s->l0_hist.ensure((size_t)B * 4096 * 4));
       HIPCHK(s->l0_npilot.ensure((size_t)B * 4));
-      HIPCHK(s->l0_pilot_off.ensure((size_t)(B + 1) * 8));
-      HIPCHK(s->l0_pilot_pid.ensure((size_t)M * 4));
-      HIPCHK(s->l0_pilot_approx.ensure((size_t)M * 4));
+      HIPCHK(s->l0_pilot_pid.ensure((size_t)B * pcap * 4));
+      HIPCHK(s->l0_pilot_approx.ensure((size_t)B * pcap * 4));
       FpL0Scratch w{s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(),
                     s->l0_ub.as<uint16_t>(), s->l0_hist.as<uint32_t>(), s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2,
-                    s->l0_npilot.as<int32_t>(), s->l0_pilot_off.as<int64_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>()};
+                    s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>()};
       fpk_l0_prepare(D, s->S8.as<uint8_t>(), sh, w, st);
       HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
       fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
       HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
-      fpk_l0_pilot(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, st);
-      // exact scores of the pilot group (<= FP_L0_PILOT x keep documents per query unless UB0 ties inflate it)
-      fpk_approx(D, s->S.as<uint16_t>(), sh, w.pilot_off, w.pilot_pid, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), w.pilot_approx, st);
+      fpk_l0_pilot(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
+      // exact scores of the pilot group (about FP_L0_PILOT x keep documents per query; ties of UB0 at the cut can add more)
+      fpk_approx(D, s->S.as<uint16_t>(), sh, nullptr, w.pilot_pid, std::min<int64_t>(M, 6 * (int64_t)B * sh.R), w.pilot_approx, st, w.npilot, pcap);
       fpk_l0_survivors(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
                        s->surv_pid.as<int32_t>(), st);
     } else {
@@ -663,6 +681,38 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st);
   HIPCHK(hipEventRecord(s->ev[ST_MAXSIM], st));
+  return FP_OK;
+}
+
+// S6+S7 with the exact-order repair: MaxSim on MFMA, then the flagged columns of the documents that are near-tied in the final
+// ranking (near_tied_only; every flagged document otherwise) are re-evaluated with the reference's ascending-k chain.
+static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, bool near_tied_only) {
+  const FpIndexDev& D = ix->d;
+  hipStream_t st = s->st;
+  const int B = sh.B;
+  static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();   // 0: off, 2: every flagged document
+  HIPCHK(s->exact.ensure((size_t)B * R * 4));
+  HIPCHK(s->ms_pref.ensure((size_t)(B + 1) * 8));
+  const bool repair = repair_env != 0 && fpk_maxsim_fast_shape(D.dim, D.nbits);
+  FpMaxsimAux aux{nullptr, nullptr, nullptr};
+  if (repair) {
+    HIPCHK(s->ms_cm16.ensure((size_t)B * R * sh.Qp * 2));
+    HIPCHK(s->ms_unc.ensure((size_t)B * R * 4));
+    HIPCHK(s->ms_flags.ensure((size_t)B * R * (sh.Qp / 32) * 4));
+    HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
+    HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
+    aux = FpMaxsimAux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>()};
+  }
+  if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(),
+                 s->ms_pref.as<int64_t>(), aux, st))
+    return fail(FP_EUNSUPPORTED, "dim/nbits");
+  if (repair) {
+    const bool marked = near_tied_only && repair_env != 2 &&
+                        fpk_final_mark(s->exact.as<float>(), aux.unc, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
+                                       s->ms_nmark.as<int32_t>(), st) == 0;
+    fpk_maxsim_repair(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R,
+                      marked ? s->ms_marks.as<int32_t>() : nullptr, marked ? s->ms_nmark.as<int32_t>() : nullptr, s->exact.as<float>(), aux, st);
+  }
   return FP_OK;
 }
 
@@ -728,9 +778,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     g_last_counts[3] += 1;
     // S6+S7
     const int64_t R = P.sh.R;
-    HIPCHK(s->exact.ensure((size_t)B * R * 4));
-    if (fpk_maxsim(D, s->qpad.as<uint16_t>(), P.sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(), st))
-      return fail(FP_EUNSUPPORTED, "dim/nbits");
+    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, true)) return rc;
     HIPCHK(hipEventRecord(s->ev[ST_TOPK], st));
     // S8
     const int64_t K = p->top_k;
@@ -973,8 +1021,8 @@ extern "C" int fp_token_scores(const fp_index* cix, const uint16_t* queries, int
 extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, int32_t dim, int32_t nbits, const uint16_t* cutoffs,
                            const uint16_t* emb, int64_t T, int64_t* out_codes, uint8_t* out_res) {
   if (!centroids || !cutoffs || C < 1 || T < 0 || (T > 0 && (!emb || !out_codes || !out_res))) return fail(FP_EINVAL, "bad argument");
-  if (!(nbits == 2 || nbits == 4)) return fail(FP_EUNSUPPORTED, "nbits must be 2 or 4");
-  if (!(dim == 64 || dim == 128)) return fail(FP_EUNSUPPORTED, "dim must be 64 or 128");
+  if (!(nbits == 1 || nbits == 2 || nbits == 4 || nbits == 8)) return fail(FP_EINVAL, "nbits must divide 8 (1, 2, 4 or 8)");
+  if (dim < 1 || dim > 256 || (dim * nbits) % 8 != 0) return fail(FP_EUNSUPPORTED, "fp_compress: dim must be in [1, 256] with dim * nbits a multiple of 8");
   if (C >= 0x7FFFFFFFll) return fail(FP_EUNSUPPORTED, "too many centroids");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FP_EHIP, "no HIP device available (this library has no CPU path)");
@@ -1009,7 +1057,7 @@ extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, 
   } while (0)
   CCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CCHK(hipMalloc(&d_cent, (size_t)C * dim * 2));
-  CCHK(hipMalloc(&d_cut, 64));
+  CCHK(hipMalloc(&d_cut, 1024));   // up to 255 cutoffs (nbits = 8)
   CCHK(hipMalloc(&d_emb, (size_t)cap * dim * 2));
   CCHK(hipMalloc(&d_c32, (size_t)cap * 4));
   CCHK(hipMalloc(&d_c64, (size_t)cap * 8));
@@ -1038,7 +1086,7 @@ extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, 
 extern "C" int fp_assign_l2(int device_id, const uint16_t* centroids, const float* half_sqnorm, int64_t C, int32_t dim, const uint16_t* emb,
                             int64_t T, int64_t* out_labels) {
   if (!centroids || !half_sqnorm || C < 1 || T < 0 || (T > 0 && (!emb || !out_labels))) return fail(FP_EINVAL, "bad argument");
-  if (!(dim == 64 || dim == 128)) return fail(FP_EUNSUPPORTED, "dim must be 64 or 128");
+  if (dim < 1 || dim > 256) return fail(FP_EUNSUPPORTED, "fp_assign_l2: dim must be in [1, 256]");
   if (C >= 0x7FFFFFFFll) return fail(FP_EUNSUPPORTED, "too many centroids");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FP_EHIP, "no HIP device available (this library has no CPU path)");
@@ -1176,9 +1224,8 @@ extern "C" int fp_shard_stage2(fp_shard_ctx* c, const float* all_approx, const i
   fpk_shard_global_cut(s->tmpf.as<float>(), s->tmpp.as<int64_t>(), G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(),
                        s->sel_cnt.as<int32_t>(), s->st);
   HIPCHK(s->exact.ensure((size_t)B * R * 4));
-  if (!c->empty_all) {
-    if (fpk_maxsim(D, s->qpad.as<uint16_t>(), c->P.sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(), s->st))
-      return fail(FP_EUNSUPPORTED, "dim/nbits");
+  if (!c->empty_all) {   // the final ranking is only known after the exchange: every flagged document of this shard is repaired
+    if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, false)) return rc;
   }
   fpk_shard_pack_scores(s->exact.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_loc_score,
                         dev_loc_pid, s->st);

@@ -43,6 +43,7 @@ struct FpIndexDev {
   const int64_t* uoff;     // [N+1]
   int64_t U;
   int max_doc_len;
+  const uint16_t* norms;   // [T]   fp16 bits of h(sqrt(sum_fp32 e_k^2)) per stored token (ascending-k sum; computed at index creation)
 };
 
 // A HIP dispatch carries its grid size in work-items as a 32-bit number: blocks * block_size must
@@ -87,8 +88,9 @@ void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkcnt /*exclusive-scanned*/, int nblk, const int64_t* cand_off, int32_t* cand_pid,
                       hipStream_t st);
+// candidate lists as CSR (cand_off) or, with cnt != nullptr, as fixed-capacity rows [B][cap] with min(cnt[b], cap) entries each
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
-                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st);
+                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt = nullptr, int64_t cap = 0);
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
@@ -103,27 +105,44 @@ struct FpL0Scratch {
   uint8_t* e8;          // [B][Cpad]
   uint32_t* esc;        // [B][64]
   uint16_t* ub;         // [M]
-  uint32_t* hist;       // [B][16384]
+  uint32_t* hist;       // [B][4096]
   int32_t* cut;         // [B]
   int32_t* blkcnt;      // [B][nblk]
   int nblk;             // ceil(max candidates per query / FP_SURV_CHUNK)
-  int32_t* npilot;      // [B]
-  int64_t* pilot_off;   // [B+1]
-  int32_t* pilot_pid;   // [M]
-  float* pilot_approx;  // [M]
+  int32_t* npilot;      // [B] (may exceed the capacity: then nothing is pruned)
+  int32_t* pilot_pid;   // [B][fpk_l0_pilot_cap()]
+  float* pilot_approx;  // [B][fpk_l0_pilot_cap()]
 };
 bool fpk_l0_fits(const FpIndexDev& ix);
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st);
 void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w,
                  hipStream_t st);
-void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, hipStream_t st);
+void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st);
+int64_t fpk_l0_pilot_cap();
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
                       int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st);
-int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid,
-               const int32_t* sel_cnt, int64_t Rcap, float* exact /*[B][Rcap]*/, hipStream_t st);
+// ---- fp_maxsim.hip ---------------------------------------------------------------------------
+// per-token norms of a freshly laid-out index (centroids / lut / codes / residuals set in `ix`)
+void fpk_token_norms(const FpIndexDev& ix, uint16_t* norms, hipStream_t st);
+// by-products of the MaxSim kernel for the exact-order repair (all three or none)
+struct FpMaxsimAux {
+  uint16_t* cm16;    // [B][Rcap][Qp] per-column maxima (fp16 bits)
+  float* unc;        // [B][Rcap]     uncertainty budget: sum of the fp16 ulps of the flagged columns (0 = certainly the reference's score)
+  uint32_t* flags;   // [B][Rcap][Qp/32] flagged columns
+};
+bool fpk_maxsim_fast_shape(int dim, int nbits);
+// exact scores of the rerank lists; pref = [B+1] int64 scratch
+int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
+               int64_t Rcap, float* exact /*[B][Rcap]*/, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st);
+// flagged documents that are near-tied in the final ranking -> marks [B][stride], nmark [B]; -1 when stride is too large for LDS
+int fpk_final_mark(const float* score, const float* unc, const int32_t* cnt, int64_t stride, int B, int64_t top_k, int32_t* marks, int32_t* nmark,
+                   hipStream_t st);
+// exact (ascending-k) re-evaluation of the flagged columns of the marked documents (marks == nullptr: of every flagged document)
+void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
+                       int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st);
 // final ranking: sort (score desc, id asc), emit top_k with pid_offset applied
 void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local /*[B][stride] or null*/,
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,

@@ -24,77 +24,7 @@
 
 #include "fp_internal.h"
 
-typedef _Float16 half_t;
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-#define NEG_MASK_F (-10000.0f)  // masked_fill(-9999.0) stored in fp16 (search.rs:395)
-
-__device__ __forceinline__ uint32_t h2_as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ h2 u32_as_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
-__device__ __forceinline__ h2 pk_max(h2 a, h2 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
-
-// order-preserving maps (larger float <-> larger unsigned)
-__device__ __forceinline__ uint32_t mono16(uint16_t h) {
-  if ((h & 0x7FFF) == 0) h = 0;  // -0 == +0
-  return (h & 0x8000) ? (uint32_t)(uint16_t)~h : (uint32_t)(h | 0x8000);
-}
-__device__ __forceinline__ uint32_t mono32(float f) {
-  uint32_t b = __float_as_uint(f + 0.0f);  // -0 -> +0
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float unmono32(uint32_t k) {
-  uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-  return __uint_as_float(b);
-}
-
-// two-term reciprocal: r_hi + r_lo = 1/n to ~2^-47; specials (n = 0, inf, nan) keep IEEE semantics
-__device__ __forceinline__ void recip2(float n, float& r_hi, float& r_lo) {
-  r_hi = 1.0f / n;
-  const float t = __builtin_fmaf(-n, r_hi, 1.0f) * r_hi;
-  const bool ok = (r_hi != 0.0f) && (__builtin_fabsf(r_hi) < __builtin_inff());  // false for nan too
-  r_lo = ok ? t : 0.0f;
-}
-__device__ __forceinline__ float quot2(float e, float r_hi, float r_lo) { return __builtin_fmaf(e, r_hi, e * r_lo); }
-// h(fl32(fma(e, r_hi, e*r_lo))) for two packed fp16 pairs in 10 VALU instructions (2.5 per
-// element, no separate fp16->fp32 conversions: v_fma_mix_f32 takes fp16 sources in place).
-// The result is rounded to fp32 FIRST and then to fp16 by v_cvt_pk_f16_f32, exactly like the
-// reference's h(fl32(e/n)); v_fma_mixlo/hi_f16 would round once and disagree on exact
-// subnormal ties (measured: 5,626 of 2^32 pairs).  Every consumer sits >= 2 instructions after
-// its producer (mix -> dependent op needs one wait state; hipcc does not pad inside asm).
-// fp_selftest_arith runs THIS function over all 2^32 (e, n) pairs.
-__device__ __forceinline__ void norm_pair2(uint32_t& a, uint32_t& b, float r_hi, float r_lo) {
-  uint32_t da, db;
-  float t0, t1, t2, t3;
-  asm("v_fma_mix_f32 %2, %6, %9, 0 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %3, %6, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %4, %7, %9, 0 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %5, %7, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %2, %6, %8, %2 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %3, %6, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %4, %7, %8, %4 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %5, %7, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
-      "v_cvt_pk_f16_f32 %1, %4, %5"
-      : "=&v"(da), "=&v"(db), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-      : "v"(a), "v"(b), "v"(r_hi), "v"(r_lo));
-  a = da;
-  b = db;
-}
-
-// More than 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (gfx950: 160 KiB per workgroup); one process
-// may drive several GPUs (FastPlaid(device=[...])), so the "done" flag is a bit per device.
-static void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done, int bytes) {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const uint64_t bit = 1ull << (dev & 63);
-  if (!(done.load(std::memory_order_relaxed) & bit)) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    done.fetch_or(bit, std::memory_order_relaxed);
-  }
-}
+#include "fp_device.h"
 
 // ============================================================================================
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
@@ -130,15 +60,15 @@ void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, i
 //     maxima at 128-centroid granularity for free.
 // ============================================================================================
 #define S1_TILE 128
-template <int D>
+template <int KS>
 __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
                                                          uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
-                                                         int nch) {
+                                                         int nch, int D) {
   // K is consumed in slices of KS dims: the operand tiles take 2 x 128 x KS x 2 B of LDS (32 KiB at KS = 64) instead of
   // 64 KiB for the whole K = 128, which lifts the kernel from 2 to 3 workgroups per CU (VGPR limit) so that one
-  // workgroup's store phase overlaps another's MFMA phase.
-  constexpr int KS = D < 64 ? D : 64;    // dims per slice
+  // workgroup's store phase overlaps another's MFMA phase.  Any dim that is a multiple of 8 (one 16-byte piece): KS = 64 /
+  // 32 / 16 is the widest slice that divides dim, or 16 with the last slice's upper half zero-filled when dim % 16 == 8.
   constexpr int CH = KS / 8;             // 16-byte chunks per slice row
   constexpr int ROWB = KS * 2;           // bytes per slice row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -164,8 +94,9 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
       int row = i / CH, j = i % CH;
       int js = j ^ (row & (CH - 1));
       uint4 vq = make_uint4(0, 0, 0, 0), vc = make_uint4(0, 0, 0, 0);
-      if (n0 + row < Ntot) vq = *reinterpret_cast<const uint4*>(qpad + (n0 + row) * D + k0 + j * 8);
-      if (c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + k0 + j * 8);
+      const bool kin = k0 + j * 8 < D;
+      if (kin && n0 + row < Ntot) vq = *reinterpret_cast<const uint4*>(qpad + (n0 + row) * D + k0 + j * 8);
+      if (kin && c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + k0 + j * 8);
       *reinterpret_cast<uint4*>(Qs + row * ROWB + js * 16) = vq;
       *reinterpret_cast<uint4*>(Cs + row * ROWB + js * 16) = vc;
     }
@@ -284,14 +215,17 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
   if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
   const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
-  if (ix.dim == 128) {
+  const int D = ix.dim;
+  if (D % 8 != 0 || D < 8) return -1;
+  if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<128>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch);
-  } else if (ix.dim == 64) {
-    const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch);
+    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch, D);
+  } else if (D % 32 == 0) {
+    const size_t lds = std::max<size_t>(2 * 128 * 32 * 2, out_lds);
+    hipLaunchKernelGGL(k_centroid_scores<32>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch, D);
   } else {
-    return -1;
+    const size_t lds = std::max<size_t>(2 * 128 * 16 * 2, out_lds);
+    hipLaunchKernelGGL(k_centroid_scores<16>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch, D);
   }
   return 0;
 }
@@ -580,11 +514,7 @@ static void launch_probe_partial(const uint16_t* S, const FpIndexDev& ix, const 
   hipLaunchKernelGGL(k_probe_partial<NP>, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, nchunk, allow, Cw, partial, flag);
 }
 
-static int next_pow2(int x) {
-  int p = 1;
-  while (p < x) p <<= 1;
-  return p;
-}
+static int next_pow2(int x) { return fp_next_pow2(x); }
 
 // scratch layout inside `partial` (bytes): [cand B*Qp*CAP*8][fallback partial B*Qp*nchunk*8*NP*8][cmax B*Qp*nch2*2][tau B*Qp*4][cnt B*Qp*4][flag 4]
 size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk) {
@@ -944,12 +874,13 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
-                                                float* __restrict__ approx) {
+                                                float* __restrict__ approx, const int32_t* __restrict__ cnt, int64_t cap) {
+  // candidate lists: CSR (cand_off [B+1]) or, with cnt != nullptr, fixed-capacity rows [B][cap] holding min(cnt[b], cap) entries
   const int b = blockIdx.y;
   const int bxi = blockIdx.x;
   const int bx = gridDim.x;
-  const int64_t beg = cand_off[b];
-  const int64_t n = cand_off[b + 1] - beg;
+  const int64_t beg = cnt ? (int64_t)b * cap : cand_off[b];
+  const int64_t n = cnt ? (cnt[b] < cap ? (int64_t)cnt[b] : cap) : cand_off[b + 1] - beg;
   const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
   const int grp = threadIdx.x >> 2;           // candidate slot within the block (0..63)
   const half_t negm = (half_t)NEG_MASK_F;
@@ -1050,7 +981,7 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
 }
 
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
-                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st) {
+                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt, int64_t cap) {
   if (M <= 0) return;
   // enough blocks to cover the largest per-query candidate list a few times over
   int64_t per_q = (M + sh.B - 1) / sh.B;
@@ -1060,7 +991,7 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   // walks the per-document UNIQUE code lists (max over a multiset == max over its set).
   // (an XCD-affine query assignment was measured slower: 8.3 vs 7.6 ms)
   hipLaunchKernelGGL(k_approx, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                     ix.uoff, ix.ucodes, approx);
+                     ix.uoff, ix.ucodes, approx, cnt, cap);
 }
 
 // ============================================================================================
@@ -1467,7 +1398,6 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 #define L0_ESC_BASE 192
 #define L0_ESC_SLOTS 63
 #define L0_INF 0xFFFFu
-#define L0_HIST_BINS 16384      // histogram of min(UB0 - F, 16383)
 #define L0_SAMPLE 8192          // centroids sampled for the column quantiles
 
 // floors[b][Qp] u8 (pad columns 0), Fsum[b]; one workgroup per query
@@ -1562,109 +1492,152 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
   e8[(int64_t)b * Cpad + c] = (uint8_t)out;
 }
 
-// ub[cand] = min(F + sum e(c), 0xFFFE), or 0xFFFF when some code has an infinite excess.  8 lanes per candidate, each
-// lane one 16-byte piece (4 codes) of the candidate's unique-code list per step.
+// ub[cand] = min(F + sum e(c), 0xFFFE), or 0xFFFF when some code has an infinite excess.
+// 8 lanes per candidate, each lane one 16-byte piece (4 codes) of the candidate's unique-code list; a lane group takes TWO
+// consecutive candidates per iteration and issues the first two pieces of both lists before it consumes any of them (4 loads
+// in flight per lane; the kernel was latency-bound at one: 3.3 TB/s of fabric traffic, VALU 32 % busy), the offsets of the
+// next iteration's candidates and the ids of the one after are fetched in the shadow.  Escape slots / infinite entries take a
+// rare second pass over the candidate.  The histogram of (ub - F) >> 2 that the pilot cut needs is built here in LDS.
+#define L0_HBINS 4096
+__device__ __forceinline__ uint32_t l0_red8(uint32_t v) {   // sum over the 8 lanes of a group, in all of them (no lane outside the group is read)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the group
+  return v;
+}
+__device__ __forceinline__ uint32_t l0_max8(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  return v;
+}
 __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int64_t* __restrict__ uoff,
-                                                  const int32_t* __restrict__ ucodes, uint16_t* __restrict__ ub) {
+                                                  const int32_t* __restrict__ ucodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
-  uint8_t* tab = l0s;                                             // [Cpad]
-  uint32_t* es = reinterpret_cast<uint32_t*>(l0s + Cpad);         // [64]
+  uint8_t* tab = l0s;                                                  // [Cpad + 16]: the 16 bytes behind the table are 0 (index of masked codes)
+  uint32_t* es = reinterpret_cast<uint32_t*>(l0s + Cpad + 16);         // [64]
+  uint32_t* hl = es + 64;                                              // [L0_HBINS]
   const int b = blockIdx.y, tid = threadIdx.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
-  if ((int64_t)blockIdx.x * 128 >= n) return;
+  if ((int64_t)blockIdx.x * 256 >= n) return;
   {
     const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad);
     uint4* dst = reinterpret_cast<uint4*>(tab);
     for (int64_t i = tid; i < Cpad / 16; i += 1024) dst[i] = src[i];
+    if (tid < 4) reinterpret_cast<uint32_t*>(tab + Cpad)[tid] = 0u;
     if (tid < 64) es[tid] = esc[(int64_t)b * 64 + tid];
+    for (int i = tid; i < L0_HBINS; i += 1024) hl[i] = 0u;
   }
   __syncthreads();
   const uint32_t F = Fsum[b];
   const int sub = tid & 7;
-  const int64_t stride = (int64_t)gridDim.x * 128;
-  int64_t i = (int64_t)blockIdx.x * 128 + (tid >> 3);
-  // metadata one candidate ahead
-  int64_t u0 = 0;
-  int len = 0;
-  if (i < n) {
-    const int32_t pid = cand_pid[beg + i];
-    u0 = uoff[pid];
-    len = (int)(uoff[pid + 1] - u0);
-  }
-  for (; i < n; i += stride) {
-    int64_t nu0 = 0;
-    int nlen = 0;
-    if (i + stride < n) {
-      const int32_t npid = cand_pid[beg + i + stride];
-      nu0 = uoff[npid];
-      nlen = (int)(uoff[npid + 1] - nu0);
-    }
-    uint32_t sum = 0;
-    bool inf = false;
-    const int32_t* cp = ucodes + u0;
-    for (int t = sub * 4; t < len; t += 32) {
-      int4 cd;
-      __builtin_memcpy(&cd, cp + t, 16);    // dword-aligned only; the list buffer is padded past its end
-      const int32_t c4[4] = {cd.x, cd.y, cd.z, cd.w};
+  const int32_t zidx = (int32_t)Cpad;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int32_t* cpids = cand_pid + beg;
+  // pipeline registers: [0] / [1] = the group's two candidates
+  int64_t i = (int64_t)blockIdx.x * 256 + (tid >> 3) * 2;
+  int32_t pidn[2] = {0, 0};          // ids of the next iteration
+  int64_t u0[2] = {0, 0};
+  int len[2] = {0, 0};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (t + k < len) {
-          uint32_t v = tab[c4[k]];
+  for (int k = 0; k < 2; ++k) {
+    if (i + k < n) {
+      const int32_t pid = cpids[i + k];
+      const longlong2 o = *reinterpret_cast<const longlong2*>(uoff + pid);
+      u0[k] = o.x;
+      len[k] = (int)(o.y - o.x);
+    }
+    if (i + stride + k < n) pidn[k] = cpids[i + stride + k];
+  }
+  auto lookup4 = [&](const int4& cd, int rem, uint32_t& sum, uint32_t& mx) {   // rem = codes of this piece that exist (may be <= 0)
+    const int32_t c4[4] = {cd.x, cd.y, cd.z, cd.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t v = tab[k < rem ? c4[k] : zidx];
+      sum += v;
+      mx = max(mx, v);
+    }
+  };
+  for (; i < n; i += stride) {
+    // this iteration's code pieces: two per candidate up front
+    int4 cd[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int32_t* cp = ucodes + u0[k] + sub * 4;
+      cd[k][0] = make_int4(0, 0, 0, 0);
+      cd[k][1] = make_int4(0, 0, 0, 0);
+      if (sub * 4 < len[k]) __builtin_memcpy(&cd[k][0], cp, 16);        // dword-aligned only; the list buffer is padded past its end
+      if (32 + sub * 4 < len[k]) __builtin_memcpy(&cd[k][1], cp + 32, 16);
+    }
+    // next iteration's offsets, the ids of the one after
+    int64_t nu0[2] = {0, 0};
+    int nlen[2] = {0, 0};
+    int32_t pidnn[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (i + stride + k < n) {
+        const longlong2 o = *reinterpret_cast<const longlong2*>(uoff + pidn[k]);
+        nu0[k] = o.x;
+        nlen[k] = (int)(o.y - o.x);
+      }
+      if (i + 2 * stride + k < n) pidnn[k] = cpids[i + 2 * stride + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint32_t sum = 0, mx = 0;
+      lookup4(cd[k][0], len[k] - sub * 4, sum, mx);
+      lookup4(cd[k][1], len[k] - 32 - sub * 4, sum, mx);
+      for (int t = 64 + sub * 4; t < len[k]; t += 32) {   // long lists (documents with more than 64 distinct codes)
+        int4 c;
+        __builtin_memcpy(&c, ucodes + u0[k] + t, 16);
+        lookup4(c, len[k] - t, sum, mx);
+      }
+      sum = l0_red8(sum);
+      mx = l0_max8(mx);
+      if (mx >= L0_ESC_BASE) {   // rare: a code with an escaped or infinite excess -- redo this candidate with the slow decode
+        uint32_t s2 = 0, inf = 0;
+        for (int t = sub; t < len[k]; t += 8) {
+          uint32_t v = tab[ucodes[u0[k] + t]];
           if (v >= L0_ESC_BASE) {
-            inf |= (v == 255u);
+            inf |= (v == 255u) ? 1u : 0u;
             v = es[(v - L0_ESC_BASE) & 63];
           }
-          sum += v;
+          s2 += v;
         }
+        sum = l0_red8(s2);
+        mx = l0_max8(inf);
+        sum = mx ? 0xFFFFFFu : sum;
+      }
+      if (sub == 0 && i + k < n) {
+        uint32_t v = F + sum;
+        v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
+        ub[beg + i + k] = (uint16_t)v;
+        uint32_t hb = (v >= F ? v - F : 0u) >> 2;
+        atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
       }
     }
-    uint32_t infu = inf ? 1u : 0u;
 #pragma unroll
-    for (int m = 1; m < 8; m <<= 1) {
-      sum += shfl_xor_u32(sum, m);
-      infu |= shfl_xor_u32(infu, m);
+    for (int k = 0; k < 2; ++k) {
+      u0[k] = nu0[k];
+      len[k] = nlen[k];
+      pidn[k] = pidnn[k];
     }
-    if (sub == 0) {
-      uint32_t v = F + sum;
-      v = v > 0xFFFEu ? 0xFFFEu : v;
-      ub[beg + i] = (uint16_t)(infu ? L0_INF : v);
-    }
-    u0 = nu0;
-    len = nlen;
+  }
+  __syncthreads();
+  uint32_t* hg = hist + (int64_t)b * L0_HBINS;
+  for (int i2 = tid; i2 < L0_HBINS; i2 += 1024) {
+    const uint32_t v = hl[i2];
+    if (v) atomicAdd(&hg[i2], v);
   }
 }
 
-// histogram of min(ub - F, L0_HIST_BINS - 1) per query (hist zeroed by the caller)
-__global__ __launch_bounds__(1024) void k_l0_hist(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
-                                                  const uint32_t* __restrict__ Fsum, uint32_t* __restrict__ hist) {
-  extern __shared__ uint32_t l0hh[];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int64_t beg = cand_off[b];
-  const int64_t n = cand_off[b + 1] - beg;
-  if ((int64_t)blockIdx.x * 1024 >= n) return;
-  for (int i = tid; i < L0_HIST_BINS; i += 1024) l0hh[i] = 0u;
-  __syncthreads();
-  const uint32_t F = Fsum[b];
-  for (int64_t i = (int64_t)blockIdx.x * 1024 + tid; i < n; i += (int64_t)gridDim.x * 1024) {
-    const uint32_t v = ub[beg + i];
-    uint32_t k = v >= F ? v - F : 0u;
-    k = k > L0_HIST_BINS - 1 ? L0_HIST_BINS - 1 : k;
-    atomicAdd(&l0hh[k], 1u);
-  }
-  __syncthreads();
-  uint32_t* hg = hist + (int64_t)b * L0_HIST_BINS;
-  for (int i = tid; i < L0_HIST_BINS; i += 1024) {
-    const uint32_t v = l0hh[i];
-    if (v) atomicAdd(&hg[i], v);
-  }
-}
-
-// cut[b] = the largest u with #{ub >= u} >= want (want = min(mult * keep, n)); 0 when nothing is pruned
+// cut[b] = F + 4 * (the largest histogram bin k with #{bin >= k} >= want), want = min(mult * keep, n); 0 when nothing is pruned
 __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__ hist, const int64_t* __restrict__ cand_off, int64_t n_full,
-                                                    int64_t R, int mult, const uint32_t* __restrict__ Fsum, int32_t* __restrict__ cut) {
+                                                    int64_t R, int mult, const uint32_t* __restrict__ Fsum, int32_t* __restrict__ cut,
+                                                    int32_t* __restrict__ npilot) {
   __shared__ uint32_t part[1024];
   __shared__ int s_k;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -1673,13 +1646,14 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
   if (n_full < keep) keep = n_full;
   if (R < keep) keep = R;
   int64_t want = keep * mult;
+  if (tid == 0) npilot[b] = 0;
   if (want >= n) {
     if (tid == 0) cut[b] = 0;
     return;
   }
   if (tid == 0) s_k = 0;
-  const uint32_t* hg = hist + (int64_t)b * L0_HIST_BINS;
-  constexpr int BPT = L0_HIST_BINS / 1024;
+  const uint32_t* hg = hist + (int64_t)b * L0_HBINS;
+  constexpr int BPT = L0_HBINS / 1024;
   uint32_t own[BPT];
   uint32_t loc = 0;
 #pragma unroll
@@ -1707,23 +1681,46 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
     s_k = kk;
   }
   __syncthreads();
-  if (tid == 0) {
-    // bin L0_HIST_BINS-1 collects everything above it (and the infinite ones): cutting there keeps exactly that bin
-    cut[b] = s_k <= 0 ? 0 : (int32_t)(Fsum[b] + (uint32_t)s_k);
+  // the last bin collects everything above it (and the infinite bounds): cutting there keeps exactly that bin
+  if (tid == 0) cut[b] = s_k <= 0 ? 0 : (int32_t)(Fsum[b] + 4u * (uint32_t)s_k);
+}
+
+// pilot group = { ub >= cut[b] }, in ANY order (only the keep-th largest of their exact scores is used): one pass, one atomic
+// per wave.  pilot_pid[b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the capacity (then nothing is pruned).
+#define L0_PILOT_MAX 32768
+__global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
+                                                  const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
+                                                  int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid) {
+  const int b = blockIdx.y;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  const uint32_t ct = (uint32_t)cut[b];
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x - lane); i0 < n; i0 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i0 + lane;
+    const bool take = (i < n) && ((uint32_t)ub[beg + i] >= ct);
+    const unsigned long long m = __ballot(take);
+    if (!m) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&npilot[b], __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (take) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < L0_PILOT_MAX) pilot_pid[(int64_t)b * L0_PILOT_MAX + pos] = cand_pid[beg + i];
+    }
   }
 }
 
-// A_T = keep-th largest exact score of the pilot group -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).
-// One workgroup per query; the pilot scores are sorted in LDS (at most L0_PILOT_MAX of them, else nothing is pruned).
-#define L0_PILOT_MAX 32768
-__global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int64_t* __restrict__ pilot_off,
+// A_T = keep-th largest exact score of the pilot group (radix select over the monotone keys, 4 x 8 bits, LDS histogram)
+// -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).  One workgroup per query.
+__global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int32_t* __restrict__ npilot,
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
                                                  int32_t* __restrict__ cut) {
-  extern __shared__ uint32_t l0k[];
+  __shared__ uint32_t h[256];
+  __shared__ uint32_t s_prefix, s_rem;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t n = cand_off[b + 1] - cand_off[b];
-  const int64_t pb = pilot_off[b];
-  const int64_t np = pilot_off[b + 1] - pb;
+  const int np = npilot[b];
   int64_t keep = n;
   if (n_full < keep) keep = n_full;
   if (R < keep) keep = R;
@@ -1731,25 +1728,32 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
     if (tid == 0) cut[b] = 0;
     return;
   }
-  int np2 = 2;
-  while (np2 < (int)np) np2 <<= 1;
-  for (int i = tid; i < np2; i += 1024) l0k[i] = (i < (int)np) ? mono32(pilot[pb + i]) : 0u;
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += 1024) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint32_t a = l0k[i], c = l0k[ixj];
-          const bool desc = ((i & k) == 0);
-          if ((a < c) == desc) { l0k[i] = c; l0k[ixj] = a; }
-        }
-      }
-      __syncthreads();
+  const float* pv = pilot + (int64_t)b * L0_PILOT_MAX;
+  if (tid == 0) { s_prefix = 0u; s_rem = (uint32_t)keep; }
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) h[tid] = 0u;
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    for (int i = tid; i < np; i += 1024) {
+      const uint32_t k = mono32(pv[i]);
+      if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
     }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t rem = s_rem, acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + h[d] >= rem) break;
+        acc += h[d];
+      }
+      s_prefix = (prefix << 8) | (uint32_t)d;
+      s_rem = rem - acc;
+    }
+    __syncthreads();
   }
   if (tid == 0) {
-    const float at = unmono32(l0k[keep - 1]);
+    const float at = unmono32(s_prefix);
     int32_t c = 0;
     if (at == at) {   // NaN scores: prune nothing
       const double t = floor(128.0 * (double)at + 99.0 * (double)Q) + 1.0;
@@ -1820,11 +1824,11 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
   }
 }
 
-size_t fpk_l0_lds_bytes(const FpIndexDev& ix) { return (size_t)((ix.C + 15) & ~(int64_t)15) + 256; }
-bool fpk_l0_fits(const FpIndexDev& ix) { return fpk_l0_lds_bytes(ix) <= 158 * 1024; }
+size_t fpk_l0_lds_bytes(const FpIndexDev& ix) { return (size_t)((ix.C + 15) & ~(int64_t)15) + 16 + 256 + L0_HBINS * 4; }
+bool fpk_l0_fits(const FpIndexDev& ix) { return fpk_l0_lds_bytes(ix) <= 160 * 1024; }
 
-// level 0 in three launch groups so that the scan kernel can be timed alone:
-//   prepare: floors + excess table;  scan: UB0 of every candidate;  pilot: the top mult*keep documents by UB0, compacted
+// level 0 in launch groups so that the scan kernel can be timed alone:
+//   prepare: floors + excess table;  scan: UB0 of every candidate (+ its histogram);  pilot: the top mult*keep documents by UB0
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st) {
   const int B = sh.B;
   const int nch = sh.Qp / 32;
@@ -1834,6 +1838,7 @@ void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum);
   (void)hipMemsetAsync(w.esc, 0, (size_t)B * 64 * 4, st);
+  (void)hipMemsetAsync(w.hist, 0, (size_t)B * L0_HBINS * 4, st);
   hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,
                      w.esc);
 }
@@ -1845,38 +1850,34 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   static std::atomic<uint64_t> ok2{0};
   fp_allow_big_lds((const void*)k_l0_scan, ok2, 160 * 1024);
   const int64_t per_q = (M + B - 1) / B;
-  // each workgroup copies the table (Cpad bytes) into LDS first: give it at least ~8 rounds of 128 candidates
-  static const int cpw = [] { const char* e = getenv("FP_L0_CPW"); const int v = e ? atoi(e) : 1024; return v >= 128 ? v : 1024; }();
+  // each workgroup copies the table (Cpad bytes) into LDS first: candidates per workgroup (measured at cfg2: 256 / 512 / 1024 /
+  // 2048 / 4096 -> 1.99 / 1.76 / 1.60 / 1.51 / 1.51 ms with the first version of the kernel)
+  static const int cpw = [] { const char* e = getenv("FP_L0_CPW"); const int v = e ? atoi(e) : 4096; return v >= 256 ? v : 4096; }();
   int64_t bx = (per_q + cpw - 1) / cpw;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, w.esc, w.Fsum, cand_off,
-                     cand_pid, ix.uoff, ix.ucodes, w.ub);
+                     cand_pid, ix.uoff, ix.ucodes, w.ub, w.hist);
 }
 
-void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, hipStream_t st) {
+void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st) {
   const int B = sh.B;
   static const int mult = [] { const char* e = getenv("FP_L0_PILOT"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
-  static std::atomic<uint64_t> ok3{0};
-  fp_allow_big_lds((const void*)k_l0_hist, ok3, 72 * 1024);
-  (void)hipMemsetAsync(w.hist, 0, (size_t)B * L0_HIST_BINS * 4, st);
-  hipLaunchKernelGGL(k_l0_hist, dim3(16, (unsigned)B), dim3(1024), (size_t)L0_HIST_BINS * 4, st, w.ub, cand_off, w.Fsum, w.hist);
-  hipLaunchKernelGGL(k_l0_topcut, dim3((unsigned)B), dim3(1024), 0, st, w.hist, cand_off, sh.n_full, sh.R, mult, w.Fsum, w.cut);
-  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.cut, w.blkcnt, w.nblk);
-  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, w.npilot);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, w.npilot, B, w.pilot_off);
-  hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.blkcnt, w.nblk,
-                     w.pilot_off, w.pilot_pid);
+  hipLaunchKernelGGL(k_l0_topcut, dim3((unsigned)B), dim3(1024), 0, st, w.hist, cand_off, sh.n_full, sh.R, mult, w.Fsum, w.cut, w.npilot);
+  const int64_t per_q = (M + B - 1) / B;
+  int64_t bx = (per_q + 4095) / 4096;
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(k_l0_pilot, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.npilot, w.pilot_pid);
 }
+
+int64_t fpk_l0_pilot_cap() { return L0_PILOT_MAX; }
 
 // level 0, second half (the pilot group's exact scores are in w.pilot_approx): threshold, ordered survivors
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
                       int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
   const int B = sh.B;
-  static std::atomic<uint64_t> ok{0};
-  fp_allow_big_lds((const void*)k_l0_thr, ok, 136 * 1024);
-  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), (size_t)L0_PILOT_MAX * 4, st, w.pilot_approx, w.pilot_off, cand_off, sh.n_full, sh.R,
-                     sh.Q, w.cut);
+  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.cut);
   hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.cut, w.blkcnt, w.nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv);
   hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
@@ -2151,300 +2152,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
                      sel_approx);
 }
 
-// ============================================================================================
-// S6+S7  fused decompress + exact MaxSim.  One wave per (query, document) pair, 32 tokens per
-// step, everything in registers:
-//   lane (tok = lane&31, h = lane>>5) owns dims [h*D/2, (h+1)*D/2) of token tok:
-//     e   = h(cent[code] + lut[byte])          packed fp16 add  (== fp32 add + round)
-//     n   = h(sqrt(sum_fp32 e^2))              dot2 accumulate, halves combined by one shuffle
-//     e^  = h(float(e) / float(n))             IEEE fp32 divide, one rounding to fp16
-//   and those 8-dim groups ARE the A fragments of v_mfma_f32_32x32x16_f16 (A row = token,
-//   k = 8*h + j  <->  dim h*D/2 + 8*m + j for k-step m); the query B fragments use the same
-//   k <-> dim map, so no LDS staging and no transposes are needed.
-//   sim = h(acc) ; running max over tokens per query column ; fp32 sum over q.
-// ============================================================================================
-#ifndef FP_ABL
-#define FP_ABL 0  // ablation bits (timing experiments only): 1 no norm chain, 2 no normalise, 4 no LUT decode, 8 no centroid gather, 16 no residual stream
-#endif
-// Layout of the MaxSim kernel (v3).  ONE TOKEN PER LANE: a wave carries two independent
-// 32-token streams (lanes 0-31 and 32-63), each walking its own sequence of documents chunk by
-// chunk.  A lane decompresses all D dims of its token (one 128-step ascending norm chain, no
-// work duplicated between lanes), then v_permlane32_swap turns the per-token registers into the
-// two A operands of v_mfma_f32_32x32x16_f16:
-//   regs G0 = dims [16m, 16m+8), G1 = dims [16m+8, 16m+16) of the lane's own token;
-//   swap(vdst=G0, src=G1): lanes 32-63 of G0 <-> lanes 0-31 of G1
-//   => G0 = A operand for the LOWER stream's 32 tokens (rows), G1 = A operand for the UPPER one.
-// The query B fragments are staged once per block in LDS (all 4 waves serve the same query),
-// the byte->weights LUT is replicated per LDS bank.  Next chunk's centroid codes and the next
-// document's (offset, length) are prefetched one step ahead.
-template <int D, int NBITS, int NCH>
-__global__ __launch_bounds__(256) void k_maxsim_reg(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
-                                                const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
-                                                const int64_t* __restrict__ doc_off, const uint16_t* __restrict__ qpad, int Q,
-                                                int Qp, int ch_begin, const int32_t* __restrict__ sel_pid,
-                                                const int32_t* __restrict__ sel_cnt, int64_t Rcap, float* __restrict__ exact,
-                                                int accumulate, int dpw) {
-  constexpr int PR = D * NBITS / 8;   // packed residual bytes per token
-  constexpr int RW = PR / 4;          // 32-bit residual words per token
-  constexpr int PB = 8 / NBITS;       // dims per byte
-  constexpr int KS = D / 16;          // MFMA k-steps
-  constexpr int NE = D / 2;           // half2 registers per token
-  constexpr int COPIES = (PB == 2) ? 32 : 16;
-  constexpr int EW = PB / 2;          // 32-bit words per LUT entry
-  __shared__ __attribute__((aligned(16))) uint32_t lut[256 * EW * COPIES];   // 32 KiB
-  __shared__ __attribute__((aligned(16))) uint4 qs[NCH * KS * 64];           // B fragments, 1 KiB per (chunk, k-step)
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < 256 * COPIES; i += 256) {
-    const int entry = i / COPIES, copy = i % COPIES;
-#pragma unroll
-    for (int w = 0; w < EW; ++w) lut[(entry * COPIES + copy) * EW + w] = reinterpret_cast<const uint32_t*>(lut_g)[entry * EW + w];
-  }
-  for (int i = threadIdx.x; i < NCH * KS * 64; i += 256) {
-    const int ln = i & 63, m = (i >> 6) % KS, c = (i >> 6) / KS;
-    const int ch = ch_begin + c;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ch * 32 < Qp)  // B[k = 8*(ln>>5) + j][n = ln&31] = Q[q = ch*32 + (ln&31)][16m + 8*(ln>>5) + j]
-      v = *reinterpret_cast<const uint4*>(qpad + ((int64_t)b * Qp + ch * 32 + (ln & 31)) * D + 16 * m + 8 * (ln >> 5));
-    qs[i] = v;
-  }
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cnt = sel_cnt[b];
-  const int r0 = (blockIdx.x * 4 + wave) * dpw;
-  if (r0 >= cnt) return;
-  const int rend = (r0 + dpw < cnt) ? (r0 + dpw) : cnt;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const uint32_t* mylut = lut + (lane & (COPIES - 1)) * EW;
-  const half_t negm = (half_t)NEG_MASK_F;
-  int nq = Q - ch_begin * 32;  // valid query columns handled by this launch
-  nq = nq < 0 ? 0 : (nq > NCH * 32 ? NCH * 32 : nq);
-  const int32_t* selp = sel_pid + (int64_t)b * Rcap;
-  float* outp = exact + (int64_t)b * Rcap;
-
-  // ---- per-stream state (identical in the 32 lanes of a stream) ----
-  int r = r0 + hi;          // document slot of this stream: r0+hi, r0+hi+2, ...
-  int t0 = 0, len = 0;
-  long long off = 0;
-  bool valid = r < rend;
-  long long n_off = 0;      // prefetched metadata of the stream's next document
-  int n_len = 0;
-  auto meta = [&](int rr, long long& o, int& l) {
-    const int32_t pid = selp[rr];
-    o = doc_off[pid];
-    l = (int)(doc_off[pid + 1] - o);
-  };
-  if (valid) meta(r, off, len);
-  if (r + 2 < rend) meta(r + 2, n_off, n_len);
-  // skip leading empty documents / advance helper
-  auto next_doc = [&]() {  // move the stream to its next document (may be empty or absent)
-    r += 2;
-    valid = r < rend;
-    off = n_off;
-    len = n_len;
-    t0 = 0;
-    if (r + 2 < rend) meta(r + 2, n_off, n_len);
-  };
-  auto emit_empty = [&]() {
-    if (l31 == 0) {
-      const float v = (float)nq * NEG_MASK_F;  // every column keeps the masked value
-      outp[r] = accumulate ? (outp[r] + v) : v;
-    }
-  };
-  while (valid && len == 0) { emit_empty(); next_doc(); }
-
-  auto tok_row = [&]() -> long long {
-    int tok = t0 + l31;
-    tok = tok < len ? tok : len - 1;  // clamp: loads stay in bounds, rows masked at the max
-    return off + tok;
-  };
-  int32_t code = 0;
-  if (valid) code = codes[tok_row()];
-
-  h2 mx[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) mx[c] = h2{negm, negm};
-
-  while (__any(valid)) {
-    uint32_t e[NE];
-    uint32_t rw[RW];
-    // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
-    const long long row = (valid && !(FP_ABL & 16)) ? tok_row() : 0;   // ablation 16: every lane reads residual row 0
-    const int32_t ccode = (valid && !(FP_ABL & 8)) ? code : 0;          // ablation 8: every lane reads centroid row 0
-    {
-      const uint8_t* rp = resid + row * (long long)PR;
-      if constexpr (RW >= 4) {
-#pragma unroll
-        for (int i = 0; i < RW / 4; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
-          rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
-        }
-      } else {
-        const uint2 v = *reinterpret_cast<const uint2*>(rp);
-        rw[0] = v.x; rw[1] = v.y;
-      }
-      const uint16_t* cp = cent + (long long)ccode * D;
-#pragma unroll
-      for (int i = 0; i < NE / 4; ++i) {
-        const uint4 v = *reinterpret_cast<const uint4*>(cp + 8 * i);
-        e[4 * i] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
-      }
-    }
-    // ---- this chunk's bookkeeping, then step the stream and prefetch the next code ----
-    const int c_t0 = t0, c_len = len, c_r = r;
-    const bool c_valid = valid;
-    const bool c_last = valid && (t0 + 32 >= len);
-    if (valid) {
-      t0 += 32;
-      if (t0 >= len) {
-        next_doc();
-        while (valid && len == 0) { emit_empty(); next_doc(); }
-      }
-      if (valid) code = codes[tok_row()];
-    }
-    // ---- e = h(cent + w) ----
-    if (FP_ABL & 4) { e[1] ^= rw[0] ^ rw[RW - 1]; }
-    else
-#pragma unroll
-    for (int w = 0; w < RW; ++w) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const uint32_t byte = (rw[w] >> (8 * kk)) & 0xFFu;
-        const int bi = w * 4 + kk;  // byte index -> dims [bi*PB, bi*PB+PB)
-        if constexpr (PB == 2) {
-          e[bi] = h2_as_u32(u32_as_h2(e[bi]) + u32_as_h2(mylut[byte * COPIES]));
-        } else {
-          const uint2 wv = *reinterpret_cast<const uint2*>(mylut + byte * COPIES * 2);
-          e[2 * bi] = h2_as_u32(u32_as_h2(e[2 * bi]) + u32_as_h2(wv.x));
-          e[2 * bi + 1] = h2_as_u32(u32_as_h2(e[2 * bi + 1]) + u32_as_h2(wv.y));
-        }
-      }
-    }
-    // ---- n = h(sqrt(sum_k e_k^2)): fp32, ascending k, exactly the CPU reference's order ----
-    float ss = 0.f;
-    if (!(FP_ABL & 1)) {
-#pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        const h2 v = u32_as_h2(e[i]);
-        ss = __builtin_fmaf((float)v.x, (float)v.x, ss);
-        ss = __builtin_fmaf((float)v.y, (float)v.y, ss);
-      }
-    }
-    if (FP_ABL & 1) ss = __uint_as_float(e[0] & 0x3FFFFFFFu) + 1.0f;  // ablation: no norm chain
-    const float nf = (float)(half_t)__builtin_sqrtf(ss);  // clamp_min(1e-12) is a no-op in fp16
-    float r_hi, r_lo;
-    recip2(nf, r_hi, r_lo);
-    if (!(FP_ABL & 2)) {
-#pragma unroll
-      for (int i = 0; i < NE; i += 2) norm_pair2(e[i], e[i + 1], r_hi, r_lo);
-    } else {
-      e[0] ^= __float_as_uint(r_hi) & 1u;
-    }
-    // ---- MFMA: acc0 rows = lower stream's tokens, acc1 rows = upper stream's tokens ----
-    f16v acc0[NCH], acc1[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[c][i] = 0.f; acc1[c][i] = 0.f; }
-#pragma unroll
-    for (int m = 0; m < KS; ++m) {
-      uint32_t g0[4], g1[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        auto sw = __builtin_amdgcn_permlane32_swap(e[8 * m + j], e[8 * m + 4 + j], false, false);
-        g0[j] = sw[0];
-        g1[j] = sw[1];
-      }
-      const h8 a0 = __builtin_bit_cast(h8, make_uint4(g0[0], g0[1], g0[2], g0[3]));
-      const h8 a1 = __builtin_bit_cast(h8, make_uint4(g1[0], g1[1], g1[2], g1[3]));
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const h8 bq = __builtin_bit_cast(h8, qs[(c * KS + m) * 64 + lane]);
-        acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bq, acc0[c], 0, 0, 0);
-        acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1[c], 0, 0, 0);
-      }
-    }
-    // ---- epilogue.  acc0 belongs to the lower stream (state in lane 0), acc1 to the upper
-    // (lane 32); D[row = token][col = q = lane&31], this lane's rows (i&3) + 8*(i>>2) + 4*hi.
-    // mx[] tracks the running max of the stream THIS lane belongs to, so the two accumulators'
-    // lane-halves are exchanged first: lower-stream lanes need acc0 from both halves. ----
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int s_t0 = __shfl(c_t0, 32 * s, 64), s_len = __shfl(c_len, 32 * s, 64), s_r = __shfl(c_r, 32 * s, 64);
-      const bool s_valid = __shfl((int)c_valid, 32 * s, 64) != 0;
-      const bool s_last = __shfl((int)c_last, 32 * s, 64) != 0;
-      if (!s_valid) continue;
-      const bool partial = (s_t0 + 32 > s_len);
-      float total = 0.f;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        h2 m = h2{negm, negm};
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          h2 v;
-          v.x = (half_t)(s == 0 ? acc0[c][i] : acc1[c][i]);
-          v.y = (half_t)(s == 0 ? acc0[c][i + 1] : acc1[c][i + 1]);
-          if (partial) {
-            const int row0 = (i & 3) + 8 * (i >> 2) + 4 * hi;
-            if (s_t0 + row0 >= s_len) v.x = negm;
-            if (s_t0 + row0 + 1 >= s_len) v.y = negm;
-          }
-          m = pk_max(m, v);
-        }
-        // this chunk's max over the 32 tokens for column q = lane&31 (both lane halves agree after the exchange)
-        half_t mm = m.x > m.y ? m.x : m.y;
-        const uint32_t ou = shfl_xor_u32((uint32_t)__builtin_bit_cast(uint16_t, mm), 32);
-        const half_t o = __builtin_bit_cast(half_t, (uint16_t)ou);
-        mm = o > mm ? o : mm;
-        // running max lives in the lanes of stream s
-        if (hi == s) {
-          const half_t cur = mx[c].x;
-          mx[c].x = mm > cur ? mm : cur;
-        }
-        if (s_last) {
-          const int q = (ch_begin + c) * 32 + l31;
-          float sv = (hi == s && q < Q) ? (float)mx[c].x : 0.f;
-#pragma unroll
-          for (int sft = 32; sft > 0; sft >>= 1) sv += __shfl_xor(sv, sft, 64);
-          total += sv;
-          if (hi == s) mx[c] = h2{negm, negm};
-        }
-      }
-      if (s_last && lane == 0) outp[s_r] = accumulate ? (outp[s_r] + total) : total;
-    }
-  }
-}
-
-#define MAXSIM_DPW 8
-template <int D, int NBITS>
-static void launch_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid,
-                          const int32_t* sel_cnt, int64_t Rcap, float* exact, hipStream_t st) {
-  const int dpw = MAXSIM_DPW;  // documents per wave (two streams x dpw/2); 4 and 16 measured slower
-  dim3 grid((unsigned)((Rcap + 4 * dpw - 1) / (4 * dpw)), (unsigned)sh.B);
-  const int nch = sh.Qp / 32;
-  int acc = 0;
-  for (int ch = 0; ch < nch;) {  // 32-column query chunks: two per launch where possible (the tokens are decompressed once per launch)
-    if (nch - ch >= 2) {
-      hipLaunchKernelGGL((k_maxsim_reg<D, NBITS, 2>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
-      ch += 2;
-    } else {
-      hipLaunchKernelGGL((k_maxsim_reg<D, NBITS, 1>), grid, dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off,
-                         qpad, sh.Q, sh.Qp, ch, sel_pid, sel_cnt, Rcap, exact, acc, dpw);
-      ch += 1;
-    }
-    acc = 1;
-  }
-}
-
-int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
-               int64_t Rcap, float* exact, hipStream_t st) {
-  if (ix.dim == 128 && ix.nbits == 4) launch_maxsim<128, 4>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
-  else if (ix.dim == 128 && ix.nbits == 2) launch_maxsim<128, 2>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
-  else if (ix.dim == 64 && ix.nbits == 4) launch_maxsim<64, 4>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
-  else if (ix.dim == 64 && ix.nbits == 2) launch_maxsim<64, 2>(ix, qpad, sh, sel_pid, sel_cnt, Rcap, exact, st);
-  else return -1;
-  return 0;
-}
+// S6+S7 (fused decompress + exact MaxSim, per-token norms, exact-order repair): fp_maxsim.hip
 
 // ============================================================================================
 // S8  final ranking: LDS bitonic sort of 64-bit keys (mono32(score) << 32 | ~id), descending.
@@ -2761,25 +2469,30 @@ int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const
 // one ascending-k fp32 chain per (token, centroid): 64 tokens x 64 centroids per tile, 4x4 outputs per thread, operands
 // in LDS as fp32.  Ties go to the lowest centroid index (torch.argmax: first maximal value).
 // L2 = true (k-means assignment): score = dot - half_sqnorm[c] compared in fp32 instead of the fp16-rounded dot.
-template <int D, bool L2>
+template <bool L2>
 __global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict__ emb, int64_t T, const uint16_t* __restrict__ cent,
-                                                      int64_t C, const float* __restrict__ half_sqnorm, int32_t* __restrict__ codes) {
-  __shared__ float As[64][D + 1];
-  __shared__ float Bs[64][D + 1];
-  __shared__ unsigned long long best_s[64][16];
+                                                      int64_t C, const float* __restrict__ half_sqnorm, int32_t* __restrict__ codes, int D) {
+  // any dim (runtime): As / Bs [64][D + 1] fp32 and best_s [64][16] in dynamic LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+  const int ld = D + 1;
+  float* As_ = reinterpret_cast<float*>(xsm);
+  float* Bs_ = As_ + 64 * ld;
+  unsigned long long (*best_s)[16] = reinterpret_cast<unsigned long long (*)[16]>(xsm + (size_t)2 * 64 * ld * 4);
+#define As(r, d) As_[(r) * ld + (d)]
+#define Bs(r, d) Bs_[(r) * ld + (d)]
   const int tid = threadIdx.x;
   const int tr = tid >> 4, tc = tid & 15;       // 16 x 16 threads, 4 rows x 4 cols each
   const int64_t t0 = (int64_t)blockIdx.x * 64;
   for (int i = tid; i < 64 * D; i += 256) {
     const int r = i / D, d = i % D;
-    As[r][d] = (t0 + r < T) ? (float)__builtin_bit_cast(half_t, emb[(t0 + r) * D + d]) : 0.f;
+    As(r, d) = (t0 + r < T) ? (float)__builtin_bit_cast(half_t, emb[(t0 + r) * D + d]) : 0.f;
   }
   unsigned long long best[4] = {0ull, 0ull, 0ull, 0ull};
   for (int64_t c0 = 0; c0 < C; c0 += 64) {
     __syncthreads();
     for (int i = tid; i < 64 * D; i += 256) {
       const int r = i / D, d = i % D;
-      Bs[r][d] = (c0 + r < C) ? (float)__builtin_bit_cast(half_t, cent[(c0 + r) * D + d]) : 0.f;
+      Bs(r, d) = (c0 + r < C) ? (float)__builtin_bit_cast(half_t, cent[(c0 + r) * D + d]) : 0.f;
     }
     __syncthreads();
     float acc[4][4];
@@ -2790,9 +2503,9 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict
     for (int kk = 0; kk < D; ++kk) {   // ascending k: each accumulator is the reference's chain (products of fp16 pairs are exact in fp32)
       float a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[tr * 4 + i][kk];
+      for (int i = 0; i < 4; ++i) a[i] = As(tr * 4 + i, kk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[tc + 16 * j][kk];
+      for (int j = 0; j < 4; ++j) b[j] = Bs(tc + 16 * j, kk);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -2824,7 +2537,11 @@ __global__ __launch_bounds__(256) void k_assign_exact(const uint16_t* __restrict
     for (int j = 0; j < 16; ++j) m = best_s[tid][j] > m ? best_s[tid][j] : m;
     codes[t0 + tid] = (int32_t)(0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull));
   }
+#undef As
+#undef Bs
 }
+static size_t assign_exact_lds(int D) { return (size_t)2 * 64 * (D + 1) * 4 + 64 * 16 * 8; }
+#define ASSIGN_MAX_DIM 256   // 2 x 64 x (D+1) fp32 operand tiles + 8 KiB must fit the 160 KiB of LDS
 
 // ---- MFMA fast path of the nearest-centroid search, still exact -------------------------------------------------------
 // The exact kernel above runs at 30 TFLOP/s.  MFMA sums in another order, so its scores cannot decide near-ties; but they
@@ -3011,11 +2728,12 @@ static int assign_codes(const uint16_t* emb, int64_t T, const uint16_t* cent, in
   const unsigned eblocks = fp_grid_cap((T + 63) / 64, 256);
   if ((int64_t)eblocks * 64 < T) return -2;   // callers chunk far below this
   auto exact = [&]() {
-    if (D == 128) hipLaunchKernelGGL((k_assign_exact<128, false>), dim3(eblocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
-    else hipLaunchKernelGGL((k_assign_exact<64, false>), dim3(eblocks), dim3(256), 0, st, emb, T, cent, C, (const float*)nullptr, codes32);
+    static std::atomic<uint64_t> ok{0};
+    fp_allow_big_lds((const void*)k_assign_exact<false>, ok, 160 * 1024);
+    hipLaunchKernelGGL((k_assign_exact<false>), dim3(eblocks), dim3(256), assign_exact_lds(D), st, emb, T, cent, C, (const float*)nullptr, codes32, D);
   };
-  if (D != 128 && D != 64) return -1;
-  if (impl_env || !work || C < 256) {   // tiny tables: the exact kernel is as fast
+  if (D < 1 || D > ASSIGN_MAX_DIM) return -1;
+  if (impl_env || !work || C < 256 || (D != 128 && D != 64)) {   // tiny tables: the exact kernel is as fast; the MFMA narrowing is built for dim 64 / 128
     exact();
     return 0;
   }
@@ -3067,9 +2785,10 @@ int fpk_assign_l2(const uint16_t* emb, int64_t T, const uint16_t* cent, const fl
   if (T <= 0) return 0;
   const unsigned blocks = fp_grid_cap((T + 63) / 64, 256);
   if ((int64_t)blocks * 64 < T) return -2;
-  if (D == 128) hipLaunchKernelGGL((k_assign_exact<128, true>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, half_sqnorm, codes32);
-  else if (D == 64) hipLaunchKernelGGL((k_assign_exact<64, true>), dim3(blocks), dim3(256), 0, st, emb, T, cent, C, half_sqnorm, codes32);
-  else return -1;
+  if (D < 1 || D > ASSIGN_MAX_DIM) return -1;
+  static std::atomic<uint64_t> ok{0};
+  fp_allow_big_lds((const void*)k_assign_exact<true>, ok, 160 * 1024);
+  hipLaunchKernelGGL((k_assign_exact<true>), dim3(blocks), dim3(256), assign_exact_lds(D), st, emb, T, cent, C, half_sqnorm, codes32, D);
   hipLaunchKernelGGL(k_widen_i32, dim3(fp_grid_cap((T + 255) / 256, 256)), dim3(256), 0, st, codes32, codes64, T);
   return 0;
 }

@@ -148,10 +148,13 @@ __global__ __launch_bounds__(64) void k_doc_sort(int32_t* __restrict__ codes, co
   }
 }
 
-// new_res[off + i] = old_res[off + perm[i]]; 16 bytes per thread
+// new_res[off + i] = old_res[off + perm[i]]; one piece per thread: 16 bytes when the rows are multiples of 16 bytes, 4 bytes when
+// they are multiples of 4, else the whole row byte by byte
+__host__ __device__ static inline int permute_piece_bytes(int pr) { return pr % 16 == 0 ? 16 : (pr % 4 == 0 ? 4 : pr); }
 __global__ void k_permute_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint16_t* __restrict__ perm,
                                const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t T, int pr) {
-  const int ppr = pr / 16 > 0 ? pr / 16 : 1;
+  const int pb = permute_piece_bytes(pr);
+  const int ppr = pr / pb;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < T * ppr; g += (int64_t)gridDim.x * blockDim.x) {
   const int64_t row = g / ppr;
   const int piece = (int)(g % ppr);
@@ -163,8 +166,10 @@ __global__ void k_permute_rows(const uint8_t* __restrict__ src, uint8_t* __restr
   }
   const int64_t off = doc_off[lo];
   const int64_t srow = off + perm[row];
-  if (pr >= 16) {
+  if (pb == 16) {
     *reinterpret_cast<uint4*>(dst + row * pr + piece * 16) = *reinterpret_cast<const uint4*>(src + srow * pr + piece * 16);
+  } else if (pb == 4) {
+    *reinterpret_cast<uint32_t*>(dst + row * pr + piece * 4) = *reinterpret_cast<const uint32_t*>(src + srow * pr + piece * 4);
   } else {
     for (int b = 0; b < pr; ++b) dst[row * pr + b] = src[srow * pr + b];
   }
@@ -189,7 +194,7 @@ int fps_sort_docs(int32_t* codes, uint8_t* residuals, const int64_t* doc_off_dev
   hipLaunchKernelGGL(k_doc_sort, dim3(fp_grid_cap(n_docs, 64)), dim3(64), (size_t)np2 * 8, st, codes, doc_off_dev, n_docs, *perm);
   HCHK0(hipMalloc((void**)&tmp, (size_t)T * pr + 64));
   {
-    const int ppr = pr / 16 > 0 ? pr / 16 : 1;
+    const int ppr = pr / permute_piece_bytes(pr);
     const int64_t threads = T * ppr;
     hipLaunchKernelGGL(k_permute_rows, dim3(fp_grid_cap((threads + 255) / 256, 256)), dim3(256), 0, st, residuals, tmp, *perm, doc_off_dev, n_docs,
                        T, pr);

@@ -10,7 +10,7 @@ Each case is checked for ambiguity before it is written: exact ties at the probe
 at the candidate-pruning cut or between final scores would make "the expected ids"
 implementation-defined (ATen topk/sort are not stable), so such seeds are rejected.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case names ...]
 """
 from __future__ import annotations
 
@@ -48,6 +48,20 @@ CASES = [
          n_probe=8, n_full=4096, top_k=80, empty_docs=(3, 41)),
     dict(name="unnormalised_docs", n_docs=60, lens=(20, 80), dim=128, nbits=4, C=128, B=2, Q=30,
          n_probe=8, n_full=4096, top_k=10, raw_randn=True),
+    # shapes beyond dim 64/128 x nbits 2/4 (residual_codec.rs:83-140 and search.rs:53-107 are generic in both; the reference's
+    # own benchmark model, answerai-colbert-small-v1, is dim 96: docs/benchmark/benchmark.py:44-45)
+    dict(name="d96_nb4", n_docs=110, lens=(10, 90), dim=96, nbits=4, C=128, B=3, Q=32,
+         n_probe=8, n_full=4096, top_k=10),
+    dict(name="d48_nb2", n_docs=100, lens=(10, 70), dim=48, nbits=2, C=128, B=3, Q=24,
+         n_probe=4, n_full=64, top_k=8),
+    dict(name="d128_nb8", n_docs=80, lens=(10, 60), dim=128, nbits=8, C=128, B=2, Q=32,
+         n_probe=8, n_full=4096, top_k=10),
+    dict(name="d128_nb1", n_docs=80, lens=(10, 60), dim=128, nbits=1, C=128, B=2, Q=20,
+         n_probe=4, n_full=4096, top_k=10),
+    dict(name="d256_nb4", n_docs=60, lens=(10, 50), dim=256, nbits=4, C=64, B=2, Q=16,
+         n_probe=4, n_full=4096, top_k=10),
+    dict(name="d40_nb4", n_docs=80, lens=(10, 60), dim=40, nbits=4, C=64, B=2, Q=12,
+         n_probe=4, n_full=32, top_k=6),
 ]
 
 
@@ -149,7 +163,10 @@ def make_case(cfg, seed):
 
 def main():
     torch.set_num_threads(1)
+    only = set(sys.argv[1:])   # optional case names: regenerate only those
     for cfg in CASES:
+        if only and cfg["name"] not in only:
+            continue
         seed = 1000
         while True:
             out, why = make_case(cfg, seed)
