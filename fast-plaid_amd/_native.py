@@ -63,9 +63,9 @@ SYMBOLS = {
     "fp_token_scores": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i64]),
     "fp_shard_begin": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(FpSearchParams), C.POINTER(_vp)]),
     "fp_shard_R": (_i64, [_vp]),
-    "fp_shard_stage1": (C.c_int, [_vp, _vp, _vp]),
-    "fp_shard_stage2": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
-    "fp_shard_stage3": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "fp_shard_stage1": (C.c_int, [_vp, _vp]),
+    "fp_shard_stage2": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "fp_shard_stage3": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "fp_shard_end": (None, [_vp]),
     "fp_index_create_synthetic": (C.c_int, [C.POINTER(FpSynthDesc), C.c_int, C.POINTER(_vp)]),
     "fp_index_read_doc": (_i64, [_vp, _i64, _vp, _vp, _i64]),

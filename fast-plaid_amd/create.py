@@ -8,9 +8,12 @@ rust/index/create.rs:206-583) -- SURVEY.md section 8, row f1:
 
 K-means is not here: the reference runs it in Python through the external `fastkmeans` package
 (python/fast_plaid/search/kmeans.py), which is not part of this image; centroids are an input.
-The sampling of held-out passages uses numpy's generator instead of Rust's StdRng, so a directory created
-here is a valid index for the same centroids but not byte-identical to one the reference would create from
-the same seed; every deterministic step is bit-identical to the ATen restatement (tests).
+The sampling of held-out passages follows create.rs:222-281 (shuffle, take 16*sqrt(120 N) passages, walk the SHUFFLED
+sample from its end until 5 % of its tokens -- at most 50 000 -- are collected) but draws the shuffle from numpy's
+generator instead of Rust's StdRng, so a directory created here is a valid index for the same centroids but not
+byte-identical to one the reference would create from the same seed; every deterministic step is bit-identical to
+the ATen restatement (tests).  The directory holds every file the reference writes, including plan.json (:296-299) and
+cluster_threshold.npy (:331-339), which the reference's update path loads unconditionally (python update.py:365-366).
 """
 from __future__ import annotations
 
@@ -58,8 +61,9 @@ def _quantile(sorted_flat: np.ndarray, q: float) -> np.float32:
     return np.float32(a + w * d) if w < np.float32(0.5) else np.float32(b - d * np.float32(np.float32(1.0) - w))
 
 
-def train_codec(heldout, centroids, nbits: int, device: str = "cuda:0"):
-    """create.rs:317-364 -> (bucket_cutoffs f32 [2^nbits-1], bucket_weights f32 [2^nbits], avg_residual f32 [dim])."""
+def train_codec(heldout, centroids, nbits: int, device: str = "cuda:0", with_threshold: bool = False):
+    """create.rs:317-364 -> (bucket_cutoffs f32 [2^nbits-1], bucket_weights f32 [2^nbits], avg_residual f32 [dim]);
+    with_threshold: also the cluster threshold of create.rs:331-334, the 0.75 quantile of the held-out residual norms."""
     held = _np(heldout, np.float16)
     cent = _np(centroids, np.float16)
     n_opt = 1 << nbits
@@ -69,44 +73,74 @@ def train_codec(heldout, centroids, nbits: int, device: str = "cuda:0"):
     cut = np.array([_quantile(flat, i / n_opt) for i in range(1, n_opt)], np.float32)
     wts = np.array([_quantile(flat, (i + 0.5) / n_opt) for i in range(n_opt)], np.float32)
     avg = np.abs(res).mean(axis=0, dtype=np.float32)
+    if with_threshold:
+        return cut, wts, avg, cluster_threshold(res)
     return cut, wts, avg
+
+
+def cluster_threshold(residuals_f32: np.ndarray) -> np.float32:
+    """create.rs:331-334: norm_scalaropt_dim(2, [1]) of the fp32 held-out residuals, then the 0.75 quantile."""
+    r = np.asarray(residuals_f32, np.float32)
+    dist = np.sqrt(np.einsum("ij,ij->i", r, r, dtype=np.float32), dtype=np.float32)
+    return _quantile(np.sort(dist, kind="stable"), 0.75)
+
+
+def heldout_sample(docs16, rng) -> np.ndarray:
+    """create.rs:222-281: shuffle the passage ids, keep the first min(1 + 16 sqrt(120 N), N); the held-out set is the LAST
+    round(min(5 % of the sample's tokens, 50 000)) tokens of the sample IN ITS SHUFFLED ORDER (whole passages from the end, the
+    first one taken possibly cut to its tail), so it comes from random documents, not from the end of the corpus."""
+    n = len(docs16)
+    k = int(min(1.0 + 16.0 * math.sqrt(120.0 * n), n))
+    sample = rng.permutation(n)[:k]
+    total = int(sum(docs16[int(i)].shape[0] for i in sample))
+    need = int(round(min(0.05 * total, 50_000.0)))
+    parts = []
+    for i in sample[::-1]:
+        if need <= 0:
+            break
+        d = docs16[int(i)]
+        if d.shape[0] <= need:
+            parts.append(d)
+            need -= d.shape[0]
+        else:
+            parts.append(d[d.shape[0] - need:])
+            need = 0
+    parts.reverse()
+    dim = docs16[0].shape[1] if n else 0
+    return np.concatenate(parts) if parts else np.zeros((0, dim), np.float16)
 
 
 def build_index_arrays(docs, centroids, nbits: int, device: str = "cuda:0", heldout=None, num_partitions: int | None = None) -> dict:
     """The construct_index argument set for a list of [len, dim] document embeddings (the whole corpus is the
-    held-out sample unless one is given), without the reference loader's trailing padding rows."""
+    held-out sample unless one is given), without the reference loader's trailing padding rows; plus `cluster_threshold`."""
     cent = _np(centroids, np.float16)
     docs16 = [_np(d, np.float16) for d in docs]
     lens = np.array([d.shape[0] for d in docs16], np.int64)
     allemb = np.concatenate(docs16) if docs16 else np.zeros((0, cent.shape[1]), np.float16)
-    cut, wts, avg = train_codec(allemb if heldout is None else heldout, cent, nbits, device)
+    cut, wts, avg, thr = train_codec(allemb if heldout is None else heldout, cent, nbits, device, with_threshold=True)
     codes, packed = compress(cent, cut.astype(np.float16), allemb, nbits, device)
     P = num_partitions if num_partitions is not None else max(cent.shape[0], 1)
     ivf, ivf_lengths = synth.build_ivf(codes, lens, P)
     return dict(nbits=nbits, centroids=cent, avg_residual=avg.astype(np.float16), bucket_cutoffs=cut.astype(np.float16),
                 bucket_weights=wts.astype(np.float16), ivf=ivf, ivf_lengths=ivf_lengths, doc_codes=codes, doc_residuals=packed,
-                doc_lengths=lens)
+                doc_lengths=lens, cluster_threshold=np.float32(thr))
 
 
 def create_index(index_path: str, documents_embeddings, centroids, nbits: int = 4, device: str = "cuda:0", seed: int | None = 42,
                  compress_only: bool = False, chunk_docs: int = 25_000) -> dict:
-    """rust/index/create.rs:206-583 given centroids: sample held-out passages (:222-290: 16*sqrt(120*N) passages, the
-    last 5 % of their tokens capped at 50 000), train the codec, compress every document, build the IVF, write the
-    directory.  Returns the array set it wrote."""
+    """rust/index/create.rs:206-583 given centroids: sample held-out passages (heldout_sample), train the codec (+ the cluster
+    threshold), compress every document, build the IVF, write the directory.  Returns the array set it wrote."""
     from .search import index_io
     docs16 = [_np(d, np.float16) for d in documents_embeddings]
     n = len(docs16)
     if n == 0:
         raise ValueError("Cannot create an index from zero documents")
-    rng = np.random.default_rng(seed)
-    k = int(min(1.0 + 16.0 * math.sqrt(120.0 * n), n))
-    sample = np.sort(rng.permutation(n)[:k])
-    total = int(sum(docs16[i].shape[0] for i in sample))
-    held_n = int(round(min(0.05 * total, 50_000.0)))
-    held = np.concatenate([docs16[i] for i in sample])[-max(held_n, 1):]
+    held = heldout_sample(docs16, np.random.default_rng(seed))
+    if held.shape[0] == 0:
+        raise ValueError("Cannot train codec: no heldout samples were generated.")   # create.rs:301-305
     arr = build_index_arrays(docs16, centroids, nbits, device, heldout=held)
     if compress_only:
         arr["ivf"] = None
         arr["ivf_lengths"] = None
-    index_io.save_index_arrays(index_path, arr, chunk_docs=chunk_docs)
+    index_io.save_index_arrays(index_path, arr, chunk_docs=chunk_docs, write_plan=True)
     return arr

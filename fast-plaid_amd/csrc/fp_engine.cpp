@@ -103,6 +103,7 @@ struct Scratch {
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
       l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark;
   HostBuf h_out, h_small;
+  bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
@@ -278,6 +279,14 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     if (ucodes) { ix->owned.push_back(ucodes); ix->bytes += U * 4; }
     if (urc != 0) return fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")");
     D.ucodes = ucodes; D.uoff = uoff; D.U = U;
+  }
+  if (D.C <= (1ll << 17)) {   // packed code lines for S4's level 0 (codes of up to 17 bits)
+    void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
+    const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, &lines, &poff, &nl, st);
+    if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; }
+    if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 4; }
+    if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
+    D.pcodes = static_cast<const uint4*>(lines); D.poff = poff;
   }
   return FP_OK;
 }
@@ -684,9 +693,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   return FP_OK;
 }
 
-// S6+S7 with the exact-order repair: MaxSim on MFMA, then the flagged columns of the documents that are near-tied in the final
-// ranking (near_tied_only; every flagged document otherwise) are re-evaluated with the reference's ascending-k chain.
-static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, bool near_tied_only) {
+// S6+S7 with the exact-order repair.  mode 1 (fp_search): MaxSim on MFMA, then the flagged columns of the documents that are
+// near-tied in the final ranking are re-evaluated with the reference's ascending-k chain.  The sharded search splits this:
+// mode 0 = MFMA pass only (scores + budgets stay in the scratch), mode 2 = repair every flagged document of the previous
+// mode-0 pass (the final ranking is only known after the exchange).
+static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, int mode) {
   const FpIndexDev& D = ix->d;
   hipStream_t st = s->st;
   const int B = sh.B;
@@ -694,6 +705,7 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
   HIPCHK(s->exact.ensure((size_t)B * R * 4));
   HIPCHK(s->ms_pref.ensure((size_t)(B + 1) * 8));
   const bool repair = repair_env != 0 && fpk_maxsim_fast_shape(D.dim, D.nbits);
+  s->ms_repairable = repair;
   FpMaxsimAux aux{nullptr, nullptr, nullptr};
   if (repair) {
     HIPCHK(s->ms_cm16.ensure((size_t)B * R * sh.Qp * 2));
@@ -703,11 +715,13 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
     HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
     aux = FpMaxsimAux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>()};
   }
-  if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(),
-                 s->ms_pref.as<int64_t>(), aux, st))
-    return fail(FP_EUNSUPPORTED, "dim/nbits");
-  if (repair) {
-    const bool marked = near_tied_only && repair_env != 2 &&
+  if (mode != 2) {
+    if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(),
+                   s->ms_pref.as<int64_t>(), aux, st))
+      return fail(FP_EUNSUPPORTED, "dim/nbits");
+  }
+  if (repair && mode != 0) {
+    const bool marked = mode == 1 && repair_env != 2 &&
                         fpk_final_mark(s->exact.as<float>(), aux.unc, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
                                        s->ms_nmark.as<int32_t>(), st) == 0;
     fpk_maxsim_repair(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R,
@@ -778,7 +792,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     g_last_counts[3] += 1;
     // S6+S7
     const int64_t R = P.sh.R;
-    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, true)) return rc;
+    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1)) return rc;
     HIPCHK(hipEventRecord(s->ev[ST_TOPK], st));
     // S8
     const int64_t K = p->top_k;
@@ -1183,8 +1197,8 @@ extern "C" void fp_shard_end(fp_shard_ctx* c) {
   delete c;
 }
 
-extern "C" int fp_shard_stage1(fp_shard_ctx* c, float* dev_top_approx, int64_t* dev_top_pid) {
-  if (!c || !dev_top_approx || !dev_top_pid) return fail(FP_EINVAL, "null argument");
+extern "C" int fp_shard_stage1(fp_shard_ctx* c, void* dev_rec1) {
+  if (!c || !dev_rec1) return fail(FP_EINVAL, "null argument");
   HIPCHK(hipSetDevice(c->ix->device));
   Scratch* s = c->s;
   const int64_t R = c->P.sh.R;
@@ -1197,45 +1211,41 @@ extern "C" int fp_shard_stage1(fp_shard_ctx* c, float* dev_top_approx, int64_t* 
   } else {
     if (int rc = run_front(c->P, nullptr, nullptr, false)) return rc;
   }
-  fpk_shard_pack_top(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, c->ix->d.pid_offset,
-                     dev_top_approx, dev_top_pid, s->st);
+  fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, c->ix->d.pid_offset, dev_rec1, s->st);
   HIPCHK(hipStreamSynchronize(s->st));
   return FP_OK;
 }
 
-extern "C" int fp_shard_stage2(fp_shard_ctx* c, const float* all_approx, const int64_t* all_pid, int32_t G, float* dev_loc_score,
-                               int64_t* dev_loc_pid) {
-  if (!c || !all_approx || !all_pid || !dev_loc_score || !dev_loc_pid || G < 1) return fail(FP_EINVAL, "bad argument");
+extern "C" int fp_shard_stage2(fp_shard_ctx* c, const void* dev_all_rec1, int32_t G, void* dev_rec2) {
+  if (!c || !dev_all_rec1 || !dev_rec2 || G < 1) return fail(FP_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(c->ix->device));
   Scratch* s = c->s;
   const FpIndexDev& D = c->ix->d;
   const int64_t R = c->P.sh.R;
   const int B = c->B;
-  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 16384 is not supported");
-  {  // the global cut sorts G*R keys (8 B) next to an R-entry output list (4 B) in one workgroup's LDS
-    size_t np2 = 2, rp2 = 2;
-    while ((int64_t)np2 < (int64_t)G * R) np2 <<= 1;
-    while ((int64_t)rp2 < R) rp2 <<= 1;
-    if (np2 * 8 + rp2 * 4 + 16 > 160 * 1024) return fail(FP_EUNSUPPORTED, "n_ranks * n_full_scores too large for the LDS cut");
-  }
-  HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
-  HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
-  fpk_transpose_ranks(all_approx, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);
-  fpk_shard_global_cut(s->tmpf.as<float>(), s->tmpp.as<int64_t>(), G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(),
-                       s->sel_cnt.as<int32_t>(), s->st);
+  if (fpk_shard_global_cut(dev_all_rec1, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), s->st))
+    return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
   HIPCHK(s->exact.ensure((size_t)B * R * 4));
-  if (!c->empty_all) {   // the final ranking is only known after the exchange: every flagged document of this shard is repaired
-    if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, false)) return rc;
+  if (!c->empty_all) {
+    // MFMA scores + budgets first (what the unsharded search ranks by), then EVERY flagged document of this shard repaired: the
+    // last stage marks the near-tied ones on the union and picks `exact` for exactly those
+    if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, /*mode*/ 0)) return rc;
+    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
+                    D.pid_offset, dev_rec2, 0, s->st);
+    if (s->ms_repairable) {
+      if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, /*mode*/ 2)) return rc;
+      fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, 1, s->st);
+    }
+  } else {
+    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, 0, s->st);
   }
-  fpk_shard_pack_scores(s->exact.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_loc_score,
-                        dev_loc_pid, s->st);
   HIPCHK(hipStreamSynchronize(s->st));
   return FP_OK;
 }
 
-extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const int64_t* all_pid, int32_t G, int64_t* out_pids,
-                               float* out_scores, int32_t* out_counts) {
-  if (!c || !all_score || !all_pid || G < 1 || !out_counts) return fail(FP_EINVAL, "bad argument");
+extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_t G, int64_t* out_pids, float* out_scores,
+                               int32_t* out_counts) {
+  if (!c || !dev_all_rec2 || G < 1 || !out_counts) return fail(FP_EINVAL, "bad argument");
   HIPCHK(hipSetDevice(c->ix->device));
   Scratch* s = c->s;
   const int64_t R = c->P.sh.R;
@@ -1243,15 +1253,29 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const float* all_score, const in
   const int64_t K = c->params.top_k;
   for (int i = 0; i < B; ++i) out_counts[i] = 0;
   if (K == 0) return FP_OK;
-  if ((int64_t)G * R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4,1) > 16384 is not supported");
-  HIPCHK(s->tmpf.ensure((size_t)G * B * R * 4));
-  HIPCHK(s->tmpp.ensure((size_t)G * B * R * 8));
-  fpk_transpose_ranks(all_score, all_pid, G, B, R, s->tmpf.as<float>(), s->tmpp.as<int64_t>(), s->st);
+  // the union of the ranks' survivors in ascending id order == the unsharded rerank list
+  HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
+  HIPCHK(s->tmpf.ensure((size_t)3 * B * R * 4));
+  HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
+  HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
+  HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
+  float* u_score = s->tmpf.as<float>();
+  float* u_exact = u_score + (size_t)B * R;
+  float* u_unc = u_exact + (size_t)B * R;
+  if (fpk_shard_union(dev_all_rec2, G, B, R, s->tmpp.as<int64_t>(), u_score, u_exact, u_unc, s->sel_cnt.as<int32_t>(), s->st))
+    return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS merge of the sharded search (limit 16384 entries)");
+  static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();
+  if (repair_env != 0) {
+    if (repair_env != 2 && fpk_final_mark(u_score, u_unc, s->sel_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), s->st) == 0)
+      fpk_apply_marks(s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), B, R, u_exact, u_score, s->st);
+    else
+      HIPCHK(hipMemcpyAsync(u_score, u_exact, (size_t)B * R * 4, hipMemcpyDeviceToDevice, s->st));   // every flagged document was repaired
+  }
   OutLayout ol(B, K);
   HIPCHK(s->out_all.ensure(ol.total));
   HIPCHK(s->h_out.ensure(ol.total));
   char* od = s->out_all.as<char>();
-  fpk_final_topk(s->tmpf.as<float>(), nullptr, s->tmpp.as<int64_t>(), nullptr, (int64_t)G * R, B, K, 0, reinterpret_cast<int64_t*>(od),
+  fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->sel_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
                  reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), s->st);
   HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, s->st));
   HIPCHK(hipStreamSynchronize(s->st));

@@ -43,6 +43,9 @@ struct FpIndexDev {
   const int64_t* uoff;     // [N+1]
   int64_t U;
   int max_doc_len;
+  const uint4* pcodes;     // [NL] x 128 B: the unique codes again, packed into whole lines per document (fp_synth.hip, "packed unique
+                           //       codes"); nullptr when C > 2^17
+  const int32_t* poff;     // [N+1] line offsets into pcodes
   const uint16_t* norms;   // [T]   fp16 bits of h(sqrt(sum_fp32 e_k^2)) per stored token (ascending-k sum; computed at index creation)
 };
 
@@ -148,16 +151,16 @@ void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,
                     int64_t stride, int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid /*[B][top_k]*/,
                     float* out_score, int32_t* out_cnt, hipStream_t st);
-// sharded helpers
-void fpk_shard_pack_top(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
-                        int64_t pid_offset, float* top_approx, int64_t* top_pid, hipStream_t st);
-void fpk_shard_global_cut(const float* all_approx /*[G][B][R]*/, const int64_t* all_pid, int G, int B, int64_t R,
-                          int64_t pid_lo, int64_t pid_hi, int32_t* sel_pid /*[B][R] local*/, int32_t* sel_cnt,
-                          hipStream_t st);
-void fpk_shard_pack_scores(const float* exact, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
-                           int64_t pid_offset, float* loc_score, int64_t* loc_pid, hipStream_t st);
-void fpk_transpose_ranks(const float* in_f /*[G][B][R]*/, const int64_t* in_p, int G, int B, int64_t R,
-                         float* out_f /*[B][G*R]*/, int64_t* out_p, hipStream_t st);
+// sharded helpers (record layouts: include/fastplaid.h)
+void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
+                     hipStream_t st);
+void fpk_shard_pack2(const float* score, const float* unc /*nullable*/, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
+                     int64_t pid_offset, void* rec2, int phase, hipStream_t st);
+int fpk_shard_global_cut(const void* all_rec1 /*[G][B][R]*/, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
+                         int32_t* sel_pid /*[B][R] local*/, int32_t* sel_cnt, hipStream_t st);
+int fpk_shard_union(const void* all_rec2 /*[G][B][R]*/, int G, int B, int64_t R, int64_t* u_pid, float* u_score, float* u_exact, float* u_unc,
+                    int32_t* u_cnt, hipStream_t st);
+void fpk_apply_marks(const int32_t* marks, const int32_t* nmark, int B, int64_t R, const float* u_exact, float* u_score, hipStream_t st);
 // misc
 void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
 // create.rs:148-184, :404-428 on device pointers: nearest centroid (MFMA narrowing + exact re-check of the near-ties, or the exact
@@ -202,6 +205,9 @@ int fps_sort_docs(int32_t* codes, uint8_t* residuals, const int64_t* doc_off_dev
 // Per-document sorted unique codes (allocates *ucodes, fills uoff_dev [N+1]).
 int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int max_len, int32_t** ucodes, int64_t* U,
                      int64_t* uoff_dev, hipStream_t st);
+// The unique codes packed into 128-byte lines per document (S4 level 0).  Allocates *lines and *poff [N+1].
+int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, void** lines, int32_t** poff, int64_t* n_lines,
+                     hipStream_t st);
 // Builds the IVF (per-cell ascending unique local doc ids) from the per-document unique codes.
 // Allocates *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
 int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t U, int64_t P, int32_t** ivf_pids,

@@ -1493,12 +1493,14 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
 }
 
 // ub[cand] = min(F + sum e(c), 0xFFFE), or 0xFFFF when some code has an infinite excess.
-// 8 lanes per candidate, each lane one 16-byte piece (4 codes) of the candidate's unique-code list; a lane group takes TWO
-// consecutive candidates per iteration and issues the first two pieces of both lists before it consumes any of them (4 loads
-// in flight per lane; the kernel was latency-bound at one: 3.3 TB/s of fabric traffic, VALU 32 % busy), the offsets of the
-// next iteration's candidates and the ids of the one after are fetched in the shadow.  Escape slots / infinite entries take a
-// rare second pass over the candidate.  The histogram of (ub - F) >> 2 that the pilot cut needs is built here in LDS.
+// The candidates' codes come from the packed lines (fp_synth.hip "packed unique codes"): one aligned 128-byte line per document
+// (more for documents with > 56 distinct codes), 8 lanes per line, one 16-byte piece = 7 codes per lane, nothing shared
+// between lanes but the final sum.  A lane group takes FOUR consecutive candidates per iteration and issues their four line
+// loads before it consumes any (the offsets of the next iteration's candidates and the ids of the one after are fetched in
+// the shadow).  Escape slots / infinite entries take a rare second pass over the candidate.  The histogram of (ub - F) >> 2
+// that the pilot cut needs is built here in LDS.
 #define L0_HBINS 4096
+#define L0_UNROLL 4
 __device__ __forceinline__ uint32_t l0_red8(uint32_t v) {   // sum over the 8 lanes of a group, in all of them (no lane outside the group is read)
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
@@ -1513,16 +1515,17 @@ __device__ __forceinline__ uint32_t l0_max8(uint32_t v) {
 }
 __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
-                                                  const int32_t* __restrict__ cand_pid, const int64_t* __restrict__ uoff,
-                                                  const int32_t* __restrict__ ucodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist) {
+                                                  const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ poff,
+                                                  const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
-  uint8_t* tab = l0s;                                                  // [Cpad + 16]: the 16 bytes behind the table are 0 (index of masked codes)
+  uint8_t* tab = l0s;                                                  // [Cpad + 16]: the 16 bytes behind the table are 0 (index of absent codes)
   uint32_t* es = reinterpret_cast<uint32_t*>(l0s + Cpad + 16);         // [64]
   uint32_t* hl = es + 64;                                              // [L0_HBINS]
   const int b = blockIdx.y, tid = threadIdx.x;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
-  if ((int64_t)blockIdx.x * 256 >= n) return;
+  constexpr int CPI = 128 * L0_UNROLL;   // candidates per workgroup iteration
+  if ((int64_t)blockIdx.x * CPI >= n) return;
   {
     const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad);
     uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -1534,78 +1537,79 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   __syncthreads();
   const uint32_t F = Fsum[b];
   const int sub = tid & 7;
-  const int32_t zidx = (int32_t)Cpad;
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const uint32_t zidx = (uint32_t)Cpad;
+  const int64_t stride = (int64_t)gridDim.x * CPI;
   const int32_t* cpids = cand_pid + beg;
-  // pipeline registers: [0] / [1] = the group's two candidates
-  int64_t i = (int64_t)blockIdx.x * 256 + (tid >> 3) * 2;
-  int32_t pidn[2] = {0, 0};          // ids of the next iteration
-  int64_t u0[2] = {0, 0};
-  int len[2] = {0, 0};
+  int64_t i = (int64_t)blockIdx.x * CPI + (tid >> 3) * L0_UNROLL;
+  int32_t pidn[L0_UNROLL];           // ids of the next iteration
+  int32_t l0[L0_UNROLL], nl[L0_UNROLL];   // first line / line count of this iteration's candidates
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < L0_UNROLL; ++k) {
+    l0[k] = 0; nl[k] = 0; pidn[k] = 0;
     if (i + k < n) {
       const int32_t pid = cpids[i + k];
-      const longlong2 o = *reinterpret_cast<const longlong2*>(uoff + pid);
-      u0[k] = o.x;
-      len[k] = (int)(o.y - o.x);
+      l0[k] = poff[pid];
+      nl[k] = poff[pid + 1] - l0[k];
     }
     if (i + stride + k < n) pidn[k] = cpids[i + stride + k];
   }
-  auto lookup4 = [&](const int4& cd, int rem, uint32_t& sum, uint32_t& mx) {   // rem = codes of this piece that exist (may be <= 0)
-    const int32_t c4[4] = {cd.x, cd.y, cd.z, cd.w};
+  // sum / max of the 7 table entries of one piece (absent codes index the zero behind the table)
+  auto piece = [&](const uint4& pc, uint32_t& sum, uint32_t& mx) {
+    const uint32_t w[4] = {pc.x, pc.y, pc.z, pc.w};
+    const uint32_t cnt = pc.w >> 24;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t v = tab[k < rem ? c4[k] : zidx];
+    for (int j = 0; j < 7; ++j) {
+      const uint32_t lo = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      const uint32_t c = lo | (((pc.w >> (16 + j)) & 1u) << 16);
+      const uint32_t v = tab[(uint32_t)j < cnt ? c : zidx];
       sum += v;
       mx = max(mx, v);
     }
   };
   for (; i < n; i += stride) {
-    // this iteration's code pieces: two per candidate up front
-    int4 cd[2][2];
+    uint4 pc[L0_UNROLL];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int32_t* cp = ucodes + u0[k] + sub * 4;
-      cd[k][0] = make_int4(0, 0, 0, 0);
-      cd[k][1] = make_int4(0, 0, 0, 0);
-      if (sub * 4 < len[k]) __builtin_memcpy(&cd[k][0], cp, 16);        // dword-aligned only; the list buffer is padded past its end
-      if (32 + sub * 4 < len[k]) __builtin_memcpy(&cd[k][1], cp + 32, 16);
+    for (int k = 0; k < L0_UNROLL; ++k) {
+      pc[k] = make_uint4(0, 0, 0, 0);
+      if (nl[k] > 0) pc[k] = pcodes[(int64_t)l0[k] * 8 + sub];
     }
     // next iteration's offsets, the ids of the one after
-    int64_t nu0[2] = {0, 0};
-    int nlen[2] = {0, 0};
-    int32_t pidnn[2] = {0, 0};
+    int32_t nl0[L0_UNROLL], nnl[L0_UNROLL], pidnn[L0_UNROLL];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < L0_UNROLL; ++k) {
+      nl0[k] = 0; nnl[k] = 0; pidnn[k] = 0;
       if (i + stride + k < n) {
-        const longlong2 o = *reinterpret_cast<const longlong2*>(uoff + pidn[k]);
-        nu0[k] = o.x;
-        nlen[k] = (int)(o.y - o.x);
+        nl0[k] = poff[pidn[k]];
+        nnl[k] = poff[pidn[k] + 1] - nl0[k];
       }
       if (i + 2 * stride + k < n) pidnn[k] = cpids[i + 2 * stride + k];
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < L0_UNROLL; ++k) {
       uint32_t sum = 0, mx = 0;
-      lookup4(cd[k][0], len[k] - sub * 4, sum, mx);
-      lookup4(cd[k][1], len[k] - 32 - sub * 4, sum, mx);
-      for (int t = 64 + sub * 4; t < len[k]; t += 32) {   // long lists (documents with more than 64 distinct codes)
-        int4 c;
-        __builtin_memcpy(&c, ucodes + u0[k] + t, 16);
-        lookup4(c, len[k] - t, sum, mx);
+      piece(pc[k], sum, mx);
+      for (int t = 1; t < nl[k]; ++t) {   // documents with more than 56 distinct codes
+        const uint4 more = pcodes[((int64_t)l0[k] + t) * 8 + sub];
+        piece(more, sum, mx);
       }
       sum = l0_red8(sum);
       mx = l0_max8(mx);
       if (mx >= L0_ESC_BASE) {   // rare: a code with an escaped or infinite excess -- redo this candidate with the slow decode
         uint32_t s2 = 0, inf = 0;
-        for (int t = sub; t < len[k]; t += 8) {
-          uint32_t v = tab[ucodes[u0[k] + t]];
-          if (v >= L0_ESC_BASE) {
-            inf |= (v == 255u) ? 1u : 0u;
-            v = es[(v - L0_ESC_BASE) & 63];
+        for (int t = 0; t < nl[k]; ++t) {
+          const uint4 q = pcodes[((int64_t)l0[k] + t) * 8 + sub];
+          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+          const uint32_t cnt = q.w >> 24;
+          for (int j = 0; j < 7; ++j) {
+            if ((uint32_t)j >= cnt) break;
+            const uint32_t c = ((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) | (((q.w >> (16 + j)) & 1u) << 16);
+            uint32_t v = tab[c];
+            if (v >= L0_ESC_BASE) {
+              inf |= (v == 255u) ? 1u : 0u;
+              v = es[(v - L0_ESC_BASE) & 63];
+            }
+            s2 += v;
           }
-          s2 += v;
         }
         sum = l0_red8(s2);
         mx = l0_max8(inf);
@@ -1615,14 +1619,14 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         uint32_t v = F + sum;
         v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
         ub[beg + i + k] = (uint16_t)v;
-        uint32_t hb = (v >= F ? v - F : 0u) >> 2;
+        const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
         atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      u0[k] = nu0[k];
-      len[k] = nlen[k];
+    for (int k = 0; k < L0_UNROLL; ++k) {
+      l0[k] = nl0[k];
+      nl[k] = nnl[k];
       pidn[k] = pidnn[k];
     }
   }
@@ -1685,27 +1689,51 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
   if (tid == 0) cut[b] = s_k <= 0 ? 0 : (int32_t)(Fsum[b] + 4u * (uint32_t)s_k);
 }
 
-// pilot group = { ub >= cut[b] }, in ANY order (only the keep-th largest of their exact scores is used): one pass, one atomic
-// per wave.  pilot_pid[b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the capacity (then nothing is pruned).
+// pilot group = { ub >= cut[b] }, in ANY order (only the keep-th largest of their exact scores is used).  Every workgroup counts
+// its slice, reserves its range with ONE global atomic (a per-wave atomic on the query's counter cost 1.1 ms at cfg2: ~3000
+// same-address atomics per query serialise at the memory side), then writes.
+// pilot_pid[b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the capacity (then nothing is pruned).
 #define L0_PILOT_MAX 32768
 __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
                                                   int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid) {
+  __shared__ int s_cnt, s_base;
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const uint32_t ct = (uint32_t)cut[b];
-  const int lane = threadIdx.x & 63;
-  for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x - lane); i0 < n; i0 += (int64_t)gridDim.x * 256) {
-    const int64_t i = i0 + lane;
-    const bool take = (i < n) && ((uint32_t)ub[beg + i] >= ct);
+  // this workgroup's contiguous slice
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  if (lo >= hi) return;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) mine += ((uint32_t)ub[beg + i] >= ct) ? 1 : 0;
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) mine += __shfl_xor(mine, sft, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  const int total = s_cnt;
+  if (total == 0) return;
+  if (threadIdx.x == 0) {
+    s_base = atomicAdd(&npilot[b], total);
+    s_cnt = 0;
+  }
+  __syncthreads();
+  const int base = s_base;
+  for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+    const int64_t i = i0 + threadIdx.x;
+    const bool take = (i < hi) && ((uint32_t)ub[beg + i] >= ct);
     const unsigned long long m = __ballot(take);
     if (!m) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&npilot[b], __popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
+    const int lane = threadIdx.x & 63;
+    int wbase = 0;
+    if (lane == 0) wbase = atomicAdd(&s_cnt, __popcll(m));   // LDS atomic: order inside the workgroup's range is irrelevant
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
     if (take) {
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      const int pos = base + wbase + __popcll(m & ((1ull << lane) - 1ull));
       if (pos < L0_PILOT_MAX) pilot_pid[(int64_t)b * L0_PILOT_MAX + pos] = cand_pid[beg + i];
     }
   }
@@ -1825,7 +1853,7 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
 }
 
 size_t fpk_l0_lds_bytes(const FpIndexDev& ix) { return (size_t)((ix.C + 15) & ~(int64_t)15) + 16 + 256 + L0_HBINS * 4; }
-bool fpk_l0_fits(const FpIndexDev& ix) { return fpk_l0_lds_bytes(ix) <= 160 * 1024; }
+bool fpk_l0_fits(const FpIndexDev& ix) { return ix.pcodes != nullptr && fpk_l0_lds_bytes(ix) <= 160 * 1024; }
 
 // level 0 in launch groups so that the scan kernel can be timed alone:
 //   prepare: floors + excess table;  scan: UB0 of every candidate (+ its histogram);  pilot: the top mult*keep documents by UB0
@@ -1857,7 +1885,7 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, w.esc, w.Fsum, cand_off,
-                     cand_pid, ix.uoff, ix.ucodes, w.ub, w.hist);
+                     cand_pid, ix.poff, ix.pcodes, w.ub, w.hist);
 }
 
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st) {
@@ -1865,8 +1893,8 @@ void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_
   static const int mult = [] { const char* e = getenv("FP_L0_PILOT"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
   hipLaunchKernelGGL(k_l0_topcut, dim3((unsigned)B), dim3(1024), 0, st, w.hist, cand_off, sh.n_full, sh.R, mult, w.Fsum, w.cut, w.npilot);
   const int64_t per_q = (M + B - 1) / B;
-  int64_t bx = (per_q + 4095) / 4096;
-  if (bx > 256) bx = 256;
+  int64_t bx = (per_q + 8191) / 8192;
+  if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_l0_pilot, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.npilot, w.pilot_pid);
 }
@@ -2225,64 +2253,74 @@ void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t*
 }
 
 // ============================================================================================
-// sharded-search helpers
+// sharded-search helpers.  Both exchanges move ONE fixed-size record buffer per rank (include/fastplaid.h):
+//   rec1 {i64 pid; f32 approx; i32 pad}                       local top-R candidates by approximate score
+//   rec2 {i64 pid; f32 score; f32 exact; f32 unc; i32 pad}    exact scores of the local survivors of the global cut: the MFMA score,
+//                                                             its uncertainty budget, and the fully repaired (reference) score
+// all_rec* = [G][B][R] as an all-gather lays them out.  The last stage marks the near-tied flagged documents on the UNION exactly
+// as the unsharded search does on its rerank list and takes `exact` for them, `score` for the others: same result bit for bit.
 // ============================================================================================
-__global__ void k_shard_pack(const float* __restrict__ val, const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt,
-                             int64_t R, int64_t pid_offset, float* __restrict__ oval, int64_t* __restrict__ opid, int64_t total) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+struct ShardRec1 { long long pid; float approx; int pad; };
+struct ShardRec2 { long long pid; float score; float exact; float unc; int pad; };
+static_assert(sizeof(ShardRec1) == 16 && sizeof(ShardRec2) == 24, "record layout is part of the C ABI");
+
+__global__ void k_shard_pack1(const float* __restrict__ approx, const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt, int64_t R,
+                              int64_t pid_offset, ShardRec1* __restrict__ out, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  int b = (int)(i / R);
-  int r = (int)(i % R);
-  if (r < cnt[b]) { oval[i] = val[i]; opid[i] = (int64_t)pid[i] + pid_offset; }
-  else { oval[i] = -__builtin_inff(); opid[i] = -1; }
+  const int b = (int)(i / R), r = (int)(i % R);
+  ShardRec1 o;
+  o.pad = 0;
+  if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.approx = approx[i]; }
+  else { o.pid = -1; o.approx = -__builtin_inff(); }
+  out[i] = o;
+}
+void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
+                     hipStream_t st) {
+  const int64_t total = (int64_t)B * R;
+  hipLaunchKernelGGL(k_shard_pack1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sel_approx, sel_pid, sel_cnt, R, pid_offset,
+                     static_cast<ShardRec1*>(rec1), total);
 }
 
-void fpk_shard_pack_top(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
-                        int64_t pid_offset, float* top_approx, int64_t* top_pid, hipStream_t st) {
-  int64_t total = (int64_t)B * R;
-  hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sel_approx, sel_pid, sel_cnt, R, pid_offset,
-                     top_approx, top_pid, total);
-}
-
-void fpk_shard_pack_scores(const float* exact, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset,
-                           float* loc_score, int64_t* loc_pid, hipStream_t st) {
-  fpk_shard_pack_top(exact, sel_pid, sel_cnt, B, R, pid_offset, loc_score, loc_pid, st);
-}
-
-// [G][B][R] -> [B][G*R]
-__global__ void k_transpose_ranks(const float* __restrict__ in_f, const int64_t* __restrict__ in_p, int G, int B, int64_t R,
-                                  float* __restrict__ out_f, int64_t* __restrict__ out_p) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t total = (int64_t)G * B * R;
+// phase 0: pid / score / unc (exact := score); phase 1: exact only (after the repair pass)
+__global__ void k_shard_pack2(const float* __restrict__ score, const float* __restrict__ unc, const int32_t* __restrict__ pid,
+                              const int32_t* __restrict__ cnt, int64_t R, int64_t pid_offset, ShardRec2* __restrict__ out, int64_t total,
+                              int phase) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  int64_t r = i % R;
-  int64_t b = (i / R) % B;
-  int64_t g = i / (R * B);
-  int64_t o = b * (G * R) + g * R + r;
-  out_f[o] = in_f[i];
-  out_p[o] = in_p[i];
+  const int b = (int)(i / R), r = (int)(i % R);
+  const bool live = r < cnt[b];
+  if (phase == 0) {
+    ShardRec2 o;
+    o.pad = 0;
+    if (live) { o.pid = (long long)pid[i] + pid_offset; o.score = score[i]; o.exact = score[i]; o.unc = unc ? unc[i] : 0.f; }
+    else { o.pid = -1; o.score = -__builtin_inff(); o.exact = -__builtin_inff(); o.unc = 0.f; }
+    out[i] = o;
+  } else if (live) {
+    out[i].exact = score[i];
+  }
+}
+void fpk_shard_pack2(const float* score, const float* unc, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset,
+                     void* rec2, int phase, hipStream_t st) {
+  const int64_t total = (int64_t)B * R;
+  hipLaunchKernelGGL(k_shard_pack2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, score, unc, sel_pid, sel_cnt, R, pid_offset,
+                     static_cast<ShardRec2*>(rec2), total, phase);
 }
 
-void fpk_transpose_ranks(const float* in_f, const int64_t* in_p, int G, int B, int64_t R, float* out_f, int64_t* out_p,
-                         hipStream_t st) {
-  int64_t total = (int64_t)G * B * R;
-  hipLaunchKernelGGL(k_transpose_ranks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in_f, in_p, G, B, R, out_f, out_p);
-}
-
-// global cut: sort the union [B][G*R] by (approx desc, id asc), keep the first R valid, and
+// global cut: sort the union of the G ranks' local top-R by (approx desc, id asc), keep the first R valid, and
 // of those the ones that live on this rank, written as local ids in ascending order.
-__global__ __launch_bounds__(1024) void k_shard_cut(const float* __restrict__ val, const int64_t* __restrict__ pid, int n, int npow2,
-                                                    int64_t R, int64_t pid_lo, int64_t pid_hi, int32_t* __restrict__ sel_pid,
-                                                    int32_t* __restrict__ sel_cnt) {
+__global__ __launch_bounds__(1024) void k_shard_cut(const ShardRec1* __restrict__ all, int G, int B, int npow2, int64_t R, int64_t pid_lo,
+                                                    int64_t pid_hi, int32_t* __restrict__ sel_pid, int32_t* __restrict__ sel_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* s_cntp = reinterpret_cast<int*>(smem);
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem + 16);
   const int b = blockIdx.x;
+  const int n = (int)(G * R);
   for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
     unsigned long long key = 0ull;
     if (i < n) {
-      int64_t id = pid[(int64_t)b * n + i];
-      if (id >= 0) key = ((unsigned long long)mono32(val[(int64_t)b * n + i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+      const ShardRec1 e = all[((int64_t)(i / R) * B + b) * R + (i % R)];
+      if (e.pid >= 0) key = ((unsigned long long)mono32(e.approx) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e.pid);
     }
     v[i] = key;
   }
@@ -2301,7 +2339,6 @@ __global__ __launch_bounds__(1024) void k_shard_cut(const float* __restrict__ va
     }
   }
   // first R entries (valid ones have key != 0): keep local ids; then sort them ascending.
-  // Reuse LDS: write local ids (or sentinel) into a second region after a barrier.
   const int lim = (int)(R < npow2 ? R : npow2);
   unsigned int* ids = reinterpret_cast<unsigned int*>(smem + 16 + (size_t)npow2 * 8);  // [rpow2]
   int rpow2 = 2;
@@ -2338,16 +2375,92 @@ __global__ __launch_bounds__(1024) void k_shard_cut(const float* __restrict__ va
   if (threadIdx.x == 0) sel_cnt[b] = cnt;
 }
 
-void fpk_shard_global_cut(const float* all_approx, const int64_t* all_pid, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
-                          int32_t* sel_pid, int32_t* sel_cnt, hipStream_t st) {
-  // all_* already transposed to [B][G*R]
+int fpk_shard_global_cut(const void* all_rec1, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi, int32_t* sel_pid, int32_t* sel_cnt,
+                         hipStream_t st) {
   const int n = (int)(G * R);
   const int np2 = next_pow2(n < 2 ? 2 : n);
-  int rp2 = next_pow2((int)(R < 2 ? 2 : R));
+  const int rp2 = next_pow2((int)(R < 2 ? 2 : R));
+  const size_t lds = (size_t)np2 * 8 + (size_t)rp2 * 4 + 16;
+  if (lds > 160 * 1024) return -1;
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_shard_cut, lds_ok, 160 * 1024);
-  hipLaunchKernelGGL(k_shard_cut, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + (size_t)rp2 * 4 + 16, st, all_approx, all_pid, n, np2, R,
-                     pid_lo, pid_hi, sel_pid, sel_cnt);
+  hipLaunchKernelGGL(k_shard_cut, dim3((unsigned)B), dim3(1024), lds, st, static_cast<const ShardRec1*>(all_rec1), G, B, np2, R, pid_lo, pid_hi,
+                     sel_pid, sel_cnt);
+  return 0;
+}
+
+// union of the ranks' exact-scored documents of one query, in ascending doc id order (== the unsharded rerank list):
+// u_pid / u_score / u_exact / u_unc [B][R], u_cnt [B]
+__global__ __launch_bounds__(1024) void k_shard_union(const ShardRec2* __restrict__ all, int G, int B, int npow2, int64_t R,
+                                                      int64_t* __restrict__ u_pid, float* __restrict__ u_score, float* __restrict__ u_exact,
+                                                      float* __restrict__ u_unc, int32_t* __restrict__ u_cnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);   // id << 32 | index into the [G*R] union
+  __shared__ int s_n;
+  const int b = blockIdx.x;
+  const int n = (int)(G * R);
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      const long long pid = all[((int64_t)(i / R) * B + b) * R + (i % R)].pid;
+      if (pid >= 0) { key = ((unsigned long long)(uint32_t)pid << 32) | (unsigned long long)(uint32_t)i; ++mine; }
+    }
+    v[i] = key;
+  }
+  if (mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = v[i], c = v[ixj];
+          const bool up = ((i & k) == 0);
+          if ((a > c) == up) { v[i] = c; v[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int nv = s_n < (int)R ? s_n : (int)R;   // the global cut keeps at most R documents over all ranks
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+    const int idx = (int)(uint32_t)v[i];
+    const ShardRec2 e = all[((int64_t)(idx / R) * B + b) * R + (idx % R)];
+    const int64_t o = (int64_t)b * R + i;
+    u_pid[o] = e.pid;
+    u_score[o] = e.score;
+    u_exact[o] = e.exact;
+    u_unc[o] = e.unc;
+  }
+  if (threadIdx.x == 0) u_cnt[b] = nv;
+}
+int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pid, float* u_score, float* u_exact, float* u_unc, int32_t* u_cnt,
+                    hipStream_t st) {
+  const int n = (int)(G * R);
+  const int np2 = next_pow2(n < 2 ? 2 : n);
+  if ((size_t)np2 * 8 > 160 * 1024) return -1;
+  static std::atomic<uint64_t> lds_ok{0};
+  fp_allow_big_lds((const void*)k_shard_union, lds_ok, 160 * 1024);
+  hipLaunchKernelGGL(k_shard_union, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8, st, static_cast<const ShardRec2*>(all_rec2), G, B, np2, R, u_pid,
+                     u_score, u_exact, u_unc, u_cnt);
+  return 0;
+}
+
+// marked documents take their repaired score
+__global__ void k_apply_marks(const int32_t* __restrict__ marks, const int32_t* __restrict__ nmark, int64_t R, const float* __restrict__ u_exact,
+                              float* __restrict__ u_score) {
+  const int b = blockIdx.x;
+  const int n = nmark[b];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int64_t o = (int64_t)b * R + marks[(int64_t)b * R + i];
+    u_score[o] = u_exact[o];
+  }
+}
+void fpk_apply_marks(const int32_t* marks, const int32_t* nmark, int B, int64_t R, const float* u_exact, float* u_score, hipStream_t st) {
+  hipLaunchKernelGGL(k_apply_marks, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, R, u_exact, u_score);
 }
 
 // ============================================================================================

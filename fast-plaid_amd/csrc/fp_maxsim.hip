@@ -325,16 +325,22 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) mx[c] = NEG_MASK_F;
 
-    while (__any(valid)) {
-      uint32_t e[NE];
-      uint32_t rw[RW];
-      // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
+    // Software pipeline: `fetch` records the bookkeeping of the stream's current chunk, issues the loads of its rows, then steps
+    // the stream and prefetches the following chunk's code / norm.  It runs once before the loop and then right after the MFMAs
+    // of every chunk have been issued -- the row registers are dead by then -- so that the next chunk's loads are in flight
+    // during the epilogue instead of being waited for at the top of the next iteration.
+    uint32_t e[NE];
+    uint32_t rw[RW];
+    float nf = 1.f;
+    int c_t0 = 0, c_len = 0, c_r = 0;
+    bool c_valid = false, c_last = false;
+    auto fetch = [&]() {
+      c_t0 = t0; c_len = len; c_r = r;
+      c_valid = valid;
+      c_last = valid && (t0 + 32 >= len);
+      // (exhausted streams read row 0 of the arrays: harmless)
       ms_load_token<D, NBITS>(a.resid, a.cent, valid ? tok_row() : 0, valid ? code : 0, rw, e);
-      const float nf = (float)__builtin_bit_cast(half_t, nrm);
-      // ---- this chunk's bookkeeping, then step the stream and prefetch the next code / norm ----
-      const int c_t0 = t0, c_len = len, c_r = r;
-      const bool c_valid = valid;
-      const bool c_last = valid && (t0 + 32 >= len);
+      nf = (float)__builtin_bit_cast(half_t, nrm);
       if (valid) {
         t0 += 32;
         if (t0 >= len) {
@@ -343,6 +349,10 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
         }
         if (valid) { const long long rr = tok_row(); code = a.codes[rr]; nrm = a.norms[rr]; }
       }
+    };
+    fetch();
+
+    while (__any(c_valid)) {
       // ---- e = h(cent + w);  e^ = h(fl32(e / n)) through the compensated reciprocal product (fp_selftest_arith out[0]) ----
       ms_decode<D, NBITS>(laneoff, rw, e);
       float r_hi, r_lo;
@@ -373,15 +383,25 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
           acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1[c], 0, 0, 0);
         }
       }
+      // ---- the chunk just computed (scalars), then the next chunk's loads ----
+      int p_t0[2], p_len[2], p_r[2];
+      bool p_valid[2], p_last[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        p_t0[s] = __builtin_amdgcn_readlane(c_t0, 32 * s);
+        p_len[s] = __builtin_amdgcn_readlane(c_len, 32 * s);
+        p_r[s] = __builtin_amdgcn_readlane(c_r, 32 * s);
+        p_valid[s] = __builtin_amdgcn_readlane((int)c_valid, 32 * s) != 0;
+        p_last[s] = __builtin_amdgcn_readlane((int)c_last, 32 * s) != 0;
+      }
+      fetch();
       // ---- epilogue.  acc0 belongs to the lower stream (state in lane 0), acc1 to the upper (lane 32);
       // D[row = token][col = q = lane&31], this lane's rows (i&3) + 8*(i>>2) + 4*hi.  The maximum over tokens is taken on
       // the fp32 accumulators (rounding is monotone, so it commutes with the maximum) ----
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int s_t0 = __builtin_amdgcn_readlane(c_t0, 32 * s), s_len = __builtin_amdgcn_readlane(c_len, 32 * s);
-        const int s_r = __builtin_amdgcn_readlane(c_r, 32 * s);
-        const bool s_valid = __builtin_amdgcn_readlane((int)c_valid, 32 * s) != 0;
-        const bool s_last = __builtin_amdgcn_readlane((int)c_last, 32 * s) != 0;
+        const int s_t0 = p_t0[s], s_len = p_len[s], s_r = p_r[s];
+        const bool s_valid = p_valid[s], s_last = p_last[s];
         if (!s_valid) continue;
         const bool partial = (s_t0 + 32 > s_len);
         float total = 0.f, ubud = 0.f;
@@ -512,35 +532,36 @@ __global__ __launch_bounds__(64) void k_maxsim_generic(const uint16_t* __restric
 
 // ---- exact-order repair --------------------------------------------------------------------------------------------------
 // k_final_mark: sort the exact scores of a query (score desc, slot asc == doc id asc: the rerank list is in ascending id
-// order), W = the largest uncertainty budget of the query; a flagged document is marked when a neighbour of the ranking lies
-// within its own budget + W and at least one of the two is inside the emitted top_k.  marks[b][0..nmark[b]) = rerank slots.
+// order).  A flagged document's true (reference) score lies in [s - u, s + u], u = its uncertainty budget; the order of two
+// documents is only in doubt when their intervals overlap.  With the list sorted, document i overlaps some higher-ranked one
+// iff s_i + u_i >= min_{j<i} (s_j - u_j) and some lower-ranked one iff s_i - u_i <= max_{j>i} (s_j + u_j): one prefix-min and one
+// suffix-max scan.  Flagged documents in such a conflict (with at least one of the two inside the emitted top_k) are marked;
+// every unmarked document's interval is disjoint from all others, so after the marked ones are re-scored exactly the order is
+// the reference's.  marks[b][0..nmark[b]) = rerank slots.
 __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ score, const float* __restrict__ unc, const int32_t* __restrict__ cnt,
                                                      int64_t stride, int npow2, int64_t top_k, int32_t* __restrict__ marks,
                                                      int32_t* __restrict__ nmark) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
-  __shared__ float s_w[16];
-  __shared__ int s_n;
+  unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);          // [npow2] keys
+  float* lo = reinterpret_cast<float*>(smem + (size_t)npow2 * 8);              // [npow2] s - u, then its exclusive prefix-min
+  float* hi = lo + npow2;                                                        // [npow2] s + u, then its exclusive suffix-max
+  __shared__ int s_any, s_n;
   const int b = blockIdx.x;
   const int n = cnt[b];
-  float wmax = 0.f;
+  if (threadIdx.x == 0) { s_any = 0; s_n = 0; }
+  __syncthreads();
+  int any = 0;
   for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
     unsigned long long key = 0ull;
     if (i < n) {
       key = ((unsigned long long)mono32(score[(int64_t)b * stride + i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-      const float u = unc[(int64_t)b * stride + i];
-      wmax = u > wmax ? u : wmax;
+      any |= unc[(int64_t)b * stride + i] > 0.f ? 1 : 0;
     }
     v[i] = key;
   }
-#pragma unroll
-  for (int sft = 32; sft > 0; sft >>= 1) { const float o = __shfl_xor(wmax, sft, 64); wmax = o > wmax ? o : wmax; }
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = wmax;
-  if (threadIdx.x == 0) s_n = 0;
+  if (any) s_any = 1;
   __syncthreads();
-  float W = 0.f;
-  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) W = s_w[i] > W ? s_w[i] : W;
-  if (W > 0.f) {   // (uniform) nothing is flagged -> nothing to mark, no sort needed
+  if (s_any) {   // (uniform) nothing flagged -> nothing to mark, no sort needed
     for (int k = 2; k <= npow2; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
         for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
@@ -554,21 +575,50 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
         __syncthreads();
       }
     }
+    const float inf = __builtin_inff();
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+      float l = inf, h = -inf;
+      if (i < n) {
+        const unsigned long long key = v[i];
+        const float si = unmono32((uint32_t)(key >> 32));
+        const float u = unc[(int64_t)b * stride + (int)(0xFFFFFFFFu - (uint32_t)key)];
+        l = si - u;
+        h = si + u;
+      }
+      lo[i] = l;
+      hi[i] = h;
+    }
+    __syncthreads();
+    // inclusive scans (Hillis-Steele): lo <- prefix-min, hi <- suffix-max; the exclusive values are read from the neighbours below
+    for (int off = 1; off < npow2; off <<= 1) {
+      float nl[16], nh[16];   // npow2 / blockDim.x <= 16 elements per thread (npow2 <= 8192 here)
+      int c = 0;
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x, ++c) {
+        nl[c] = (i >= off) ? __builtin_fminf(lo[i], lo[i - off]) : lo[i];
+        nh[c] = (i + off < npow2) ? __builtin_fmaxf(hi[i], hi[i + off]) : hi[i];
+      }
+      __syncthreads();
+      c = 0;
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x, ++c) { lo[i] = nl[c]; hi[i] = nh[c]; }
+      __syncthreads();
+    }
     const int kk = (int)(top_k < n ? top_k : n);   // emitted positions [0, kk)
+    const float lmin_top = kk > 0 ? lo[kk - 1] : inf;   // min over the emitted documents of s - u
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const unsigned long long key = v[i];
       const int slot = (int)(0xFFFFFFFFu - (uint32_t)key);
       const float u = unc[(int64_t)b * stride + slot];
       if (!(u > 0.f)) continue;
       const float si = unmono32((uint32_t)(key >> 32));
-      bool near = false;
+      bool conflict;
       if (i < kk) {
-        if (i > 0) near |= !(unmono32((uint32_t)(v[i - 1] >> 32)) - si > u + W);
-        if (i + 1 < n) near |= !(si - unmono32((uint32_t)(v[i + 1] >> 32)) > u + W);
-      } else if (kk > 0) {   // outside the emitted range: only the last emitted position can be displaced
-        near = !(unmono32((uint32_t)(v[kk - 1] >> 32)) - si > u + W);
+        const float lmin = i > 0 ? lo[i - 1] : inf;               // higher-ranked documents
+        const float hmax = i + 1 < npow2 ? hi[i + 1] : -inf;      // lower-ranked documents (also those below the cut)
+        conflict = !(si + u < lmin) || !(si - u > hmax);
+      } else {
+        conflict = !(si + u < lmin_top);                          // outside the emitted range: only a jump into it matters
       }
-      if (near) marks[(int64_t)b * stride + atomicAdd(&s_n, 1)] = slot;
+      if (conflict) marks[(int64_t)b * stride + atomicAdd(&s_n, 1)] = slot;
     }
   }
   __syncthreads();
@@ -576,8 +626,9 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
 }
 
 // k_maxsim_repair: one wave per marked (query, slot) -- or, with marks == nullptr, per slot whose budget is > 0.  Tokens are
-// decompressed exactly as in k_maxsim5; every flagged column is re-evaluated with the ascending-k fp32 chain for all tokens,
-// the stored column maxima are patched and the score re-summed (same reduction tree as k_maxsim5).
+// decompressed exactly as in k_maxsim5 (once per 64-token step); every flagged column is re-evaluated with the ascending-k fp32
+// chain against the query row staged in LDS, the stored column maxima are patched and the score re-summed (same reduction
+// tree as k_maxsim5).  One workgroup = 4 waves of one query.
 template <int D, int NBITS>
 __global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
                                                        const int32_t* __restrict__ codes, const uint16_t* __restrict__ norms,
@@ -590,13 +641,16 @@ __global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restric
   constexpr int NE = Cf::NE, RW = Cf::RW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* lut = smem;
+  uint32_t* qsh = reinterpret_cast<uint32_t*>(smem + MS_LUT_BYTES);   // [Qp][D/2] the query's rows (packed halves)
+  const int b = blockIdx.y;
+  const int nwork = marks ? nmark[b] : sel_cnt[b];
+  if ((int)blockIdx.x * 4 >= nwork) return;
   ms_lds_base_is_zero(smem);
   ms_fill_lut<D, NBITS>(lut, lut_g, threadIdx.x, 256);
+  for (int i = threadIdx.x; i < Qp * (D / 2); i += 256) qsh[i] = reinterpret_cast<const uint32_t*>(qpad + (int64_t)b * Qp * D)[i];
   __syncthreads();
-  const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t laneoff = (uint32_t)((lane & (Cf::COPIES - 1)) * Cf::EW * 4);
-  const int nwork = marks ? nmark[b] : sel_cnt[b];
   const int nflag = Qp / 32;
   for (int wi = blockIdx.x * 4 + wave; wi < nwork; wi += gridDim.x * 4) {
     const int r = marks ? marks[(int64_t)b * Rcap + wi] : wi;
@@ -611,12 +665,9 @@ __global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restric
     for (int ch = 0; ch < nflag; ++ch) {
       const int q = ch * 32 + (lane & 31);
       float cv = (lane < 32 && q < Q) ? (float)__builtin_bit_cast(half_t, cm16[slot * Qp + q]) : 0.f;
-      uint32_t fm = flags[slot * nflag + ch];
-      while (fm) {
-        const int col = __builtin_ctz(fm);
-        fm &= fm - 1;
-        const uint16_t* qq = qpad + ((int64_t)b * Qp + ch * 32 + col) * D;
-        float m = NEG_MASK_F;
+      const uint32_t fm = flags[slot * nflag + ch];
+      if (fm) {
+        float colmax = NEG_MASK_F;   // lane c: running exact maximum of column c
         for (int t0 = 0; t0 < len; t0 += 64) {
           int tok = t0 + lane;
           const bool live = tok < len;
@@ -630,25 +681,32 @@ __global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restric
           recip2(nf, r_hi, r_lo);
 #pragma unroll
           for (int i = 0; i < NE; i += 2) norm_pair2(e[i], e[i + 1], r_hi, r_lo);
-          float acc = 0.f;
+          uint32_t f2 = fm;
+          while (f2) {
+            const int col = __builtin_ctz(f2);
+            f2 &= f2 - 1;
+            const uint32_t* qq = qsh + (ch * 32 + col) * (D / 2);
+            float acc = 0.f;
 #pragma unroll
-          for (int i = 0; i < NE; ++i) {   // ascending k: the CPU reference's order
-            const h2 ev = u32_as_h2(e[i]);
-            const h2 qv = u32_as_h2(reinterpret_cast<const uint32_t*>(qq)[i]);
-            acc = __builtin_fmaf((float)ev.x, (float)qv.x, acc);
-            acc = __builtin_fmaf((float)ev.y, (float)qv.y, acc);
+            for (int i = 0; i < NE; ++i) {   // ascending k: the CPU reference's order
+              const h2 ev = u32_as_h2(e[i]);
+              const h2 qv = u32_as_h2(qq[i]);
+              acc = __builtin_fmaf((float)ev.x, (float)qv.x, acc);
+              acc = __builtin_fmaf((float)ev.y, (float)qv.y, acc);
+            }
+            float sim = live ? (float)(half_t)acc : NEG_MASK_F;
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) { const float o = __shfl_xor(sim, sft, 64); sim = o > sim ? o : sim; }
+            // (a NaN sim is dropped by `o > sim`: a NaN column keeps what the MFMA pass produced)
+            if (lane == col) colmax = sim > colmax ? sim : colmax;
           }
-          float sim = live ? (float)(half_t)acc : NEG_MASK_F;
-#pragma unroll
-          for (int sft = 32; sft > 0; sft >>= 1) { const float o = __shfl_xor(sim, sft, 64); sim = o > sim ? o : sim; }
-          m = sim > m ? sim : m;   // (a NaN sim is dropped here: a NaN column keeps what the MFMA pass produced)
         }
-        if (lane == col) {
-          cv = m;
-          cm16[slot * Qp + q] = __builtin_bit_cast(uint16_t, (half_t)m);
+        if (lane < 32 && ((fm >> lane) & 1u)) {
+          cv = colmax;
+          cm16[slot * Qp + q] = __builtin_bit_cast(uint16_t, (half_t)colmax);
         }
+        if (lane == 0) flags[slot * nflag + ch] = 0u;
       }
-      if (lane == 0) flags[slot * nflag + ch] = 0u;
       float sv = cv;
 #pragma unroll
       for (int sft = 32; sft > 0; sft >>= 1) sv += __shfl_xor(sv, sft, 64);
@@ -737,10 +795,10 @@ int fpk_final_mark(const float* score, const float* unc, const int32_t* cnt, int
                    hipStream_t st) {
   int np2 = fp_next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
-  if ((size_t)np2 * 8 > 150 * 1024) return -1;
+  if (np2 > 8192) return -1;   // 16 B of LDS per entry, 16 scan elements per thread
   static std::atomic<uint64_t> lds_ok{0};
-  fp_allow_big_lds((const void*)k_final_mark, lds_ok, 152 * 1024);
-  hipLaunchKernelGGL(k_final_mark, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8, st, score, unc, cnt, stride, np2, top_k, marks, nmark);
+  fp_allow_big_lds((const void*)k_final_mark, lds_ok, 136 * 1024);
+  hipLaunchKernelGGL(k_final_mark, dim3((unsigned)B), dim3(1024), (size_t)np2 * 16, st, score, unc, cnt, stride, np2, top_k, marks, nmark);
   return 0;
 }
 
@@ -748,13 +806,15 @@ int fpk_final_mark(const float* score, const float* unc, const int32_t* cnt, int
 void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
                        int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st) {
   if (!fpk_maxsim_fast_shape(ix.dim, ix.nbits) || !aux.unc) return;   // the generic kernel never flags
-  // marked documents are a few per cent of the rerank lists: a fixed grid of 16 x 4 waves per query walks them
-  const dim3 grid((unsigned)(marks ? 16 : (Rcap + 3) / 4), (unsigned)sh.B);
+  const size_t lds = MS_LUT_BYTES + (size_t)sh.Qp * ix.dim * 2;
+  if (lds > 160 * 1024) return;   // q_len > ~370 at dim 128: no repair (scores stay within 1e-3, the order of near-ties is MFMA's)
+  // marked documents are a few per cent of the rerank lists: workgroups beyond a query's marked count exit at once
+  const dim3 grid((unsigned)(marks ? std::min<int64_t>(64, (Rcap + 3) / 4) : (Rcap + 3) / 4), (unsigned)sh.B);
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
     static std::atomic<uint64_t> ok{0}; \
-    fp_allow_big_lds((const void*)k_maxsim_repair<D_, NB_>, ok, 72 * 1024); \
-    hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(256), MS_LUT_BYTES, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \
+    fp_allow_big_lds((const void*)k_maxsim_repair<D_, NB_>, ok, 160 * 1024); \
+    hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(256), lds, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \
                        ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags); \
     return; \
   }

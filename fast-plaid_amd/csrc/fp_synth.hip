@@ -299,6 +299,89 @@ fail:
   return rc;
 }
 
+// ---- packed unique codes for S4's level-0 scan ---------------------------------------------------------
+// The level-0 kernel reads every candidate's unique-code list once per query; as int32 lists at arbitrary offsets (133 B on
+// the benchmark corpus) each candidate touched 2-3 128-byte lines, most of whose bytes belonged to non-candidates (6.7 GB
+// requested, 5.3 GB over the fabric for 2.8 GB of codes).  Here every document owns whole 128-byte LINES: a line is 8 pieces
+// of 16 bytes, a piece = 7 codes of up to 17 bits: bytes 0-13 the low 16 bits, byte 14 bit j = bit 16 of code j, byte 15 =
+// number of codes in the piece.  56 codes per line (one line per document on the benchmark corpus: 33 codes), any number of
+// lines per document; a lane reads ONE aligned 16-byte piece and needs nothing from its neighbours.  C <= 2^17 only.
+#define PCODES_PER_PIECE 7
+#define PCODES_PER_LINE 56
+__global__ void k_pcode_lines(const int64_t* __restrict__ uoff, int64_t n_docs, int64_t* __restrict__ nlines) {
+  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= n_docs; d += (int64_t)gridDim.x * blockDim.x)
+    nlines[d] = d < n_docs ? (uoff[d + 1] - uoff[d] + PCODES_PER_LINE - 1) / PCODES_PER_LINE : 0;
+}
+__global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff, int64_t n_docs,
+                                                    const int64_t* __restrict__ loff, int32_t* __restrict__ poff, uint4* __restrict__ lines) {
+  // one thread per piece
+  const int64_t nl = loff[n_docs];
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nl * 8 + n_docs + 1; g += (int64_t)gridDim.x * blockDim.x) {
+    if (g >= nl * 8) {   // the narrowed line offsets
+      const int64_t d = g - nl * 8;
+      poff[d] = (int32_t)loff[d];
+      continue;
+    }
+    const int64_t line = g >> 3;
+    const int piece = (int)(g & 7);
+    // document of `line`: last d with loff[d] <= line
+    int64_t lo = 0, hi = n_docs;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (loff[mid] <= line) lo = mid; else hi = mid;
+    }
+    const int64_t u0 = uoff[lo], n = uoff[lo + 1] - u0;
+    const int64_t first = (line - loff[lo]) * PCODES_PER_LINE + (int64_t)piece * PCODES_PER_PIECE;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    uint32_t hib = 0, cnt = 0;
+    for (int j = 0; j < PCODES_PER_PIECE; ++j) {
+      if (first + j < n) {
+        const uint32_t c = (uint32_t)ucodes[u0 + first + j];
+        w[j >> 1] |= (c & 0xFFFFu) << (16 * (j & 1));
+        hib |= ((c >> 16) & 1u) << j;
+        ++cnt;
+      }
+    }
+    w[3] |= (hib << 16) | (cnt << 24);
+    lines[g] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// allocates *lines ([NL] x 128 B) and *poff ([N+1] i32 line offsets); returns 0 or a hipError
+int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, void** lines, int32_t** poff, int64_t* n_lines,
+                     hipStream_t st) {
+  int rc = 0;
+  int64_t* nlines = nullptr;
+  int64_t* loff = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  *lines = nullptr;
+  *poff = nullptr;
+  *n_lines = 0;
+  HCHK(hipMalloc((void**)poff, (size_t)(n_docs + 1) * 4 + 64));
+  HCHK(hipMalloc((void**)&nlines, (size_t)(n_docs + 1) * 8));
+  HCHK(hipMalloc((void**)&loff, (size_t)(n_docs + 1) * 8));
+  hipLaunchKernelGGL(k_pcode_lines, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, uoff_dev, n_docs, nlines);
+  HCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, nlines, loff, (int)(n_docs + 1), st));
+  HCHK(hipMalloc(&tmp, tb ? tb : 16));
+  HCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, nlines, loff, (int)(n_docs + 1), st));
+  HCHK(hipMemcpyAsync(n_lines, loff + n_docs, 8, hipMemcpyDeviceToHost, st));
+  HCHK(hipStreamSynchronize(st));
+  if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
+  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 128 + 64));
+  {
+    const int64_t work = *n_lines * 8 + n_docs + 1;
+    hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, loff, *poff,
+                       static_cast<uint4*>(*lines));
+  }
+  HCHK(hipStreamSynchronize(st));
+fail:
+  if (nlines) (void)hipFree(nlines);
+  if (loff) (void)hipFree(loff);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
+}
+
 // ---- IVF: per-cell ascending unique local doc ids, from the per-document unique codes -------------
 __global__ __launch_bounds__(256) void k_make_keys(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff,
                                                    int64_t n_docs, unsigned long long* __restrict__ keys) {

@@ -5,6 +5,7 @@
   centroids.npy (f16)  bucket_weights.npy / bucket_cutoffs.npy / avg_residual.npy (f32 or f16)
   {i}.codes.npy (i64)  {i}.residuals.npy (u8 [T_i, dim*nbits/8])  doclens.{i}.json
   ivf.npy (i64)  ivf_lengths.npy (i32)          (absent for compress_only indexes)
+  cluster_threshold.npy (f32 scalar, create.rs:331-339)  plan.json {nbits, num_chunks} (create.rs:296-299)
 
 The reference merges the chunk files into one padded mmap before construct_index
 (load.py:35-217); here the chunks are simply concatenated -- the device index owns its copy.
@@ -64,9 +65,10 @@ def load_index_arrays(index_path: str) -> dict | None:
     return data
 
 
-def save_index_arrays(index_path: str, arr: dict, chunk_docs: int = 25_000) -> None:
+def save_index_arrays(index_path: str, arr: dict, chunk_docs: int = 25_000, write_plan: bool = False) -> None:
     """Writes arrays in the reference's directory format (used by tests and by tools that
-    hand an MI355X-built index back to the reference)."""
+    hand an MI355X-built index back to the reference).  `cluster_threshold` (when the array set carries one) goes to
+    cluster_threshold.npy as the reference's 0-dim f32; write_plan adds create.rs's plan.json."""
     os.makedirs(index_path, exist_ok=True)
     lens = np.asarray(arr["doc_lengths"], dtype=np.int64)
     T = int(lens.sum())
@@ -87,6 +89,11 @@ def save_index_arrays(index_path: str, arr: dict, chunk_docs: int = 25_000) -> N
             json.dump(lens[d0:d1].tolist(), f)
         with open(os.path.join(index_path, f"{i}.metadata.json"), "w") as f:
             json.dump({"num_documents": d1 - d0, "num_embeddings": t1 - t0, "embedding_offset": t0}, f)
+    if arr.get("cluster_threshold") is not None:
+        np.save(os.path.join(index_path, "cluster_threshold.npy"), np.asarray(arr["cluster_threshold"], dtype=np.float32).reshape(()))
+    if write_plan:   # create.rs:296-299 (serde_json pretty print + newline)
+        with open(os.path.join(index_path, "plan.json"), "w") as f:
+            f.write(json.dumps({"nbits": int(arr["nbits"]), "num_chunks": n_chunks}, indent=2) + "\n")
     compress_only = arr.get("ivf") is None
     if not compress_only:
         np.save(os.path.join(index_path, "ivf.npy"), np.asarray(arr["ivf"], dtype=np.int64))

@@ -6,16 +6,16 @@ New relative to the reference, whose multi-GPU mode is full replicas + query spl
 and a contiguous, token-balanced range of documents.  Per batch of queries:
 
   stage1  (local)   S1..S4 on the shard, local top-R candidates by approximate score
-  all-gather        [B,R] f32 approx + [B,R] i64 global ids, packed into ONE byte tensor  (R = max(n_full/4, 1))
+  all-gather        [B,R] records {i64 id, f32 approx} (16 B)                                  (R = max(n_full/4, 1))
   stage2  (local)   global top-R cut == search.rs:605-619 applied to the union, exact
                     MaxSim of the survivors that live here
-  all-gather        [B,R] f32 scores + [B,R] i64 ids, packed likewise
-  stage3  (local)   global (score desc, id asc) sort, top_k
+  all-gather        [B,R] records {i64 id, f32 score, f32 exact, f32 budget} (24 B)
+  stage3  (local)   union in id order, near-tie marking as in the unsharded search, global (score desc, id asc) sort, top_k
 
-Both messages are B*R*12 bytes per rank (3 MB at B=256, R=1024): latency-bound on xGMI, so
-they are issued as two fixed-size all_gather_into_tensor calls (one per exchange) on device buffers -- no host
-staging, no variable-length exchange.  The result is identical to the unsharded search on
-the concatenated corpus (tests/test_hip_parity.py::test_sharded_equals_unsharded).
+Both messages are fixed-size byte buffers (B*R*16 and B*R*24 bytes per rank; 6 MB at B=256, R=1024): latency-bound on
+xGMI, so each is ONE all_gather_into_tensor call on a device buffer -- no host staging, no variable-length exchange, no
+repacking (the library writes and reads the record layout directly).  The result is identical to the unsharded search on
+the concatenated corpus, bit for bit (tests/test_hip_parity.py::test_sharded_equals_unsharded).
 """
 from __future__ import annotations
 
@@ -67,6 +67,12 @@ def shard_arrays(arrays: dict, begin: int, end: int) -> dict:
     return out
 
 
+REC1_BYTES = 16   # fp_shard_rec1 {i64 pid; f32 approx; i32 pad}
+REC2_BYTES = 24   # fp_shard_rec2 {i64 pid; f32 score; f32 exact; f32 unc; i32 pad}
+REC1_DTYPE = np.dtype([("pid", "<i8"), ("approx", "<f4"), ("pad", "<i4")])
+REC2_DTYPE = np.dtype([("pid", "<i8"), ("score", "<f4"), ("exact", "<f4"), ("unc", "<f4"), ("pad", "<i4")])
+
+
 class HipShardEngine:
     """Per-rank engine over the C ABI's fp_shard_* entry points.  Device buffers are torch
     tensors so that torch.distributed (RCCL) can move them without host staging."""
@@ -92,26 +98,23 @@ class HipShardEngine:
 
     def stage1(self, st):
         t = self.torch
-        a = t.empty((st["B"], st["R"]), dtype=t.float32, device=self.device)
-        p = t.empty((st["B"], st["R"]), dtype=t.int64, device=self.device)
-        N.check(N.lib().fp_shard_stage1(st["ctx"], a.data_ptr(), p.data_ptr()))
-        return a, p
+        rec = t.empty((st["B"], st["R"] * REC1_BYTES), dtype=t.uint8, device=self.device)
+        N.check(N.lib().fp_shard_stage1(st["ctx"], rec.data_ptr()))
+        return rec
 
-    def stage2(self, st, all_a, all_p, world):
+    def stage2(self, st, all_rec1, world):
         t = self.torch
-        s = t.empty((st["B"], st["R"]), dtype=t.float32, device=self.device)
-        p = t.empty((st["B"], st["R"]), dtype=t.int64, device=self.device)
-        N.check(N.lib().fp_shard_stage2(st["ctx"], all_a.data_ptr(), all_p.data_ptr(), world, s.data_ptr(), p.data_ptr()))
-        return s, p
+        rec = t.empty((st["B"], st["R"] * REC2_BYTES), dtype=t.uint8, device=self.device)
+        N.check(N.lib().fp_shard_stage2(st["ctx"], all_rec1.data_ptr(), world, rec.data_ptr()))
+        return rec
 
-    def stage3(self, st, all_s, all_p, world):
+    def stage3(self, st, all_rec2, world):
         B, k = st["B"], max(st["top_k"], 1)
         pids = np.full((B, k), -1, np.int64)
         scores = np.zeros((B, k), np.float32)
         counts = np.zeros(B, np.int32)
-        N.check(N.lib().fp_shard_stage3(st["ctx"], all_s.data_ptr(), all_p.data_ptr(), world,
-                                        pids.ctypes.data_as(C.c_void_p), scores.ctypes.data_as(C.c_void_p),
-                                        counts.ctypes.data_as(C.c_void_p)))
+        N.check(N.lib().fp_shard_stage3(st["ctx"], all_rec2.data_ptr(), world, pids.ctypes.data_as(C.c_void_p),
+                                        scores.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
         return pids[:, : st["top_k"]], scores[:, : st["top_k"]], counts
 
     def end(self, st):
@@ -130,19 +133,6 @@ def _all_gather(torch, dist, x, world, group, force=False):
     return out.view((world,) + tuple(x.shape)).to(x.device)
 
 
-def _all_gather_pair(torch, dist, f, i, world, group, force=False):
-    """one exchange for a ([B,R] f32, [B,R] i64) pair: both are viewed as bytes and travel in ONE all-gather
-    (the exchanges are latency-bound: B*R*12 bytes per rank)."""
-    if dist is None or (world == 1 and not force):
-        return f.unsqueeze(0).contiguous(), i.unsqueeze(0).contiguous()
-    B, R = f.shape
-    packed = torch.cat([f.contiguous().view(torch.uint8).reshape(B, R * 4), i.contiguous().view(torch.uint8).reshape(B, R * 8)], dim=1)
-    g = _all_gather(torch, dist, packed, world, group, force)            # [G, B, R*12] bytes
-    gf = g[:, :, : R * 4].contiguous().view(torch.float32).reshape(world, B, R)
-    gi = g[:, :, R * 4:].contiguous().view(torch.int64).reshape(world, B, R)
-    return gf, gi
-
-
 def sharded_search(engine, queries_f16, params, dist=None, group=None, force_collectives=False):
     """Runs one batch through the three stages with the two all-gathers in between.
     `engine` implements begin/stage1/stage2/stage3/end (HipShardEngine in production).
@@ -151,15 +141,15 @@ def sharded_search(engine, queries_f16, params, dist=None, group=None, force_col
     world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
     st = engine.begin(queries_f16, params)
     try:
-        a, p = engine.stage1(st)
-        all_a, all_p = _all_gather_pair(torch, dist, a, p, world, group, force_collectives)
-        if all_a.is_cuda:
+        rec1 = engine.stage1(st)                                     # [B, R*16] bytes (the library's stream is idle on return)
+        all1 = _all_gather(torch, dist, rec1, world, group, force_collectives)
+        if all1.is_cuda:
             torch.cuda.current_stream().synchronize()  # library kernels run on their own stream
-        s, sp = engine.stage2(st, all_a, all_p, world)
-        all_s, all_sp = _all_gather_pair(torch, dist, s, sp, world, group, force_collectives)
-        if all_s.is_cuda:
+        rec2 = engine.stage2(st, all1, world)                        # [B, R*24] bytes
+        all2 = _all_gather(torch, dist, rec2, world, group, force_collectives)
+        if all2.is_cuda:
             torch.cuda.current_stream().synchronize()
-        return engine.stage3(st, all_s, all_sp, world)
+        return engine.stage3(st, all2, world)
     finally:
         engine.end(st)
 

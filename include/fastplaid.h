@@ -177,26 +177,31 @@ int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int
  * New relative to the reference, which only runs full replicas per device
  * (fast_plaid.py:893-928).  Every rank holds the full centroid table and a disjoint
  * document shard (fp_index_desc.pid_offset = first global id).  The three stages are
- * separated exactly where data must cross ranks; the caller moves the fixed-size device
- * buffers with RCCL all-gather (torch.distributed "nccl" on ROCm) between stages:
+ * separated exactly where data must cross ranks; between them the caller all-gathers ONE
+ * fixed-size device buffer of records per rank (RCCL: torch.distributed "nccl" on ROCm, or
+ * ncclAllGather on bytes):
  *
  *   stage1: S1-S4 on the local shard + local top-R candidates by approximate score
- *           -> dev top_approx [B,R] f32 (-inf padded), top_pid [B,R] i64 global (-1 padded)
- *   (all-gather both to [G,B,R])
+ *           -> dev rec1 [B,R]  (fp_shard_rec1; padding: pid -1, approx -inf)
+ *   (all-gather to [G,B,R])
  *   stage2: global top-R cut (reproduces search.rs:605-619 on the union), exact MaxSim of
  *           the survivors that live on this rank
- *           -> dev loc_score [B,R] f32 (-inf padded), loc_pid [B,R] i64 (-1 padded)
- *   (all-gather both to [G,B,R])
- *   stage3: global sort + top_k -> host outputs as fp_search.
- * R = max(n_full_scores/4, 1).  With G == 1 the result is identical to fp_search. */
+ *           -> dev rec2 [B,R]  (fp_shard_rec2: the MFMA score, its uncertainty budget, and
+ *              the score with every flagged column re-evaluated in the reference's order)
+ *   (all-gather to [G,B,R])
+ *   stage3: union in ascending id order, the unsharded search's near-tie marking on it
+ *           (marked documents take `exact`), global sort + top_k -> host outputs as fp_search.
+ * R = max(n_full_scores/4, 1).  The result is identical to fp_search on the whole corpus,
+ * bit for bit, for any G. */
+typedef struct fp_shard_rec1 { int64_t pid; float approx; int32_t pad; } fp_shard_rec1;                        /* 16 bytes */
+typedef struct fp_shard_rec2 { int64_t pid; float score; float exact; float unc; int32_t pad; } fp_shard_rec2; /* 24 bytes */
 int fp_shard_begin(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
                    const fp_search_params* params, fp_shard_ctx** out);
 int64_t fp_shard_R(const fp_shard_ctx* ctx);
-int fp_shard_stage1(fp_shard_ctx* ctx, float* dev_top_approx, int64_t* dev_top_pid);
-int fp_shard_stage2(fp_shard_ctx* ctx, const float* dev_all_approx, const int64_t* dev_all_pid, int32_t n_ranks,
-                    float* dev_loc_score, int64_t* dev_loc_pid);
-int fp_shard_stage3(fp_shard_ctx* ctx, const float* dev_all_score, const int64_t* dev_all_pid, int32_t n_ranks,
-                    int64_t* out_pids, float* out_scores, int32_t* out_counts);
+int fp_shard_stage1(fp_shard_ctx* ctx, void* dev_rec1 /*[B,R] fp_shard_rec1*/);
+int fp_shard_stage2(fp_shard_ctx* ctx, const void* dev_all_rec1 /*[G,B,R]*/, int32_t n_ranks, void* dev_rec2 /*[B,R] fp_shard_rec2*/);
+int fp_shard_stage3(fp_shard_ctx* ctx, const void* dev_all_rec2 /*[G,B,R]*/, int32_t n_ranks, int64_t* out_pids, float* out_scores,
+                    int32_t* out_counts);
 void fp_shard_end(fp_shard_ctx* ctx);
 
 /* ---- synthetic corpora generated in HBM (benchmark + full-size property tests) ------- */

@@ -31,41 +31,47 @@ class OracleShardEngine:
 
     def stage1(self, st):
         B, R, p = st["B"], st["R"], st["p"]
-        a = torch.full((B, R), float("-inf"))
-        pid = torch.full((B, R), -1, dtype=torch.int64)
+        rec = np.zeros((B, R), sharded.REC1_DTYPE)
+        rec["pid"] = -1
+        rec["approx"] = -np.inf
         for b in range(B):
             t = self.idx.search_trace(st["q"][b], p.top_k, p.n_full_scores, p.n_ivf_probe)
             amap = dict(zip(t["cand"].tolist(), t["approx"].tolist()))
             for i, d in enumerate(t["rerank"].tolist()):
-                a[b, i] = amap[d]
-                pid[b, i] = d + self.begin_
-        return a, pid
+                rec[b, i]["approx"] = amap[d]
+                rec[b, i]["pid"] = d + self.begin_
+        return torch.from_numpy(rec.view(np.uint8).reshape(B, R * sharded.REC1_BYTES))
 
-    def stage2(self, st, all_a, all_p, world):
+    def stage2(self, st, all_rec1, world):
         B, R = st["B"], st["R"]
-        s = torch.full((B, R), float("-inf"))
-        sp = torch.full((B, R), -1, dtype=torch.int64)
+        all1 = all_rec1.numpy().reshape(world, B, R * sharded.REC1_BYTES).view(sharded.REC1_DTYPE).reshape(world, B, R)
+        rec = np.zeros((B, R), sharded.REC2_DTYPE)
+        rec["pid"] = -1
+        rec["score"] = -np.inf
+        rec["exact"] = -np.inf
         for b in range(B):
-            a = all_a[:, b, :].reshape(-1).numpy()
-            p = all_p[:, b, :].reshape(-1).numpy()
+            a = all1[:, b, :]["approx"].reshape(-1)
+            p = all1[:, b, :]["pid"].reshape(-1)
             ok = p >= 0
             a, p = a[ok], p[ok]
             order = np.lexsort((p, -a))[:R]  # (approx desc, id asc)
             mine = np.sort(p[order][(p[order] >= self.begin_) & (p[order] < self.end_)])
             if len(mine):
-                ex = self.idx.exact_scores(st["q"][b], mine - self.begin_)
-                s[b, : len(mine)] = torch.from_numpy(ex)
-                sp[b, : len(mine)] = torch.from_numpy(mine)
-        return s, sp
+                ex = self.idx.exact_scores(st["q"][b], mine - self.begin_)   # the oracle's scores are exact: budget 0
+                rec[b, : len(mine)]["score"] = ex
+                rec[b, : len(mine)]["exact"] = ex
+                rec[b, : len(mine)]["pid"] = mine
+        return torch.from_numpy(rec.view(np.uint8).reshape(B, R * sharded.REC2_BYTES))
 
-    def stage3(self, st, all_s, all_p, world):
-        B, k = st["B"], st["top_k"]
+    def stage3(self, st, all_rec2, world):
+        B, k, R = st["B"], st["top_k"], st["R"]
+        all2 = all_rec2.numpy().reshape(world, B, R * sharded.REC2_BYTES).view(sharded.REC2_DTYPE).reshape(world, B, R)
         pids = np.full((B, k), -1, np.int64)
         scores = np.zeros((B, k), np.float32)
         counts = np.zeros(B, np.int32)
         for b in range(B):
-            s = all_s[:, b, :].reshape(-1).numpy()
-            p = all_p[:, b, :].reshape(-1).numpy()
+            s = all2[:, b, :]["exact"].reshape(-1)
+            p = all2[:, b, :]["pid"].reshape(-1)
             ok = p >= 0
             s, p = s[ok], p[ok]
             order = np.lexsort((p, -s))[:k]

@@ -30,16 +30,12 @@ def main():
     ranges = sharded.plan_shards(arr["doc_lengths"], G)
     engines = [sharded.HipShardEngine(mk(sharded.shard_arrays(arr, b, e), pid_offset=b), "cuda:0") for (b, e) in ranges]
     sts = [en.begin(q, params) for en in engines]
-    s1 = [en.stage1(st) for en, st in zip(engines, sts)]
-    all_a = torch.stack([x[0] for x in s1]).contiguous()
-    all_p = torch.stack([x[1] for x in s1]).contiguous()
+    all1 = torch.stack([en.stage1(st) for en, st in zip(engines, sts)]).contiguous()    # [G, B, R*16] bytes == an all-gather's layout
     torch.cuda.synchronize()
-    s2 = [en.stage2(st, all_a, all_p, G) for en, st in zip(engines, sts)]
-    all_s = torch.stack([x[0] for x in s2]).contiguous()
-    all_sp = torch.stack([x[1] for x in s2]).contiguous()
+    all2 = torch.stack([en.stage2(st, all1, G) for en, st in zip(engines, sts)]).contiguous()
     torch.cuda.synchronize()
     for en, st in zip(engines, sts):
-        p3, s3, c3 = en.stage3(st, all_s, all_sp, G)
+        p3, s3, c3 = en.stage3(st, all2, G)
         assert np.array_equal(c3, counts), (c3, counts)
         for b in range(q.shape[0]):
             assert np.array_equal(p3[b, : c3[b]], pids[b, : counts[b]]), b

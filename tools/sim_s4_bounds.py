@@ -77,3 +77,29 @@ for b in range(nq):
         e255 = float((e > 254).mean())
         print(f"   floor p{pct}: F {F} hot centroids {hot.mean():.3f} hot (doc,code) pairs {hot_pairs:.3f} e>254 {e255:.4f} | survivors UB_b {sb} ({sb/n:.4f})  "
               f"UB_b with T from top-4R {sb4} ({sb4/n:.4f}) T4 {T4} | UB_a {sa} ({sa/n:.4f})", flush=True)
+
+# ---- grouped bound: one table entry per 2^gs consecutive centroids (e_g = max over the group), codes stored as u16 group ids ----
+print("grouped bounds (floor p97.5):", flush=True)
+for b in range(nq):
+    q = qs[b].astype(np.float32)
+    Sc = (cent32 @ q.T).astype(np.float16)
+    S8 = np.clip(np.floor(Sc.astype(np.float32) * 128.0) + 100, 0, 255).astype(np.int32)
+    cells = np.unique(np.argpartition(-Sc.astype(np.float32), NPROBE, axis=0)[:NPROBE].ravel())
+    iscell = np.zeros(C, bool); iscell[cells] = True
+    cand = np.nonzero((iscell[codes]).any(1))[0]
+    cc = codes[cand]
+    colmax = np.zeros((len(cand), Q), np.int32)
+    for j in range(L):
+        np.maximum(colmax, S8[cc[:, j]], out=colmax)
+    K = colmax.sum(1); n = len(cand)
+    T = np.sort(K)[-R] if n > R else 0
+    f = np.percentile(S8, 97.5, axis=0).astype(np.int32); F = int(f.sum())
+    e = np.maximum(S8 - f[None, :], 0).sum(1)
+    for gs in (0, 1, 2, 3):
+        eg = e.reshape(-1, 1 << gs).max(1)
+        gc = cc >> gs
+        gu = np.ones(gc.shape, bool); gu[:, 1:] = gc[:, 1:] != gc[:, :-1]   # codes sorted -> group ids sorted
+        ub = F + (eg[gc] * gu).sum(1)
+        assert (ub >= K).all()
+        top = np.argsort(-ub)[: 4 * R]; T4 = np.sort(K[top])[-R] if n > R else 0
+        print(f"  q{b} gs={gs}: unique groups/doc {gu.sum(1).mean():.1f}  survivors {int((ub + Q > T4).sum())} ({(ub + Q > T4).mean():.4f})  T4 {T4} vs T {T}", flush=True)
