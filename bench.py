@@ -160,6 +160,7 @@ def main():
         lat = []
         cand_total = 0
         exact_total = 0
+        repaired_total = 0
         sync()
         t_start = time.perf_counter()
         for i in range(a.steps):
@@ -172,6 +173,7 @@ def main():
                 cnts = R.last_search_counts()
                 cand_total += cnts["candidates"]
                 exact_total += cnts["approx_exact"]
+                repaired_total += cnts.get("repaired", 0)
         sync()
         elapsed = time.perf_counter() - t_start
         if use_dist:
@@ -193,6 +195,7 @@ def main():
             dev_elapsed = time.perf_counter() - t1
             del dq, dp, dsc, dc
         return dict(index=index, elapsed=elapsed, lat=lat, stage_acc=stage_acc, cand_total=cand_total, exact_total=exact_total,
+                    repaired_total=repaired_total,
                     t_build=t_build, dev_elapsed=dev_elapsed)
 
     if use_dist:
@@ -247,6 +250,7 @@ def main():
     if not use_dist and rank == 0:
         stages = {k: v / a.steps for k, v in stage_acc.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        out["docs_repaired_per_batch"] = res["repaired_total"] / a.steps
         Rr = max(a.nfull // 4, 1)
         rer_docs = a.batch * min(Rr, a.docs)
         pr = a.dim * a.nbits // 8

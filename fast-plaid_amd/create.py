@@ -42,6 +42,17 @@ def compress(centroids, bucket_cutoffs, embeddings, nbits: int, device: str = "c
     return codes, res
 
 
+def cutoffs_for_f32_compare(cutoffs_f32) -> np.ndarray:
+    """create.rs:413 compares the fp16 residuals with the FLOAT cutoffs it has just computed (torch.bucketize promotes), while the
+    device kernel (and update.rs, through the loader's Half cast) compares with fp16 cutoffs.  For an fp16 residual r and an fp32
+    cutoff c, (c < r) == (c_dn < r) with c_dn = the largest fp16 value <= c: no fp16 value lies strictly between c_dn and c.  So
+    the cutoffs rounded DOWN to fp16 reproduce the reference's first-time compression exactly."""
+    c = np.asarray(cutoffs_f32, np.float32)
+    h = c.astype(np.float16)
+    up = h.astype(np.float32) > c          # round-to-nearest went up: step one fp16 value down
+    return np.where(up, np.nextafter(h, np.float16(-np.inf)), h).astype(np.float16)
+
+
 def _kth(sorted_flat: np.ndarray, k: int) -> np.float32:
     return sorted_flat[k]
 
@@ -118,7 +129,7 @@ def build_index_arrays(docs, centroids, nbits: int, device: str = "cuda:0", held
     lens = np.array([d.shape[0] for d in docs16], np.int64)
     allemb = np.concatenate(docs16) if docs16 else np.zeros((0, cent.shape[1]), np.float16)
     cut, wts, avg, thr = train_codec(allemb if heldout is None else heldout, cent, nbits, device, with_threshold=True)
-    codes, packed = compress(cent, cut.astype(np.float16), allemb, nbits, device)
+    codes, packed = compress(cent, cutoffs_for_f32_compare(cut), allemb, nbits, device)
     P = num_partitions if num_partitions is not None else max(cent.shape[0], 1)
     ivf, ivf_lengths = synth.build_ivf(codes, lens, P)
     return dict(nbits=nbits, centroids=cent, avg_residual=avg.astype(np.float16), bucket_cutoffs=cut.astype(np.float16),
@@ -127,18 +138,21 @@ def build_index_arrays(docs, centroids, nbits: int, device: str = "cuda:0", held
 
 
 def create_index(index_path: str, documents_embeddings, centroids, nbits: int = 4, device: str = "cuda:0", seed: int | None = 42,
-                 compress_only: bool = False, chunk_docs: int = 25_000) -> dict:
+                 compress_only: bool = False, chunk_docs: int = 25_000, heldout=None) -> dict:
     """rust/index/create.rs:206-583 given centroids: sample held-out passages (heldout_sample), train the codec (+ the cluster
-    threshold), compress every document, build the IVF, write the directory.  Returns the array set it wrote."""
+    threshold), compress every document, build the IVF, write the directory.  Returns the array set it wrote.  `heldout` (tests)
+    replaces the sampled held-out embeddings."""
     from .search import index_io
     docs16 = [_np(d, np.float16) for d in documents_embeddings]
     n = len(docs16)
     if n == 0:
         raise ValueError("Cannot create an index from zero documents")
-    held = heldout_sample(docs16, np.random.default_rng(seed))
+    held = heldout_sample(docs16, np.random.default_rng(seed)) if heldout is None else _np(heldout, np.float16)
     if held.shape[0] == 0:
         raise ValueError("Cannot train codec: no heldout samples were generated.")   # create.rs:301-305
-    arr = build_index_arrays(docs16, centroids, nbits, device, heldout=held)
+    n_tok = float(sum(d.shape[0] for d in docs16))
+    num_partitions = int(2 ** math.floor(math.log2(16.0 * math.sqrt(n_tok))))        # create.rs:292-294: the IVF's list count
+    arr = build_index_arrays(docs16, centroids, nbits, device, heldout=held, num_partitions=num_partitions)
     if compress_only:
         arr["ivf"] = None
         arr["ivf_lengths"] = None

@@ -104,6 +104,7 @@ struct Scratch {
       l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
+  bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
@@ -592,7 +593,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->cand_off.ensure((size_t)(B + 1) * 8));
   fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                  s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st);
-  HIPCHK(s->h_small.ensure(64));
+  HIPCHK(s->h_small.ensure(4096));
   HIPCHK(hipMemcpyAsync(s->h_small.p, s->cand_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(s->ev[ST_COMPACT], st));
   HIPCHK(hipStreamSynchronize(st));  // the one mid-pipeline host sync: candidate total sizes the buffers
@@ -724,6 +725,12 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
     const bool marked = mode == 1 && repair_env != 2 &&
                         fpk_final_mark(s->exact.as<float>(), aux.unc, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
                                        s->ms_nmark.as<int32_t>(), st) == 0;
+    s->ms_have_marks = false;
+    if (marked && (size_t)B * 4 + 64 <= 4096) {   // marked documents per query -> pinned memory, summed for fp_last_search_counts after the final sync
+      HIPCHK(s->h_small.ensure(4096));
+      HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 64, s->ms_nmark.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+      s->ms_have_marks = true;
+    }
     fpk_maxsim_repair(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R,
                       marked ? s->ms_marks.as<int32_t>() : nullptr, marked ? s->ms_nmark.as<int32_t>() : nullptr, s->exact.as<float>(), aux, st);
   }
@@ -815,6 +822,11 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     }
     g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : P.M;
+    if (s->ms_have_marks) {
+      const int32_t* nm = reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 64);
+      for (int i = 0; i < B; ++i) g_last_counts[2] += nm[i];
+      s->ms_have_marks = false;
+    }
     if (b0 == 0) {
       for (int i = 0; i < ST_N; ++i) {
         float ms = 0.f;

@@ -1516,7 +1516,8 @@ __device__ __forceinline__ uint32_t l0_max8(uint32_t v) {
 __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ poff,
-                                                  const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist) {
+                                                  const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist,
+                                                  int abl /*timing experiments only: 1 no table lookups, 2 no line loads*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
   uint8_t* tab = l0s;                                                  // [Cpad + 16]: the 16 bytes behind the table are 0 (index of absent codes)
   uint32_t* es = reinterpret_cast<uint32_t*>(l0s + Cpad + 16);         // [64]
@@ -1557,6 +1558,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   auto piece = [&](const uint4& pc, uint32_t& sum, uint32_t& mx) {
     const uint32_t w[4] = {pc.x, pc.y, pc.z, pc.w};
     const uint32_t cnt = pc.w >> 24;
+    if (abl & 1) { sum += (pc.x ^ pc.y ^ pc.z ^ pc.w) & 7u; return; }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const uint32_t lo = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
@@ -1571,7 +1573,8 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
       pc[k] = make_uint4(0, 0, 0, 0);
-      if (nl[k] > 0) pc[k] = pcodes[(int64_t)l0[k] * 8 + sub];
+      if (abl & 2) pc[k] = make_uint4((uint32_t)l0[k] * 2654435761u, (uint32_t)l0[k] * 40503u, (uint32_t)l0[k] * 7919u, 0x07000000u | ((uint32_t)l0[k] & 0xFFFFu));
+      else if (nl[k] > 0) pc[k] = pcodes[(int64_t)l0[k] * 8 + sub];
     }
     // next iteration's offsets, the ids of the one after
     int32_t nl0[L0_UNROLL], nnl[L0_UNROLL], pidnn[L0_UNROLL];
@@ -1584,6 +1587,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       }
       if (i + 2 * stride + k < n) pidnn[k] = cpids[i + 2 * stride + k];
     }
+    uint32_t outv[L0_UNROLL];
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
       uint32_t sum = 0, mx = 0;
@@ -1615,12 +1619,21 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         mx = l0_max8(inf);
         sum = mx ? 0xFFFFFFu : sum;
       }
+      uint32_t v = F + sum;
+      v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
+      outv[k] = v;
       if (sub == 0 && i + k < n) {
-        uint32_t v = F + sum;
-        v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
-        ub[beg + i + k] = (uint16_t)v;
         const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
         atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
+      }
+    }
+    if (sub == 0) {   // the group's four bounds leave as one 8-byte store when they can (2-byte stores are one fabric write each)
+      if (i + L0_UNROLL <= n && ((beg + i) & 3) == 0) {
+        *reinterpret_cast<uint2*>(ub + beg + i) = make_uint2(outv[0] | (outv[1] << 16), outv[2] | (outv[3] << 16));
+      } else {
+#pragma unroll
+        for (int k = 0; k < L0_UNROLL; ++k)
+          if (i + k < n) ub[beg + i + k] = (uint16_t)outv[k];
       }
     }
 #pragma unroll
@@ -1884,8 +1897,9 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   int64_t bx = (per_q + cpw - 1) / cpw;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
+  static const int abl = [] { const char* e = getenv("FP_L0_ABL"); return e ? atoi(e) : 0; }();   // timing experiments only (results are wrong)
   hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, w.esc, w.Fsum, cand_off,
-                     cand_pid, ix.poff, ix.pcodes, w.ub, w.hist);
+                     cand_pid, ix.poff, ix.pcodes, w.ub, w.hist, abl);
 }
 
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st) {

@@ -325,22 +325,18 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) mx[c] = NEG_MASK_F;
 
-    // Software pipeline: `fetch` records the bookkeeping of the stream's current chunk, issues the loads of its rows, then steps
-    // the stream and prefetches the following chunk's code / norm.  It runs once before the loop and then right after the MFMAs
-    // of every chunk have been issued -- the row registers are dead by then -- so that the next chunk's loads are in flight
-    // during the epilogue instead of being waited for at the top of the next iteration.
-    uint32_t e[NE];
-    uint32_t rw[RW];
-    float nf = 1.f;
-    int c_t0 = 0, c_len = 0, c_r = 0;
-    bool c_valid = false, c_last = false;
-    auto fetch = [&]() {
-      c_t0 = t0; c_len = len; c_r = r;
-      c_valid = valid;
-      c_last = valid && (t0 + 32 >= len);
-      // (exhausted streams read row 0 of the arrays: harmless)
+    // (issuing the next chunk's loads before the epilogue -- software pipelining -- measured slower: 251 -> 266 us, 8 dwords of
+    // scratch; the kernel is VALU-issue bound, not latency bound)
+    while (__any(valid)) {
+      uint32_t e[NE];
+      uint32_t rw[RW];
+      // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
       ms_load_token<D, NBITS>(a.resid, a.cent, valid ? tok_row() : 0, valid ? code : 0, rw, e);
-      nf = (float)__builtin_bit_cast(half_t, nrm);
+      const float nf = (float)__builtin_bit_cast(half_t, nrm);
+      // ---- this chunk's bookkeeping, then step the stream and prefetch the next code / norm ----
+      const int c_t0 = t0, c_len = len, c_r = r;
+      const bool c_valid = valid;
+      const bool c_last = valid && (t0 + 32 >= len);
       if (valid) {
         t0 += 32;
         if (t0 >= len) {
@@ -349,10 +345,6 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
         }
         if (valid) { const long long rr = tok_row(); code = a.codes[rr]; nrm = a.norms[rr]; }
       }
-    };
-    fetch();
-
-    while (__any(c_valid)) {
       // ---- e = h(cent + w);  e^ = h(fl32(e / n)) through the compensated reciprocal product (fp_selftest_arith out[0]) ----
       ms_decode<D, NBITS>(laneoff, rw, e);
       float r_hi, r_lo;
@@ -383,25 +375,15 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
           acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bq, acc1[c], 0, 0, 0);
         }
       }
-      // ---- the chunk just computed (scalars), then the next chunk's loads ----
-      int p_t0[2], p_len[2], p_r[2];
-      bool p_valid[2], p_last[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        p_t0[s] = __builtin_amdgcn_readlane(c_t0, 32 * s);
-        p_len[s] = __builtin_amdgcn_readlane(c_len, 32 * s);
-        p_r[s] = __builtin_amdgcn_readlane(c_r, 32 * s);
-        p_valid[s] = __builtin_amdgcn_readlane((int)c_valid, 32 * s) != 0;
-        p_last[s] = __builtin_amdgcn_readlane((int)c_last, 32 * s) != 0;
-      }
-      fetch();
       // ---- epilogue.  acc0 belongs to the lower stream (state in lane 0), acc1 to the upper (lane 32);
       // D[row = token][col = q = lane&31], this lane's rows (i&3) + 8*(i>>2) + 4*hi.  The maximum over tokens is taken on
       // the fp32 accumulators (rounding is monotone, so it commutes with the maximum) ----
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int s_t0 = p_t0[s], s_len = p_len[s], s_r = p_r[s];
-        const bool s_valid = p_valid[s], s_last = p_last[s];
+        const int s_t0 = __builtin_amdgcn_readlane(c_t0, 32 * s), s_len = __builtin_amdgcn_readlane(c_len, 32 * s);
+        const int s_r = __builtin_amdgcn_readlane(c_r, 32 * s);
+        const bool s_valid = __builtin_amdgcn_readlane((int)c_valid, 32 * s) != 0;
+        const bool s_last = __builtin_amdgcn_readlane((int)c_last, 32 * s) != 0;
         if (!s_valid) continue;
         const bool partial = (s_t0 + 32 > s_len);
         float total = 0.f, ubud = 0.f;
@@ -625,34 +607,30 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
   if (threadIdx.x == 0) nmark[b] = s_n;
 }
 
-// k_maxsim_repair: one wave per marked (query, slot) -- or, with marks == nullptr, per slot whose budget is > 0.  Tokens are
-// decompressed exactly as in k_maxsim5 (once per 64-token step); every flagged column is re-evaluated with the ascending-k fp32
-// chain against the query row staged in LDS, the stored column maxima are patched and the score re-summed (same reduction
-// tree as k_maxsim5).  One workgroup = 4 waves of one query.
+// k_maxsim_repair: ONE WAVE (= one 64-thread workgroup) per marked (query, slot) -- or, with marks == nullptr, per slot whose
+// budget is > 0.  Tokens are decompressed to the same bits as in k_maxsim5 (once per 64-token step; the byte -> weights table
+// is a plain 1 KiB LDS copy here: filling the 64 KiB conflict-free table per workgroup cost more than the few documents a
+// workgroup repairs); every flagged column is re-evaluated with the ascending-k fp32 chain, the stored column maxima are
+// patched and the score re-summed (same reduction tree as k_maxsim5).
 template <int D, int NBITS>
-__global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
-                                                       const int32_t* __restrict__ codes, const uint16_t* __restrict__ norms,
-                                                       const uint8_t* __restrict__ resid, const int64_t* __restrict__ doc_off,
-                                                       const uint16_t* __restrict__ qpad, int Q, int Qp, const int32_t* __restrict__ sel_pid,
-                                                       const int32_t* __restrict__ sel_cnt, int64_t Rcap, const int32_t* __restrict__ marks,
-                                                       const int32_t* __restrict__ nmark, float* __restrict__ exact, float* __restrict__ unc,
-                                                       uint16_t* __restrict__ cm16, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
+                                                      const int32_t* __restrict__ codes, const uint16_t* __restrict__ norms,
+                                                      const uint8_t* __restrict__ resid, const int64_t* __restrict__ doc_off,
+                                                      const uint16_t* __restrict__ qpad, int Q, int Qp, const int32_t* __restrict__ sel_pid,
+                                                      const int32_t* __restrict__ sel_cnt, int64_t Rcap, const int32_t* __restrict__ marks,
+                                                      const int32_t* __restrict__ nmark, float* __restrict__ exact, float* __restrict__ unc,
+                                                      uint16_t* __restrict__ cm16, uint32_t* __restrict__ flags) {
   using Cf = MsCfg<D, NBITS>;
-  constexpr int NE = Cf::NE, RW = Cf::RW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* lut = smem;
-  uint32_t* qsh = reinterpret_cast<uint32_t*>(smem + MS_LUT_BYTES);   // [Qp][D/2] the query's rows (packed halves)
+  constexpr int NE = Cf::NE, RW = Cf::RW, PB = Cf::PB;
+  __shared__ uint16_t slut[256 * PB];
   const int b = blockIdx.y;
   const int nwork = marks ? nmark[b] : sel_cnt[b];
-  if ((int)blockIdx.x * 4 >= nwork) return;
-  ms_lds_base_is_zero(smem);
-  ms_fill_lut<D, NBITS>(lut, lut_g, threadIdx.x, 256);
-  for (int i = threadIdx.x; i < Qp * (D / 2); i += 256) qsh[i] = reinterpret_cast<const uint32_t*>(qpad + (int64_t)b * Qp * D)[i];
+  if ((int)blockIdx.x >= nwork) return;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 256 * PB; i += 64) slut[i] = lut_g[i];
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t laneoff = (uint32_t)((lane & (Cf::COPIES - 1)) * Cf::EW * 4);
   const int nflag = Qp / 32;
-  for (int wi = blockIdx.x * 4 + wave; wi < nwork; wi += gridDim.x * 4) {
+  for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const int r = marks ? marks[(int64_t)b * Rcap + wi] : wi;
     const int64_t slot = (int64_t)b * Rcap + r;
     if (!(unc[slot] > 0.f)) continue;
@@ -676,7 +654,26 @@ __global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restric
           uint32_t rw[RW];
           ms_load_token<D, NBITS>(resid, cent, off + tok, codes[off + tok], rw, e);
           const float nf = (float)__builtin_bit_cast(half_t, norms[off + tok]);
-          ms_decode<D, NBITS>(laneoff, rw, e);
+          // e = h(cent + w): same packed fp16 adds as ms_decode, weights from the small table
+#pragma unroll
+          for (int w = 0; w < RW; ++w) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int bi = w * 4 + kk;
+              const uint32_t byte = (rw[w] >> (8 * kk)) & 0xFFu;
+              if constexpr (PB >= 2) {
+#pragma unroll
+                for (int j = 0; j < PB / 2; ++j) {
+                  const uint32_t wv = *reinterpret_cast<const uint32_t*>(&slut[byte * PB + 2 * j]);
+                  e[bi * (PB / 2) + j] = h2_as_u32(u32_as_h2(e[bi * (PB / 2) + j]) + u32_as_h2(wv));
+                }
+              } else if ((kk & 1) == 0) {   // nbits 8: two bytes make one packed register
+                const uint32_t byte1 = (rw[w] >> (8 * (kk + 1))) & 0xFFu;
+                const uint32_t wv = (uint32_t)slut[byte] | ((uint32_t)slut[byte1] << 16);
+                e[bi / 2] = h2_as_u32(u32_as_h2(e[bi / 2]) + u32_as_h2(wv));
+              }
+            }
+          }
           float r_hi, r_lo;
           recip2(nf, r_hi, r_lo);
 #pragma unroll
@@ -685,7 +682,7 @@ __global__ __launch_bounds__(256) void k_maxsim_repair(const uint16_t* __restric
           while (f2) {
             const int col = __builtin_ctz(f2);
             f2 &= f2 - 1;
-            const uint32_t* qq = qsh + (ch * 32 + col) * (D / 2);
+            const uint32_t* qq = reinterpret_cast<const uint32_t*>(qpad + ((int64_t)b * Qp + ch * 32 + col) * D);   // uniform address
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < NE; ++i) {   // ascending k: the CPU reference's order
@@ -806,15 +803,11 @@ int fpk_final_mark(const float* score, const float* unc, const int32_t* cnt, int
 void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
                        int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st) {
   if (!fpk_maxsim_fast_shape(ix.dim, ix.nbits) || !aux.unc) return;   // the generic kernel never flags
-  const size_t lds = MS_LUT_BYTES + (size_t)sh.Qp * ix.dim * 2;
-  if (lds > 160 * 1024) return;   // q_len > ~370 at dim 128: no repair (scores stay within 1e-3, the order of near-ties is MFMA's)
-  // marked documents are a few per cent of the rerank lists: workgroups beyond a query's marked count exit at once
-  const dim3 grid((unsigned)(marks ? std::min<int64_t>(64, (Rcap + 3) / 4) : (Rcap + 3) / 4), (unsigned)sh.B);
+  // one wave per document; workgroups beyond a query's marked count exit at once
+  const dim3 grid((unsigned)std::min<int64_t>(marks ? 512 : 4096, Rcap), (unsigned)sh.B);
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
-    static std::atomic<uint64_t> ok{0}; \
-    fp_allow_big_lds((const void*)k_maxsim_repair<D_, NB_>, ok, 160 * 1024); \
-    hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(256), lds, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \
+    hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \
                        ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags); \
     return; \
   }

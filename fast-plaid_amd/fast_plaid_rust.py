@@ -304,7 +304,7 @@ def last_search_timings() -> dict:
 def last_search_counts() -> dict:
     out = (C.c_int64 * 4)()
     N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 4)
-    return dict(candidates=int(out[0]), approx_exact=int(out[1]), sub_batches=int(out[3]))
+    return dict(candidates=int(out[0]), approx_exact=int(out[1]), repaired=int(out[2]), sub_batches=int(out[3]))
 
 
 def export_index_arrays(index: PyLoadedIndex, centroids=None, bucket_weights=None) -> dict:

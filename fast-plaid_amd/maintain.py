@@ -57,6 +57,8 @@ def update_index(index_path: str, documents_embeddings, device: str = "cuda:0", 
     nbits = int(meta["nbits"])
     n_partitions = int(meta["num_partitions"])
     old_total = int(meta.get("num_embeddings", 0))
+    old_docs = int(meta.get("num_documents", 0))
+    old_avg = float(meta.get("avg_doclen", 0.0))
     compress_only = bool(meta.get("compress_only", False))
     cent = np.load(os.path.join(index_path, "centroids.npy")).astype(np.float16)
     cut = np.load(os.path.join(index_path, "bucket_cutoffs.npy")).astype(np.float16)
@@ -100,15 +102,15 @@ def update_index(index_path: str, documents_embeddings, device: str = "cuda:0", 
         if os.path.exists(tp):
             old_thr = float(np.load(tp))
             new_thr = (old_thr * old_total + new_thr * new.shape[0]) / (old_total + new.shape[0])
-        np.save(tp, np.asarray(new_thr, np.float32))
+        np.save(tp, np.asarray(new_thr, np.float64))   # update.rs:303: Tensor::from(f64) -> a 0-dim Double
     total_chunks = start + n_new_chunks
-    if compress_only:
-        T = sum(int(_read_json(os.path.join(index_path, f"{i}.metadata.json"))["num_embeddings"]) for i in range(total_chunks))
-        N = sum(len(_read_json(os.path.join(index_path, f"doclens.{i}.json"))) for i in range(total_chunks))
-    else:
-        T, N = _rebuild_ivf(index_path, total_chunks, n_partitions)
-    _write_json(meta_path, {"num_chunks": total_chunks, "nbits": nbits, "num_partitions": n_partitions, "num_embeddings": T,
-                            "avg_doclen": (T / N) if N else 0.0, "num_documents": N, "compress_only": compress_only}, pretty=True)
+    if not compress_only:   # update.rs:325-444 merges the new ids into the old lists; rebuilding from every chunk yields the same lists
+        _rebuild_ivf(index_path, total_chunks, n_partitions)
+    new_tokens = int(sum(d.shape[0] for d in docs))
+    N = old_docs + len(docs)                      # update.rs:447-471 (avg_doclen from the OLD average, as the reference computes it)
+    _write_json(meta_path, {"num_chunks": total_chunks, "nbits": nbits, "num_partitions": n_partitions, "num_embeddings": old_total + new_tokens,
+                            "num_documents": N, "avg_doclen": ((old_avg * old_docs + new_tokens) / N) if N else 0.0,
+                            "compress_only": compress_only}, pretty=True)
 
 
 def delete_from_index(index_path: str, subset) -> None:

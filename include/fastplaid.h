@@ -133,7 +133,8 @@ int fp_last_search_timings(const char** names, float* ms, int cap);
 
 /* Work counters of the most recent fp_search on this thread: out[0] = candidate documents
  * summed over queries (S3 output), out[1] = candidates that reached the exact approximate-score
- * kernel (== out[0] unless the 8-bit bound stage pruned), out[3] = sub-batches.  Returns entries written. */
+ * kernel (== out[0] unless a bound stage pruned), out[2] = documents whose near-tied final score was re-evaluated in the
+ * reference's summation order (exact-order repair), out[3] = sub-batches.  Returns entries written. */
 int fp_last_search_counts(int64_t* out, int cap);
 
 /* ---- `pysearch_with_token_scores` (rust/lib.rs:243-290 -> search_many_with_token_scores,

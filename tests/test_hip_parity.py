@@ -909,6 +909,60 @@ def test_full_size_properties(fp, name):
     assert np.abs(ref - got).max() <= SCORE_TOL
 
 
+def test_create_update_delete_vs_reference_restatement(fp, tmp_path):
+    """SURVEY 8 rows f1 / f4 against the ATen restatement of the reference's directory writers (oracle/plaid_index_oracle_torch.py:
+    rust/index/create.rs, update.rs, delete.rs), not against this repo's own one-shot compression: tests/golden/maintain/snapshots.npz holds
+    the four directory snapshots the oracle wrote (created -> updated with the threshold -> updated -> deleted); create.py /
+    maintain.py (device compression through fp_compress) must write the same files -- integer arrays and packed bytes identical,
+    codec floats and json numbers within an ulp-level tolerance."""
+    import json
+    from fast_plaid_amd import create as CR, maintain as MT
+    z = np.load(os.path.join(GOLDEN_DIR, "maintain", "snapshots.npz"))
+
+    def docs_of(name):
+        lens = z[name + "_lens"]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        return [z[name][offs[i]: offs[i + 1]] for i in range(len(lens))]
+
+    def check(tag, path):
+        want = {k[len(tag) + 1:]: z[k] for k in z.files if k.startswith(tag + "/")}
+        have = set(os.listdir(path))
+        assert set(want) <= have, f"{tag}: missing files {sorted(set(want) - have)}"
+        for fn, w in want.items():
+            if fn.endswith(".npy"):
+                g = np.load(os.path.join(path, fn))
+                assert g.shape == w.shape, (tag, fn, g.shape, w.shape)
+                if w.dtype.kind in "iu":
+                    assert g.dtype.kind in "iu" and np.array_equal(g, w), f"{tag}/{fn} differs"
+                elif fn == "centroids.npy":
+                    assert np.array_equal(g.astype(np.float16), w)
+                else:   # codec floats / thresholds
+                    assert np.allclose(g.astype(np.float64), w.astype(np.float64), rtol=2e-6, atol=1e-9), f"{tag}/{fn}: {g} vs {w}"
+            else:
+                wj = json.loads(bytes(w).decode())
+                with open(os.path.join(path, fn)) as f:
+                    gj = json.load(f)
+                if isinstance(wj, dict):
+                    for k, v in wj.items():
+                        assert k in gj, (tag, fn, k)
+                        if isinstance(v, float):
+                            assert abs(gj[k] - v) <= 1e-9 * max(1.0, abs(v)), (tag, fn, k, gj[k], v)
+                        else:
+                            assert gj[k] == v, (tag, fn, k, gj[k], v)
+                else:
+                    assert gj == wj, (tag, fn)
+
+    d = str(tmp_path / "ix")
+    CR.create_index(d, docs_of("docs"), z["centroids"], nbits=int(z["nbits"]), device="cuda:0", heldout=z["heldout"], chunk_docs=25)
+    check("created", d)
+    MT.update_index(d, docs_of("new1"), device="cuda:0", update_threshold=True)
+    check("updated", d)
+    MT.update_index(d, docs_of("new2"), device="cuda:0", update_threshold=False)
+    check("updated2", d)
+    MT.delete_from_index(d, z["subset"].tolist())
+    check("deleted", d)
+
+
 def _same_order_modulo_ref_ties(ids_hip, ids_ref, score_ref):
     """ids_hip must list the documents of ids_ref in the same order, except that documents the oracle scores identically may
     be permuted among themselves (ATen's sort is not stable: their order is implementation-defined)."""

@@ -188,3 +188,81 @@ def test_delete_from_index_matches_rebuild(tmp_path):
     assert meta["num_documents"] == int(keep.sum()) and meta["num_embeddings"] == int(keep_tok.sum()) and meta["num_chunks"] == 3
     for k in ("centroids", "bucket_weights", "bucket_cutoffs"):
         assert np.array_equal(after[k], before[k])
+
+
+def test_heldout_sample_follows_the_shuffled_sample_not_the_corpus_tail():
+    """create.rs:222-281: the held-out embeddings are the last 5 % (<= 50 000) tokens of the SHUFFLED passage sample, walked from
+    its end -- whole passages, the first one cut to its tail -- not the tail of the corpus in input order."""
+    import math
+    from fast_plaid_amd import create as CR
+    rng = np.random.default_rng(5)
+    n, dim = 400, 8
+    # every token carries its document id in dim 0 and its position in dim 1
+    docs = []
+    for i in range(n):
+        ln = int(rng.integers(3, 30))
+        d = np.zeros((ln, dim), np.float16)
+        d[:, 0] = i
+        d[:, 1] = np.arange(ln)
+        docs.append(d)
+    held = CR.heldout_sample(docs, np.random.default_rng(42))
+    perm = np.random.default_rng(42).permutation(n)
+    k = int(min(1.0 + 16.0 * math.sqrt(120.0 * n), n))
+    sample = perm[:k]
+    total = sum(docs[int(i)].shape[0] for i in sample)
+    want_n = int(round(min(0.05 * total, 50_000.0)))
+    assert held.shape == (want_n, dim)
+    # the held-out rows are the tail of the sample's concatenation in SHUFFLED order
+    cat = np.concatenate([docs[int(i)] for i in sample])
+    assert np.array_equal(held, cat[-want_n:])
+    ids = held[:, 0].astype(int)
+    assert len(set(ids.tolist())) > 1 and not np.all(ids >= n - len(set(ids.tolist())) - 1), "held-out rows are the corpus tail"
+    # documents appear whole except possibly the first, which is cut to its tail
+    first = ids[0]
+    assert held[0, 1] == docs[first].shape[0] - (ids == first).sum()
+
+
+def test_cutoffs_rounded_down_reproduce_the_fp32_comparison():
+    """create.rs:413 buckets fp16 residuals against fp32 cutoffs; the device kernel compares with fp16 cutoffs.  Rounding the cutoffs
+    DOWN to fp16 gives the same buckets for every fp16 residual (exhaustive over all finite fp16 values)."""
+    from fast_plaid_amd import create as CR
+    rng = np.random.default_rng(0)
+    cut32 = np.sort(rng.normal(0, 0.05, 15).astype(np.float32))
+    cut16 = CR.cutoffs_for_f32_compare(cut32)
+    allh = np.arange(65536, dtype=np.uint16).view(np.float16)
+    allh = allh[np.isfinite(allh)]
+    want = (cut32[None, :] < allh.astype(np.float32)[:, None]).sum(1)     # torch.bucketize(right=False) after promotion to fp32
+    got = (cut16.astype(np.float32)[None, :] < allh.astype(np.float32)[:, None]).sum(1)
+    assert np.array_equal(want, got)
+    assert np.all(cut16.astype(np.float32) <= cut32)
+
+
+def test_index_directory_oracle_roundtrip():
+    """the ATen restatement of create / update / delete (oracle/plaid_index_oracle_torch.py) reproduces the committed snapshots
+    (tests/golden/maintain/): guards the fixture and its generator against drift."""
+    import json
+    import shutil
+    import tempfile
+    import torch
+    import plaid_index_oracle_torch as IO
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maintain", "snapshots.npz"))
+
+    def docs_of(name):
+        lens = z[name + "_lens"]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        return [torch.from_numpy(z[name][offs[i]: offs[i + 1]]) for i in range(len(lens))]
+
+    tmp = tempfile.mkdtemp()
+    try:
+        d = os.path.join(tmp, "ix")
+        IO.create_index(docs_of("docs"), d, torch.from_numpy(z["centroids"]), int(z["nbits"]), torch.from_numpy(z["heldout"]), batch_size=25)
+        IO.update_index(docs_of("new1"), d, batch_size=25, update_threshold=True)
+        snap = IO.read_directory(d)
+        for fn, v in snap.items():
+            w = z["updated/" + fn]
+            if fn.endswith(".npy"):
+                assert np.array_equal(v, w), fn
+            else:
+                assert v == json.loads(bytes(w).decode()), fn
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
