@@ -60,6 +60,9 @@ def parse():
                     help="N>1: replica = full index per GPU, batch split across ranks (the reference's multi-GPU mode); "
                          "shard = document shards + 2 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
     ap.add_argument("--no-alt-mode", action="store_true", help="N>1: do not also time the other distribution mode")
+    ap.add_argument("--dist-impl", choices=["native", "torch"], default="native",
+                    help="shard mode: native = fp_shard_search (the library issues the RCCL all-gathers itself); torch = the three stage calls "
+                         "with torch.distributed all-gathers in between (forced with --dist-backend gloo)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = result gather through CPU tensors, ranks wrapped onto the visible GPUs (testing the multi-process "
                          "path on a box with fewer GPUs than ranks)")
@@ -139,7 +142,13 @@ def main():
         t0 = time.time()
         index = R.construct_synthetic_index(spec, dev, doc_begin=lo, doc_end=hi, centroids=cent, bucket_weights=bw)
         t_build = time.time() - t0
-        engine = sharded.HipShardEngine(index, dev) if mode == "shard" else None
+        native_comm = None
+        engine = None
+        if mode == "shard":
+            if a.dist_impl == "native" and a.dist_backend == "nccl":
+                native_comm = sharded.NativeComm.from_torch_dist(index.device_id, dist)
+            else:
+                engine = sharded.HipShardEngine(index, dev)
 
         # single-GPU mode: the timed path is the boundary call fp_search -- host query buffer in, host results out (the index is
         # resident in HBM; + 512 KB up, 768 KB down per batch over PCIe); fp_search_device (queries / results resident in HBM) is
@@ -148,6 +157,8 @@ def main():
         def step(i):
             q = batches[i % n_batches]
             if mode == "shard":
+                if native_comm is not None:
+                    return sharded.native_sharded_search(index, native_comm, q, params)
                 return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
             if mode == "replica":
                 return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist,
@@ -224,7 +235,8 @@ def main():
     par = {"single": "1 GPU",
            "replica": "full index replica per GPU, batch split %d-way, result all-gather over %s" % (
                world, "RCCL" if a.dist_backend == "nccl" else "gloo (test mode: ranks share the visible GPUs)"),
-           "shard": "document-sharded x%d, 2 RCCL all-gathers/batch" % world}[primary]
+           "shard": "document-sharded x%d, 2 RCCL all-gathers/batch (%s)" % (
+               world, "issued by the library on the search stream" if (a.dist_impl == "native" and a.dist_backend == "nccl") else "torch.distributed between three stage calls")}[primary]
 
     out = {
         "metric": "queries/sec @ top_k=%d (batch=%d, dim=%d); p50 search latency" % (a.topk, a.batch, a.dim),

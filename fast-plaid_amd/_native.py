@@ -60,6 +60,7 @@ SYMBOLS = {
     "fp_reconstruct_embeddings": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "fp_compress": (C.c_int, [C.c_int, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "fp_assign_l2": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "fp_maxsim_columns": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fp_token_scores": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _i64]),
     "fp_shard_begin": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(FpSearchParams), C.POINTER(_vp)]),
     "fp_shard_R": (_i64, [_vp]),
@@ -67,6 +68,12 @@ SYMBOLS = {
     "fp_shard_stage2": (C.c_int, [_vp, _vp, _i32, _vp]),
     "fp_shard_stage3": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "fp_shard_end": (None, [_vp]),
+    "fp_comm_unique_id": (C.c_int, [_vp]),
+    "fp_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "fp_comm_destroy": (None, [_vp]),
+    "fp_comm_n_ranks": (C.c_int, [_vp]),
+    "fp_comm_rank": (C.c_int, [_vp]),
+    "fp_shard_search": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(FpSearchParams), _vp, _vp, _vp]),
     "fp_index_create_synthetic": (C.c_int, [C.POINTER(FpSynthDesc), C.c_int, C.POINTER(_vp)]),
     "fp_index_read_doc": (_i64, [_vp, _i64, _vp, _vp, _i64]),
     "fp_index_read_ivf": (_i64, [_vp, _i64, _vp, _i64]),

@@ -101,7 +101,7 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -109,7 +109,7 @@ struct Scratch {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark})
+                      &ms_nmark, &sh_rec, &sh_all})
       b->release();
     h_out.release();
     h_small.release();
@@ -956,6 +956,68 @@ extern "C" int fp_last_search_timings(const char** names, float* ms, int cap) {
 }
 
 // ------------------------------------------------------------------------------------------
+// diagnostic / test entry point: the MFMA pass of S6+S7 on given documents, without the exact-order repair
+// ------------------------------------------------------------------------------------------
+extern "C" int fp_maxsim_columns(const fp_index* cix, const uint16_t* query, int32_t Q, int32_t dim, const int64_t* pids, int64_t n,
+                                 float* scores, uint16_t* col_max, float* unc, uint32_t* flags) {
+  fp_index* ix = const_cast<fp_index*>(cix);
+  if (!ix || !query || Q < 1 || (n > 0 && (!pids || !scores))) return fail(FP_EINVAL, "bad argument");
+  if (dim != ix->d.dim) return fail(FP_EINVAL, "query dim does not match the index dim");
+  if (n == 0) return FP_OK;
+  if (n > (1 << 24)) return fail(FP_EINVAL, "too many documents");
+  const FpIndexDev& D = ix->d;
+  HIPCHK(hipSetDevice(ix->device));
+  std::vector<int32_t> loc((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t d = pids[i] - D.pid_offset;
+    if (d < 0 || d >= D.N) return fail(FP_EINVAL, "document id out of range");
+    loc[(size_t)i] = (int32_t)d;
+  }
+  Scratch* s = acquire(ix);
+  if (!s) return fail(FP_EHIP, "could not create a HIP stream");
+  struct Rel { fp_index* ix; Scratch* s; ~Rel() { release(ix, s); } } rel{ix, s};
+  hipStream_t st = s->st;
+  fp_search_params prm{0, 4, 1, 1};
+  FpSearchShape sh = make_shape(1, Q, &prm);
+  const int nflag = sh.Qp / 32;
+  const int32_t cnt = (int32_t)n;
+  HIPCHK(s->qin.ensure((size_t)Q * dim * 2));
+  HIPCHK(s->qpad.ensure((size_t)sh.Qp * dim * 2));
+  HIPCHK(s->sel_pid.ensure((size_t)n * 4));
+  HIPCHK(s->sel_cnt.ensure(4));
+  HIPCHK(s->exact.ensure((size_t)n * 4));
+  HIPCHK(s->ms_pref.ensure(16));
+  HIPCHK(s->ms_cm16.ensure((size_t)n * sh.Qp * 2));
+  HIPCHK(s->ms_unc.ensure((size_t)n * 4));
+  HIPCHK(s->ms_flags.ensure((size_t)n * nflag * 4));
+  HIPCHK(hipMemcpyAsync(s->qin.p, query, (size_t)Q * dim * 2, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->sel_pid.p, loc.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(s->sel_cnt.p, &cnt, 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(s->ms_unc.p, 0, (size_t)n * 4, st));
+  HIPCHK(hipMemsetAsync(s->ms_flags.p, 0, (size_t)n * nflag * 4, st));
+  HIPCHK(hipMemsetAsync(s->ms_cm16.p, 0, (size_t)n * sh.Qp * 2, st));
+  fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), 1, Q, sh.Qp, dim, st);
+  const bool fast = fpk_maxsim_fast_shape(D.dim, D.nbits);
+  FpMaxsimAux aux{fast ? s->ms_cm16.as<uint16_t>() : nullptr, s->ms_unc.as<float>(), fast ? s->ms_flags.as<uint32_t>() : nullptr};
+  if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), n, s->exact.as<float>(),
+                 s->ms_pref.as<int64_t>(), aux, st))
+    return fail(FP_EUNSUPPORTED, "dim/nbits");
+  HIPCHK(hipMemcpyAsync(scores, s->exact.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (unc) HIPCHK(hipMemcpyAsync(unc, s->ms_unc.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (flags) HIPCHK(hipMemcpyAsync(flags, s->ms_flags.p, (size_t)n * nflag * 4, hipMemcpyDeviceToHost, st));
+  std::vector<uint16_t> cm;
+  if (col_max) {
+    cm.resize((size_t)n * sh.Qp);
+    HIPCHK(hipMemcpyAsync(cm.data(), s->ms_cm16.p, cm.size() * 2, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  if (col_max)
+    for (int64_t i = 0; i < n; ++i)
+      for (int q = 0; q < Q; ++q) col_max[i * Q + q] = cm[(size_t)i * sh.Qp + q];
+  return FP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // reconstruct_embeddings (embeddings.rs:12-69)
 // ------------------------------------------------------------------------------------------
 extern "C" int fp_reconstruct_embeddings(const fp_index* cix, const int64_t* doc_ids, int64_t n, float* out, int64_t cap_rows,
@@ -1291,6 +1353,172 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_
                  reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), s->st);
   HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, s->st));
   HIPCHK(hipStreamSynchronize(s->st));
+  ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);
+  return FP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// document-sharded search with the collectives issued by the library itself (RCCL over xGMI): the two all-gathers go on the
+// search stream right behind the kernels that fill their send buffers -- no host synchronisation between the stages, no
+// framework in the data path.  librccl is bound at run time (dlopen), so single-GPU users never need it.
+// ------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+struct FpNcclUid { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+struct RcclApi {
+  void* h = nullptr;
+  int (*GetUniqueId)(FpNcclUid*) = nullptr;
+  int (*CommInitRank)(void**, int, FpNcclUid, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string why;
+};
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* env = getenv("FP_RCCL_LIB");
+    const char* names[] = {env ? env : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // a process that already carries an RCCL (torch bundles one) must keep using THAT copy: look for a loaded one first
+    for (const char* n : names)
+      if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names)
+      if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.h) { api.why = std::string("librccl not found (") + (dlerror() ? dlerror() : "dlopen failed") + "); set FP_RCCL_LIB"; return; }
+    api.GetUniqueId = reinterpret_cast<int (*)(FpNcclUid*)>(dlsym(api.h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<int (*)(void**, int, FpNcclUid, int)>(dlsym(api.h, "ncclCommInitRank"));
+    api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(api.h, "ncclAllGather"));
+    api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.h, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.h, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { api.why = "librccl lacks the expected symbols"; api.h = nullptr; }
+  });
+  return api.h ? &api : nullptr;
+}
+static int rccl_fail(const char* what, int rc) {
+  RcclApi* a = rccl_api();
+  return fail(FP_EHIP, std::string("RCCL: ") + what + " failed: " + ((a && a->GetErrorString) ? a->GetErrorString(rc) : "error ") + " (" + std::to_string(rc) + ")");
+}
+
+struct fp_comm {
+  void* comm = nullptr;
+  int device = 0, n_ranks = 1, rank = 0;
+};
+
+extern "C" int fp_comm_unique_id(void* out_id_128) {
+  if (!out_id_128) return fail(FP_EINVAL, "null argument");
+  RcclApi* a = rccl_api();
+  if (!a) return fail(FP_EUNSUPPORTED, "RCCL unavailable: librccl could not be loaded (set FP_RCCL_LIB)");
+  FpNcclUid id;
+  if (int rc = a->GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+  memcpy(out_id_128, &id, sizeof(id));
+  return FP_OK;
+}
+
+extern "C" int fp_comm_create(int device_id, int n_ranks, int rank, const void* unique_id_128, fp_comm** out) {
+  if (!out || !unique_id_128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(FP_EINVAL, "bad argument");
+  *out = nullptr;
+  RcclApi* a = rccl_api();
+  if (!a) return fail(FP_EUNSUPPORTED, "RCCL unavailable: librccl could not be loaded (set FP_RCCL_LIB)");
+  HIPCHK(hipSetDevice(device_id));
+  FpNcclUid id;
+  memcpy(&id, unique_id_128, sizeof(id));
+  fp_comm* c = new fp_comm();
+  c->device = device_id; c->n_ranks = n_ranks; c->rank = rank;
+  if (int rc = a->CommInitRank(&c->comm, n_ranks, id, rank)) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+  *out = c;
+  return FP_OK;
+}
+
+extern "C" void fp_comm_destroy(fp_comm* c) {
+  if (!c) return;
+  RcclApi* a = rccl_api();
+  if (a && c->comm) { (void)hipSetDevice(c->device); (void)a->CommDestroy(c->comm); }
+  delete c;
+}
+extern "C" int fp_comm_n_ranks(const fp_comm* c) { return c ? c->n_ranks : 0; }
+extern "C" int fp_comm_rank(const fp_comm* c) { return c ? c->rank : -1; }
+
+extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_t* queries, int32_t nq, int32_t Q, int32_t dim,
+                               const fp_search_params* p, int64_t* out_pids, float* out_scores, int32_t* out_counts) {
+  if (!comm || !comm->comm) return fail(FP_EINVAL, "null communicator");
+  if (int rc = validate_search(cix, nq, Q, dim, p)) return rc;
+  if (nq < 1 || !queries || !out_counts || (p->top_k > 0 && (!out_pids || !out_scores))) return fail(FP_EINVAL, "bad argument");
+  RcclApi* api = rccl_api();
+  if (!api) return fail(FP_EUNSUPPORTED, "RCCL unavailable");
+  fp_index* ix = const_cast<fp_index*>(cix);
+  if (ix->device != comm->device) return fail(FP_EINVAL, "index and communicator live on different devices");
+  const FpIndexDev& D = ix->d;
+  const int G = comm->n_ranks;
+  HIPCHK(hipSetDevice(ix->device));
+  for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+  if (p->top_k == 0) return FP_OK;
+  Scratch* s = acquire(ix);
+  if (!s) return fail(FP_EHIP, "could not create a HIP stream");
+  struct Rel { fp_index* ix; Scratch* s; ~Rel() { (void)hipStreamSynchronize(s->st); release(ix, s); } } rel{ix, s};
+  hipStream_t st = s->st;
+  const int B = nq;
+  Pipe P{};
+  P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
+  const int64_t R = P.sh.R;
+  const int64_t K = p->top_k;
+  // every rank must issue both collectives whatever its shard holds (an empty shard contributes only padding records)
+  const bool empty_local = (p->n_ivf_probe > D.C) || D.N == 0;
+  HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
+  HIPCHK(hipMemcpyAsync(s->qin.p, queries, (size_t)B * Q * D.dim * 2, hipMemcpyHostToDevice, st));
+  HIPCHK(s->sh_rec.ensure((size_t)B * R * 24));
+  HIPCHK(s->sh_all.ensure((size_t)G * B * R * 24));
+  if (empty_local) {
+    HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
+    HIPCHK(s->sel_pid.ensure((size_t)B * R * 4));
+    HIPCHK(s->sel_approx.ensure((size_t)B * R * 4));
+    HIPCHK(s->exact.ensure((size_t)B * R * 4));
+    HIPCHK(hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, st));
+  } else {
+    if (int rc = run_front(P, nullptr, nullptr, false)) return rc;
+  }
+  // exchange 1: local top-R by approximate score
+  fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
+  if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+  if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st))
+    return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
+  // exchange 2: exact scores of the local survivors
+  if (!empty_local) {
+    if (int rc = run_maxsim(ix, s, P.sh, R, K, 0)) return rc;
+    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
+                    D.pid_offset, s->sh_rec.p, 0, st);
+    if (s->ms_repairable) {
+      if (int rc = run_maxsim(ix, s, P.sh, R, K, 2)) return rc;
+      fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, 1, st);
+    }
+  } else {
+    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, 0, st);
+  }
+  if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+  // merge (identical on every rank)
+  HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
+  HIPCHK(s->tmpf.ensure((size_t)3 * B * R * 4));
+  HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
+  HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
+  float* u_score = s->tmpf.as<float>();
+  float* u_exact = u_score + (size_t)B * R;
+  float* u_unc = u_exact + (size_t)B * R;
+  if (fpk_shard_union(s->sh_all.p, G, B, R, s->tmpp.as<int64_t>(), u_score, u_exact, u_unc, s->sel_cnt.as<int32_t>(), st))
+    return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS merge of the sharded search (limit 16384 entries)");
+  static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();
+  if (repair_env != 0) {
+    if (repair_env != 2 && fpk_final_mark(u_score, u_unc, s->sel_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), st) == 0)
+      fpk_apply_marks(s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), B, R, u_exact, u_score, st);
+    else
+      HIPCHK(hipMemcpyAsync(u_score, u_exact, (size_t)B * R * 4, hipMemcpyDeviceToDevice, st));
+  }
+  OutLayout ol(B, K);
+  HIPCHK(s->out_all.ensure(ol.total));
+  HIPCHK(s->h_out.ensure(ol.total));
+  char* od = s->out_all.as<char>();
+  fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->sel_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
+                 reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
+  HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);
   return FP_OK;
 }

@@ -301,6 +301,19 @@ def last_search_timings() -> dict:
     return {names[i].decode(): float(ms[i]) for i in range(n)}
 
 
+def maxsim_columns(index: PyLoadedIndex, query_f16, pids) -> dict:
+    """fp_maxsim_columns: the exact stage's MFMA pass on `pids` for one query [q_len, dim], before the exact-order repair."""
+    q = np.ascontiguousarray(query_f16, dtype=np.float16)
+    p = np.ascontiguousarray(pids, dtype=np.int64)
+    n, Q = int(p.shape[0]), int(q.shape[0])
+    scores = np.zeros(n, np.float32)
+    cm = np.zeros((n, Q), np.uint16)
+    unc = np.zeros(n, np.float32)
+    flags = np.zeros((n, (Q + 31) // 32), np.uint32)
+    N.check(N.lib().fp_maxsim_columns(index._h, _ptr(q), Q, int(q.shape[1]), _ptr(p), n, _ptr(scores), _ptr(cm), _ptr(unc), _ptr(flags)))
+    return dict(scores=scores, col_max=cm.view(np.float16), unc=unc, flags=flags)
+
+
 def last_search_counts() -> dict:
     out = (C.c_int64 * 4)()
     N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 4)

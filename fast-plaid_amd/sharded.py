@@ -121,6 +121,60 @@ class HipShardEngine:
         N.lib().fp_shard_end(st["ctx"])
 
 
+class NativeComm:
+    """RCCL communicator owned by the library (include/fastplaid.h fp_comm_*): rank 0 draws the 128-byte unique id, the caller's
+    `broadcast(bytes_or_None) -> bytes` ships it (torch.distributed / MPI / a file -- any out-of-band channel), every rank joins."""
+
+    def __init__(self, device_id: int, world: int, rank: int, broadcast):
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            N.check(N.lib().fp_comm_unique_id(C.cast(uid, C.c_void_p)))
+        raw = broadcast(bytes(uid) if rank == 0 else None)
+        buf = (C.c_ubyte * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        N.check(N.lib().fp_comm_create(int(device_id), int(world), int(rank), C.cast(buf, C.c_void_p), C.byref(h)))
+        self._h, self.world, self.rank = h, world, rank
+
+    @classmethod
+    def from_torch_dist(cls, device_id: int, dist, group=None):
+        """bootstrap through an initialised torch.distributed process group (the id travels as a CPU byte tensor)."""
+        import torch
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def bcast(raw):
+            t = torch.zeros(128, dtype=torch.uint8) if raw is None else torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            return bytes(t.cpu().numpy().tobytes())
+        return cls(device_id, world, rank, bcast)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            N.lib().fp_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def native_sharded_search(index: native.PyLoadedIndex, comm: NativeComm, queries_f16, params):
+    """fp_shard_search: the three stages and the two RCCL all-gathers inside ONE library call (collective over `comm`)."""
+    q = np.ascontiguousarray(queries_f16, dtype=np.float16)
+    B, Q, D = q.shape
+    k = max(params.top_k, 1)
+    pids = np.full((B, k), -1, np.int64)
+    scores = np.zeros((B, k), np.float32)
+    counts = np.zeros(B, np.int32)
+    p = params._c()
+    N.check(N.lib().fp_shard_search(index._h, comm._h, q.ctypes.data_as(C.c_void_p), B, Q, D, C.byref(p), pids.ctypes.data_as(C.c_void_p),
+                                    scores.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
+    return pids[:, : params.top_k], scores[:, : params.top_k], counts
+
+
 def _all_gather(torch, dist, x, world, group, force=False):
     """[B,R] per rank -> [G,B,R] on every rank."""
     if dist is None or (world == 1 and not force):

@@ -137,6 +137,15 @@ int fp_last_search_timings(const char** names, float* ms, int cap);
  * reference's summation order (exact-order repair), out[3] = sub-batches.  Returns entries written. */
 int fp_last_search_counts(int64_t* out, int cap);
 
+/* Diagnostic / test entry point: the MFMA pass of the exact stage (S6+S7) on the given documents for ONE query, before the
+ * exact-order repair.  scores [n]; col_max [n, q_len] f16 bits = per query column the maximum over the document's tokens as the
+ * kernel rounds it; unc [n] = uncertainty budget (sum of the fp16 ulps of the flagged columns); flags [n, ceil(q_len/32)] = bit
+ * per flagged column (a column is flagged when its fp32 maximum lies so close to an fp16 rounding boundary that the
+ * reference's summation order could round it the other way).  Shapes without an MFMA kernel: col_max / flags come back zero
+ * (that path is exact: nothing is ever flagged).  Any output but scores may be NULL. */
+int fp_maxsim_columns(const fp_index* index, const uint16_t* query_f16, int32_t q_len, int32_t dim, const int64_t* pids, int64_t n,
+                      float* scores, uint16_t* col_max, float* unc, uint32_t* flags);
+
 /* ---- `pysearch_with_token_scores` (rust/lib.rs:243-290 -> search_many_with_token_scores,
  *      rust/search/search.rs:294-363; matrix extraction :668-686) ------------------------------
  * Token-level similarity matrices of search hits: for hit h = (query b, rank i) the matrix
@@ -204,6 +213,23 @@ int fp_shard_stage2(fp_shard_ctx* ctx, const void* dev_all_rec1 /*[G,B,R]*/, int
 int fp_shard_stage3(fp_shard_ctx* ctx, const void* dev_all_rec2 /*[G,B,R]*/, int32_t n_ranks, int64_t* out_pids, float* out_scores,
                     int32_t* out_counts);
 void fp_shard_end(fp_shard_ctx* ctx);
+
+/* The same sharded search with the collectives issued by the library (RCCL over xGMI, bound with dlopen at first use): both
+ * all-gathers are enqueued on the search stream behind the kernels that fill their send buffers -- no host synchronisation
+ * between the stages, no framework in the data path.  One communicator per process / GPU:
+ *   rank 0: fp_comm_unique_id(id) -> the caller ships the 128 bytes to every rank (any out-of-band channel)
+ *   all   : fp_comm_create(device, n_ranks, rank, id, &comm)      (collective: ncclCommInitRank)
+ *   all   : fp_shard_search(shard_index, comm, ...)                (collective; identical results on every rank, == fp_search
+ *                                                                   on the whole corpus)
+ * Every rank passes the same queries / parameters.  Not re-entrant on one communicator. */
+typedef struct fp_comm fp_comm;
+int fp_comm_unique_id(void* out_id_128_bytes);
+int fp_comm_create(int device_id, int n_ranks, int rank, const void* unique_id_128_bytes, fp_comm** out);
+void fp_comm_destroy(fp_comm* comm);
+int fp_comm_n_ranks(const fp_comm* comm);
+int fp_comm_rank(const fp_comm* comm);
+int fp_shard_search(const fp_index* index, fp_comm* comm, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                    const fp_search_params* params, int64_t* out_pids, float* out_scores, int32_t* out_counts);
 
 /* ---- synthetic corpora generated in HBM (benchmark + full-size property tests) ------- */
 /* Builds an index whose codes / residual bytes / lengths / IVF are generated on the

@@ -430,13 +430,15 @@ def train_codec(heldout: torch.Tensor, centroids: torch.Tensor, nbits: int):
     return cut, wts, avg
 
 
-def compress_documents(docs: list[torch.Tensor], centroids: torch.Tensor, cutoffs: torch.Tensor, nbits: int):
-    """create.rs:404-428 process_batch: codes + packed residual bytes."""
+def compress_documents(docs: list[torch.Tensor], centroids: torch.Tensor, cutoffs: torch.Tensor, nbits: int, cast_cutoffs: bool = True):
+    """create.rs:404-428 process_batch: codes + packed residual bytes.  cast_cutoffs=True buckets against the cutoffs cast to Half
+    (what update.rs does with the loaded codec, and what the committed search fixtures were generated with); False hands
+    torch.bucketize the fp32 cutoffs as create.rs:413 does (ATen promotes the Half residuals: an fp32 comparison)."""
     dim = centroids.shape[1]
     emb = torch.cat([d.to(torch.float16) for d in docs])
     codes = compress_into_codes(emb, centroids)
     res = emb - centroids.index_select(0, codes)
-    b = torch.bucketize(res, cutoffs.to(res.dtype), out_int32=True, right=False)  # :413
+    b = torch.bucketize(res, cutoffs.to(res.dtype) if cast_cutoffs else cutoffs, out_int32=True, right=False)  # :413
     b = b.unsqueeze(-1).expand(*b.shape, nbits)
     b = b.bitwise_right_shift(torch.arange(nbits, dtype=torch.int8))  # :416-418 bit_helper
     b = b.bitwise_and(torch.ones_like(b))
@@ -465,14 +467,15 @@ def num_partitions_for(n_tokens_est: float) -> int:
     return int(2 ** math.floor(math.log2(16 * math.sqrt(n_tokens_est))))
 
 
-def build_index_arrays(docs: list[torch.Tensor], centroids: torch.Tensor, nbits: int, num_partitions: int | None = None):
+def build_index_arrays(docs: list[torch.Tensor], centroids: torch.Tensor, nbits: int, num_partitions: int | None = None,
+                       cast_cutoffs: bool = True):
     """End-to-end array set that ``construct_index`` consumes (load.py:220-322 layout:
     codes/residuals carry ``max_len - last_len`` trailing padding rows)."""
     centroids = centroids.to(torch.float16)
     doclens = torch.tensor([d.shape[0] for d in docs], dtype=torch.int64)
     allemb = torch.cat([d.to(torch.float16) for d in docs])
     cut, wts, avg = train_codec(allemb, centroids, nbits)
-    codes, packed = compress_documents(docs, centroids, cut, nbits)
+    codes, packed = compress_documents(docs, centroids, cut, nbits, cast_cutoffs)
     if num_partitions is None:
         num_partitions = max(centroids.shape[0], 1)
     ivf, ivf_lengths = build_ivf(codes, doclens, num_partitions)

