@@ -498,9 +498,7 @@ static int validate_search(const fp_index* ix, int32_t nq, int32_t q_len, int32_
   if (nq < 0 || q_len < 1) return fail(FP_EINVAL, "Expected a 3D tensor for queries with at least one token per query");
   if (dim != ix->d.dim) return fail(FP_EINVAL, "query dim does not match the index dim");
   if (p->top_k < 0 || p->n_full_scores < 0 || p->n_ivf_probe < 0) return fail(FP_EINVAL, "negative search parameter");
-  if (p->n_ivf_probe > FP_MAX_PROBE) return fail(FP_EUNSUPPORTED, "n_ivf_probe > 32 is not supported by the probe kernel");
-  if ((int64_t)q_len * std::max<int64_t>(p->n_ivf_probe, 1) > FP_MAX_CELLS)
-    return fail(FP_EUNSUPPORTED, "q_len * n_ivf_probe > 8192 is not supported");
+  if ((int64_t)q_len * std::max<int64_t>(p->n_ivf_probe, 1) > (1ll << 28)) return fail(FP_EUNSUPPORTED, "q_len * n_ivf_probe > 2^28");
   const int64_t R = std::max<int64_t>(p->n_full_scores / 4, 1);
   if (R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_full_scores > 65536 is not supported by the LDS sort");
   return FP_OK;

@@ -305,6 +305,131 @@ __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __
   }
 }
 
+// ---- any n_probe: exact radix select per column (generic path: n_probe > 32, or the overflow fallback of those) -------------
+// One workgroup per (query, 32-column group); thread = (column, one of 8 contiguous centroid slices).  Two histogram passes over
+// the monotone 16-bit keys give the n_probe-th largest key of the column and how many centroids at that key are still needed;
+// the collect pass takes everything above it and, among the equal ones, the lowest centroid ids (slices are contiguous ranges,
+// so a per-slice prefix of the equal counts orders them).  Four reads of S: slower than the threshold probe, any n_probe <= C.
+__global__ __launch_bounds__(256) void k_probe_select(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp, int n_probe,
+                                                      const uint32_t* __restrict__ allow, int64_t Cw, int32_t* __restrict__ cells,
+                                                      const int32_t* __restrict__ flag) {
+  if (flag && !*flag) return;
+  __shared__ uint32_t hist[32][257];
+  __shared__ uint32_t thr_key[32], need_eq[32], cnt_eq[32][8], out_pos[32];
+  const int groups = Qp / 32;
+  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int q = g * 32 + col;
+  const int64_t per = (C + 7) / 8;
+  const int64_t cb = slice * per, ce = (cb + per < C) ? cb + per : C;
+  const uint16_t* Sb = S + (int64_t)b * C * Qp + q;
+  const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
+  const bool live = q < Q;
+  auto key_of = [&](int64_t c) -> uint32_t { return mono16(Sb[c * Qp]); };
+  auto allowed = [&](int64_t c) -> bool { return !al || ((al[c >> 5] >> (c & 31)) & 1u); };
+  uint32_t prefix = 0, rem = (uint32_t)n_probe;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = threadIdx.x; i < 32 * 257; i += 256) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    if (live)
+      for (int64_t c = cb; c < ce; ++c) {
+        if (!allowed(c)) continue;
+        const uint32_t k = key_of(c);
+        if (pass == 0) atomicAdd(&hist[col][k >> 8], 1u);
+        else if ((k >> 8) == prefix) atomicAdd(&hist[col][k & 0xFFu], 1u);
+      }
+    __syncthreads();
+    if (slice == 0 && live) {
+      if (pass == 1) { prefix = thr_key[col]; rem = need_eq[col]; }
+      uint32_t acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[col][d] >= rem) break;
+        acc += hist[col][d];
+      }
+      // fewer than `rem` allowed centroids in total: d ends at 0 and everything is taken
+      thr_key[col] = pass == 0 ? (uint32_t)d : ((prefix << 8) | (uint32_t)d);
+      need_eq[col] = rem - acc;
+    }
+    __syncthreads();
+    prefix = thr_key[col];
+    rem = need_eq[col];
+  }
+  const uint32_t tk = thr_key[col];
+  // equal-key counts per slice -> exclusive prefix over the slices (ascending centroid order)
+  uint32_t my_eq = 0;
+  if (live)
+    for (int64_t c = cb; c < ce; ++c)
+      if (allowed(c) && key_of(c) == tk) ++my_eq;
+  cnt_eq[col][slice] = my_eq;
+  if (slice == 0) out_pos[col] = 0u;
+  __syncthreads();
+  uint32_t eq_before = 0;
+  for (int s2 = 0; s2 < slice; ++s2) eq_before += cnt_eq[col][s2];
+  if (live) {
+    int32_t* out = cells + ((int64_t)b * Q + q) * n_probe;
+    const uint32_t want_eq = need_eq[col];
+    uint32_t eq_seen = eq_before;
+    for (int64_t c = cb; c < ce; ++c) {
+      if (!allowed(c)) continue;
+      const uint32_t k = key_of(c);
+      bool take = k > tk;
+      if (k == tk) { take = eq_seen < want_eq; ++eq_seen; }
+      if (take) {
+        const uint32_t pos = atomicAdd(&out_pos[col], 1u);
+        if (pos < (uint32_t)n_probe) out[pos] = (int32_t)c;
+      }
+    }
+  }
+  __syncthreads();
+  if (slice == 0 && live) {
+    int32_t* out = cells + ((int64_t)b * Q + q) * n_probe;
+    for (uint32_t i = out_pos[col]; i < (uint32_t)n_probe; ++i) out[i] = -1;
+  }
+}
+
+// ---- sorted unique cells through a bitmap over the centroid ids (any number of probed cells per query) --------------------
+__global__ void k_cells_mark(const int32_t* __restrict__ cells, int n, int64_t C, uint32_t* __restrict__ bm, int64_t Cw) {
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t c = cells[(int64_t)b * n + i];
+    if (c >= 0 && c < C) atomicOr(&bm[(int64_t)b * Cw + (c >> 5)], 1u << (c & 31));
+  }
+}
+__global__ __launch_bounds__(256) void k_cells_from_bitmap(const uint32_t* __restrict__ bm, int64_t Cw, int n, int32_t* __restrict__ ucells,
+                                                           int32_t* __restrict__ ncells) {
+  __shared__ int s[256];
+  const int b = blockIdx.x;
+  const uint32_t* w = bm + (int64_t)b * Cw;
+  int32_t* out = ucells + (int64_t)b * n;
+  int base = 0;
+  for (int64_t start = 0; start < Cw; start += 256) {
+    const int64_t i = start + threadIdx.x;
+    const uint32_t x = i < Cw ? w[i] : 0u;
+    const int c = __popc(x);
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int pos = base + s[threadIdx.x] - c;
+    uint32_t y = x;
+    while (y) {
+      const int bit = __ffs(y) - 1;
+      if (pos < n) out[pos] = (int32_t)(i * 32 + bit);
+      ++pos;
+      y &= y - 1;
+    }
+    const int tot = s[255];
+    __syncthreads();
+    base += tot;
+  }
+  if (threadIdx.x == 0) ncells[b] = base < n ? base : n;
+}
+
 // LDS bitonic sort (ascending) of n <= cap int32 values, then unique.  one block per query.
 __global__ __launch_bounds__(256) void k_cells_unique(const int32_t* __restrict__ cells, int n, int npow2,
                                                       int32_t* __restrict__ ucells, int32_t* __restrict__ ncells) {
@@ -522,7 +647,9 @@ size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, in
   while (NP < (sh.n_probe > 1 ? sh.n_probe : 1)) NP <<= 1;
   const size_t cols = (size_t)sh.B * sh.Qp;
   const size_t nch2 = (size_t)((ix.C + PROBE_CHUNK - 1) / PROBE_CHUNK);
-  return cols * PROBE_CAP * 8 + cols * nchunk * 8 * NP * 8 + ((cols * nch2 * 2 + 15) & ~(size_t)15) + cols * 4 + cols * 4 + 64;
+  if (NP > 32) NP = 32;
+  const size_t bitmap = (int64_t)sh.Q * sh.n_probe > FP_MAX_CELLS ? (size_t)sh.B * ((ix.C + 31) / 32) * 4 : 0;
+  return cols * PROBE_CAP * 8 + cols * nchunk * 8 * NP * 8 + ((cols * nch2 * 2 + 15) & ~(size_t)15) + cols * 4 + cols * 4 + 64 + bitmap;
 }
 
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
@@ -530,8 +657,8 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
               const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st) {
   const int64_t Cw = (ix.C + 31) / 32;
   int NP = 1;
-  while (NP < sh.n_probe) NP <<= 1;
-  if (NP > 32) return -1;
+  while (NP < sh.n_probe && NP < 32) NP <<= 1;   // register top-k fallback: n_probe <= 32 (beyond: k_probe_select)
+  const bool big_probe = sh.n_probe > 32;
   const size_t cols = (size_t)sh.B * sh.Qp;
   const int nch2 = (int)((ix.C + PROBE_CHUNK - 1) / PROBE_CHUNK);
   unsigned char* base = reinterpret_cast<unsigned char*>(partial);
@@ -546,7 +673,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
   // the chunk index must fit the 12 low bits of the tau keys
   static int force_fb = -1;
   if (force_fb < 0) force_fb = getenv("FP_PROBE_FALLBACK") ? 1 : 0;
-  const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP && !force_fb;
+  const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP / 2 && !force_fb;   // room for ties at the cut in the candidate list
   if (threshold_ok) {
     (void)hipMemsetAsync(cand, 0, cols * PROBE_CAP * 8, st);
     (void)hipMemsetAsync(cnt, 0, cols * 4 + 4, st);  // counters + flag
@@ -570,6 +697,10 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
   }
   // fallback (runs only when the flag is set)
+  if (big_probe) {
+    hipLaunchKernelGGL(k_probe_select, dim3((unsigned)(sh.B * (sh.Qp / 32))), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, sh.n_probe, allow, Cw,
+                       cells, flag);
+  } else {
   switch (NP) {
     case 1: launch_probe_partial<1>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
     case 2: launch_probe_partial<2>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
@@ -580,9 +711,19 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
   }
   hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, fb_partial, sh.Q, sh.Qp, nchunk * 8 * NP, sh.n_probe,
                      cells, flag, 1);
-  const int n = sh.Q * sh.n_probe;
-  const int np2 = next_pow2(n);
-  hipLaunchKernelGGL(k_cells_unique, dim3((unsigned)sh.B), dim3(256), (size_t)np2 * 4, st, cells, n, np2, ucells, ncells);
+  }
+  const int64_t n64 = (int64_t)sh.Q * sh.n_probe;
+  if (n64 > 0x7FFFFFFFll / 4) return -1;
+  const int n = (int)n64;
+  if (n <= FP_MAX_CELLS) {
+    const int np2 = next_pow2(n);
+    hipLaunchKernelGGL(k_cells_unique, dim3((unsigned)sh.B), dim3(256), (size_t)np2 * 4, st, cells, n, np2, ucells, ncells);
+  } else {   // more probed cells than the LDS sort holds: mark them in a bitmap over the centroid ids and read it back in order
+    uint32_t* bm = reinterpret_cast<uint32_t*>(flag + 4);   // [B][Cw] behind the flag (fpk_probe_scratch_bytes)
+    (void)hipMemsetAsync(bm, 0, (size_t)sh.B * Cw * 4, st);
+    hipLaunchKernelGGL(k_cells_mark, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256), (unsigned)sh.B), dim3(256), 0, st, cells, n, ix.C, bm, Cw);
+    hipLaunchKernelGGL(k_cells_from_bitmap, dim3((unsigned)sh.B), dim3(256), 0, st, bm, Cw, n, ucells, ncells);
+  }
   return 0;
 }
 
@@ -625,7 +766,8 @@ void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int6
 //              tiles / long lists).
 #define MARK_TILE_WORDS_MAX 8192   // 32 KiB of LDS bitmap = 262144 documents per tile
 __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
-                                                   int maxcells, const int64_t* __restrict__ ivf_off,
+                                                   int maxcells /*cells per pass (LDS capacity)*/, int ucstride /*row stride of ucells*/,
+                                                   const int64_t* __restrict__ ivf_off,
                                                    const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
                                                    int64_t W, int search, int tw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -640,7 +782,12 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   const int64_t tile_hi64 = (word0 + tw) * 32;
   const int32_t tile_hi = tile_hi64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tile_hi64;
   for (int i = tid; i < tw; i += 1024) tile[i] = 0u;
-  const int nc = ncells[b];
+  const int nc_all = ncells[b];
+  const int lane = tid & 63, wave = tid >> 6;
+  // the probed cells are walked in chunks of at most `maxcells` (the LDS arrays' capacity)
+  for (int cb = 0; cb < nc_all; cb += maxcells) {
+  const int nc = (nc_all - cb) < maxcells ? (nc_all - cb) : maxcells;
+  __syncthreads();   // the previous chunk's lo_s / pre are no longer read
   // phase 1: per-cell [lo, lo+len) and exclusive prefix of the lengths
   uint32_t base = 0;
   for (int start = 0; start < nc; start += 1024) {
@@ -648,7 +795,7 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
     uint32_t len = 0;
     long long lo = 0;
     if (j < nc) {
-      const int32_t cell = ucells[(int64_t)b * maxcells + j];
+      const int32_t cell = ucells[(int64_t)b * ucstride + cb + j];
       if (cell >= 0 && cell < P) {
         long long beg = ivf_off[cell], end = ivf_off[cell + 1];
         if (search) {
@@ -681,7 +828,6 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   __syncthreads();
   const uint32_t total = base;
   // phase 2: walk the concatenated stream, 512 elements per wave-chunk
-  const int lane = tid & 63, wave = tid >> 6;
   for (uint32_t c0 = (uint32_t)wave * 512u; c0 < total; c0 += 16u * 512u) {
     int cell = 0;
     {  // last cell with pre[cell] <= c0
@@ -705,6 +851,7 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
       if (p >= tile_lo && p < tile_hi) atomicOr(&tile[(p - tile_lo) >> 5], 1u << (p & 31));
     }
   }
+  }
   __syncthreads();
   // phase 3: write the tile (W is a multiple of 64 words; tiles may overhang the end)
   uint32_t* dst = bitmap + (int64_t)b * W + word0;
@@ -713,8 +860,9 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   }
 }
 
-void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B, uint32_t* bitmap,
+void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int ucstride, int B, uint32_t* bitmap,
                   int64_t W, hipStream_t st) {
+  const int maxcells = ucstride < FP_MAX_CELLS ? ucstride : FP_MAX_CELLS;   // probed cells per pass of the kernel
   // tile size: the largest that still gives the chip ~4 workgroups per CU (measured at cfg2: B=64 -> 2048 words 0.11 ms vs 8192 words 0.26 ms; B=8 -> 512 words 0.04 vs 0.22 ms)
   int tw = MARK_TILE_WORDS_MAX;
   while (tw > 512 && ((W + tw - 1) / tw) * B < 1024) tw >>= 1;
@@ -723,7 +871,7 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_ivf_mark, lds_ok, 144 * 1024);
   const int search = ntile > 8 ? 1 : 0;
-  hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ix.ivf_off,
+  hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ucstride, ix.ivf_off,
                      ix.ivf_pids, ix.P, bitmap, W, search, tw);
 }
 

@@ -427,6 +427,18 @@ RANDOM_SHAPES = [
     (900, 70, 2048, 128, 4, 3, 31, 16, 4096, 100, False),
     (50, 300, 5000, 128, 4, 2, 50, 8, 8, 3, False),
     (4000, 12, 129, 64, 4, 9, 8, 1, 2000, 1000, True),
+    # beyond the round-1 limits (search.rs:518-529 takes any n_ivf_probe <= C): 32 < n_probe <= 64 (threshold probe, radix-select
+    # fallback), n_probe > 64 (radix select), n_probe == C, q_len * n_probe > 8192 (bitmap unique + chunked IVF marking), and the
+    # shapes without an MFMA MaxSim kernel (dim 96 / 48 / 40 / 256, nbits 1 / 8)
+    (800, 40, 600, 64, 4, 2, 16, 40, 256, 10, False),
+    (800, 40, 600, 64, 4, 2, 16, 100, 256, 10, True),
+    (500, 30, 256, 96, 4, 2, 8, 256, 64, 5, False),
+    (600, 30, 300, 128, 2, 2, 48, 200, 128, 8, False),
+    (400, 50, 512, 48, 2, 3, 20, 8, 64, 10, True),
+    (300, 40, 256, 40, 4, 2, 12, 4, 64, 6, False),
+    (200, 30, 128, 256, 4, 2, 16, 4, 64, 6, False),
+    (300, 40, 256, 128, 8, 2, 32, 8, 64, 6, False),
+    (300, 40, 256, 128, 1, 2, 32, 8, 64, 6, True),
 ]
 
 
