@@ -93,6 +93,11 @@ def _pmc_traffic(kernel_prefix, applicable):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line (rank 0's JSON): RCCL prints a version banner to stdout when a communicator is created, and
+    # any library may do likewise, so fd 1 points at stderr until the result is printed
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
     default_cfg = (a.docs == 1_000_000 and a.doc_len == 128 and a.centroids == 0 and a.batch == 64 and a.qlen == 32 and
                    a.topk == 1000 and a.nfull == 4096 and a.nprobe == 8 and a.dim == 128 and a.nbits == 4)
     rank = int(os.environ.get("RANK", "0"))
@@ -351,7 +356,8 @@ def main():
                         md = max(md, abs(rm[p] - s))
             out["parity_vs_cpu"] = {"queries": ncpu, "identical_id_lists": ident, "mean_id_overlap": overlap, "max_abs_score_diff": md}
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(_real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -134,7 +134,10 @@ def build_index_arrays(docs, centroids, nbits: int, device: str = "cuda:0", held
     ivf, ivf_lengths = synth.build_ivf(codes, lens, P)
     return dict(nbits=nbits, centroids=cent, avg_residual=avg.astype(np.float16), bucket_cutoffs=cut.astype(np.float16),
                 bucket_weights=wts.astype(np.float16), ivf=ivf, ivf_lengths=ivf_lengths, doc_codes=codes, doc_residuals=packed,
-                doc_lengths=lens, cluster_threshold=np.float32(thr))
+                doc_lengths=lens, cluster_threshold=np.float32(thr),
+                # what create.rs writes to the directory: the fp32 values themselves (the loader casts them to fp16)
+                codec_f32=dict(avg_residual=np.asarray(avg, np.float32), bucket_cutoffs=np.asarray(cut, np.float32),
+                               bucket_weights=np.asarray(wts, np.float32)))
 
 
 def create_index(index_path: str, documents_embeddings, centroids, nbits: int = 4, device: str = "cuda:0", seed: int | None = 42,

@@ -71,7 +71,14 @@ static inline void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done,
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (!(done.load(std::memory_order_relaxed) & bit)) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    // the limit covers static + dynamic LDS: a kernel with static __shared__ variables can only be granted the remainder
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, fn) == hipSuccess) {
+      const int room = 160 * 1024 - (int)fa.sharedSizeBytes;
+      if (bytes > room) bytes = room;
+    }
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+      (void)hipGetLastError();   // the launch that needs the room reports the failure itself (stage-boundary check)
     done.fetch_or(bit, std::memory_order_relaxed);
   }
 }

@@ -30,6 +30,21 @@ static int fail(int code, const std::string& msg) {
       return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x);            \
   } while (0)
 
+// a kernel launch reports a bad configuration only through hipGetLastError: every stage boundary checks it, so a failed launch
+// stops the search with the stage named instead of surfacing later in somebody else's HIP call
+#define STAGE_DONE(X)                                                                                  \
+  do {                                                                                                 \
+    hipError_t l_ = hipGetLastError();                                                                 \
+    if (l_ != hipSuccess)                                                                              \
+      return fail(FP_EHIP, std::string("HIP launch error: ") + hipGetErrorString(l_) + " before the end of stage " #X); \
+    HIPCHK(hipEventRecord(s->ev[X], st));                                                              \
+  } while (0)
+#define LAUNCHCHK(where)                                                                               \
+  do {                                                                                                 \
+    hipError_t l_ = hipGetLastError();                                                                 \
+    if (l_ != hipSuccess) return fail(FP_EHIP, std::string("HIP launch error: ") + hipGetErrorString(l_) + " in " where); \
+  } while (0)
+
 extern "C" const char* fp_last_error(void) { return g_err.c_str(); }
 extern "C" const char* fp_version(void) { return "fastplaid-hip 0.1 (gfx950)"; }
 extern "C" int fp_device_count(void) {
@@ -101,14 +116,14 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
-                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
+                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
                       &ms_nmark, &sh_rec, &sh_all})
       b->release();
     h_out.release();
@@ -527,7 +542,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   const int B = sh.B;
   HIPCHK(s->qpad.ensure((size_t)B * sh.Qp * D.dim * 2));
   fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st);
-  HIPCHK(hipEventRecord(s->ev[ST_CENTROID], st));
+  STAGE_DONE(ST_CENTROID);
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
   // per-128-centroid column maxima for the threshold probe
@@ -543,7 +558,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
                           s->cmax128.as<uint16_t>(), st))
     return fail(FP_EUNSUPPORTED, "dim");
-  HIPCHK(hipEventRecord(s->ev[ST_PROBE], st));
+  STAGE_DONE(ST_PROBE);
   // subset bitmaps
   P.W = ((D.N + 31) / 32 + 63) & ~63ll;
   if (P.W < 64) P.W = 64;
@@ -580,7 +595,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   } else {
     HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result
   }
-  HIPCHK(hipEventRecord(s->ev[ST_IVF], st));
+  STAGE_DONE(ST_IVF);
   // S3
   HIPCHK(s->bitmap.ensure((size_t)B * P.W * 4));
   // k_ivf_mark writes every word of the bitmap (tiles are built in LDS): no memset needed
@@ -593,7 +608,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                  s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st);
   HIPCHK(s->h_small.ensure(4096));
   HIPCHK(hipMemcpyAsync(s->h_small.p, s->cand_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(s->ev[ST_COMPACT], st));
+  STAGE_DONE(ST_COMPACT);
   HIPCHK(hipStreamSynchronize(st));  // the one mid-pipeline host sync: candidate total sizes the buffers
   const int64_t M = *reinterpret_cast<const int64_t*>(s->h_small.p);
   P.M = M;
@@ -601,7 +616,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->approx.ensure((size_t)std::max<int64_t>(M, 1) * 4));
   fpk_cand_compact(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                    s->blkcnt.as<int32_t>(), P.nblk, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), st);
-  HIPCHK(hipEventRecord(s->ev[ST_APREP], st));
+  STAGE_DONE(ST_APREP);
   // S4.  Three forms, all giving the selection of "score every candidate exactly":
   //   level 0  (k_l0_scan): a scalar bound per centroid in LDS prunes ~99 % of the candidates without touching S -- when the
   //            byte table of C entries fits LDS and there is something to prune;
@@ -642,25 +657,38 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       HIPCHK(s->l0_npilot.ensure((size_t)B * 4));
       HIPCHK(s->l0_pilot_pid.ensure((size_t)B * pcap * 4));
       HIPCHK(s->l0_pilot_approx.ensure((size_t)B * pcap * 4));
+      HIPCHK(s->l0_pilot_idx.ensure((size_t)B * pcap * 4));
+      HIPCHK(s->l0_capprox.ensure((size_t)M * 4));
+      HIPCHK(s->l0_thr.ensure((size_t)B * 4));
+      HIPCHK(s->l0_nextra.ensure((size_t)B * 4));
+      HIPCHK(s->l0_xpid.ensure((size_t)M * 4));
+      HIPCHK(s->l0_xdst.ensure((size_t)M * 4));
       FpL0Scratch w{s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(),
                     s->l0_ub.as<uint16_t>(), s->l0_hist.as<uint32_t>(), s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2,
-                    s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>()};
+                    s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>(),
+                    s->l0_pilot_idx.as<int32_t>(), s->l0_capprox.as<float>(), s->l0_thr.as<int32_t>(), s->l0_nextra.as<int32_t>(),
+                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>()};
       fpk_l0_prepare(D, s->S8.as<uint8_t>(), sh, w, st);
-      HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
+      STAGE_DONE(ST_APPROX);
       fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
-      HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
+      STAGE_DONE(ST_REFINE);
       fpk_l0_pilot(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
       // exact scores of the pilot group (about FP_L0_PILOT x keep documents per query; ties of UB0 at the cut can add more)
-      fpk_approx(D, s->S.as<uint16_t>(), sh, nullptr, w.pilot_pid, std::min<int64_t>(M, 6 * (int64_t)B * sh.R), w.pilot_approx, st, w.npilot, pcap);
+      // (each score also lands at the document's candidate position: a pilot member that survives is not scored again)
+      fpk_approx(D, s->S.as<uint16_t>(), sh, nullptr, w.pilot_pid, std::min<int64_t>(M, 6 * (int64_t)B * sh.R), w.pilot_approx, st, w.npilot, pcap,
+                 w.cand_approx, w.pilot_idx, s->cand_off.as<int64_t>());
       fpk_l0_survivors(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
-                       s->surv_pid.as<int32_t>(), st);
+                       s->surv_pid.as<int32_t>(), s->approx.as<float>(), st);
+      // survivors outside the pilot group (none when the threshold lies above the pilot cut, the usual case)
+      fpk_approx(D, s->S.as<uint16_t>(), sh, s->surv_off.as<int64_t>(), w.xpid, std::min<int64_t>(M, 2 * (int64_t)B * sh.R), nullptr, st, w.nextra,
+                 INT64_MAX, s->approx.as<float>(), w.xdst, s->surv_off.as<int64_t>());
     } else {
       const int nch8 = sh.Qp / 32;
       HIPCHK(s->kq.ensure((size_t)M * 4 * (nch8 > 1 ? 1 + nch8 : 1)));
       HIPCHK(s->q8hist.ensure((size_t)B * 8192 * nch8 * 4));
-      HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
+      STAGE_DONE(ST_APPROX);
       fpk_approx_q8_bounds(D, s->S8.as<uint8_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->kq.as<uint32_t>(), st);
-      HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
+      STAGE_DONE(ST_REFINE);
       fpk_approx_q8_cut(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
                         s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
                         s->surv_pid.as<int32_t>(), st);
@@ -669,15 +697,16 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     sel_src = s->surv_pid.as<int32_t>();
     // survivor total for fp_last_search_counts: lands in pinned memory by the time the caller's final sync returns
     HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 8, s->surv_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
-    // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2 after the 8-bit bounds, ~4 x R after level 0); the
-    // kernel walks a grid-stride loop if there are more
-    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), s->approx.as<float>(), st);
+    // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2 after the 8-bit bounds); the kernel walks a
+    // grid-stride loop if there are more
+    if (P.approx_impl != 2)
+      fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), s->approx.as<float>(), st);
   } else {
-    HIPCHK(hipEventRecord(s->ev[ST_APPROX], st));
+    STAGE_DONE(ST_APPROX);
     fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st);
-    HIPCHK(hipEventRecord(s->ev[ST_REFINE], st));
+    STAGE_DONE(ST_REFINE);
   }
-  HIPCHK(hipEventRecord(s->ev[ST_SELECT], st));
+  STAGE_DONE(ST_SELECT);
   // S5
   HIPCHK(s->hist.ensure((size_t)3 * B * FP_SEL_BINS * 4));
   HIPCHK(s->selstate.ensure((size_t)B * 8 * 4));
@@ -688,7 +717,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   fpk_select(sh, sel_off, sel_src, s->approx.as<float>(), s->hist.as<uint32_t>(),
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st);
-  HIPCHK(hipEventRecord(s->ev[ST_MAXSIM], st));
+  STAGE_DONE(ST_MAXSIM);
   return FP_OK;
 }
 
@@ -718,6 +747,7 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
     if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(),
                    s->ms_pref.as<int64_t>(), aux, st))
       return fail(FP_EUNSUPPORTED, "dim/nbits");
+    LAUNCHCHK("MaxSim");
   }
   if (repair && mode != 0) {
     const bool marked = mode == 1 && repair_env != 2 &&
@@ -731,6 +761,7 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
     }
     fpk_maxsim_repair(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R,
                       marked ? s->ms_marks.as<int32_t>() : nullptr, marked ? s->ms_nmark.as<int32_t>() : nullptr, s->exact.as<float>(), aux, st);
+    LAUNCHCHK("MaxSim repair");
   }
   return FP_OK;
 }
@@ -781,7 +812,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
     P.exact_all = tr != nullptr;   // the trace reports the approximate score of every candidate
     hipStream_t st = s->st;
-    HIPCHK(hipEventRecord(s->ev[ST_UPLOAD], st));
+    STAGE_DONE(ST_UPLOAD);
     HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
     HIPCHK(hipMemcpyAsync(s->qin.p, queries + (size_t)b0 * Q * D.dim, (size_t)B * Q * D.dim * 2,
                           dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -798,7 +829,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     // S6+S7
     const int64_t R = P.sh.R;
     if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1)) return rc;
-    HIPCHK(hipEventRecord(s->ev[ST_TOPK], st));
+    STAGE_DONE(ST_TOPK);
     // S8
     const int64_t K = p->top_k;
     OutLayout ol(B, K);
@@ -811,11 +842,11 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, od, ol.nk * 8, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, od + ol.score_off, ol.nk * 4, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(out_counts + b0, od + ol.cnt_off, ol.n * 4, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipEventRecord(s->ev[ST_N], st));
+      STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));   // results are complete in HBM when the call returns
     } else {
       HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipEventRecord(s->ev[ST_N], st));
+      STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));
       ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     }
@@ -1284,6 +1315,7 @@ extern "C" int fp_shard_stage1(fp_shard_ctx* c, void* dev_rec1) {
     if (int rc = run_front(c->P, nullptr, nullptr, false)) return rc;
   }
   fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, c->ix->d.pid_offset, dev_rec1, s->st);
+  LAUNCHCHK("fp_shard_stage1");
   HIPCHK(hipStreamSynchronize(s->st));
   return FP_OK;
 }
@@ -1311,6 +1343,7 @@ extern "C" int fp_shard_stage2(fp_shard_ctx* c, const void* dev_all_rec1, int32_
   } else {
     fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, 0, s->st);
   }
+  LAUNCHCHK("fp_shard_stage2");
   HIPCHK(hipStreamSynchronize(s->st));
   return FP_OK;
 }
@@ -1349,6 +1382,7 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_
   char* od = s->out_all.as<char>();
   fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->sel_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
                  reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), s->st);
+  LAUNCHCHK("fp_shard_stage3");
   HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, s->st));
   HIPCHK(hipStreamSynchronize(s->st));
   ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);
@@ -1476,7 +1510,9 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   }
   // exchange 1: local top-R by approximate score
   fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
+  LAUNCHCHK("fp_shard_search (front half)");
   if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+  LAUNCHCHK("fp_shard_search (first all-gather)");
   if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st))
     return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
   // exchange 2: exact scores of the local survivors
@@ -1491,7 +1527,9 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   } else {
     fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, 0, st);
   }
+  LAUNCHCHK("fp_shard_search (cut + MaxSim)");
   if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+  LAUNCHCHK("fp_shard_search (second all-gather)");
   // merge (identical on every rank)
   HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
   HIPCHK(s->tmpf.ensure((size_t)3 * B * R * 4));
@@ -1515,6 +1553,7 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   char* od = s->out_all.as<char>();
   fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->sel_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
                  reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
+  LAUNCHCHK("fp_shard_search (merge)");
   HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);

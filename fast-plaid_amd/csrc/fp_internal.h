@@ -91,9 +91,11 @@ void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkcnt /*exclusive-scanned*/, int nblk, const int64_t* cand_off, int32_t* cand_pid,
                       hipStream_t st);
-// candidate lists as CSR (cand_off) or, with cnt != nullptr, as fixed-capacity rows [B][cap] with min(cnt[b], cap) entries each
+// candidate rows start at cand_off[b] (CSR) or, without cand_off, at b * cap; a row holds min(cnt[b], cap) entries when cnt is
+// given, else the whole CSR row.  Scores go to approx[row position] (if given) and/or scat[scat_off[b] + scat_idx[row position]].
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
-                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt = nullptr, int64_t cap = 0);
+                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt = nullptr, int64_t cap = 0,
+                float* scat = nullptr, const int32_t* scat_idx = nullptr, const int64_t* scat_off = nullptr);
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
@@ -115,6 +117,12 @@ struct FpL0Scratch {
   int32_t* npilot;      // [B] (may exceed the capacity: then nothing is pruned)
   int32_t* pilot_pid;   // [B][fpk_l0_pilot_cap()]
   float* pilot_approx;  // [B][fpk_l0_pilot_cap()]
+  int32_t* pilot_idx;   // [B][fpk_l0_pilot_cap()] position of the pilot document in the query's candidate list
+  float* cand_approx;   // [M] exact scores by candidate position (only the pilot members' entries are written / read)
+  int32_t* thr;         // [B] survivor threshold on ub (0 = keep everything)
+  int32_t* nextra;      // [B] survivors outside the pilot group
+  int32_t* xpid;        // [M] rows at surv_off[b]: their document ids ...
+  int32_t* xdst;        // [M] ... and positions in the survivor list
 };
 bool fpk_l0_fits(const FpIndexDev& ix);
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st);
@@ -123,7 +131,7 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st);
 int64_t fpk_l0_pilot_cap();
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
-                      int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
+                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st);

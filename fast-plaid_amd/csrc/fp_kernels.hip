@@ -1022,13 +1022,18 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
-                                                float* __restrict__ approx, const int32_t* __restrict__ cnt, int64_t cap) {
-  // candidate lists: CSR (cand_off [B+1]) or, with cnt != nullptr, fixed-capacity rows [B][cap] holding min(cnt[b], cap) entries
+                                                float* __restrict__ approx, const int32_t* __restrict__ cnt, int64_t cap,
+                                                float* __restrict__ scat, const int32_t* __restrict__ scat_idx,
+                                                const int64_t* __restrict__ scat_off) {
+  // candidate lists: rows start at cand_off[b] (CSR) or, without cand_off, at b * cap (fixed-capacity rows); a row holds
+  // min(cnt[b], cap) entries when cnt is given, else the whole CSR row.  Results go to approx[row position] (if given) and/or
+  // scat[scat_off[b] + scat_idx[row position]].
   const int b = blockIdx.y;
   const int bxi = blockIdx.x;
   const int bx = gridDim.x;
-  const int64_t beg = cnt ? (int64_t)b * cap : cand_off[b];
+  const int64_t beg = cand_off ? cand_off[b] : (int64_t)b * cap;
   const int64_t n = cnt ? (cnt[b] < cap ? (int64_t)cnt[b] : cap) : cand_off[b + 1] - beg;
+  const int64_t sbase = scat ? scat_off[b] : 0;
   const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
   const int grp = threadIdx.x >> 2;           // candidate slot within the block (0..63)
   const half_t negm = (half_t)NEG_MASK_F;
@@ -1122,14 +1127,18 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     // counts, so the shuffles are convergent within the group; other groups may have exited)
     total += __shfl_xor(total, 1, 64);
     total += __shfl_xor(total, 2, 64);
-    if (sub == 0) approx[beg + i] = total;
+    if (sub == 0) {
+      if (approx) approx[beg + i] = total;
+      if (scat) scat[sbase + scat_idx[beg + i]] = total;
+    }
     u0 = nu0;
     len = nlen;
   }
 }
 
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
-                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt, int64_t cap) {
+                const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt, int64_t cap, float* scat,
+                const int32_t* scat_idx, const int64_t* scat_off) {
   if (M <= 0) return;
   // enough blocks to cover the largest per-query candidate list a few times over
   int64_t per_q = (M + sh.B - 1) / sh.B;
@@ -1139,7 +1148,7 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   // walks the per-document UNIQUE code lists (max over a multiset == max over its set).
   // (an XCD-affine query assignment was measured slower: 8.3 vs 7.6 ms)
   hipLaunchKernelGGL(k_approx, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                     ix.uoff, ix.ucodes, approx, cnt, cap);
+                     ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off);
 }
 
 // ============================================================================================
@@ -1545,6 +1554,9 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 // ============================================================================================
 #define L0_ESC_BASE 192
 #define L0_ESC_SLOTS 63
+#define L0_SHIFT 2              // the table holds ceil(e / 4): UB0 = F + 4 * sum (at most 3 looser per hot code) and only excesses above
+                                // 764 escape -- at shift 0 the query's own topic centroids (e = 200..600) escaped, and a third of
+                                // the candidates holds one of them
 #define L0_INF 0xFFFFu
 #define L0_SAMPLE 8192          // centroids sampled for the column quantiles
 
@@ -1623,6 +1635,7 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
         }
       }
     }
+    e = (e + ((1u << L0_SHIFT) - 1u)) >> L0_SHIFT;
     if (inf) {
       out = 255u;
     } else if (e < L0_ESC_BASE) {
@@ -1690,18 +1703,34 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   const int64_t stride = (int64_t)gridDim.x * CPI;
   const int32_t* cpids = cand_pid + beg;
   int64_t i = (int64_t)blockIdx.x * CPI + (tid >> 3) * L0_UNROLL;
-  int32_t pidn[L0_UNROLL];           // ids of the next iteration
-  int32_t l0[L0_UNROLL], nl[L0_UNROLL];   // first line / line count of this iteration's candidates
+  // Software pipeline over the dependent chain  id -> line offsets -> code line(s):  while iteration t is computed, the code
+  // lines of t+1, the offsets of t+2 and the ids of t+3 are in flight, so no load of the chain is waited for in the iteration
+  // that issues it (one workgroup per CU -- the table takes the LDS -- leaves only 4 waves per SIMD to hide latency otherwise).
+  int32_t l0[L0_UNROLL], nl[L0_UNROLL];     // first line / line count: iteration t
+  int32_t l1[L0_UNROLL], nl1[L0_UNROLL];    // ... t+1
+  int32_t pid2[L0_UNROLL];                  // ids of t+2
+  uint4 pc[L0_UNROLL];                      // first code line of t
 #pragma unroll
   for (int k = 0; k < L0_UNROLL; ++k) {
-    l0[k] = 0; nl[k] = 0; pidn[k] = 0;
+    l0[k] = 0; nl[k] = 0; l1[k] = 0; nl1[k] = 0; pid2[k] = 0;
     if (i + k < n) {
       const int32_t pid = cpids[i + k];
       l0[k] = poff[pid];
       nl[k] = poff[pid + 1] - l0[k];
     }
-    if (i + stride + k < n) pidn[k] = cpids[i + stride + k];
+    if (i + stride + k < n) {
+      const int32_t pid = cpids[i + stride + k];
+      l1[k] = poff[pid];
+      nl1[k] = poff[pid + 1] - l1[k];
+    }
+    if (i + 2 * stride + k < n) pid2[k] = cpids[i + 2 * stride + k];
   }
+  auto load_line = [&](int32_t line, int32_t cnt) -> uint4 {
+    if (abl & 2) return make_uint4((uint32_t)line * 2654435761u, (uint32_t)line * 40503u, (uint32_t)line * 7919u, 0x07000000u | ((uint32_t)line & 0xFFFFu));
+    return cnt > 0 ? pcodes[(int64_t)line * 8 + sub] : make_uint4(0, 0, 0, 0);
+  };
+#pragma unroll
+  for (int k = 0; k < L0_UNROLL; ++k) pc[k] = load_line(l0[k], nl[k]);
   // sum / max of the 7 table entries of one piece (absent codes index the zero behind the table)
   auto piece = [&](const uint4& pc, uint32_t& sum, uint32_t& mx) {
     const uint32_t w[4] = {pc.x, pc.y, pc.z, pc.w};
@@ -1717,23 +1746,19 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     }
   };
   for (; i < n; i += stride) {
-    uint4 pc[L0_UNROLL];
+    // issue: lines of t+1, offsets of t+2, ids of t+3
+    uint4 pcn[L0_UNROLL];
+    int32_t l2[L0_UNROLL], nl2[L0_UNROLL], pid3[L0_UNROLL];
+#pragma unroll
+    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(l1[k], nl1[k]);
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
-      pc[k] = make_uint4(0, 0, 0, 0);
-      if (abl & 2) pc[k] = make_uint4((uint32_t)l0[k] * 2654435761u, (uint32_t)l0[k] * 40503u, (uint32_t)l0[k] * 7919u, 0x07000000u | ((uint32_t)l0[k] & 0xFFFFu));
-      else if (nl[k] > 0) pc[k] = pcodes[(int64_t)l0[k] * 8 + sub];
-    }
-    // next iteration's offsets, the ids of the one after
-    int32_t nl0[L0_UNROLL], nnl[L0_UNROLL], pidnn[L0_UNROLL];
-#pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) {
-      nl0[k] = 0; nnl[k] = 0; pidnn[k] = 0;
-      if (i + stride + k < n) {
-        nl0[k] = poff[pidn[k]];
-        nnl[k] = poff[pidn[k] + 1] - nl0[k];
+      l2[k] = 0; nl2[k] = 0; pid3[k] = 0;
+      if (i + 2 * stride + k < n) {
+        l2[k] = poff[pid2[k]];
+        nl2[k] = poff[pid2[k] + 1] - l2[k];
       }
-      if (i + 2 * stride + k < n) pidnn[k] = cpids[i + 2 * stride + k];
+      if (i + 3 * stride + k < n) pid3[k] = cpids[i + 3 * stride + k];
     }
     uint32_t outv[L0_UNROLL];
 #pragma unroll
@@ -1769,7 +1794,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         mx = l0_max8(inf);
         sum = mx ? 0xFFFFFFu : sum;
       }
-      uint32_t v = F + sum;
+      uint32_t v = F + (sum << L0_SHIFT);
       v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
       outv[k] = v;
       if (sub == 0 && i + k < n) {
@@ -1788,9 +1813,10 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     }
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
-      l0[k] = nl0[k];
-      nl[k] = nnl[k];
-      pidn[k] = pidnn[k];
+      pc[k] = pcn[k];
+      l0[k] = l1[k]; nl[k] = nl1[k];
+      l1[k] = l2[k]; nl1[k] = nl2[k];
+      pid2[k] = pid3[k];
     }
   }
   __syncthreads();
@@ -1859,7 +1885,8 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
 #define L0_PILOT_MAX 32768
 __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
-                                                  int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid) {
+                                                  int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid,
+                                                  int32_t* __restrict__ pilot_idx) {
   __shared__ int s_cnt, s_base;
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
@@ -1897,7 +1924,10 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
     wbase = __builtin_amdgcn_readfirstlane(wbase);
     if (take) {
       const int pos = base + wbase + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < L0_PILOT_MAX) pilot_pid[(int64_t)b * L0_PILOT_MAX + pos] = cand_pid[beg + i];
+      if (pos < L0_PILOT_MAX) {
+        pilot_pid[(int64_t)b * L0_PILOT_MAX + pos] = cand_pid[beg + i];
+        pilot_idx[(int64_t)b * L0_PILOT_MAX + pos] = (int32_t)i;   // position in the query's candidate list: where its exact score is kept
+      }
     }
   }
 }
@@ -1906,10 +1936,11 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
 // -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).  One workgroup per query.
 __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int32_t* __restrict__ npilot,
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
-                                                 int32_t* __restrict__ cut) {
+                                                 int32_t* __restrict__ cut, int32_t* __restrict__ nextra) {
   __shared__ uint32_t h[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) nextra[b] = 0;
   const int64_t n = cand_off[b + 1] - cand_off[b];
   const int np = npilot[b];
   int64_t keep = n;
@@ -1980,26 +2011,39 @@ __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ u
   if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
 }
 
+// ordered compaction of the survivors { ub >= thr[b] }.  A survivor that was in the pilot group (ub >= cutp[b], the group held
+// in full) already has its exact score at cand_approx[position]: it is copied; the others go on the query's "extra" list
+// (any order) as (document, destination) and are scored by one more k_approx that scatters into surv_approx.
 __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
-                                                    const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
-                                                    const int32_t* __restrict__ blkoff, int nblk, const int64_t* __restrict__ surv_off,
-                                                    int32_t* __restrict__ surv_pid) {
+                                                    const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ thr,
+                                                    const int32_t* __restrict__ cutp, const int32_t* __restrict__ npilot,
+                                                    const float* __restrict__ cand_approx, const int32_t* __restrict__ blkoff, int nblk,
+                                                    const int64_t* __restrict__ surv_off, int32_t* __restrict__ surv_pid,
+                                                    float* __restrict__ surv_approx, int32_t* __restrict__ nextra,
+                                                    int32_t* __restrict__ xpid, int32_t* __restrict__ xdst) {
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
   if (c0 >= n) return;
-  const uint32_t ct = (uint32_t)cut[b];
+  const uint32_t ct = (uint32_t)thr[b];
+  const bool reuse = npilot[b] <= L0_PILOT_MAX;
+  const uint32_t cp = (uint32_t)cutp[b];
   constexpr int PER = SURV_CHUNK / 256;
-  bool keep[PER];
-  int cnt = 0;
+  bool keep[PER], inp[PER];
+  int cnt = 0, cx = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int64_t i = c0 + threadIdx.x * PER + k;
-    keep[k] = (i < n) && ((uint32_t)ub[beg + i] >= ct);
+    const uint32_t u = (i < n) ? (uint32_t)ub[beg + i] : 0u;
+    keep[k] = (i < n) && (u >= ct);
+    inp[k] = reuse && (u >= cp);
     cnt += keep[k] ? 1 : 0;
+    cx += (keep[k] && !inp[k]) ? 1 : 0;
   }
   __shared__ int s[256];
+  __shared__ int s_xcnt, s_xbase;
+  if (threadIdx.x == 0) s_xcnt = 0;
   s[threadIdx.x] = cnt;
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
@@ -2008,10 +2052,28 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
     s[threadIdx.x] += t;
     __syncthreads();
   }
-  int64_t pos = surv_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+  int myx = cx ? atomicAdd(&s_xcnt, cx) : 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && s_xcnt) s_xbase = atomicAdd(&nextra[b], s_xcnt);
+  __syncthreads();
+  const int64_t sb = surv_off[b];
+  int64_t pos = sb + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+  int64_t xp = sb + s_xbase + myx;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    if (keep[k]) surv_pid[pos++] = cand_pid[beg + c0 + threadIdx.x * PER + k];
+    if (keep[k]) {
+      const int64_t i = c0 + threadIdx.x * PER + k;
+      const int32_t pid = cand_pid[beg + i];
+      surv_pid[pos] = pid;
+      if (inp[k]) {
+        surv_approx[pos] = cand_approx[beg + i];
+      } else {
+        xpid[xp] = pid;
+        xdst[xp] = (int32_t)(pos - sb);
+        ++xp;
+      }
+      ++pos;
+    }
   }
 }
 
@@ -2060,21 +2122,23 @@ void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_
   int64_t bx = (per_q + 8191) / 8192;
   if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(k_l0_pilot, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.npilot, w.pilot_pid);
+  hipLaunchKernelGGL(k_l0_pilot, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.npilot, w.pilot_pid,
+                     w.pilot_idx);
 }
 
 int64_t fpk_l0_pilot_cap() { return L0_PILOT_MAX; }
 
-// level 0, second half (the pilot group's exact scores are in w.pilot_approx): threshold, ordered survivors
+// level 0, second half (the pilot group's exact scores are in w.pilot_approx and, by candidate position, in w.cand_approx):
+// threshold, ordered survivors with the pilot members' scores copied, the others on the extra list (w.xpid / w.xdst / w.nextra)
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
-                      int64_t* surv_off, int32_t* surv_pid, hipStream_t st) {
+                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st) {
   const int B = sh.B;
-  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.cut);
-  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.cut, w.blkcnt, w.nblk);
+  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr, w.nextra);
+  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.thr, w.blkcnt, w.nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv);
   hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
-  hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.blkcnt, w.nblk, surv_off,
-                     surv_pid);
+  hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.thr, w.cut, w.npilot,
+                     w.cand_approx, w.blkcnt, w.nblk, surv_off, surv_pid, surv_approx, w.nextra, w.xpid, w.xdst);
 }
 
 // ============================================================================================

@@ -75,8 +75,9 @@ def save_index_arrays(index_path: str, arr: dict, chunk_docs: int = 25_000, writ
     codes = np.asarray(arr["doc_codes"])[:T]
     res = np.asarray(arr["doc_residuals"])[:T]
     np.save(os.path.join(index_path, "centroids.npy"), np.asarray(arr["centroids"], dtype=np.float16))
+    f32 = arr.get("codec_f32") or {}   # create.py: the trained fp32 values (create.rs:380-397 writes those, not their fp16 roundings)
     for k in ("bucket_weights", "bucket_cutoffs", "avg_residual"):
-        np.save(os.path.join(index_path, k + ".npy"), np.asarray(arr[k]).astype(np.float32))
+        np.save(os.path.join(index_path, k + ".npy"), np.asarray(f32.get(k, arr[k])).astype(np.float32))
     n_docs = int(lens.shape[0])
     n_chunks = max(1, (n_docs + chunk_docs - 1) // chunk_docs)
     offs = np.concatenate([[0], np.cumsum(lens)])

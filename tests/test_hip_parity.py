@@ -345,6 +345,19 @@ def test_level0_forced(fp, tail, pilot):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("mode", ["2", "1"])
+def test_maxsim_repair_vs_oracle(fp, mode):
+    """exact-order repair of the MFMA MaxSim pass (tests/repair_worker.py): with every flagged document repaired
+    (FP_MAXSIM_REPAIR=2) every returned score equals the oracle's bit for bit over nine dim/nbits/q_len shapes; with the default
+    near-tied repair (1) the id lists are the oracle's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FP_MAXSIM_REPAIR=mode)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "repair_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "REPAIR_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("name", ["base_d128_nb4", "d64_nb2", "empty_doc", "zero_pad_query", "topk_gt_ndocs"])
 def test_token_score_matrices(fp, name):
     """fp_token_scores / pysearch_with_token_scores (search.rs:294-363, :668-686): per hit the
@@ -719,7 +732,12 @@ def test_update_and_delete_match_one_shot_builds(fp, tmp_path):
         assert os.path.exists(os.path.join(path, "cluster_threshold.npy"))
         got = index_io.load_index_arrays(path)
         alldocs = A + B1 + B2 + B1
-        codes, packed = CR.compress(codec["centroids"], codec["bucket_cutoffs"], np.concatenate(alldocs), 4)
+        # the reference buckets a first-time compression against the fp32 cutoffs it has just computed (create.rs:413) and an update
+        # against the loaded codec's cutoffs, which the loader casts to fp16 (update.rs:149, load.py:255-258)
+        cut32 = np.load(os.path.join(path, "bucket_cutoffs.npy")).astype(np.float32)
+        codes_a, packed_a = CR.compress(codec["centroids"], CR.cutoffs_for_f32_compare(cut32), np.concatenate(A), 4)
+        codes_b, packed_b = CR.compress(codec["centroids"], codec["bucket_cutoffs"], np.concatenate(B1 + B2 + B1), 4)
+        codes, packed = np.concatenate([codes_a, codes_b]), np.concatenate([packed_a, packed_b])
         lens = np.array([d.shape[0] for d in alldocs], np.int64)
         assert np.array_equal(got["doc_lengths"], lens) and np.array_equal(got["doc_codes"], codes) and np.array_equal(got["doc_residuals"], packed)
         ivf, ivfl = synth.build_ivf(codes, lens, got["ivf_lengths"].shape[0])
