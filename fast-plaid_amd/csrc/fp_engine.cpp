@@ -300,7 +300,7 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
     const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, &lines, &poff, &nl, st);
     if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; }
-    if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 4; }
+    if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
     if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
     D.pcodes = static_cast<const uint4*>(lines); D.poff = poff;
   }
@@ -651,7 +651,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       HIPCHK(s->l0_F.ensure((size_t)B * 4));
       HIPCHK(s->l0_e8.ensure((size_t)B * Cpad));
       HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
-      HIPCHK(s->l0_ub.ensure((size_t)M * 2));
+      HIPCHK(s->l0_ub.ensure(((size_t)M + 8 * (size_t)B + 16) * 2));   // rows start on 16-byte boundaries (l0_row)
       const int64_t pcap = fpk_l0_pilot_cap();
       HIPCHK(s->l0_hist.ensure((size_t)B * 4096 * 4));
       HIPCHK(s->l0_npilot.ensure((size_t)B * 4));

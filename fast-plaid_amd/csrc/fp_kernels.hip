@@ -1552,11 +1552,14 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 //        identical to scoring every candidate exactly.  On the benchmark corpus 0.5-1.5 % of the candidates survive
 //        (tools/sim_s4_bounds.py reproduces the bound on the CPU).
 // ============================================================================================
-#define L0_ESC_BASE 192
-#define L0_ESC_SLOTS 63
-#define L0_SHIFT 2              // the table holds ceil(e / 4): UB0 = F + 4 * sum (at most 3 looser per hot code) and only excesses above
-                                // 764 escape -- at shift 0 the query's own topic centroids (e = 200..600) escaped, and a third of
-                                // the candidates holds one of them
+// byte code of an excess e:  0..159 = e itself;  160..239 = 160 + ceil((e - 160) / 8), decoded as 160 + 8 (v - 160) >= e (at
+// most 7 looser; these are the query's own topic centroids, e = 200..600, one or two per document -- as escapes they cost a
+// second pass over a third of the candidates, and a table in units of 4 loosened EVERY code by up to 3, which doubled the
+// survivors);  240..254 = escape slot 0..14 (u32 values in LDS) for e >= 800;  255 = infinite.
+// decode of v <= 239:  max(v, 8 v - 1120)
+#define L0_LIN 160
+#define L0_ESC_BASE 240
+#define L0_ESC_SLOTS 15
 #define L0_INF 0xFFFFu
 #define L0_SAMPLE 8192          // centroids sampled for the column quantiles
 
@@ -1635,11 +1638,12 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
         }
       }
     }
-    e = (e + ((1u << L0_SHIFT) - 1u)) >> L0_SHIFT;
     if (inf) {
       out = 255u;
-    } else if (e < L0_ESC_BASE) {
+    } else if (e < L0_LIN) {
       out = e;
+    } else if (e <= L0_LIN + 8u * (L0_ESC_BASE - 1u - L0_LIN)) {
+      out = L0_LIN + (e - L0_LIN + 7u) / 8u;
     } else {
       const uint32_t slot = atomicAdd(&esc[(int64_t)b * 64 + 63], 1u);
       if (slot < L0_ESC_SLOTS) {
@@ -1662,6 +1666,9 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
 // that the pilot cut needs is built here in LDS.
 #define L0_HBINS 4096
 #define L0_UNROLL 4
+// the bounds of query b live at ub[l0_row(cand_off, b) + i], i = position in the query's candidate list: rows start on 16-byte
+// boundaries (ub holds M + 8 B + 16 entries) so that the passes over them use 16-byte loads
+__device__ __forceinline__ int64_t l0_row(const int64_t* __restrict__ cand_off, int b) { return ((cand_off[b] + 7) & ~(int64_t)7) + 8 * (int64_t)b; }
 __device__ __forceinline__ uint32_t l0_red8(uint32_t v) {   // sum over the 8 lanes of a group, in all of them (no lane outside the group is read)
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
@@ -1699,102 +1706,103 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   __syncthreads();
   const uint32_t F = Fsum[b];
   const int sub = tid & 7;
-  const uint32_t zidx = (uint32_t)Cpad;
+  const int kq = sub & 3;                      // the candidate of the group's four whose id / line offsets this lane fetches
   const int64_t stride = (int64_t)gridDim.x * CPI;
   const int32_t* cpids = cand_pid + beg;
+  const uint2* pmeta = reinterpret_cast<const uint2*>(poff);
+  uint16_t* ubrow = ub + l0_row(cand_off, b);
   int64_t i = (int64_t)blockIdx.x * CPI + (tid >> 3) * L0_UNROLL;
-  // Software pipeline over the dependent chain  id -> line offsets -> code line(s):  while iteration t is computed, the code
-  // lines of t+1, the offsets of t+2 and the ids of t+3 are in flight, so no load of the chain is waited for in the iteration
-  // that issues it (one workgroup per CU -- the table takes the LDS -- leaves only 4 waves per SIMD to hide latency otherwise).
-  int32_t l0[L0_UNROLL], nl[L0_UNROLL];     // first line / line count: iteration t
-  int32_t l1[L0_UNROLL], nl1[L0_UNROLL];    // ... t+1
-  int32_t pid2[L0_UNROLL];                  // ids of t+2
-  uint4 pc[L0_UNROLL];                      // first code line of t
-#pragma unroll
-  for (int k = 0; k < L0_UNROLL; ++k) {
-    l0[k] = 0; nl[k] = 0; l1[k] = 0; nl1[k] = 0; pid2[k] = 0;
-    if (i + k < n) {
-      const int32_t pid = cpids[i + k];
-      l0[k] = poff[pid];
-      nl[k] = poff[pid + 1] - l0[k];
+  // Software pipeline over the dependent chain  id -> {first line, line count} -> code line(s):  while iteration t is
+  // computed, the code lines of t+1, the offsets of t+2 and the ids of t+3 are in flight (one workgroup per CU -- the table
+  // takes the LDS -- leaves only 4 waves per SIMD to hide latency otherwise).  Ids and offsets are fetched cooperatively: each
+  // lane of a quad loads ONE of the group's four candidates and the values are exchanged by quad broadcasts -- 2 load
+  // instructions per iteration instead of 12 through the CU's one address unit.
+  auto qb = [](uint32_t v, int k) -> uint32_t {   // value of lane k of this lane's quad
+    switch (k) {
+      case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
+      case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, true);
+      case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, true);
+      default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, true);
     }
-    if (i + stride + k < n) {
-      const int32_t pid = cpids[i + stride + k];
-      l1[k] = poff[pid];
-      nl1[k] = poff[pid + 1] - l1[k];
-    }
-    if (i + 2 * stride + k < n) pid2[k] = cpids[i + 2 * stride + k];
-  }
-  auto load_line = [&](int32_t line, int32_t cnt) -> uint4 {
-    if (abl & 2) return make_uint4((uint32_t)line * 2654435761u, (uint32_t)line * 40503u, (uint32_t)line * 7919u, 0x07000000u | ((uint32_t)line & 0xFFFFu));
+  };
+  auto load_meta = [&](int64_t at) -> uint2 {   // this lane's candidate of the iteration starting at `at`
+    return at + kq < n ? pmeta[cpids[at + kq]] : make_uint2(0u, 0u);
+  };
+  auto load_line = [&](uint32_t line, uint32_t cnt) -> uint4 {
+    if (abl & 2) return make_uint4(line * 2654435761u, line * 40503u, line * 7919u, 0x07000000u | (line & 0xFFFFu));
     return cnt > 0 ? pcodes[(int64_t)line * 8 + sub] : make_uint4(0, 0, 0, 0);
   };
+  uint2 m0 = load_meta(i);                     // iteration t
+  uint2 m1 = load_meta(i + stride);            // t+1
+  uint2 m2 = load_meta(i + 2 * stride);        // t+2
+  int32_t pid3 = i + 3 * stride + kq < n ? cpids[i + 3 * stride + kq] : 0;
+  uint4 pc[L0_UNROLL];                         // first code line of t
 #pragma unroll
-  for (int k = 0; k < L0_UNROLL; ++k) pc[k] = load_line(l0[k], nl[k]);
-  // sum / max of the 7 table entries of one piece (absent codes index the zero behind the table)
+  for (int k = 0; k < L0_UNROLL; ++k) pc[k] = load_line(qb(m0.x, k), qb(m0.y, k));
+  // sum / max of the 7 table entries of one piece.  Slots past the piece's count repeat its last code (fp_synth.hip): all
+  // seven are summed and (7 - count) x the last taken off again (an empty piece: 7 x code 0 - 7 x code 0).
   auto piece = [&](const uint4& pc, uint32_t& sum, uint32_t& mx) {
     const uint32_t w[4] = {pc.x, pc.y, pc.z, pc.w};
     const uint32_t cnt = pc.w >> 24;
     if (abl & 1) { sum += (pc.x ^ pc.y ^ pc.z ^ pc.w) & 7u; return; }
+    uint32_t s7 = 0, m7 = 0, last = 0;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const uint32_t lo = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
       const uint32_t c = lo | (((pc.w >> (16 + j)) & 1u) << 16);
-      const uint32_t v = tab[(uint32_t)j < cnt ? c : zidx];
-      sum += v;
-      mx = max(mx, v);
+      const uint32_t v = tab[c];
+      last = (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
+      s7 += last;
+      m7 = max(m7, v);
     }
+    sum += s7 - (7u - cnt) * last;
+    mx = max(mx, cnt ? m7 : 0u);
   };
   for (; i < n; i += stride) {
     // issue: lines of t+1, offsets of t+2, ids of t+3
     uint4 pcn[L0_UNROLL];
-    int32_t l2[L0_UNROLL], nl2[L0_UNROLL], pid3[L0_UNROLL];
 #pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(l1[k], nl1[k]);
-#pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) {
-      l2[k] = 0; nl2[k] = 0; pid3[k] = 0;
-      if (i + 2 * stride + k < n) {
-        l2[k] = poff[pid2[k]];
-        nl2[k] = poff[pid2[k] + 1] - l2[k];
-      }
-      if (i + 3 * stride + k < n) pid3[k] = cpids[i + 3 * stride + k];
-    }
+    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(qb(m1.x, k), qb(m1.y, k));
+    const uint2 m3 = i + 3 * stride + kq < n ? pmeta[pid3] : make_uint2(0u, 0u);
+    const int32_t pid4 = i + 4 * stride + kq < n ? cpids[i + 4 * stride + kq] : 0;
     uint32_t outv[L0_UNROLL];
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
+      const uint32_t l0k = qb(m0.x, k), nlk = qb(m0.y, k);
       uint32_t sum = 0, mx = 0;
       piece(pc[k], sum, mx);
-      for (int t = 1; t < nl[k]; ++t) {   // documents with more than 56 distinct codes
-        const uint4 more = pcodes[((int64_t)l0[k] + t) * 8 + sub];
+      for (uint32_t t = 1; t < nlk; ++t) {   // documents with more than 56 distinct codes
+        const uint4 more = pcodes[((int64_t)l0k + t) * 8 + sub];
         piece(more, sum, mx);
       }
       sum = l0_red8(sum);
       mx = l0_max8(mx);
       if (mx >= L0_ESC_BASE) {
-        // some code of this candidate has an escaped (>= 192) or infinite excess.  NOT rare: the escaped centroids are the query's
-        // own topic centroids, which a large share of the candidates contain (a per-code branch and a reload of the lines here
-        // made the kernel 3x slower: 1.6 ms against 0.6 ms with synthetic codes).  The group branches as one (mx is the same in
-        // its 8 lanes); the first line is still in registers; every code takes both table reads and a select.
+        // some code of this candidate has an escaped (e >= 800) or infinite excess: a second pass that takes the escape values
+        // from LDS.  The group branches as one (mx is the same in its 8 lanes); the first line is still in registers.
         uint32_t s2 = 0, inf = 0;
-        for (int t = 0; t < nl[k]; ++t) {
-          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)l0[k] + t) * 8 + sub];
+        for (uint32_t t = 0; t < nlk; ++t) {
+          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)l0k + t) * 8 + sub];
           const uint32_t w[4] = {q.x, q.y, q.z, q.w};
           const uint32_t cnt = q.w >> 24;
+          uint32_t s7 = 0, i7 = 0, last = 0;
 #pragma unroll
           for (int j = 0; j < 7; ++j) {
             const uint32_t c = ((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) | (((q.w >> (16 + j)) & 1u) << 16);
-            const uint32_t v = tab[(uint32_t)j < cnt ? c : zidx];
+            const uint32_t v = tab[c];
             const uint32_t ev = es[(max(v, (uint32_t)L0_ESC_BASE) - L0_ESC_BASE) & 63];
-            inf |= (v == 255u) ? 1u : 0u;
-            s2 += v >= L0_ESC_BASE ? ev : v;
+            i7 |= (v == 255u) ? 1u : 0u;
+            last = v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
+            s7 += last;
           }
+          s2 += s7 - (7u - cnt) * last;
+          inf |= cnt ? i7 : 0u;
         }
         sum = l0_red8(s2);
         mx = l0_max8(inf);
         sum = mx ? 0xFFFFFFu : sum;
       }
-      uint32_t v = F + (sum << L0_SHIFT);
+      uint32_t v = F + sum;
       v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
       outv[k] = v;
       if (sub == 0 && i + k < n) {
@@ -1803,21 +1811,18 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       }
     }
     if (sub == 0) {   // the group's four bounds leave as one 8-byte store when they can (2-byte stores are one fabric write each)
-      if (i + L0_UNROLL <= n && ((beg + i) & 3) == 0) {
-        *reinterpret_cast<uint2*>(ub + beg + i) = make_uint2(outv[0] | (outv[1] << 16), outv[2] | (outv[3] << 16));
+      if (i + L0_UNROLL <= n) {
+        *reinterpret_cast<uint2*>(ubrow + i) = make_uint2(outv[0] | (outv[1] << 16), outv[2] | (outv[3] << 16));
       } else {
 #pragma unroll
         for (int k = 0; k < L0_UNROLL; ++k)
-          if (i + k < n) ub[beg + i + k] = (uint16_t)outv[k];
+          if (i + k < n) ubrow[i + k] = (uint16_t)outv[k];
       }
     }
 #pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) {
-      pc[k] = pcn[k];
-      l0[k] = l1[k]; nl[k] = nl1[k];
-      l1[k] = l2[k]; nl1[k] = nl2[k];
-      pid2[k] = pid3[k];
-    }
+    for (int k = 0; k < L0_UNROLL; ++k) pc[k] = pcn[k];
+    m0 = m1; m1 = m2; m2 = m3;
+    pid3 = pid4;
   }
   __syncthreads();
   uint32_t* hg = hist + (int64_t)b * L0_HBINS;
@@ -1878,56 +1883,64 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
   if (tid == 0) cut[b] = s_k <= 0 ? 0 : (int32_t)(Fsum[b] + 4u * (uint32_t)s_k);
 }
 
-// pilot group = { ub >= cut[b] }, in ANY order (only the keep-th largest of their exact scores is used).  Every workgroup counts
-// its slice, reserves its range with ONE global atomic (a per-wave atomic on the query's counter cost 1.1 ms at cfg2: ~3000
-// same-address atomics per query serialise at the memory side), then writes.
-// pilot_pid[b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the capacity (then nothing is pruned).
+// pilot group = { ub >= cut[b] }, in ANY order (only the keep-th largest of their exact scores is used).  A workgroup walks
+// its slice 2048 bounds at a time (16-byte loads), stages the few that pass in LDS and reserves their range with ONE global
+// atomic per step (a per-wave atomic on the query's counter cost 1.1 ms at cfg2: ~3000 same-address atomics per query
+// serialise at the memory side).  pilot_pid / pilot_idx [b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the
+// capacity (then nothing is pruned).
 #define L0_PILOT_MAX 32768
+__device__ __forceinline__ uint32_t l0_u16(const uint4& v, int k) {
+  const uint32_t w = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
+  return (k & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
 __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
                                                   int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid,
                                                   int32_t* __restrict__ pilot_idx) {
   __shared__ int s_cnt, s_base;
+  __shared__ int32_t s_idx[2048];
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const uint32_t ct = (uint32_t)cut[b];
-  // this workgroup's contiguous slice
-  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint16_t* row = ub + l0_row(cand_off, b);
+  int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  per = (per + 2047) & ~(int64_t)2047;
   const int64_t lo = (int64_t)blockIdx.x * per;
   const int64_t hi = lo + per < n ? lo + per : n;
-  if (lo >= hi) return;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  int mine = 0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) mine += ((uint32_t)ub[beg + i] >= ct) ? 1 : 0;
+  for (int64_t i0 = lo; i0 < hi; i0 += 2048) {
+    const int64_t i = i0 + threadIdx.x * 8;
+    if (i < hi) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+      uint32_t m = 0;
 #pragma unroll
-  for (int sft = 32; sft > 0; sft >>= 1) mine += __shfl_xor(mine, sft, 64);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
-  __syncthreads();
-  const int total = s_cnt;
-  if (total == 0) return;
-  if (threadIdx.x == 0) {
-    s_base = atomicAdd(&npilot[b], total);
-    s_cnt = 0;
-  }
-  __syncthreads();
-  const int base = s_base;
-  for (int64_t i0 = lo; i0 < hi; i0 += 256) {
-    const int64_t i = i0 + threadIdx.x;
-    const bool take = (i < hi) && ((uint32_t)ub[beg + i] >= ct);
-    const unsigned long long m = __ballot(take);
-    if (!m) continue;
-    const int lane = threadIdx.x & 63;
-    int wbase = 0;
-    if (lane == 0) wbase = atomicAdd(&s_cnt, __popcll(m));   // LDS atomic: order inside the workgroup's range is irrelevant
-    wbase = __builtin_amdgcn_readfirstlane(wbase);
-    if (take) {
-      const int pos = base + wbase + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < L0_PILOT_MAX) {
-        pilot_pid[(int64_t)b * L0_PILOT_MAX + pos] = cand_pid[beg + i];
-        pilot_idx[(int64_t)b * L0_PILOT_MAX + pos] = (int32_t)i;   // position in the query's candidate list: where its exact score is kept
+      for (int k = 0; k < 8; ++k) m |= (i + k < hi && l0_u16(v, k) >= ct) ? (1u << k) : 0u;
+      if (m) {
+        int pos = atomicAdd(&s_cnt, __popc(m));   // LDS atomic: the order inside the group is irrelevant
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (m & (1u << k)) s_idx[pos++] = (int32_t)(i + k);
       }
+    }
+    __syncthreads();
+    const int total = s_cnt;
+    if (total) {
+      if (threadIdx.x == 0) s_base = atomicAdd(&npilot[b], total);
+      __syncthreads();
+      const int base = s_base;
+      for (int j = threadIdx.x; j < total; j += 256) {
+        const int pos = base + j;
+        if (pos < L0_PILOT_MAX) {
+          const int32_t idx = s_idx[j];
+          pilot_pid[(int64_t)b * L0_PILOT_MAX + pos] = cand_pid[beg + idx];
+          pilot_idx[(int64_t)b * L0_PILOT_MAX + pos] = idx;   // position in the query's candidate list: where its exact score is kept
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_cnt = 0;
+      __syncthreads();
     }
   }
 }
@@ -1937,7 +1950,7 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
 __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int32_t* __restrict__ npilot,
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
                                                  int32_t* __restrict__ cut, int32_t* __restrict__ nextra) {
-  __shared__ uint32_t h[256];
+  __shared__ uint32_t h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) nextra[b] = 0;
@@ -1962,15 +1975,23 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
       if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t rem = s_rem, acc = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (acc + h[d] >= rem) break;
-        acc += h[d];
+    // the largest digit d with #{digit >= d} >= rem (d = 0 if none): inclusive suffix sums of the 256 bins
+    const uint32_t rem = s_rem;
+    const uint32_t own = tid < 256 ? h[tid] : 0u;
+    if (tid < 256) sfx[tid] = own;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t v = (tid < 256 && tid + off < 256) ? sfx[tid + off] : 0u;
+      __syncthreads();
+      if (tid < 256) sfx[tid] += v;
+      __syncthreads();
+    }
+    if (tid < 256) {
+      const uint32_t above = sfx[tid] - own;
+      if (above < rem && (sfx[tid] >= rem || tid == 0)) {
+        s_prefix = (prefix << 8) | (uint32_t)tid;
+        s_rem = rem - above;
       }
-      s_prefix = (prefix << 8) | (uint32_t)d;
-      s_rem = rem - acc;
     }
     __syncthreads();
   }
@@ -1985,21 +2006,19 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
   }
 }
 
-// ordered compaction of { ub >= cut[b] } (same scheme as k_surv_count / k_surv_compact)
+// ordered compaction of { ub >= thr[b] } (same scheme as k_surv_count / k_surv_compact; 8 bounds per thread in one 16-byte load)
+static_assert(SURV_CHUNK == 256 * 8, "one 16-byte load per thread covers a chunk");
 __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
-                                                  const int32_t* __restrict__ cut, int32_t* __restrict__ blkcnt, int nblk) {
+                                                  const int32_t* __restrict__ thr, int32_t* __restrict__ blkcnt, int nblk) {
   const int b = blockIdx.y;
-  const int64_t beg = cand_off[b];
-  const int64_t n = cand_off[b + 1] - beg;
-  const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
+  const int64_t n = cand_off[b + 1] - cand_off[b];
+  const int64_t i = (int64_t)blockIdx.x * SURV_CHUNK + threadIdx.x * 8;
   int cnt = 0;
-  if (c0 < n) {
-    const uint32_t ct = (uint32_t)cut[b];
+  if (i < n) {
+    const uint32_t ct = (uint32_t)thr[b];
+    const uint4 v = *reinterpret_cast<const uint4*>(ub + l0_row(cand_off, b) + i);
 #pragma unroll
-    for (int k = 0; k < SURV_CHUNK / 256; ++k) {
-      const int64_t i = c0 + threadIdx.x * (SURV_CHUNK / 256) + k;
-      if (i < n) cnt += ((uint32_t)ub[beg + i] >= ct) ? 1 : 0;
-    }
+    for (int k = 0; k < 8; ++k) cnt += (i + k < n && l0_u16(v, k) >= ct) ? 1 : 0;
   }
   __shared__ int s[256];
   s[threadIdx.x] = cnt;
@@ -2011,9 +2030,9 @@ __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ u
   if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
 }
 
-// ordered compaction of the survivors { ub >= thr[b] }.  A survivor that was in the pilot group (ub >= cutp[b], the group held
-// in full) already has its exact score at cand_approx[position]: it is copied; the others go on the query's "extra" list
-// (any order) as (document, destination) and are scored by one more k_approx that scatters into surv_approx.
+// A survivor that was in the pilot group (ub >= cutp[b], the group held in full) already has its exact score at
+// cand_approx[position]: it is copied; the others go on the query's "extra" list (any order) as (document, destination) and
+// are scored by one more k_approx that scatters into surv_approx.
 __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                     const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ thr,
                                                     const int32_t* __restrict__ cutp, const int32_t* __restrict__ npilot,
@@ -2029,18 +2048,20 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
   const uint32_t ct = (uint32_t)thr[b];
   const bool reuse = npilot[b] <= L0_PILOT_MAX;
   const uint32_t cp = (uint32_t)cutp[b];
-  constexpr int PER = SURV_CHUNK / 256;
-  bool keep[PER], inp[PER];
-  int cnt = 0, cx = 0;
+  const int64_t i = c0 + threadIdx.x * 8;
+  uint32_t keep = 0, inp = 0;
+  if (i < n) {
+    const uint4 v = *reinterpret_cast<const uint4*>(ub + l0_row(cand_off, b) + i);
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int64_t i = c0 + threadIdx.x * PER + k;
-    const uint32_t u = (i < n) ? (uint32_t)ub[beg + i] : 0u;
-    keep[k] = (i < n) && (u >= ct);
-    inp[k] = reuse && (u >= cp);
-    cnt += keep[k] ? 1 : 0;
-    cx += (keep[k] && !inp[k]) ? 1 : 0;
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t u = l0_u16(v, k);
+      if (i + k < n && u >= ct) {
+        keep |= 1u << k;
+        if (reuse && u >= cp) inp |= 1u << k;
+      }
+    }
   }
+  const int cnt = __popc(keep), cx = __popc(keep & ~inp);
   __shared__ int s[256];
   __shared__ int s_xcnt, s_xbase;
   if (threadIdx.x == 0) s_xcnt = 0;
@@ -2052,21 +2073,21 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
     s[threadIdx.x] += t;
     __syncthreads();
   }
-  int myx = cx ? atomicAdd(&s_xcnt, cx) : 0;
+  const int myx = cx ? atomicAdd(&s_xcnt, cx) : 0;
   __syncthreads();
   if (threadIdx.x == 0 && s_xcnt) s_xbase = atomicAdd(&nextra[b], s_xcnt);
   __syncthreads();
+  if (!keep) return;
   const int64_t sb = surv_off[b];
   int64_t pos = sb + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
-  int64_t xp = sb + s_xbase + myx;
+  int64_t xp = sb + (cx ? s_xbase + myx : 0);
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    if (keep[k]) {
-      const int64_t i = c0 + threadIdx.x * PER + k;
-      const int32_t pid = cand_pid[beg + i];
+  for (int k = 0; k < 8; ++k) {
+    if (keep & (1u << k)) {
+      const int32_t pid = cand_pid[beg + i + k];
       surv_pid[pos] = pid;
-      if (inp[k]) {
-        surv_approx[pos] = cand_approx[beg + i];
+      if (inp & (1u << k)) {
+        surv_approx[pos] = cand_approx[beg + i + k];
       } else {
         xpid[xp] = pid;
         xdst[xp] = (int32_t)(pos - sb);

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
 // is a plain 1 KiB LDS copy here: filling the 64 KiB conflict-free table per workgroup cost more than the few documents a
 // workgroup repairs); every flagged column is re-evaluated with the ascending-k fp32 chain, the stored column maxima are
 // patched and the score re-summed (same reduction tree as k_maxsim5).
-template <int D, int NBITS, int CHAIN = 1>
+template <int D, int NBITS>
 __global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut_g,
                                                       const int32_t* __restrict__ codes, const uint16_t* __restrict__ norms,
                                                       const uint8_t* __restrict__ resid, const int64_t* __restrict__ doc_off,
@@ -683,44 +683,18 @@ __global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict
             const int col = __builtin_ctz(f2);
             f2 &= f2 - 1;
             const uint32_t* qq = reinterpret_cast<const uint32_t*>(qpad + ((int64_t)b * Qp + ch * 32 + col) * D);   // uniform address
+            // the reference's chain  acc = fma(e_k, q_k, acc), k ascending, one fp32 rounding per step.  Written out as the
+            // instruction sequence: left to the compiler, fmaf((float)e.x, (float)q.x, fmaf(...)) on packed halves is open to
+            // its dot-product combines (v_dot2c_f32_f16 rounds differently: tools/probe/chain_probe.hip counts 79 % of random
+            // 128-term chains off in the last fp32 bit), and the forms tried here that kept plain fp32 FMAs still missed the
+            // oracle on ~0.1 % of the columns, while this one matched on all of them (tests/repair_worker.py).
             float acc = 0.f;
-            if constexpr (CHAIN == 1) {   // experiment: explicit v_fma_mix with both fp16 sources, one wait state after each
 #pragma unroll
-              for (int i = 0; i < NE; ++i) {
-                const uint32_t qv = qq[i];
-                asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\ts_nop 0\n\t"
-                             "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\ts_nop 0"
-                             : "+v"(acc) : "v"(e[i]), "v"(qv));
-              }
-            } else if constexpr (CHAIN == 3) {   // experiment: fp32 fma, conversions without SDWA
-#pragma unroll
-              for (int i = 0; i < NE; ++i) {
-                float ex, ey, qx, qy;
-                const uint32_t ew = e[i], qw = qq[i];
-                asm volatile("v_cvt_f32_f16 %0, %4\n\tv_lshrrev_b32 %1, 16, %4\n\tv_cvt_f32_f16 %1, %1\n\t"
-                             "v_cvt_f32_f16 %2, %5\n\tv_lshrrev_b32 %3, 16, %5\n\tv_cvt_f32_f16 %3, %3"
-                             : "=&v"(ex), "=&v"(ey), "=&v"(qx), "=&v"(qy) : "v"(ew), "v"(qw));
-                acc = __builtin_fmaf(ex, qx, acc);
-                acc = __builtin_fmaf(ey, qy, acc);
-              }
-            } else if constexpr (CHAIN == 2) {   // experiment: plain fp32 fma on converted values
-#pragma unroll
-              for (int i = 0; i < NE; ++i) {
-                const h2 ev = u32_as_h2(e[i]);
-                const h2 qv = u32_as_h2(qq[i]);
-                float ex = (float)ev.x, ey = (float)ev.y, qx = (float)qv.x, qy = (float)qv.y;
-                asm volatile("" : "+v"(ex), "+v"(ey), "+v"(qx), "+v"(qy));
-                acc = __builtin_fmaf(ex, qx, acc);
-                acc = __builtin_fmaf(ey, qy, acc);
-              }
-            } else {
-#pragma unroll
-              for (int i = 0; i < NE; ++i) {   // ascending k: the CPU reference's order
-                const h2 ev = u32_as_h2(e[i]);
-                const h2 qv = u32_as_h2(qq[i]);
-                acc = __builtin_fmaf((float)ev.x, (float)qv.x, acc);
-                acc = __builtin_fmaf((float)ev.y, (float)qv.y, acc);
-              }
+            for (int i = 0; i < NE; ++i) {
+              const uint32_t qv = qq[i];
+              asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\ts_nop 0\n\t"
+                           "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\ts_nop 0"
+                           : "+v"(acc) : "v"(e[i]), "v"(qv));
             }
             float sim = live ? (float)(half_t)acc : NEG_MASK_F;
 #pragma unroll
@@ -836,22 +810,6 @@ void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* qpad, const FpSearc
   if (!fpk_maxsim_fast_shape(ix.dim, ix.nbits) || !aux.unc) return;   // the generic kernel never flags
   // one wave per document; workgroups beyond a query's marked count exit at once
   const dim3 grid((unsigned)std::min<int64_t>(marks ? 512 : 4096, Rcap), (unsigned)sh.B);
-  static const int chain_env = [] { const char* e = getenv("FP_REPAIR_CHAIN"); return e ? atoi(e) : 1; }();   // experiment switch
-  if (ix.dim == 128 && ix.nbits == 4 && chain_env == 0) {
-    hipLaunchKernelGGL((k_maxsim_repair<128, 4, 0>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals,
-                       ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags);
-    return;
-  }
-  if (ix.dim == 128 && ix.nbits == 4 && chain_env == 3) {
-    hipLaunchKernelGGL((k_maxsim_repair<128, 4, 3>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals,
-                       ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags);
-    return;
-  }
-  if (ix.dim == 128 && ix.nbits == 4 && chain_env == 2) {
-    hipLaunchKernelGGL((k_maxsim_repair<128, 4, 2>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals,
-                       ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags);
-    return;
-  }
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
     hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \

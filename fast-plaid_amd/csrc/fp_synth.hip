@@ -317,9 +317,12 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
   // one thread per piece
   const int64_t nl = loff[n_docs];
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nl * 8 + n_docs + 1; g += (int64_t)gridDim.x * blockDim.x) {
-    if (g >= nl * 8) {   // the narrowed line offsets
+    if (g >= nl * 8) {   // per document {first line, line count}
       const int64_t d = g - nl * 8;
-      poff[d] = (int32_t)loff[d];
+      if (d < n_docs) {
+        poff[2 * d] = (int32_t)loff[d];
+        poff[2 * d + 1] = (int32_t)(loff[d + 1] - loff[d]);
+      }
       continue;
     }
     const int64_t line = g >> 3;
@@ -332,22 +335,26 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
     }
     const int64_t u0 = uoff[lo], n = uoff[lo + 1] - u0;
     const int64_t first = (line - loff[lo]) * PCODES_PER_LINE + (int64_t)piece * PCODES_PER_PIECE;
+    // slots past the piece's last code repeat that code (an empty piece holds code 0 seven times): the scan sums all seven
+    // table entries and takes (7 - count) x the last one off again, instead of predicating every lookup
     uint32_t w[4] = {0u, 0u, 0u, 0u};
-    uint32_t hib = 0, cnt = 0;
+    uint32_t hib = 0, cnt = 0, last = 0;
     for (int j = 0; j < PCODES_PER_PIECE; ++j) {
+      uint32_t c = last;
       if (first + j < n) {
-        const uint32_t c = (uint32_t)ucodes[u0 + first + j];
-        w[j >> 1] |= (c & 0xFFFFu) << (16 * (j & 1));
-        hib |= ((c >> 16) & 1u) << j;
+        c = (uint32_t)ucodes[u0 + first + j];
+        last = c;
         ++cnt;
       }
+      w[j >> 1] |= (c & 0xFFFFu) << (16 * (j & 1));
+      hib |= ((c >> 16) & 1u) << j;
     }
     w[3] |= (hib << 16) | (cnt << 24);
     lines[g] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 
-// allocates *lines ([NL] x 128 B) and *poff ([N+1] i32 line offsets); returns 0 or a hipError
+// allocates *lines ([NL] x 128 B) and *poff ([N] x {first line, line count} i32 pairs); returns 0 or a hipError
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, void** lines, int32_t** poff, int64_t* n_lines,
                      hipStream_t st) {
   int rc = 0;
@@ -358,7 +365,7 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   *lines = nullptr;
   *poff = nullptr;
   *n_lines = 0;
-  HCHK(hipMalloc((void**)poff, (size_t)(n_docs + 1) * 4 + 64));
+  HCHK(hipMalloc((void**)poff, (size_t)(n_docs + 1) * 8 + 64));
   HCHK(hipMalloc((void**)&nlines, (size_t)(n_docs + 1) * 8));
   HCHK(hipMalloc((void**)&loff, (size_t)(n_docs + 1) * 8));
   hipLaunchKernelGGL(k_pcode_lines, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, uoff_dev, n_docs, nlines);
