@@ -112,7 +112,8 @@ struct FpL0Scratch {
   uint16_t* ub;         // [M]
   uint32_t* hist;       // [B][4096]
   int32_t* cut;         // [B]
-  int32_t* blkcnt;      // [B][nblk]
+  int32_t* blkcnt;      // [B][nblk] survivors per chunk
+  int32_t* blkcntx;     // [B][nblk] survivors outside the pilot group per chunk
   int nblk;             // ceil(max candidates per query / FP_SURV_CHUNK)
   int32_t* npilot;      // [B] (may exceed the capacity: then nothing is pruned)
   int32_t* pilot_pid;   // [B][fpk_l0_pilot_cap()]

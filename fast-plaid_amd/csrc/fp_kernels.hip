@@ -1744,16 +1744,20 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   auto piece = [&](const uint4& pc, uint32_t& sum, uint32_t& mx) {
     const uint32_t w[4] = {pc.x, pc.y, pc.z, pc.w};
     const uint32_t cnt = pc.w >> 24;
-    if (abl & 1) { sum += (pc.x ^ pc.y ^ pc.z ^ pc.w) & 7u; return; }
+    uint32_t c[7], v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {   // code j = 16 low bits | bit (16 + j) of the last word moved to bit 16
+      const uint32_t lo = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu);
+      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c[j]) : "v"(pc.w >> j), "s"(0x10000u), "v"(lo));
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = tab[c[j]];
     uint32_t s7 = 0, m7 = 0, last = 0;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      const uint32_t lo = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-      const uint32_t c = lo | (((pc.w >> (16 + j)) & 1u) << 16);
-      const uint32_t v = tab[c];
-      last = (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
+      last = (uint32_t)max((int)v[j], 8 * (int)v[j] - 8 * L0_LIN + L0_LIN);
       s7 += last;
-      m7 = max(m7, v);
+      m7 = max(m7, v[j]);
     }
     sum += s7 - (7u - cnt) * last;
     mx = max(mx, cnt ? m7 : 0u);
@@ -1765,12 +1769,20 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(qb(m1.x, k), qb(m1.y, k));
     const uint2 m3 = i + 3 * stride + kq < n ? pmeta[pid3] : make_uint2(0u, 0u);
     const int32_t pid4 = i + 4 * stride + kq < n ? cpids[i + 4 * stride + kq] : 0;
-    uint32_t outv[L0_UNROLL];
+    uint32_t outv[L0_UNROLL], sums[L0_UNROLL], mxs[L0_UNROLL];
+#pragma unroll
+    for (int k = 0; k < L0_UNROLL; ++k) { sums[k] = 0; mxs[k] = 0; }
+    if (abl & 1) {
+#pragma unroll
+      for (int k = 0; k < L0_UNROLL; ++k) sums[k] = (pc[k].x ^ pc[k].y ^ pc[k].z ^ pc[k].w) & 7u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < L0_UNROLL; ++k) piece(pc[k], sums[k], mxs[k]);   // straight-line: all 28 table reads of the lane in flight together
+    }
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
       const uint32_t l0k = qb(m0.x, k), nlk = qb(m0.y, k);
-      uint32_t sum = 0, mx = 0;
-      piece(pc[k], sum, mx);
+      uint32_t sum = sums[k], mx = mxs[k];
       for (uint32_t t = 1; t < nlk; ++t) {   // documents with more than 56 distinct codes
         const uint4 more = pcodes[((int64_t)l0k + t) * 8 + sub];
         piece(more, sum, mx);
@@ -1898,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
                                                   int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid,
                                                   int32_t* __restrict__ pilot_idx) {
   __shared__ int s_cnt, s_base;
-  __shared__ int32_t s_idx[2048];
+  __shared__ int32_t s_idx[4096];   // flushed when more than half full (a step adds at most 2048), and at the end
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
@@ -1926,7 +1938,7 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
     }
     __syncthreads();
     const int total = s_cnt;
-    if (total) {
+    if (total > 2048 || (total && i0 + 2048 >= hi)) {
       if (threadIdx.x == 0) s_base = atomicAdd(&npilot[b], total);
       __syncthreads();
       const int base = s_base;
@@ -1949,11 +1961,10 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
 // -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).  One workgroup per query.
 __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int32_t* __restrict__ npilot,
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
-                                                 int32_t* __restrict__ cut, int32_t* __restrict__ nextra) {
+                                                 int32_t* __restrict__ cut) {
   __shared__ uint32_t h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) nextra[b] = 0;
   const int64_t n = cand_off[b + 1] - cand_off[b];
   const int np = npilot[b];
   int64_t keep = n;
@@ -2008,46 +2019,57 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
 
 // ordered compaction of { ub >= thr[b] } (same scheme as k_surv_count / k_surv_compact; 8 bounds per thread in one 16-byte load)
 static_assert(SURV_CHUNK == 256 * 8, "one 16-byte load per thread covers a chunk");
+// blkcnt: survivors per chunk; blkcntx: those of them outside the pilot group ("extras": ub < cutp[b], or the group overflowed)
 __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
-                                                  const int32_t* __restrict__ thr, int32_t* __restrict__ blkcnt, int nblk) {
+                                                  const int32_t* __restrict__ thr, const int32_t* __restrict__ cutp,
+                                                  const int32_t* __restrict__ npilot, int32_t* __restrict__ blkcnt,
+                                                  int32_t* __restrict__ blkcntx, int nblk) {
   const int b = blockIdx.y;
   const int64_t n = cand_off[b + 1] - cand_off[b];
   const int64_t i = (int64_t)blockIdx.x * SURV_CHUNK + threadIdx.x * 8;
-  int cnt = 0;
+  int cnt = 0, cx = 0;
   if (i < n) {
     const uint32_t ct = (uint32_t)thr[b];
+    const uint32_t cp = npilot[b] <= L0_PILOT_MAX ? (uint32_t)cutp[b] : 0x10000u;
     const uint4 v = *reinterpret_cast<const uint4*>(ub + l0_row(cand_off, b) + i);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cnt += (i + k < n && l0_u16(v, k) >= ct) ? 1 : 0;
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t u = l0_u16(v, k);
+      const bool keep = i + k < n && u >= ct;
+      cnt += keep ? 1 : 0;
+      cx += (keep && u < cp) ? 1 : 0;
+    }
   }
   __shared__ int s[256];
-  s[threadIdx.x] = cnt;
+  s[threadIdx.x] = cnt | (cx << 16);   // both fit 16 bits (<= 2048 per chunk)
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+  if (threadIdx.x == 0) {
+    blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0] & 0xFFFF;
+    blkcntx[(int64_t)b * nblk + blockIdx.x] = s[0] >> 16;
+  }
 }
 
 // A survivor that was in the pilot group (ub >= cutp[b], the group held in full) already has its exact score at
-// cand_approx[position]: it is copied; the others go on the query's "extra" list (any order) as (document, destination) and
-// are scored by one more k_approx that scatters into surv_approx.
+// cand_approx[position]: it is copied; the others go on the query's "extra" list, in candidate order, as (document,
+// destination) and are scored by one more k_approx that scatters into surv_approx.
 __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                     const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ thr,
                                                     const int32_t* __restrict__ cutp, const int32_t* __restrict__ npilot,
-                                                    const float* __restrict__ cand_approx, const int32_t* __restrict__ blkoff, int nblk,
+                                                    const float* __restrict__ cand_approx, const int32_t* __restrict__ blkoff,
+                                                    const int32_t* __restrict__ blkoffx, int nblk,
                                                     const int64_t* __restrict__ surv_off, int32_t* __restrict__ surv_pid,
-                                                    float* __restrict__ surv_approx, int32_t* __restrict__ nextra,
-                                                    int32_t* __restrict__ xpid, int32_t* __restrict__ xdst) {
+                                                    float* __restrict__ surv_approx, int32_t* __restrict__ xpid, int32_t* __restrict__ xdst) {
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
   if (c0 >= n) return;
   const uint32_t ct = (uint32_t)thr[b];
-  const bool reuse = npilot[b] <= L0_PILOT_MAX;
-  const uint32_t cp = (uint32_t)cutp[b];
+  const uint32_t cp = npilot[b] <= L0_PILOT_MAX ? (uint32_t)cutp[b] : 0x10000u;
   const int64_t i = c0 + threadIdx.x * 8;
   uint32_t keep = 0, inp = 0;
   if (i < n) {
@@ -2057,15 +2079,13 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
       const uint32_t u = l0_u16(v, k);
       if (i + k < n && u >= ct) {
         keep |= 1u << k;
-        if (reuse && u >= cp) inp |= 1u << k;
+        if (u >= cp) inp |= 1u << k;
       }
     }
   }
   const int cnt = __popc(keep), cx = __popc(keep & ~inp);
   __shared__ int s[256];
-  __shared__ int s_xcnt, s_xbase;
-  if (threadIdx.x == 0) s_xcnt = 0;
-  s[threadIdx.x] = cnt;
+  s[threadIdx.x] = cnt | (cx << 16);
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
     const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
@@ -2073,14 +2093,11 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
     s[threadIdx.x] += t;
     __syncthreads();
   }
-  const int myx = cx ? atomicAdd(&s_xcnt, cx) : 0;
-  __syncthreads();
-  if (threadIdx.x == 0 && s_xcnt) s_xbase = atomicAdd(&nextra[b], s_xcnt);
-  __syncthreads();
   if (!keep) return;
   const int64_t sb = surv_off[b];
-  int64_t pos = sb + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
-  int64_t xp = sb + (cx ? s_xbase + myx : 0);
+  const int incl = s[threadIdx.x];
+  int64_t pos = sb + blkoff[(int64_t)b * nblk + blockIdx.x] + ((incl & 0xFFFF) - cnt);
+  int64_t xp = sb + blkoffx[(int64_t)b * nblk + blockIdx.x] + ((incl >> 16) - cx);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (keep & (1u << k)) {
@@ -2154,12 +2171,14 @@ int64_t fpk_l0_pilot_cap() { return L0_PILOT_MAX; }
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
                       int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st) {
   const int B = sh.B;
-  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr, w.nextra);
-  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.thr, w.blkcnt, w.nblk);
+  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr);
+  hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.thr, w.cut, w.npilot, w.blkcnt,
+                     w.blkcntx, w.nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv);
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcntx, w.nblk, w.nextra);
   hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
   hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.thr, w.cut, w.npilot,
-                     w.cand_approx, w.blkcnt, w.nblk, surv_off, surv_pid, surv_approx, w.nextra, w.xpid, w.xdst);
+                     w.cand_approx, w.blkcnt, w.blkcntx, w.nblk, surv_off, surv_pid, surv_approx, w.xpid, w.xdst);
 }
 
 // ============================================================================================
