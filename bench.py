@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -289,27 +290,37 @@ def main():
         ap_what = {"k_l0_scan": " (S4 level 0: upper bound of every candidate from its code list and a per-centroid byte table in LDS)",
                    "k_approx_q8": " (S4: 8-bit bounds of every candidate)", "k_approx": " (S4: exact approximate score of every candidate)"}[ap_name]
         ap_traffic, ap_src = _pmc_traffic(ap_name, default_cfg)
-        # bytes the kernel's own layout makes compulsory: the per-document UNIQUE code list (4 B each) + 4 B id + 16 B offsets + 2 B out
         ucodes_per_doc = index.n_unique_codes / max(index.n_docs, 1)
-        b_layout = cand_per_step * (ucodes_per_doc * 4 + 22)
-        r_ap = {"kernel": ap_name + ap_what,
-                "bound": "hbm", "achieved": b_ap / (t_ap * 1e-3) / 1e9 if t_ap > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (b_ap / (t_ap * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ap > 0 else 0.0, "traffic": ap_traffic, "traffic_source": ap_src,
+        ach_ap = b_ap / (t_ap * 1e-3) / 1e9 if t_ap > 0 else 0.0
+        r_ap = {"kernel": ap_name + ap_what, "bound": "hbm", "achieved": ach_ap, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach_ap / HBM_PEAK_GBS, "traffic": ap_traffic, "traffic_source": ap_src,
                 "algorithmic_bytes_per_launch": b_ap,
                 "algorithmic_bytes_note": "SURVEY 8d accounting: 4 B (int32 code) per candidate document token",
-                "layout_bytes_per_launch": b_layout,
-                "frac_on_layout_bytes": (b_layout / (t_ap * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_ap > 0 else 0.0,
-                "layout_bytes_note": "what this index layout reads per candidate: %.1f unique codes x 4 B + 22 B of id / offsets / output" % ucodes_per_doc,
                 "avg_launch_ms": t_ap, "share_of_step": t_ap / ms_per_step if ms_per_step > 0 else 0.0,
                 "candidate_docs_per_batch": cand_per_step, "docs_rescored_exactly_per_batch": exact_total / a.steps,
                 "prepare_ms": stages.get("S4 prepare", 0.0), "refine_ms": stages.get("S4 refine", 0.0)}
-        traffic, traffic_src = _pmc_traffic("k_maxsim", default_cfg)
-        t_ms = stages.get("S6+S7 maxsim", 0.0)
+        if l0:
+            # Level 0 does not read the token codes SURVEY 8d counts: a candidate costs its document's UNIQUE codes packed at 17
+            # bits into whole 128-byte lines (56 codes per line), 4 B of id, 8 B of line offsets and 2 B of bound written.  Those
+            # are the algorithmic bytes of the stage as built and what `achieved` / `frac` are quoted on (PMC `traffic` agrees
+            # with them); the reference-algorithm accounting is kept beside it -- its "rate" exceeds the HBM peak because the
+            # bytes are simply not moved any more.
+            lines_per_doc = max(1.0, math.ceil(ucodes_per_doc / 56.0))
+            b_l0 = cand_per_step * (128.0 * lines_per_doc + 14.0)
+            ach_l0 = b_l0 / (t_ap * 1e-3) / 1e9 if t_ap > 0 else 0.0
+            r_ap.update({"achieved": ach_l0, "frac": ach_l0 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_l0,
+                         "algorithmic_bytes_note": "per candidate: %.0f packed-code line(s) of 128 B (%.1f unique codes at 17 bits) + 4 B id + 8 B line "
+                                                   "offsets + 2 B bound" % (lines_per_doc, ucodes_per_doc),
+                         "survey_8d_accounting": {"bytes_per_launch": b_ap, "equivalent_GBps": ach_ap, "equivalent_frac": ach_ap / HBM_PEAK_GBS,
+                                                  "note": "4 B (int32 code) per candidate document token, the reference algorithm's traffic"}})
+        traffic, traffic_src = _pmc_traffic("k_maxsim5", default_cfg)
+        t_ms = stages.get("S6+S7 maxsim", 0.0)   # the MaxSim kernel alone; the exact-order repair behind it is its own stage
         ach = bytes_maxsim / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
-        r_ms = {"kernel": "k_maxsim_reg (S6+S7: fused decompress + exact MaxSim; the north star's roofline target)", "bound": "hbm",
+        r_ms = {"kernel": "k_maxsim5 (S6+S7: fused decompress + exact MaxSim; the north star's roofline target)", "bound": "hbm",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_maxsim, "avg_launch_ms": t_ms,
                 "share_of_step": t_ms / ms_per_step if ms_per_step > 0 else 0.0,
+                "order_repair_ms": stages.get("S7 order repair", 0.0),
                 "mfma_tflops": 2.0 * a.dim * a.qlen * rer_docs * a.doc_len / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0}
         dominant_is_approx = t_ap >= t_ms
         out["roofline"] = r_ap if dominant_is_approx else r_ms

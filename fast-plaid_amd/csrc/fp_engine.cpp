@@ -101,10 +101,10 @@ struct HostBuf {
   }
 };
 
-enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APREP, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_TOPK, ST_N };
+enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APREP, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_REPAIR, ST_TOPK, ST_N };
 static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
                                         "S3 compact",  "S4 prepare",       "S4 approx",     "S4 refine",
-                                        "S5 select",   "S6+S7 maxsim",     "S8 topk+download"};
+                                        "S5 select",   "S6+S7 maxsim",     "S7 order repair", "S8 topk+download"};
 // "S4 approx" is exactly ONE kernel -- k_l0_scan (level-0 bound of every candidate), k_approx_q8 (8-bit bounds of every
 // candidate) or k_approx (exact score of every candidate), whichever form of S4 runs -- so that it can be compared with a
 // profiler's per-kernel time; "S4 prepare" = level 0's floors + excess table (zero otherwise); "S4 refine" = the cut, the
@@ -296,13 +296,21 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     if (urc != 0) return fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")");
     D.ucodes = ucodes; D.uoff = uoff; D.U = U;
   }
-  if (D.C <= (1ll << 17)) {   // packed code lines for S4's level 0 (codes of up to 17 bits)
-    void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
-    const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, &lines, &poff, &nl, st);
-    if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; }
-    if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
-    if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
-    D.pcodes = static_cast<const uint4*>(lines); D.poff = poff;
+  // packed code lines for S4's level 0: one set per range of 2^17 centroids (17-bit codes relative to the range), up to 2^20
+  D.n_ranges = 0;
+  if (D.C <= 8 * (1ll << 17)) {
+    const int nr = (int)((D.C + (1ll << 17) - 1) >> 17);
+    for (int r = 0; r < nr; ++r) {
+      void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
+      const int64_t lo = (int64_t)r << 17, hi = std::min<int64_t>(D.C, lo + (1ll << 17));
+      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st);
+      if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; }
+      if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
+      if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
+      D.pcodes_r[r] = static_cast<const uint4*>(lines); D.poff_r[r] = poff;
+    }
+    D.n_ranges = nr;
+    D.pcodes = D.pcodes_r[0]; D.poff = D.poff_r[0];
   }
   return FP_OK;
 }
@@ -625,7 +633,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   const int64_t* sel_off = s->cand_off.as<int64_t>();
   const int32_t* sel_src = s->cand_pid.as<int32_t>();
   const bool l0_ok = want_s8 && M > 0 && fpk_l0_fits(D);
-  const bool l0_auto = l0_ok && M > 16 * (int64_t)B * sh.R;
+  // level 0 sums the excesses of a document's codes where the score takes their per-column maximum: with hundreds of distinct
+  // codes per document (cfg4's 1024-token documents: ~300) the bound is too loose to prune (61 % of the candidates survived),
+  // so it is chosen for documents of at most 64 distinct codes on average (one or two code lines each)
+  const bool l0_auto = l0_ok && M > 16 * (int64_t)B * sh.R && D.U <= 64 * D.N;
   // 8-bit bounds: (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone can
   // fill the chip (~1280 resident workgroups x 128 lane pairs; the kernel spreads a candidate over 4 pairs when there are
   // fewer than 131072 candidates per query, e.g. cfg4's 1024-token documents or a small shard)
@@ -726,7 +737,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
 // near-tied in the final ranking are re-evaluated with the reference's ascending-k chain.  The sharded search splits this:
 // mode 0 = MFMA pass only (scores + budgets stay in the scratch), mode 2 = repair every flagged document of the previous
 // mode-0 pass (the final ranking is only known after the exchange).
-static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, int mode) {
+static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, int mode, bool stage_event = false) {
   const FpIndexDev& D = ix->d;
   hipStream_t st = s->st;
   const int B = sh.B;
@@ -750,6 +761,7 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
       return fail(FP_EUNSUPPORTED, "dim/nbits");
     LAUNCHCHK("MaxSim");
   }
+  if (stage_event) STAGE_DONE(ST_REPAIR);   // "S6+S7 maxsim" is the MaxSim kernel alone (+ the 4 us prefix kernel in front of it)
   if (repair && mode != 0) {
     const bool marked = mode == 1 && repair_env != 2 &&
                         fpk_final_mark(s->exact.as<float>(), aux.unc, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
@@ -829,7 +841,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     g_last_counts[3] += 1;
     // S6+S7
     const int64_t R = P.sh.R;
-    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1)) return rc;
+    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true)) return rc;
     STAGE_DONE(ST_TOPK);
     // S8
     const int64_t K = p->top_k;

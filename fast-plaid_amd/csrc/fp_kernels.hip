@@ -1666,6 +1666,7 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
 // that the pilot cut needs is built here in LDS.
 #define L0_HBINS 4096
 #define L0_UNROLL 4
+#define L0_PILOT_MAX 98304    // capacity of a query's pilot group
 // the bounds of query b live at ub[l0_row(cand_off, b) + i], i = position in the query's candidate list: rows start on 16-byte
 // boundaries (ub holds M + 8 B + 16 entries) so that the passes over them use 16-byte loads
 __device__ __forceinline__ int64_t l0_row(const int64_t* __restrict__ cand_off, int b) { return ((cand_off[b] + 7) & ~(int64_t)7) + 8 * (int64_t)b; }
@@ -1681,14 +1682,19 @@ __device__ __forceinline__ uint32_t l0_max8(uint32_t v) {
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
   return v;
 }
-__global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, const uint32_t* __restrict__ esc,
+// Tables beyond 2^17 centroids are walked in ranges of 2^17 (one launch each, the range's slice of the table in LDS and the
+// index's per-range code lines): the first launch writes F + its sum, the later ones add theirs (saturating, infinite stays
+// infinite), the last one builds the histogram from the final values.
+__global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, int64_t tab_off, int tab_bytes,
+                                                  const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ poff,
                                                   const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist,
+                                                  int first, int last,
                                                   int abl /*timing experiments only: 1 no table lookups, 2 no line loads*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
-  uint8_t* tab = l0s;                                                  // [Cpad + 16]: the 16 bytes behind the table are 0 (index of absent codes)
-  uint32_t* es = reinterpret_cast<uint32_t*>(l0s + Cpad + 16);         // [64]
+  uint8_t* tab = l0s;                                                  // [tab_bytes + 16]
+  uint32_t* es = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [64]
   uint32_t* hl = es + 64;                                              // [L0_HBINS]
   const int b = blockIdx.y, tid = threadIdx.x;
   const int64_t beg = cand_off[b];
@@ -1696,10 +1702,10 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   constexpr int CPI = 128 * L0_UNROLL;   // candidates per workgroup iteration
   if ((int64_t)blockIdx.x * CPI >= n) return;
   {
-    const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad);
+    const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad + tab_off);
     uint4* dst = reinterpret_cast<uint4*>(tab);
-    for (int64_t i = tid; i < Cpad / 16; i += 1024) dst[i] = src[i];
-    if (tid < 4) reinterpret_cast<uint32_t*>(tab + Cpad)[tid] = 0u;
+    for (int i = tid; i < tab_bytes / 16; i += 1024) dst[i] = src[i];
+    if (tid < 4) reinterpret_cast<uint32_t*>(tab + tab_bytes)[tid] = 0u;
     if (tid < 64) es[tid] = esc[(int64_t)b * 64 + tid];
     for (int i = tid; i < L0_HBINS; i += 1024) hl[i] = 0u;
   }
@@ -1770,6 +1776,12 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     const uint2 m3 = i + 3 * stride + kq < n ? pmeta[pid3] : make_uint2(0u, 0u);
     const int32_t pid4 = i + 4 * stride + kq < n ? cpids[i + 4 * stride + kq] : 0;
     uint32_t outv[L0_UNROLL], sums[L0_UNROLL], mxs[L0_UNROLL];
+    uint16_t prev[L0_UNROLL] = {0, 0, 0, 0};   // the bounds so far (later ranges of a table beyond 2^17 centroids)
+    if (!first) {
+#pragma unroll
+      for (int k = 0; k < L0_UNROLL; ++k)
+        if (i + k < n) prev[k] = ubrow[i + k];
+    }
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) { sums[k] = 0; mxs[k] = 0; }
     if (abl & 1) {
@@ -1814,10 +1826,10 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         mx = l0_max8(inf);
         sum = mx ? 0xFFFFFFu : sum;
       }
-      uint32_t v = F + sum;
-      v = sum >= 0xFFFFFFu ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
+      uint32_t v = (first ? F : (uint32_t)prev[k]) + sum;
+      v = (sum >= 0xFFFFFFu || (!first && prev[k] == L0_INF)) ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
       outv[k] = v;
-      if (sub == 0 && i + k < n) {
+      if (last && sub == 0 && i + k < n) {
         const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
         atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
       }
@@ -1856,6 +1868,7 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
   if (n_full < keep) keep = n_full;
   if (R < keep) keep = R;
   int64_t want = keep * mult;
+  if (want > L0_PILOT_MAX / 4 * 3) want = keep > L0_PILOT_MAX / 4 * 3 ? keep : L0_PILOT_MAX / 4 * 3;   // room for the ties at the cut
   if (tid == 0) npilot[b] = 0;
   if (want >= n) {
     if (tid == 0) cut[b] = 0;
@@ -1900,7 +1913,6 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
 // atomic per step (a per-wave atomic on the query's counter cost 1.1 ms at cfg2: ~3000 same-address atomics per query
 // serialise at the memory side).  pilot_pid / pilot_idx [b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the
 // capacity (then nothing is pruned).
-#define L0_PILOT_MAX 32768
 __device__ __forceinline__ uint32_t l0_u16(const uint4& v, int k) {
   const uint32_t w = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
   return (k & 1) ? (w >> 16) : (w & 0xFFFFu);
@@ -2115,8 +2127,12 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
   }
 }
 
-size_t fpk_l0_lds_bytes(const FpIndexDev& ix) { return (size_t)((ix.C + 15) & ~(int64_t)15) + 16 + 256 + L0_HBINS * 4; }
-bool fpk_l0_fits(const FpIndexDev& ix) { return ix.pcodes != nullptr && fpk_l0_lds_bytes(ix) <= 160 * 1024; }
+#define FP_L0_RANGE (1ll << 17)
+size_t fpk_l0_lds_bytes(const FpIndexDev& ix) {
+  const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
+  return (size_t)std::min<int64_t>(Cpad, FP_L0_RANGE) + 16 + 256 + L0_HBINS * 4;
+}
+bool fpk_l0_fits(const FpIndexDev& ix) { return ix.n_ranges >= 1 && ix.pcodes != nullptr; }
 
 // level 0 in launch groups so that the scan kernel can be timed alone:
 //   prepare: floors + excess table;  scan: UB0 of every candidate (+ its histogram);  pilot: the top mult*keep documents by UB0
@@ -2141,15 +2157,19 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   static std::atomic<uint64_t> ok2{0};
   fp_allow_big_lds((const void*)k_l0_scan, ok2, 160 * 1024);
   const int64_t per_q = (M + B - 1) / B;
-  // each workgroup copies the table (Cpad bytes) into LDS first: candidates per workgroup (measured at cfg2: 256 / 512 / 1024 /
+  // each workgroup copies the table (up to 128 KiB) into LDS first: candidates per workgroup (measured at cfg2: 256 / 512 / 1024 /
   // 2048 / 4096 -> 1.99 / 1.76 / 1.60 / 1.51 / 1.51 ms with the first version of the kernel)
   static const int cpw = [] { const char* e = getenv("FP_L0_CPW"); const int v = e ? atoi(e) : 4096; return v >= 256 ? v : 4096; }();
   int64_t bx = (per_q + cpw - 1) / cpw;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
   static const int abl = [] { const char* e = getenv("FP_L0_ABL"); return e ? atoi(e) : 0; }();   // timing experiments only (results are wrong)
-  hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, w.esc, w.Fsum, cand_off,
-                     cand_pid, ix.poff, ix.pcodes, w.ub, w.hist, abl);
+  for (int r = 0; r < ix.n_ranges; ++r) {
+    const int64_t off = (int64_t)r * FP_L0_RANGE;
+    const int tb = (int)std::min<int64_t>(FP_L0_RANGE, Cpad - off);
+    hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off,
+                       cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, abl);
+  }
 }
 
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st) {

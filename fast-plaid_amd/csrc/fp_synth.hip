@@ -308,11 +308,25 @@ fail:
 // lines per document; a lane reads ONE aligned 16-byte piece and needs nothing from its neighbours.  C <= 2^17 only.
 #define PCODES_PER_PIECE 7
 #define PCODES_PER_LINE 56
-__global__ void k_pcode_lines(const int64_t* __restrict__ uoff, int64_t n_docs, int64_t* __restrict__ nlines) {
-  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= n_docs; d += (int64_t)gridDim.x * blockDim.x)
-    nlines[d] = d < n_docs ? (uoff[d + 1] - uoff[d] + PCODES_PER_LINE - 1) / PCODES_PER_LINE : 0;
+// sub-run of a document's ascending unique codes that falls in [lo, hi): rs[d] .. re[d] (positions in ucodes)
+__global__ void k_pcode_range(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff, int64_t n_docs, int32_t lo, int32_t hi,
+                              int64_t* __restrict__ rs, int64_t* __restrict__ re) {
+  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = uoff[d], e = uoff[d + 1];
+    int64_t a0 = b, a1 = e;
+    while (a0 < a1) { const int64_t m = (a0 + a1) >> 1; if (ucodes[m] < lo) a0 = m + 1; else a1 = m; }
+    int64_t z0 = a0, z1 = e;
+    while (z0 < z1) { const int64_t m = (z0 + z1) >> 1; if (ucodes[m] < hi) z0 = m + 1; else z1 = m; }
+    rs[d] = a0;
+    re[d] = z0;
+  }
 }
-__global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff, int64_t n_docs,
+__global__ void k_pcode_lines(const int64_t* __restrict__ rs, const int64_t* __restrict__ re, int64_t n_docs, int64_t* __restrict__ nlines) {
+  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= n_docs; d += (int64_t)gridDim.x * blockDim.x)
+    nlines[d] = d < n_docs ? (re[d] - rs[d] + PCODES_PER_LINE - 1) / PCODES_PER_LINE : 0;
+}
+__global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ rs,
+                                                    const int64_t* __restrict__ re, int64_t n_docs, int32_t code_base,
                                                     const int64_t* __restrict__ loff, int32_t* __restrict__ poff, uint4* __restrict__ lines) {
   // one thread per piece
   const int64_t nl = loff[n_docs];
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
       const int64_t mid = (lo + hi) >> 1;
       if (loff[mid] <= line) lo = mid; else hi = mid;
     }
-    const int64_t u0 = uoff[lo], n = uoff[lo + 1] - u0;
+    const int64_t u0 = rs[lo], n = re[lo] - u0;
     const int64_t first = (line - loff[lo]) * PCODES_PER_LINE + (int64_t)piece * PCODES_PER_PIECE;
     // slots past the piece's last code repeat that code (an empty piece holds code 0 seven times): the scan sums all seven
     // table entries and takes (7 - count) x the last one off again, instead of predicating every lookup
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
     for (int j = 0; j < PCODES_PER_PIECE; ++j) {
       uint32_t c = last;
       if (first + j < n) {
-        c = (uint32_t)ucodes[u0 + first + j];
+        c = (uint32_t)(ucodes[u0 + first + j] - code_base);
         last = c;
         ++cnt;
       }
@@ -354,12 +368,15 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
   }
 }
 
-// allocates *lines ([NL] x 128 B) and *poff ([N] x {first line, line count} i32 pairs); returns 0 or a hipError
-int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, void** lines, int32_t** poff, int64_t* n_lines,
-                     hipStream_t st) {
+// The unique codes in [code_lo, code_hi) (at most 2^17 values) of every document, packed into 128-byte lines.  Allocates
+// *lines ([NL] x 128 B) and *poff ([N] x {first line, line count} i32 pairs); returns 0 or a hipError
+int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
+                     int32_t** poff, int64_t* n_lines, hipStream_t st) {
   int rc = 0;
   int64_t* nlines = nullptr;
   int64_t* loff = nullptr;
+  int64_t* rs = nullptr;
+  int64_t* re = nullptr;
   void* tmp = nullptr;
   size_t tb = 0;
   *lines = nullptr;
@@ -368,7 +385,11 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   HCHK(hipMalloc((void**)poff, (size_t)(n_docs + 1) * 8 + 64));
   HCHK(hipMalloc((void**)&nlines, (size_t)(n_docs + 1) * 8));
   HCHK(hipMalloc((void**)&loff, (size_t)(n_docs + 1) * 8));
-  hipLaunchKernelGGL(k_pcode_lines, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, uoff_dev, n_docs, nlines);
+  HCHK(hipMalloc((void**)&rs, (size_t)(n_docs + 1) * 8));
+  HCHK(hipMalloc((void**)&re, (size_t)(n_docs + 1) * 8));
+  hipLaunchKernelGGL(k_pcode_range, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, (int32_t)code_lo,
+                     (int32_t)code_hi, rs, re);
+  hipLaunchKernelGGL(k_pcode_lines, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, rs, re, n_docs, nlines);
   HCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, nlines, loff, (int)(n_docs + 1), st));
   HCHK(hipMalloc(&tmp, tb ? tb : 16));
   HCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, nlines, loff, (int)(n_docs + 1), st));
@@ -378,13 +399,15 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 128 + 64));
   {
     const int64_t work = *n_lines * 8 + n_docs + 1;
-    hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, loff, *poff,
-                       static_cast<uint4*>(*lines));
+    hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, rs, re, n_docs, (int32_t)code_lo, loff,
+                       *poff, static_cast<uint4*>(*lines));
   }
   HCHK(hipStreamSynchronize(st));
 fail:
   if (nlines) (void)hipFree(nlines);
   if (loff) (void)hipFree(loff);
+  if (rs) (void)hipFree(rs);
+  if (re) (void)hipFree(re);
   if (tmp) (void)hipFree(tmp);
   return rc;
 }

@@ -51,7 +51,9 @@ def main():
     pruned = 0
     for (n_docs, C, Q, n_full, n_probe, seed) in ((20000, 2048, 32, 256, 8, 1), (20000, 2048, 20, 64, 4, 2), (8000, 512, 7, 32, 2, 3),
                                                   (30000, 4096, 32, 4096, 8, 4), (20000, 2048, 50, 256, 8, 5), (15000, 1024, 64, 128, 4, 6),
-                                                  (15000, 1024, 33, 64, 8, 7)):   # q_len 33..64: two 32-column chunks
+                                                  (15000, 1024, 33, 64, 8, 7),    # q_len 33..64: two 32-column chunks
+                                                  (20000, 262144, 32, 256, 8, 11),   # > 2^17 centroids: level 0 walks two centroid ranges
+                                                  (12000, 524288, 20, 128, 4, 12)):  # four ranges
         spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=48, n_centroids=C, variable_len=True, seed=seed)
         arr = fp.synth.host_index_arrays(spec)
         q = fp.synth.make_queries(spec, arr["centroids"], 6, Q)

@@ -5,7 +5,7 @@ run() { name=$1; shift; timeout 300 python $R/bench.py --steps 5 --warmup 2 --cp
 import sys,json
 d=json.loads(sys.stdin.read())
 allk=[d['roofline']]+list(d['roofline_by_kernel'].values())
-k=[v for v in allk if str(v.get('kernel','')).startswith('k_approx')][0]
+k=[v for v in allk if 'candidate_docs_per_batch' in v][0]
 m=[v for v in allk if str(v.get('kernel','')).startswith('k_maxsim')][0]
 print('$name', 'qps=%.1f ms/batch=%.2f' % (d['value'], d['ms_per_step']), d['stages_ms'], 'dominant=%s' % d['roofline']['kernel'].split(' ')[0], 'maxsim_frac=%.3f' % m['frac'], 'cand/batch=%.0f rescored=%.0f' % (k['candidate_docs_per_batch'], k['docs_rescored_exactly_per_batch']))"; }
 run cfg1 --docs 1000 --doc-len 300 --batch 16 --qlen 50 --topk 10
