@@ -116,14 +116,14 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
-                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
+                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
                       &ms_nmark, &sh_rec, &sh_all})
       b->release();
     h_out.release();
@@ -298,13 +298,14 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   }
   // packed code lines for S4's level 0: one set per range of 2^17 centroids (17-bit codes relative to the range), up to 2^20
   D.n_ranges = 0;
+  D.n_lines = 0;
   if (D.C <= 8 * (1ll << 17)) {
     const int nr = (int)((D.C + (1ll << 17) - 1) >> 17);
     for (int r = 0; r < nr; ++r) {
       void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
       const int64_t lo = (int64_t)r << 17, hi = std::min<int64_t>(D.C, lo + (1ll << 17));
       const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st);
-      if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; }
+      if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; D.n_lines += nl; }
       if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
       if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
       D.pcodes_r[r] = static_cast<const uint4*>(lines); D.poff_r[r] = poff;
@@ -404,6 +405,7 @@ extern "C" int32_t fp_index_dim(const fp_index* ix) { return ix ? ix->d.dim : 0;
 extern "C" int32_t fp_index_nbits(const fp_index* ix) { return ix ? ix->d.nbits : 0; }
 extern "C" int64_t fp_index_device_bytes(const fp_index* ix) { return ix ? ix->bytes : 0; }
 extern "C" int64_t fp_index_num_unique_codes(const fp_index* ix) { return ix ? ix->d.U : 0; }
+extern "C" int64_t fp_index_num_code_lines(const fp_index* ix) { return ix ? ix->d.n_lines : 0; }
 
 // ------------------------------------------------------------------------------------------
 // synthetic device-resident corpora
@@ -538,6 +540,7 @@ struct Pipe {
   bool exact_all = false;  // trace mode: exact approximate score of EVERY candidate (no bound-and-refine)
   bool used_q8 = false;   // a bound stage pruned the candidates (8-bit bounds or level 0)
   int approx_impl = 0;    // 0 exact for all, 1 8-bit bounds, 2 level 0
+  bool l0_ready = false;  // S1 produced level 0's floors and excess table (instead of the 8-bit table)
 };
 
 // stages S1..S5 for one sub-batch whose fp16 queries are already in s->qin
@@ -560,12 +563,36 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : (e[0] == 'l' ? 2 : 0)));
   }();
   const bool want_s8 = !P.exact_all && (sh.Qp == 32 || sh.Qp == 64) && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
+  // Level 0 is decided HERE when the index suits it (the table fits, documents of <= 64 distinct codes on average; forced by
+  // FP_APPROX_IMPL=l0): S1 then emits level 0's excess table from its epilogue -- floors from a pre-pass over a centroid
+  // sample -- and the 8-bit table (C x Qp bytes per query, written and read back twice) is never materialised.  Whether S4
+  // then prunes with it or scores everything exactly (few candidates) is still decided from the candidate count.
+  P.l0_ready = want_s8 && q8_env != 1 && fpk_l0_fits(D) && (q8_env == 2 || D.U <= 64 * D.N);
   const int nch128 = (int)((D.C + 127) / 128);
-  if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
   HIPCHK(s->cmax128.ensure((size_t)B * sh.Qp * nch128 * 2));
-  if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
-                          s->cmax128.as<uint16_t>(), st))
-    return fail(FP_EUNSUPPORTED, "dim");
+  if (P.l0_ready) {
+    const int64_t Cpad = (D.C + 15) & ~15ll;
+    int64_t ns = 0, sstride = 1;
+    fpk_l0_sample_plan(D, &ns, &sstride);
+    HIPCHK(s->S8.ensure((size_t)B * ns * sh.Qp));          // bins of the sample only
+    HIPCHK(s->Ssample.ensure((size_t)B * ns * sh.Qp * 2));
+    HIPCHK(s->l0_floors.ensure((size_t)B * sh.Qp));
+    HIPCHK(s->l0_F.ensure((size_t)B * 4));
+    HIPCHK(s->l0_e8.ensure((size_t)B * Cpad));
+    HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
+    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->Ssample.as<uint16_t>(), B, sh.Qp, s->S8.as<uint8_t>(), nullptr, st, ns, sstride))
+      return fail(FP_EUNSUPPORTED, "dim");
+    fpk_l0_floors(s->S8.as<uint8_t>(), ns, sh, s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_esc.as<uint32_t>(), st);
+    if (Cpad > D.C) HIPCHK(hipMemsetAsync(s->l0_e8.p, 0, (size_t)B * Cpad, st));   // pad entries behind the table stay 0
+    FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q};
+    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex))
+      return fail(FP_EUNSUPPORTED, "dim");
+  } else {
+    if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
+    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
+                            s->cmax128.as<uint16_t>(), st))
+      return fail(FP_EUNSUPPORTED, "dim");
+  }
   STAGE_DONE(ST_PROBE);
   // subset bitmaps
   P.W = ((D.N + 31) / 32 + 63) & ~63ll;
@@ -632,19 +659,19 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   //   exact for all (k_approx).
   const int64_t* sel_off = s->cand_off.as<int64_t>();
   const int32_t* sel_src = s->cand_pid.as<int32_t>();
-  const bool l0_ok = want_s8 && M > 0 && fpk_l0_fits(D);
   // level 0 sums the excesses of a document's codes where the score takes their per-column maximum: with hundreds of distinct
   // codes per document (cfg4's 1024-token documents: ~300) the bound is too loose to prune (61 % of the candidates survived),
-  // so it is chosen for documents of at most 64 distinct codes on average (one or two code lines each)
-  const bool l0_auto = l0_ok && M > 16 * (int64_t)B * sh.R && D.U <= 64 * D.N;
+  // so it is prepared (P.l0_ready, before S1) only for documents of at most 64 distinct codes on average
+  const bool l0_ok = P.l0_ready && M > 0;
+  const bool l0_auto = l0_ok && M > 16 * (int64_t)B * sh.R;
   // 8-bit bounds: (a) one query's slice of S overflows L2, (b) there is something to prune and (c) one query alone can
   // fill the chip (~1280 resident workgroups x 128 lane pairs; the kernel spreads a candidate over 4 pairs when there are
   // fewer than 131072 candidates per query, e.g. cfg4's 1024-token documents or a small shard)
-  const bool q8_auto = D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 32768;
+  const bool q8_auto = !P.l0_ready && D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 32768;
   P.approx_impl = 0;
   if (want_s8 && M > 0) {
     if (q8_env == 2) P.approx_impl = l0_ok ? 2 : 0;
-    else if (q8_env == 1) P.approx_impl = 1;
+    else if (q8_env == 1) P.approx_impl = P.l0_ready ? 0 : 1;
     else P.approx_impl = l0_auto ? 2 : (q8_auto ? 1 : 0);
   }
   P.used_q8 = P.approx_impl != 0;
@@ -680,7 +707,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                     s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>(),
                     s->l0_pilot_idx.as<int32_t>(), s->l0_capprox.as<float>(), s->l0_thr.as<int32_t>(), s->l0_nextra.as<int32_t>(),
                     s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>()};
-      fpk_l0_prepare(D, s->S8.as<uint8_t>(), sh, w, st);
+      fpk_l0_prepare(D, nullptr, sh, w, st);   // floors and table came with S1
       STAGE_DONE(ST_APPROX);
       fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
       STAGE_DONE(ST_REFINE);

@@ -49,6 +49,7 @@ struct FpIndexDev {
   // centroid ranges of 2^17 (FP_L0_RANGE) for tables beyond 2^17 centroids: range r has its own lines / offsets with codes
   // relative to r * 2^17; [0] aliases pcodes / poff
   int n_ranges;
+  int64_t n_lines;         // 128-byte code lines over all ranges
   const uint4* pcodes_r[8];
   const int32_t* poff_r[8];
   const uint16_t* norms;   // [T]   fp16 bits of h(sqrt(sum_fp32 e_k^2)) per stored token (ascending-k sum; computed at index creation)
@@ -79,8 +80,17 @@ struct FpSearchShape {
 void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B*Qp,D]*/, int B, int Q, int Qp, int D,
                       hipStream_t st);
 // S8 (nullable; written only when Qp == 32): 8-bit bins [B][C][32]; cmax (nullable): [B*Qp][ceil(C/128)] f16 column maxima per 128-centroid tile
-int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* q_pad, uint16_t* S /*[B][C][Qp]*/, int B, int Qp, uint8_t* S8, uint16_t* cmax,
-                        hipStream_t st);
+// S1's optional by-product for S4's level 0: the excess table e8[b][Cpad] (one byte per query and centroid) computed in the
+// epilogue from the column floors of a sampled pre-pass
+struct FpS1Excess {
+  const uint8_t* floors;   // [B][Qp]
+  uint8_t* e8;             // [B][Cpad] (nullptr: off)
+  uint32_t* esc;           // [B][64]
+  int64_t Cpad;
+  int Q;                   // real query columns
+};
+int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
+                        hipStream_t st, int64_t n_rows = 0, int64_t row_stride = 1, const FpS1Excess* exc = nullptr);
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow /*[B][Cw] or null*/,
               unsigned long long* partial, int nchunk, int32_t* cells /*[B][Q][n_probe]*/, int32_t* ucells /*[B][Q*n_probe]*/,
               int32_t* ncells /*[B]*/, const uint16_t* cmax128 /*nullable: S1's [B*Qp][ceil(C/128)] column maxima*/, hipStream_t st);
@@ -131,7 +141,10 @@ struct FpL0Scratch {
   int32_t* xdst;        // [M] ... and positions in the survivor list
 };
 bool fpk_l0_fits(const FpIndexDev& ix);
-void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st);
+void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8 /*nullptr: floors and table came with S1*/, const FpSearchShape& sh, FpL0Scratch& w,
+                    hipStream_t st);
+void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride);
+void fpk_l0_floors(const uint8_t* S8_sample, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, hipStream_t st);
 void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w,
                  hipStream_t st);
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st);

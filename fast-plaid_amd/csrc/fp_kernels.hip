@@ -59,12 +59,26 @@ void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, i
 //   * cmax, the per-column maximum over the tile's 128 centroids: the threshold probe's chunk
 //     maxima at 128-centroid granularity for free.
 // ============================================================================================
+// byte code of an excess e for S4's level-0 table (see "S4 level 0" below):  0..159 = e;  160..239 = 160 + ceil((e - 160) / 8);
+// 240..254 = escape slot 0..14 whose u32 value is kept in esc[slot] (esc[63] counts the slots handed out);  255 = infinite
+#define L0_LIN 160
+#define L0_ESC_BASE 240
+#define L0_ESC_SLOTS 15
+__device__ __forceinline__ uint8_t l0_encode(uint32_t e, bool inf, uint32_t* __restrict__ esc) {
+  if (inf) return 255u;
+  if (e < L0_LIN) return (uint8_t)e;
+  if (e <= L0_LIN + 8u * (L0_ESC_BASE - 1u - L0_LIN)) return (uint8_t)(L0_LIN + (e - L0_LIN + 7u) / 8u);
+  const uint32_t slot = atomicAdd(&esc[63], 1u);
+  if (slot >= L0_ESC_SLOTS) return 255u;
+  esc[slot] = e;
+  return (uint8_t)(L0_ESC_BASE + slot);
+}
 #define S1_TILE 128
 template <int KS>
 __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
                                                          uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
-                                                         int nch, int D) {
+                                                         int nch, int D, int64_t crow_stride, FpS1Excess ex) {
   // K is consumed in slices of KS dims: the operand tiles take 2 x 128 x KS x 2 B of LDS (32 KiB at KS = 64) instead of
   // 64 KiB for the whole K = 128, which lifts the kernel from 2 to 3 workgroups per CU (VGPR limit) so that one
   // workgroup's store phase overlaps another's MFMA phase.  Any dim that is a multiple of 8 (one 16-byte piece): KS = 64 /
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
       uint4 vq = make_uint4(0, 0, 0, 0), vc = make_uint4(0, 0, 0, 0);
       const bool kin = k0 + j * 8 < D;
       if (kin && n0 + row < Ntot) vq = *reinterpret_cast<const uint4*>(qpad + (n0 + row) * D + k0 + j * 8);
-      if (kin && c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * D + k0 + j * 8);
+      if (kin && c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * crow_stride * D + k0 + j * 8);
       *reinterpret_cast<uint4*>(Qs + row * ROWB + js * 16) = vq;
       *reinterpret_cast<uint4*>(Cs + row * ROWB + js * 16) = vc;
     }
@@ -173,8 +187,10 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
   }
   __syncthreads();
   // write-out: 2048 16-byte pieces (g, c, chunk), 8 per thread, consecutive threads -> consecutive bytes of S when Qp == 32
+  uint32_t eacc[8];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (bit 31: a clamped bin), summed over the row's 4 lanes
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
+    eacc[it] = 0u;
     const int p = it * 256 + tid;
     const int g = p >> 9, cl = (p >> 2) & 127, ch = p & 3;
     const int64_t nb = n0 + g * 32;
@@ -184,6 +200,33 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
     const int q0 = (int)(nb % Qp);
     const uint4 v = *reinterpret_cast<const uint4*>(Os + ((size_t)(g * 128 + cl)) * 64 + ((ch ^ ((cl >> 2) & 3)) * 16));
     *reinterpret_cast<uint4*>(S + (bq * C + c) * Qp + q0 + ch * 8) = v;
+    if (ex.e8) {
+      // S4 level 0's table entry, straight from the tile (instead of writing the 8-bit bins and reading them back):
+      // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass
+      const uint2 fw = *reinterpret_cast<const uint2*>(ex.floors + bq * Qp + q0 + ch * 8);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t part = 0, inf = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const h2 pr = u32_as_h2(w[t >> 1]);
+        const float x = (float)((t & 1) ? pr.y : pr.x);
+        int bin = (int)floorf(x * 128.0f) + 100;
+        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+        const int f = (int)(((t < 4 ? fw.x : fw.y) >> (8 * (t & 3))) & 0xFFu);
+        if (q0 + ch * 8 + t < ex.Q) {
+          part += (uint32_t)(bin > f ? bin - f : 0);
+          inf |= (bin == 255) ? 1u : 0u;
+        }
+      }
+      uint32_t acc = part | (inf << 31);   // (the sums stay far below 2^31: at most 64 columns x 255)
+      {
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        acc = ((acc & 0x7FFFFFFFu) + (o1 & 0x7FFFFFFFu)) | ((acc | o1) & 0x80000000u);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        acc = ((acc & 0x7FFFFFFFu) + (o2 & 0x7FFFFFFFu)) | ((acc | o2) & 0x80000000u);
+      }
+      eacc[it] = acc;
+    }
     if (S8) {
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       uint32_t o[2] = {0u, 0u};
@@ -206,12 +249,37 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
       cmax[n * nch + blockIdx.x] = (mono16(u0) > mono16(u1)) ? u0 : u1;
     }
   }
+  if (ex.e8 && (tid & 3) == 0) {
+    // one byte per (query, centroid): with Qp == 64 a query's two 32-column groups (it = 2 g + half) belong together
+    const int per_q = Qp / 32;   // groups per query: 1 or 2
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int g = it >> 1;
+      if (per_q == 2 && (g & 1)) continue;
+      const int cl = (it & 1) * 64 + (tid >> 2);
+      const int64_t nb = n0 + g * 32;
+      const int64_t c = c0 + cl;
+      if (nb >= Ntot || c >= C) continue;
+      uint32_t acc = eacc[it];
+      if (per_q == 2) {
+        const uint32_t o = eacc[it + 2];
+        acc = ((acc & 0x7FFFFFFFu) + (o & 0x7FFFFFFFu)) | ((acc | o) & 0x80000000u);
+      }
+      const int64_t bq = nb / Qp;
+      ex.e8[bq * ex.Cpad + c] = l0_encode(acc & 0x7FFFFFFFu, (acc >> 31) != 0u, ex.esc + bq * 64);
+    }
+  }
 }
 
 int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
-                        hipStream_t st) {
+                        hipStream_t st, int64_t n_rows, int64_t row_stride, const FpS1Excess* exc) {
+  // n_rows / row_stride: score only the centroids 0, row_stride, 2 row_stride, ... (n_rows of them; S / S8 are then n_rows tall)
   const int64_t Ntot = (int64_t)B * Qp;
-  const int nch = (int)((ix.C + S1_TILE - 1) / S1_TILE);
+  const int64_t C = n_rows > 0 ? n_rows : ix.C;
+  const int64_t rs = n_rows > 0 ? row_stride : 1;
+  FpS1Excess ex{};
+  if (exc) ex = *exc;
+  const int nch = (int)((C + S1_TILE - 1) / S1_TILE);
   dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
   if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
   const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
@@ -219,13 +287,13 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   if (D % 8 != 0 || D < 8) return -1;
   if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch, D);
+    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
   } else if (D % 32 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 32 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<32>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch, D);
+    hipLaunchKernelGGL(k_centroid_scores<32>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
   } else {
     const size_t lds = std::max<size_t>(2 * 128 * 16 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<16>, grid, dim3(256), lds, st, ix.centroids, qpad, S, ix.C, Ntot, Qp, S8, cmax, nch, D);
+    hipLaunchKernelGGL(k_centroid_scores<16>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
   }
   return 0;
 }
@@ -1557,9 +1625,6 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 // second pass over a third of the candidates, and a table in units of 4 loosened EVERY code by up to 3, which doubled the
 // survivors);  240..254 = escape slot 0..14 (u32 values in LDS) for e >= 800;  255 = infinite.
 // decode of v <= 239:  max(v, 8 v - 1120)
-#define L0_LIN 160
-#define L0_ESC_BASE 240
-#define L0_ESC_SLOTS 15
 #define L0_INF 0xFFFFu
 #define L0_SAMPLE 8192          // centroids sampled for the column quantiles
 
@@ -1638,21 +1703,7 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
         }
       }
     }
-    if (inf) {
-      out = 255u;
-    } else if (e < L0_LIN) {
-      out = e;
-    } else if (e <= L0_LIN + 8u * (L0_ESC_BASE - 1u - L0_LIN)) {
-      out = L0_LIN + (e - L0_LIN + 7u) / 8u;
-    } else {
-      const uint32_t slot = atomicAdd(&esc[(int64_t)b * 64 + 63], 1u);
-      if (slot < L0_ESC_SLOTS) {
-        esc[(int64_t)b * 64 + slot] = e;
-        out = L0_ESC_BASE + slot;
-      } else {
-        out = 255u;
-      }
-    }
+    out = l0_encode(e, inf, esc + (int64_t)b * 64);
   }
   e8[(int64_t)b * Cpad + c] = (uint8_t)out;
 }
@@ -1685,14 +1736,16 @@ __device__ __forceinline__ uint32_t l0_max8(uint32_t v) {
 // Tables beyond 2^17 centroids are walked in ranges of 2^17 (one launch each, the range's slice of the table in LDS and the
 // index's per-range code lines): the first launch writes F + its sum, the later ones add theirs (saturating, infinite stays
 // infinite), the last one builds the histogram from the final values.
+typedef __attribute__((address_space(3))) const uint8_t l0_lds_u8;
+template <int ABL /*timing experiments only: 1 no table lookups, 2 no line loads*/>
 __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, int64_t tab_off, int tab_bytes,
                                                   const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ poff,
                                                   const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist,
-                                                  int first, int last,
-                                                  int abl /*timing experiments only: 1 no table lookups, 2 no line loads*/) {
+                                                  int first, int last) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)l0s != 0u) __builtin_trap();   // the table must sit at LDS address 0
   uint8_t* tab = l0s;                                                  // [tab_bytes + 16]
   uint32_t* es = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [64]
   uint32_t* hl = es + 64;                                              // [L0_HBINS]
@@ -1731,100 +1784,105 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, true);
     }
   };
-  auto load_meta = [&](int64_t at) -> uint2 {   // this lane's candidate of the iteration starting at `at`
-    return at + kq < n ? pmeta[cpids[at + kq]] : make_uint2(0u, 0u);
+  // The loads are unconditional: positions past the end of the list are clamped to its last entry (their results are never
+  // stored), and a document without codes (line count 0) reads line 0 and has its sum masked -- the guards cost a branch, an
+  // exec-mask save and four zeroing moves per load otherwise.
+  const int64_t nlast = n - 1;
+  auto pos = [&](int64_t at) -> int64_t { return at + kq < nlast ? at + kq : nlast; };
+  auto load_line = [&](uint32_t line) -> uint4 {
+    if (ABL & 2) return make_uint4(line * 2654435761u & 0x1FFFFu, line * 40503u & 0x1FFFFu, line * 7919u & 0x1FFFFu, 0x06000000u | (line & 0xFFFFu));
+    return pcodes[(int64_t)line * 8 + sub];
   };
-  auto load_line = [&](uint32_t line, uint32_t cnt) -> uint4 {
-    if (abl & 2) return make_uint4(line * 2654435761u, line * 40503u, line * 7919u, 0x07000000u | (line & 0xFFFFu));
-    return cnt > 0 ? pcodes[(int64_t)line * 8 + sub] : make_uint4(0, 0, 0, 0);
-  };
-  uint2 m0 = load_meta(i);                     // iteration t
-  uint2 m1 = load_meta(i + stride);            // t+1
-  uint2 m2 = load_meta(i + 2 * stride);        // t+2
-  int32_t pid3 = i + 3 * stride + kq < n ? cpids[i + 3 * stride + kq] : 0;
-  uint4 pc[L0_UNROLL];                         // first code line of t
+  uint2 m0 = pmeta[cpids[pos(i)]];                     // iteration t
+  uint2 m1 = pmeta[cpids[pos(i + stride)]];            // t+1
+  uint2 m2 = pmeta[cpids[pos(i + 2 * stride)]];        // t+2
+  int32_t pid3 = cpids[pos(i + 3 * stride)];
+  uint4 pcA[L0_UNROLL], pcB[L0_UNROLL];                // first code lines of t / t+1, roles swapped every iteration
 #pragma unroll
-  for (int k = 0; k < L0_UNROLL; ++k) pc[k] = load_line(qb(m0.x, k), qb(m0.y, k));
-  // sum / max of the 7 table entries of one piece.  Slots past the piece's count repeat its last code (fp_synth.hip): all
-  // seven are summed and (7 - count) x the last taken off again (an empty piece: 7 x code 0 - 7 x code 0).
-  auto piece = [&](const uint4& pc, uint32_t& sum, uint32_t& mx) {
-    const uint32_t w[4] = {pc.x, pc.y, pc.z, pc.w};
+  for (int k = 0; k < L0_UNROLL; ++k) pcA[k] = load_line(qb(m0.x, k));
+  // sum of the 6 table entries of one piece (6 codes of 20 bits + the count in the top byte; 48 codes per line: 0.15 % of the
+  // benchmark corpus' documents need a second line, against 6 % with 40 -- the second line is not prefetched).  Slots past the
+  // piece's count repeat its last code (fp_synth.hip): all six are summed and (6 - count) x the last taken off again (an empty
+  // piece: 6 x code 0 - 6 x code 0).  Bit 24 of the result flags an escape / infinite code (v >= 240) among the real ones.
+  // The table sits at LDS address 0 (checked at kernel entry), so a code IS its ds_read address.
+  auto codes6 = [](const uint4& pc, uint32_t (&c)[6]) {
+    c[0] = pc.x & 0xFFFFFu;
+    c[1] = __builtin_amdgcn_alignbit(pc.y, pc.x, 20) & 0xFFFFFu;
+    c[2] = (pc.y >> 8) & 0xFFFFFu;
+    c[3] = __builtin_amdgcn_alignbit(pc.z, pc.y, 28) & 0xFFFFFu;
+    c[4] = __builtin_amdgcn_alignbit(pc.w, pc.z, 16) & 0xFFFFFu;
+    c[5] = (pc.w >> 4) & 0xFFFFFu;
+  };
+  auto piece = [&](const uint4& pc) -> uint32_t {
     const uint32_t cnt = pc.w >> 24;
-    uint32_t c[7], v[7];
+    uint32_t c[6], v[6];
+    codes6(pc, c);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {   // code j = 16 low bits | bit (16 + j) of the last word moved to bit 16
-      const uint32_t lo = (j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xFFFFu);
-      asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(c[j]) : "v"(pc.w >> j), "s"(0x10000u), "v"(lo));
-    }
+    for (int j = 0; j < 6; ++j) v[j] = *reinterpret_cast<l0_lds_u8*>((uintptr_t)c[j]);
+    uint32_t s6 = 0, m6 = 0, last = 0;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) v[j] = tab[c[j]];
-    uint32_t s7 = 0, m7 = 0, last = 0;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < 6; ++j) {
       last = (uint32_t)max((int)v[j], 8 * (int)v[j] - 8 * L0_LIN + L0_LIN);
-      s7 += last;
-      m7 = max(m7, v[j]);
+      s6 += last;
+      m6 = max(m6, v[j]);
     }
-    sum += s7 - (7u - cnt) * last;
-    mx = max(mx, cnt ? m7 : 0u);
+    s6 -= (6u - cnt) * last;
+    return s6 + ((cnt && m6 >= L0_ESC_BASE) ? (1u << 24) : 0u);
   };
-  for (; i < n; i += stride) {
+  auto body = [&](uint4 (&pc)[L0_UNROLL], uint4 (&pcn)[L0_UNROLL]) {
     // issue: lines of t+1, offsets of t+2, ids of t+3
-    uint4 pcn[L0_UNROLL];
 #pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(qb(m1.x, k), qb(m1.y, k));
-    const uint2 m3 = i + 3 * stride + kq < n ? pmeta[pid3] : make_uint2(0u, 0u);
-    const int32_t pid4 = i + 4 * stride + kq < n ? cpids[i + 4 * stride + kq] : 0;
-    uint32_t outv[L0_UNROLL], sums[L0_UNROLL], mxs[L0_UNROLL];
+    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(qb(m1.x, k));
+    const uint2 m3 = pmeta[pid3];
+    const int32_t pid4 = cpids[pos(i + 4 * stride)];
+    uint32_t outv[L0_UNROLL], sums[L0_UNROLL];
     uint16_t prev[L0_UNROLL] = {0, 0, 0, 0};   // the bounds so far (later ranges of a table beyond 2^17 centroids)
     if (!first) {
 #pragma unroll
       for (int k = 0; k < L0_UNROLL; ++k)
         if (i + k < n) prev[k] = ubrow[i + k];
     }
-#pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) { sums[k] = 0; mxs[k] = 0; }
-    if (abl & 1) {
+    if (ABL & 1) {
 #pragma unroll
       for (int k = 0; k < L0_UNROLL; ++k) sums[k] = (pc[k].x ^ pc[k].y ^ pc[k].z ^ pc[k].w) & 7u;
     } else {
 #pragma unroll
-      for (int k = 0; k < L0_UNROLL; ++k) piece(pc[k], sums[k], mxs[k]);   // straight-line: all 28 table reads of the lane in flight together
+      for (int k = 0; k < L0_UNROLL; ++k) sums[k] = piece(pc[k]);   // straight-line: all 24 table reads of the lane in flight together
     }
+#pragma unroll
+    for (int k = 0; k < L0_UNROLL; ++k) sums[k] = qb(m0.y, k) ? sums[k] : 0u;   // a document without codes read line 0
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
       const uint32_t l0k = qb(m0.x, k), nlk = qb(m0.y, k);
-      uint32_t sum = sums[k], mx = mxs[k];
-      for (uint32_t t = 1; t < nlk; ++t) {   // documents with more than 56 distinct codes
+      uint32_t sum = sums[k];
+      for (uint32_t t = 1; t < nlk; ++t) {   // documents with more than 48 distinct codes
         const uint4 more = pcodes[((int64_t)l0k + t) * 8 + sub];
-        piece(more, sum, mx);
+        sum += piece(more);
       }
-      sum = l0_red8(sum);
-      mx = l0_max8(mx);
-      if (mx >= L0_ESC_BASE) {
+      sum = l0_red8(sum);   // bits 24.. count the pieces that hold an escaped / infinite code (at most 8 x lines, far below 2^8)
+      if (sum >> 24) {
         // some code of this candidate has an escaped (e >= 800) or infinite excess: a second pass that takes the escape values
-        // from LDS.  The group branches as one (mx is the same in its 8 lanes); the first line is still in registers.
+        // from LDS.  The group branches as one (the sum is the same in its 8 lanes); the first line is still in registers.
         uint32_t s2 = 0, inf = 0;
         for (uint32_t t = 0; t < nlk; ++t) {
           const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)l0k + t) * 8 + sub];
-          const uint32_t w[4] = {q.x, q.y, q.z, q.w};
           const uint32_t cnt = q.w >> 24;
-          uint32_t s7 = 0, i7 = 0, last = 0;
+          uint32_t c[6];
+          codes6(q, c);
+          uint32_t s6 = 0, i6 = 0, last = 0;
 #pragma unroll
-          for (int j = 0; j < 7; ++j) {
-            const uint32_t c = ((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) | (((q.w >> (16 + j)) & 1u) << 16);
-            const uint32_t v = tab[c];
+          for (int j = 0; j < 6; ++j) {
+            const uint32_t v = tab[c[j]];
             const uint32_t ev = es[(max(v, (uint32_t)L0_ESC_BASE) - L0_ESC_BASE) & 63];
-            i7 |= (v == 255u) ? 1u : 0u;
+            i6 |= (v == 255u) ? 1u : 0u;
             last = v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
-            s7 += last;
+            s6 += last;
           }
-          s2 += s7 - (7u - cnt) * last;
-          inf |= cnt ? i7 : 0u;
+          s2 += s6 - (6u - cnt) * last;
+          inf |= cnt ? i6 : 0u;
         }
         sum = l0_red8(s2);
-        mx = l0_max8(inf);
-        sum = mx ? 0xFFFFFFu : sum;
+        sum = l0_max8(inf) ? 0xFFFFFFu : sum;
       }
       uint32_t v = (first ? F : (uint32_t)prev[k]) + sum;
       v = (sum >= 0xFFFFFFu || (!first && prev[k] == L0_INF)) ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
@@ -1843,10 +1901,15 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
           if (i + k < n) ubrow[i + k] = (uint16_t)outv[k];
       }
     }
-#pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) pc[k] = pcn[k];
     m0 = m1; m1 = m2; m2 = m3;
     pid3 = pid4;
+  };
+  while (i < n) {
+    body(pcA, pcB);
+    i += stride;
+    if (i >= n) break;
+    body(pcB, pcA);
+    i += stride;
   }
   __syncthreads();
   uint32_t* hg = hist + (int64_t)b * L0_HBINS;
@@ -2136,16 +2199,35 @@ bool fpk_l0_fits(const FpIndexDev& ix) { return ix.n_ranges >= 1 && ix.pcodes !=
 
 // level 0 in launch groups so that the scan kernel can be timed alone:
 //   prepare: floors + excess table;  scan: UB0 of every candidate (+ its histogram);  pilot: the top mult*keep documents by UB0
+// floors (+ their sum) from the bins of a centroid sample: S8s is [B][nch][ns][32], the bins of the centroids 0, stride, 2 stride, ...
+// (fpk_l0_sample_plan), exactly the sample k_l0_floor takes from a full table
+void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride) {
+  *stride = ix.C > L0_SAMPLE ? ix.C / L0_SAMPLE : 1;
+  *n_rows = (ix.C + *stride - 1) / *stride;
+}
+void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, hipStream_t st) {
+  const int nch = sh.Qp / 32;
+  static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
+  static std::atomic<uint64_t> ok1{0};
+  fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
+  // n_rows <= L0_SAMPLE * 2: the kernel's own sampling stride over this table is 1 or (for 8192 < n_rows) still covers it
+  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum);
+  (void)hipMemsetAsync(esc, 0, (size_t)sh.B * 64 * 4, st);
+}
+
+// S8 != nullptr: floors and the table from the full 8-bit table (two passes over it);  S8 == nullptr: both were produced
+// around S1 (fpk_l0_floors on a sampled pre-pass, the table in S1's epilogue) and only the histogram is cleared here
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st) {
   const int B = sh.B;
   const int nch = sh.Qp / 32;
   const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
+  (void)hipMemsetAsync(w.hist, 0, (size_t)B * L0_HBINS * 4, st);
+  if (!S8) return;
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum);
   (void)hipMemsetAsync(w.esc, 0, (size_t)B * 64 * 4, st);
-  (void)hipMemsetAsync(w.hist, 0, (size_t)B * L0_HBINS * 4, st);
   hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,
                      w.esc);
 }
@@ -2154,8 +2236,8 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
                  hipStream_t st) {
   const int B = sh.B;
   const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
-  static std::atomic<uint64_t> ok2{0};
-  fp_allow_big_lds((const void*)k_l0_scan, ok2, 160 * 1024);
+  static std::atomic<uint64_t> ok2{0}, ok2a{0}, ok2b{0}, ok2c{0};
+  fp_allow_big_lds((const void*)k_l0_scan<0>, ok2, 160 * 1024);
   const int64_t per_q = (M + B - 1) / B;
   // each workgroup copies the table (up to 128 KiB) into LDS first: candidates per workgroup (measured at cfg2: 256 / 512 / 1024 /
   // 2048 / 4096 -> 1.99 / 1.76 / 1.60 / 1.51 / 1.51 ms with the first version of the kernel)
@@ -2164,11 +2246,24 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
   static const int abl = [] { const char* e = getenv("FP_L0_ABL"); return e ? atoi(e) : 0; }();   // timing experiments only (results are wrong)
+  if (abl & 3) {
+    fp_allow_big_lds((const void*)k_l0_scan<1>, ok2a, 160 * 1024);
+    fp_allow_big_lds((const void*)k_l0_scan<2>, ok2b, 160 * 1024);
+    fp_allow_big_lds((const void*)k_l0_scan<3>, ok2c, 160 * 1024);
+  }
   for (int r = 0; r < ix.n_ranges; ++r) {
     const int64_t off = (int64_t)r * FP_L0_RANGE;
     const int tb = (int)std::min<int64_t>(FP_L0_RANGE, Cpad - off);
-    hipLaunchKernelGGL(k_l0_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off,
-                       cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, abl);
+#define L0_LAUNCH(A_) \
+    hipLaunchKernelGGL(k_l0_scan<A_>, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
+                       cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0)
+    switch (abl & 3) {
+      case 1: L0_LAUNCH(1); break;
+      case 2: L0_LAUNCH(2); break;
+      case 3: L0_LAUNCH(3); break;
+      default: L0_LAUNCH(0); break;
+    }
+#undef L0_LAUNCH
   }
 }
 

@@ -306,8 +306,8 @@ fail:
 // of 16 bytes, a piece = 7 codes of up to 17 bits: bytes 0-13 the low 16 bits, byte 14 bit j = bit 16 of code j, byte 15 =
 // number of codes in the piece.  56 codes per line (one line per document on the benchmark corpus: 33 codes), any number of
 // lines per document; a lane reads ONE aligned 16-byte piece and needs nothing from its neighbours.  C <= 2^17 only.
-#define PCODES_PER_PIECE 7
-#define PCODES_PER_LINE 56
+#define PCODES_PER_PIECE 6
+#define PCODES_PER_LINE 48
 // sub-run of a document's ascending unique codes that falls in [lo, hi): rs[d] .. re[d] (positions in ucodes)
 __global__ void k_pcode_range(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ uoff, int64_t n_docs, int32_t lo, int32_t hi,
                               int64_t* __restrict__ rs, int64_t* __restrict__ re) {
@@ -349,10 +349,11 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
     }
     const int64_t u0 = rs[lo], n = re[lo] - u0;
     const int64_t first = (line - loff[lo]) * PCODES_PER_LINE + (int64_t)piece * PCODES_PER_PIECE;
-    // slots past the piece's last code repeat that code (an empty piece holds code 0 seven times): the scan sums all seven
-    // table entries and takes (7 - count) x the last one off again, instead of predicating every lookup
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    uint32_t hib = 0, cnt = 0, last = 0;
+    // piece = 6 codes of 20 bits (bits 0..119) + the count in bits 120..127.  Slots past the piece's last code repeat that code
+    // (an empty piece holds code 0 six times): the scan sums all six table entries and takes (6 - count) x the last one off
+    // again, instead of predicating every lookup
+    unsigned __int128 bits = 0;
+    uint32_t cnt = 0, last = 0;
     for (int j = 0; j < PCODES_PER_PIECE; ++j) {
       uint32_t c = last;
       if (first + j < n) {
@@ -360,10 +361,11 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
         last = c;
         ++cnt;
       }
-      w[j >> 1] |= (c & 0xFFFFu) << (16 * (j & 1));
-      hib |= ((c >> 16) & 1u) << j;
+      bits |= (unsigned __int128)(c & 0xFFFFFu) << (20 * j);
     }
-    w[3] |= (hib << 16) | (cnt << 24);
+    bits |= (unsigned __int128)cnt << 120;
+    uint32_t w[4];
+    for (int k = 0; k < 4; ++k) w[k] = (uint32_t)(bits >> (32 * k));
     lines[g] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }

@@ -114,6 +114,11 @@ class PyLoadedIndex:
     def n_unique_codes(self):
         return int(N.lib().fp_index_num_unique_codes(self._h))
 
+    @property
+    def n_code_lines(self):
+        """128-byte lines of packed unique codes that S4's level-0 stage streams (all centroid ranges)."""
+        return int(N.lib().fp_index_num_code_lines(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib().fp_index_destroy(self._h)
