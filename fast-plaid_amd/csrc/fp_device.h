@@ -84,6 +84,36 @@ static inline void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done,
 }
 
 
+#if defined(__HIPCC__)
+// Bitonic sort of 1024 64-bit keys, one per thread of a 1024-thread workgroup, descending: returns the key of rank threadIdx.x.
+// Exchanges inside a wave go through lane shuffles (45 of the 55 stages: no barrier), the ten stages with partners in other
+// waves through `lds` ([1024] keys).  Same network as the all-LDS loops it replaces (k_final_topk / k_final_mark /
+// k_sel_finish took ~20 us for 1024 keys, most of it barriers).
+__device__ __forceinline__ unsigned long long fp_sort1024_desc(unsigned long long key, unsigned long long* lds) {
+  const int i = (int)threadIdx.x;
+  for (int k = 2; k <= 1024; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long other;
+      if (j >= 64) {
+        lds[i] = key;
+        __syncthreads();
+        other = lds[i ^ j];
+        __syncthreads();
+      } else {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, j, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j, 64);
+        other = ((unsigned long long)hi << 32) | lo;
+      }
+      const bool desc = ((i & k) == 0);
+      const bool lower = ((i & j) == 0);
+      const bool take_max = (lower == desc);
+      key = take_max ? (key > other ? key : other) : (key < other ? key : other);
+    }
+  }
+  return key;
+}
+#endif
+
 static inline int fp_next_pow2(int x) {
   int p = 1;
   while (p < x) p <<= 1;

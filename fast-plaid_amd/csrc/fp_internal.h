@@ -84,6 +84,7 @@ void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B
 // epilogue from the column floors of a sampled pre-pass
 struct FpS1Excess {
   const uint8_t* floors;   // [B][Qp]
+  const uint16_t* gfl;     // [B][Qp] fp16: floor - 100 (2000 for the pad columns)
   uint8_t* e8;             // [B][Cpad] (nullptr: off)
   uint32_t* esc;           // [B][64]
   int64_t Cpad;
@@ -144,7 +145,8 @@ bool fpk_l0_fits(const FpIndexDev& ix);
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8 /*nullptr: floors and table came with S1*/, const FpSearchShape& sh, FpL0Scratch& w,
                     hipStream_t st);
 void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride);
-void fpk_l0_floors(const uint8_t* S8_sample, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, hipStream_t st);
+void fpk_l0_floors(const uint8_t* S8_sample, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc,
+                   uint16_t* gfl /*[B][Qp] fp16 floors for S1's epilogue*/, hipStream_t st);
 void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w,
                  hipStream_t st);
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st);
@@ -153,7 +155,8 @@ void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const in
                       int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
-                float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st);
+                float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st,
+                bool short_lists = false /*lists of a few thousand entries: one workgroup per query does the whole radix select*/);
 // ---- fp_maxsim.hip ---------------------------------------------------------------------------
 // per-token norms of a freshly laid-out index (centroids / lut / codes / residuals set in `ix`)
 void fpk_token_norms(const FpIndexDev& ix, uint16_t* norms, hipStream_t st);

@@ -203,21 +203,25 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
     if (ex.e8) {
       // S4 level 0's table entry, straight from the tile (instead of writing the 8-bit bins and reading them back):
       // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass
-      const uint2 fw = *reinterpret_cast<const uint2*>(ex.floors + bq * Qp + q0 + ch * 8);
+      // packed fp16 throughout: 128 x, its floor, the clamp at bin 255 (floor = 155) and the difference to g = floor_q - 100
+      // are small integers, exact in fp16; pad columns carry g = 2000 (never positive) and score 0 (never clamped)
+      const uint4 gw = *reinterpret_cast<const uint4*>(ex.gfl + bq * Qp + q0 + ch * 8);
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      uint32_t part = 0, inf = 0;
+      const uint32_t gws[4] = {gw.x, gw.y, gw.z, gw.w};
+      const h2 k128 = {(half_t)128.f, (half_t)128.f}, k155 = {(half_t)155.f, (half_t)155.f}, kzero = {(half_t)0.f, (half_t)0.f};
+      h2 dsum = kzero, tmax = {(half_t)-1000.f, (half_t)-1000.f};
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const h2 pr = u32_as_h2(w[t >> 1]);
-        const float x = (float)((t & 1) ? pr.y : pr.x);
-        int bin = (int)floorf(x * 128.0f) + 100;
-        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
-        const int f = (int)(((t < 4 ? fw.x : fw.y) >> (8 * (t & 3))) & 0xFFu);
-        if (q0 + ch * 8 + t < ex.Q) {
-          part += (uint32_t)(bin > f ? bin - f : 0);
-          inf |= (bin == 255) ? 1u : 0u;
-        }
+      for (int t = 0; t < 4; ++t) {
+        h2 y = u32_as_h2(w[t]) * k128;
+        h2 fl;
+        fl.x = __builtin_floorf16(y.x);
+        fl.y = __builtin_floorf16(y.y);
+        tmax = __builtin_elementwise_max(tmax, fl);
+        const h2 d = __builtin_elementwise_min(fl, k155) - u32_as_h2(gws[t]);
+        dsum += __builtin_elementwise_max(d, kzero);
       }
+      const uint32_t part = (uint32_t)(int)(float)dsum.x + (uint32_t)(int)(float)dsum.y;
+      const uint32_t inf = ((float)tmax.x >= 155.f || (float)tmax.y >= 155.f) ? 1u : 0u;
       uint32_t acc = part | (inf << 31);   // (the sums stay far below 2^31: at most 64 columns x 255)
       {
         const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
@@ -743,8 +747,8 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
   if (force_fb < 0) force_fb = getenv("FP_PROBE_FALLBACK") ? 1 : 0;
   const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP / 2 && !force_fb;   // room for ties at the cut in the candidate list
   if (threshold_ok) {
-    (void)hipMemsetAsync(cand, 0, cols * PROBE_CAP * 8, st);
-    (void)hipMemsetAsync(cnt, 0, cols * 4 + 4, st);  // counters + flag
+    // candidate lists, counters and the flag in one fill (the chunk maxima and thresholds between them are rewritten below)
+    (void)hipMemsetAsync(cand, 0, (size_t)(reinterpret_cast<unsigned char*>(flag) + 4 - reinterpret_cast<unsigned char*>(cand)), st);
     dim3 grid((unsigned)nch2, (unsigned)(sh.B * (sh.Qp / 32)));
     // S1's 128-centroid column maxima serve as the chunk maxima when no subset masks centroids and their index fits 12 bits:
     // tau is tighter, and the collect pass skips the 128-row sub-chunks that hold nothing >= tau in any of their 32 columns
@@ -1630,22 +1634,49 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 
 // floors[b][Qp] u8 (pad columns 0), Fsum[b]; one workgroup per query
 __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S8, int64_t C, int Q, int nch, float tail,
-                                                   uint8_t* __restrict__ floors, uint32_t* __restrict__ Fsum) {
+                                                   uint8_t* __restrict__ floors, uint32_t* __restrict__ Fsum, uint32_t* __restrict__ esc,
+                                                   half_t* __restrict__ gfl /*nullable*/) {
   extern __shared__ uint32_t l0h[];   // [nch*32][256]
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) esc[(int64_t)b * 64 + tid] = 0u;   // the query's escape slots (filled by whoever builds the table next)
   const int ncol = nch * 32;
   for (int i = tid; i < ncol * 256; i += 1024) l0h[i] = 0u;
   __syncthreads();
   const int64_t stride = C > L0_SAMPLE ? C / L0_SAMPLE : 1;
   const int64_t ns = (C + stride - 1) / stride;
-  for (int64_t i = tid; i < ns * nch * 2; i += 1024) {   // (sample, chunk, 16-byte half)
-    const int half = (int)(i & 1);
-    const int ch = (int)((i >> 1) % nch);
-    const int64_t c = ((i >> 1) / nch) * stride;
-    const uint4 v = *reinterpret_cast<const uint4*>(S8 + (((int64_t)b * nch + ch) * C + c) * 32 + half * 16);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  // (sample, chunk, 16-byte half) items, four per thread and round: the four loads are issued before any of their atomics
+  // (one load per loop trip left the kernel waiting on memory latency 16 times: 34 us)
+  const int64_t items = ns * nch * 2;
+  const int rot = tid & 15;
+  for (int64_t i0 = tid; i0 < items; i0 += 4 * 1024) {
+    uint4 vv[4];
+    int colbase[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) atomicAdd(&l0h[(ch * 32 + half * 16 + j) * 256 + ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu)], 1u);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + (int64_t)u * 1024;
+      vv[u] = make_uint4(0, 0, 0, 0);
+      colbase[u] = -1;
+      if (i < items) {
+        const int half = (int)(i & 1);
+        const int ch = (int)((i >> 1) % nch);
+        const int64_t c = ((i >> 1) / nch) * stride;
+        vv[u] = *reinterpret_cast<const uint4*>(S8 + (((int64_t)b * nch + ch) * C + c) * 32 + half * 16);
+        colbase[u] = ch * 32 + half * 16;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (colbase[u] < 0) continue;
+      const uint4 v = vv[u];
+      // the lanes of a wave hold different samples of the SAME 16 columns, and a column's bins cluster around its mode: a
+      // lane-rotated column order spreads a wave's simultaneous atomics over 16 histograms instead of one
+#pragma unroll
+      for (int j0 = 0; j0 < 16; ++j0) {
+        const int j = (j0 + rot) & 15;
+        const uint32_t word = (j & 8) ? ((j & 4) ? v.w : v.z) : ((j & 4) ? v.y : v.x);
+        atomicAdd(&l0h[(colbase[u] + j) * 256 + ((word >> (8 * (j & 3))) & 0xFFu)], 1u);
+      }
+    }
   }
   __syncthreads();
   __shared__ uint32_t fl[64];
@@ -1663,6 +1694,7 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
     }
     fl[tid] = f;
     floors[(int64_t)b * ncol + tid] = (uint8_t)f;
+    if (gfl) gfl[(int64_t)b * ncol + tid] = tid < Q ? (half_t)((float)f - 100.f) : (half_t)2000.f;   // S1's epilogue form of the floors
   }
   __syncthreads();
   if (tid == 0) {
@@ -2205,14 +2237,15 @@ void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride) 
   *stride = ix.C > L0_SAMPLE ? ix.C / L0_SAMPLE : 1;
   *n_rows = (ix.C + *stride - 1) / *stride;
 }
-void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, hipStream_t st) {
+void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, uint16_t* gfl,
+                   hipStream_t st) {
   const int nch = sh.Qp / 32;
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
   // n_rows <= L0_SAMPLE * 2: the kernel's own sampling stride over this table is 1 or (for 8192 < n_rows) still covers it
-  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum);
-  (void)hipMemsetAsync(esc, 0, (size_t)sh.B * 64 * 4, st);
+  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum, esc,
+                     reinterpret_cast<half_t*>(gfl));
 }
 
 // S8 != nullptr: floors and the table from the full 8-bit table (two passes over it);  S8 == nullptr: both were produced
@@ -2226,8 +2259,8 @@ void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
-  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum);
-  (void)hipMemsetAsync(w.esc, 0, (size_t)B * 64 * 4, st);
+  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum, w.esc,
+                     (half_t*)nullptr);
   hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,
                      w.esc);
 }
@@ -2518,17 +2551,23 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
   for (int i = threadIdx.x; i < kp2; i += 1024)
     kv[i] = (i < (int)keep) ? (((unsigned long long)(uint32_t)op[i] << 32) | (unsigned long long)__float_as_uint(oa[i])) : ~0ull;
   __syncthreads();
-  for (int k = 2; k <= kp2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < kp2; i += 1024) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = kv[i], c = kv[ixj];
-          const bool up = ((i & k) == 0);
-          if ((a > c) == up) { kv[i] = c; kv[ixj] = a; }
+  if (kp2 == 1024) {   // one key per thread: ascending == descending on the complemented keys
+    const unsigned long long sorted = ~fp_sort1024_desc(~kv[threadIdx.x], kv);
+    kv[threadIdx.x] = sorted;
+    __syncthreads();
+  } else {
+    for (int k = 2; k <= kp2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < kp2; i += 1024) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = kv[i], c = kv[ixj];
+            const bool up = ((i & k) == 0);
+            if ((a > c) == up) { kv[i] = c; kv[ixj] = a; }
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   for (int i = threadIdx.x; i < (int)keep; i += 1024) {
@@ -2537,9 +2576,181 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
   }
 }
 
+// k_sel_init + the three histogram / scan rounds + k_sel_gather in ONE workgroup per query, for lists of a few thousand entries
+// (the survivors of S4's bound stages): nine launches of ~5 us each become one.  Same selstate / output contract as the
+// separate kernels; k_sel_finish / k_sel_collect follow unchanged.
+#define SEL_FRONT_REGS 16
+__global__ __launch_bounds__(1024) void k_sel_front(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                    const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R,
+                                                    uint32_t* __restrict__ st, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
+                                                    int32_t* __restrict__ tie_pid, int32_t* __restrict__ sel_cnt) {
+  __shared__ uint32_t h[FP_SEL_BINS];
+  __shared__ uint32_t sc[256];
+  __shared__ uint32_t s_prefix, s_rem, s_gt, s_eq, s_ovf, s_lo, s_hi;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
+  int64_t keep = n;
+  if (n_full < keep) keep = n_full;   // search.rs:605-611
+  if (R < keep) keep = R;             // :614-619
+  if (keep < 0) keep = 0;
+  uint32_t* s = st + (int64_t)b * 8;
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  int32_t* tp = tie_pid + (int64_t)b * R;
+  const bool need = keep < n;
+  const bool in_regs = n <= (int64_t)SEL_FRONT_REGS * 1024;   // (uniform) the list fits the workgroup's registers
+  uint32_t kreg[SEL_FRONT_REGS];
+  if (tid == 0) {
+    s[0] = need ? 1u : 0u; s[1] = (uint32_t)keep; s[4] = (uint32_t)n;
+    sel_cnt[b] = (int32_t)keep;
+    s_prefix = 0u; s_rem = (uint32_t)keep; s_gt = 0u; s_eq = 0u; s_ovf = 0u; s_lo = 0xFFFFFFFFu; s_hi = 0u;
+  }
+  if (!need) {   // everything is kept, already in ascending doc-id order
+    for (int64_t i = tid; i < keep; i += 1024) { op[i] = cand_pid[beg + i]; oa[i] = approx[beg + i]; }
+    if (tid == 0) { s[2] = 0u; s[3] = (uint32_t)keep; s[5] = 0u; s[6] = 0u; s[7] = 0u; }
+    return;
+  }
+  __syncthreads();
+  // Radix select over the RANGE of the keys, 11 bits per round: bin = (key - lo) >> shift.  (Fixed digits of the raw key put
+  // nearly every element into one or two bins in the first round -- the scores of a query share sign, exponent and leading
+  // mantissa bits -- and same-address LDS atomics serialise: 33 us for 6 k elements.)
+  {
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    if (in_regs) {   // all loads of the thread in flight together; the later rounds never touch memory
+#pragma unroll
+      for (int c = 0; c < SEL_FRONT_REGS; ++c) {
+        const int64_t i = tid + (int64_t)c * 1024;
+        kreg[c] = i < n ? mono32(approx[beg + i]) : 0u;
+      }
+#pragma unroll
+      for (int c = 0; c < SEL_FRONT_REGS; ++c) {
+        if (tid + (int64_t)c * 1024 < n) {
+          kmin = kreg[c] < kmin ? kreg[c] : kmin;
+          kmax = kreg[c] > kmax ? kreg[c] : kmax;
+        }
+      }
+    } else {
+      for (int64_t i = tid; i < n; i += 1024) {
+        const uint32_t k = mono32(approx[beg + i]);
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
+      }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const uint32_t a = (uint32_t)__shfl_xor((int)kmin, sft, 64), c = (uint32_t)__shfl_xor((int)kmax, sft, 64);
+      kmin = a < kmin ? a : kmin;
+      kmax = c > kmax ? c : kmax;
+    }
+    if ((tid & 63) == 0) { atomicMin(&s_lo, kmin); atomicMax(&s_hi, kmax); }
+  }
+  __syncthreads();
+  uint32_t lo = s_lo;
+  int shift = 0;
+  {
+    const uint32_t span = s_hi - lo;   // largest offset
+    const int bits = span ? 32 - __builtin_clz(span) : 1;
+    shift = bits > 11 ? bits - 11 : 0;
+  }
+  uint32_t nb_valid = FP_SEL_BINS;
+  for (;;) {   // at most three rounds
+    for (int i = tid; i < FP_SEL_BINS; i += 1024) h[i] = 0u;
+    __syncthreads();
+    if (in_regs) {
+#pragma unroll
+      for (int c = 0; c < SEL_FRONT_REGS; ++c) {
+        const uint32_t k = kreg[c];
+        if (tid + (int64_t)c * 1024 < n && k >= lo && ((k - lo) >> shift) < nb_valid) atomicAdd(&h[(k - lo) >> shift], 1u);
+      }
+    } else {
+      for (int64_t i = tid; i < n; i += 1024) {
+        const uint32_t k = mono32(approx[beg + i]);
+        if (k >= lo && ((k - lo) >> shift) < nb_valid) atomicAdd(&h[(k - lo) >> shift], 1u);
+      }
+    }
+    __syncthreads();
+    // 256 threads own 8 bins each from the top; inclusive scan of their sums; the thread whose bins hold the k_rem-th element
+    uint32_t loc[8];
+    uint32_t sum = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        loc[j] = h[FP_SEL_BINS - 1 - (tid * 8 + j)];
+        sum += loc[j];
+      }
+      sc[tid] = sum;
+    }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t t = (tid < 256 && tid >= off) ? sc[tid - off] : 0u;
+      __syncthreads();
+      if (tid < 256) sc[tid] += t;
+      __syncthreads();
+    }
+    if (tid < 256) {
+      const uint32_t k_rem = s_rem;
+      const uint32_t incl = sc[tid], excl = incl - sum;
+      if (excl < k_rem && incl >= k_rem) {   // exactly one thread
+        uint32_t cum = excl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (cum + loc[j] >= k_rem) {
+            s_prefix = (uint32_t)(FP_SEL_BINS - 1 - (tid * 8 + j));
+            s_rem = k_rem - cum;   // still needed from inside this bin
+            break;
+          }
+          cum += loc[j];
+        }
+      }
+    }
+    __syncthreads();
+    lo += s_prefix << shift;
+    if (shift == 0) break;
+    const int nshift = shift > 11 ? shift - 11 : 0;
+    nb_valid = 1u << (shift - nshift);   // the chosen bin, split again
+    shift = nshift;
+    __syncthreads();
+  }
+  if (tid == 0) s_prefix = lo;
+  __syncthreads();
+  const uint32_t kstar = s_prefix;
+  auto emit = [&](int64_t i, uint32_t key) {
+    if (key > kstar) {
+      const uint32_t pos = atomicAdd(&s_gt, 1u);
+      if (pos < (uint32_t)keep) { op[pos] = cand_pid[beg + i]; oa[pos] = unmono32(key); }
+    } else if (key == kstar) {
+      const uint32_t pos = atomicAdd(&s_eq, 1u);
+      if (pos < (uint32_t)R) tp[pos] = cand_pid[beg + i]; else s_ovf = 1u;
+    }
+  };
+  if (in_regs) {
+#pragma unroll
+    for (int c = 0; c < SEL_FRONT_REGS; ++c) {
+      const int64_t i = tid + (int64_t)c * 1024;
+      if (i < n) emit(i, kreg[c]);
+    }
+  } else {
+    for (int64_t i = tid; i < n; i += 1024) emit(i, mono32(approx[beg + i]));
+  }
+  __syncthreads();
+  if (tid == 0) { s[2] = kstar; s[3] = s_rem; s[5] = s_gt; s[6] = s_eq; s[7] = s_ovf; }
+}
+
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
-                uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st) {
+                uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
+                bool short_lists) {
   const int B = sh.B;
+  if (short_lists) {
+    hipLaunchKernelGGL(k_sel_front, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, sh.n_full, sh.R, selstate, sel_pid, sel_approx,
+                       tie_pid, sel_cnt);
+    static std::atomic<uint64_t> lds_ok2{0};
+    fp_allow_big_lds((const void*)k_sel_finish, lds_ok2, 144 * 1024);
+    int kp2 = 2;
+    while (kp2 < (int)sh.R) kp2 <<= 1;
+    hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8, st, selstate, sh.R, sel_pid, sel_approx, tie_pid);
+    hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx);
+    return;
+  }
   (void)hipMemsetAsync(hist, 0, (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t), st);
   hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, cand_off, B, sh.n_full, sh.R, selstate, sel_cnt);
   dim3 gh(64, (unsigned)B);
@@ -2597,17 +2808,23 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
   }
   atomicAdd(s_validp, myvalid);
   __syncthreads();
-  for (int k = 2; k <= npow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          unsigned long long a = v[i], c = v[ixj];
-          bool desc = ((i & k) == 0);
-          if ((a < c) == desc) { v[i] = c; v[ixj] = a; }
+  if (npow2 == 1024 && blockDim.x == 1024) {   // one key per thread: shuffle-based network
+    const unsigned long long sorted = fp_sort1024_desc(v[threadIdx.x], v);
+    v[threadIdx.x] = sorted;
+    __syncthreads();
+  } else {
+    for (int k = 2; k <= npow2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+          int ixj = i ^ j;
+          if (ixj > i) {
+            unsigned long long a = v[i], c = v[ixj];
+            bool desc = ((i & k) == 0);
+            if ((a < c) == desc) { v[i] = c; v[ixj] = a; }
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   const int valid = *s_validp;

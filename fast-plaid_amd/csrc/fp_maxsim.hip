@@ -544,17 +544,23 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
   if (any) s_any = 1;
   __syncthreads();
   if (s_any) {   // (uniform) nothing flagged -> nothing to mark, no sort needed
-    for (int k = 2; k <= npow2; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const unsigned long long x = v[i], y = v[ixj];
-            const bool desc = ((i & k) == 0);
-            if ((x < y) == desc) { v[i] = y; v[ixj] = x; }
+    if (npow2 == 1024 && blockDim.x == 1024) {   // one key per thread: shuffle-based network
+      const unsigned long long sorted = fp_sort1024_desc(v[threadIdx.x], v);
+      v[threadIdx.x] = sorted;
+      __syncthreads();
+    } else {
+      for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+              const unsigned long long x = v[i], y = v[ixj];
+              const bool desc = ((i & k) == 0);
+              if ((x < y) == desc) { v[i] = y; v[ixj] = x; }
+            }
           }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
     const float inf = __builtin_inff();
