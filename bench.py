@@ -241,8 +241,8 @@ def main():
     par = {"single": "1 GPU",
            "replica": "full index replica per GPU, batch split %d-way, result all-gather over %s" % (
                world, "RCCL" if a.dist_backend == "nccl" else "gloo (test mode: ranks share the visible GPUs)"),
-           "shard": "document-sharded x%d, 2 RCCL all-gathers/batch (%s)" % (
-               world, "issued by the library on the search stream" if (a.dist_impl == "native" and a.dist_backend == "nccl") else "torch.distributed between three stage calls")}[primary]
+           "shard": "document-sharded x%d, 3 RCCL all-gathers/batch (%s)" % (
+               world, "issued by the library on the search stream" if (a.dist_impl == "native" and a.dist_backend == "nccl") else "torch.distributed between four stage calls")}[primary]
 
     out = {
         "metric": "queries/sec @ top_k=%d (batch=%d, dim=%d); p50 search latency" % (a.topk, a.batch, a.dim),

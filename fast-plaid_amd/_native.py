@@ -67,7 +67,8 @@ SYMBOLS = {
     "fp_shard_R": (_i64, [_vp]),
     "fp_shard_stage1": (C.c_int, [_vp, _vp]),
     "fp_shard_stage2": (C.c_int, [_vp, _vp, _i32, _vp]),
-    "fp_shard_stage3": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "fp_shard_stage3": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
+    "fp_shard_stage4": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "fp_shard_end": (None, [_vp]),
     "fp_comm_unique_id": (C.c_int, [_vp]),
     "fp_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),

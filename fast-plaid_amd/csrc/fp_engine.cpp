@@ -116,14 +116,15 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
+  int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
-                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
+                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
                       &ms_nmark, &sh_rec, &sh_all})
       b->release();
     h_out.release();
@@ -1374,62 +1375,94 @@ extern "C" int fp_shard_stage2(fp_shard_ctx* c, const void* dev_all_rec1, int32_
     return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
   HIPCHK(s->exact.ensure((size_t)B * R * 4));
   if (!c->empty_all) {
-    // MFMA scores + budgets first (what the unsharded search ranks by), then EVERY flagged document of this shard repaired: the
-    // last stage marks the near-tied ones on the union and picks `exact` for exactly those
+    // MFMA scores + uncertainties (what the unsharded search ranks by); the near-tied documents are repaired in stage 3, once
+    // the union of all ranks' survivors is known
     if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, /*mode*/ 0)) return rc;
     fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
-                    D.pid_offset, dev_rec2, 0, s->st);
-    if (s->ms_repairable) {
-      if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, /*mode*/ 2)) return rc;
-      fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, 1, s->st);
-    }
+                    D.pid_offset, dev_rec2, s->st);
   } else {
-    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, 0, s->st);
+    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, s->st);
   }
   LAUNCHCHK("fp_shard_stage2");
   HIPCHK(hipStreamSynchronize(s->st));
   return FP_OK;
 }
 
-extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_t G, int64_t* out_pids, float* out_scores,
-                               int32_t* out_counts) {
-  if (!c || !dev_all_rec2 || G < 1 || !out_counts) return fail(FP_EINVAL, "bad argument");
-  HIPCHK(hipSetDevice(c->ix->device));
-  Scratch* s = c->s;
-  const int64_t R = c->P.sh.R;
-  const int B = c->B;
-  const int64_t K = c->params.top_k;
-  for (int i = 0; i < B; ++i) out_counts[i] = 0;
-  if (K == 0) return FP_OK;
-  // the union of the ranks' survivors in ascending id order == the unsharded rerank list
+// union + near-tie marking (identical on every rank) + repair of the marked documents this rank holds -> dev_x [B][R] f32
+static int shard_mark_and_repair(fp_index* ix, Scratch* s, const FpSearchShape& sh, const void* all_rec2, int G, int rank, bool empty_local,
+                                 int64_t K, float* x, hipStream_t st) {
+  const int B = sh.B;
+  const int64_t R = sh.R;
   HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
   HIPCHK(s->tmpf.ensure((size_t)3 * B * R * 4));
-  HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
+  HIPCHK(s->u_cnt.ensure((size_t)B * 4));
   HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
   HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
+  HIPCHK(s->sh_lmarks.ensure((size_t)B * R * 4));
+  HIPCHK(s->sh_lnmark.ensure((size_t)B * 4));
   float* u_score = s->tmpf.as<float>();
-  float* u_exact = u_score + (size_t)B * R;
-  float* u_unc = u_exact + (size_t)B * R;
-  if (fpk_shard_union(dev_all_rec2, G, B, R, s->tmpp.as<int64_t>(), u_score, u_exact, u_unc, s->sel_cnt.as<int32_t>(), s->st))
+  int32_t* u_src = reinterpret_cast<int32_t*>(u_score + (size_t)B * R);
+  float* u_unc = u_score + (size_t)2 * B * R;
+  if (fpk_shard_union(all_rec2, G, B, R, s->tmpp.as<int64_t>(), u_score, u_src, u_unc, s->u_cnt.as<int32_t>(), st))
     return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS merge of the sharded search (limit 16384 entries)");
   static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();
+  s->sh_marks_mode = 0;   // 0 nothing to exchange, 1 near-tied documents (marks), 2 every flagged document
   if (repair_env != 0) {
-    if (repair_env != 2 && fpk_final_mark(u_score, u_unc, s->sel_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), s->st) == 0)
-      fpk_apply_marks(s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), B, R, u_exact, u_score, s->st);
-    else
-      HIPCHK(hipMemcpyAsync(u_score, u_exact, (size_t)B * R * 4, hipMemcpyDeviceToDevice, s->st));   // every flagged document was repaired
+    s->sh_marks_mode = (repair_env != 2 && fpk_final_mark(u_score, u_unc, s->u_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(),
+                                                          s->ms_nmark.as<int32_t>(), st) == 0) ? 1 : 2;
+    const int32_t* marks = s->sh_marks_mode == 1 ? s->ms_marks.as<int32_t>() : nullptr;
+    fpk_shard_local_marks(marks, s->ms_nmark.as<int32_t>(), u_unc, s->u_cnt.as<int32_t>(), u_src, B, R, rank, s->sh_lmarks.as<int32_t>(),
+                          s->sh_lnmark.as<int32_t>(), st);
+    if (!empty_local && s->ms_repairable) {
+      FpMaxsimAux aux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>()};
+      fpk_maxsim_repair(ix->d, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->sh_lmarks.as<int32_t>(),
+                        s->sh_lnmark.as<int32_t>(), s->exact.as<float>(), aux, st);
+    }
+    fpk_shard_pack3(marks, s->ms_nmark.as<int32_t>(), u_unc, s->u_cnt.as<int32_t>(), u_src, B, R, rank, s->exact.as<float>(), x, st);
   }
+  return FP_OK;
+}
+
+static int shard_apply_and_rank(Scratch* s, const FpSearchShape& sh, const float* xall, int64_t K, int64_t* out_pids, float* out_scores,
+                                int32_t* out_counts, hipStream_t st) {
+  const int B = sh.B;
+  const int64_t R = sh.R;
+  float* u_score = s->tmpf.as<float>();
+  int32_t* u_src = reinterpret_cast<int32_t*>(u_score + (size_t)B * R);
+  float* u_unc = u_score + (size_t)2 * B * R;
+  if (s->sh_marks_mode != 0)
+    fpk_shard_apply3(s->sh_marks_mode == 1 ? s->ms_marks.as<int32_t>() : nullptr, s->ms_nmark.as<int32_t>(), u_unc, s->u_cnt.as<int32_t>(), u_src, B,
+                     R, xall, u_score, st);
   OutLayout ol(B, K);
   HIPCHK(s->out_all.ensure(ol.total));
   HIPCHK(s->h_out.ensure(ol.total));
   char* od = s->out_all.as<char>();
-  fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->sel_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
-                 reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), s->st);
-  LAUNCHCHK("fp_shard_stage3");
-  HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, s->st));
-  HIPCHK(hipStreamSynchronize(s->st));
+  fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->u_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
+                 reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
+  LAUNCHCHK("sharded merge");
+  HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);
   return FP_OK;
+}
+
+extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_t G, int32_t rank, void* dev_x) {
+  if (!c || !dev_all_rec2 || !dev_x || G < 1 || rank < 0 || rank >= G) return fail(FP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  Scratch* s = c->s;
+  if (c->params.top_k == 0) return FP_OK;
+  if (int rc = shard_mark_and_repair(c->ix, s, c->P.sh, dev_all_rec2, G, rank, c->empty_all, c->params.top_k, static_cast<float*>(dev_x), s->st)) return rc;
+  LAUNCHCHK("fp_shard_stage3");
+  HIPCHK(hipStreamSynchronize(s->st));
+  return FP_OK;
+}
+
+extern "C" int fp_shard_stage4(fp_shard_ctx* c, const void* dev_all_x, int32_t G, int64_t* out_pids, float* out_scores, int32_t* out_counts) {
+  if (!c || !dev_all_x || G < 1 || !out_counts) return fail(FP_EINVAL, "bad argument");
+  HIPCHK(hipSetDevice(c->ix->device));
+  for (int i = 0; i < c->B; ++i) out_counts[i] = 0;
+  if (c->params.top_k == 0) return FP_OK;
+  return shard_apply_and_rank(c->s, c->P.sh, static_cast<const float*>(dev_all_x), c->params.top_k, out_pids, out_scores, out_counts, c->s->st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1558,49 +1591,28 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   LAUNCHCHK("fp_shard_search (first all-gather)");
   if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st))
     return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
-  // exchange 2: exact scores of the local survivors
+  // exchange 2: MFMA scores + uncertainties of the local survivors
   if (!empty_local) {
     if (int rc = run_maxsim(ix, s, P.sh, R, K, 0)) return rc;
     fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
-                    D.pid_offset, s->sh_rec.p, 0, st);
-    if (s->ms_repairable) {
-      if (int rc = run_maxsim(ix, s, P.sh, R, K, 2)) return rc;
-      fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, 1, st);
-    }
+                    D.pid_offset, s->sh_rec.p, st);
   } else {
-    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, 0, st);
+    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
   }
   LAUNCHCHK("fp_shard_search (cut + MaxSim)");
   if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
   LAUNCHCHK("fp_shard_search (second all-gather)");
-  // merge (identical on every rank)
-  HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
-  HIPCHK(s->tmpf.ensure((size_t)3 * B * R * 4));
-  HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
-  HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
-  float* u_score = s->tmpf.as<float>();
-  float* u_exact = u_score + (size_t)B * R;
-  float* u_unc = u_exact + (size_t)B * R;
-  if (fpk_shard_union(s->sh_all.p, G, B, R, s->tmpp.as<int64_t>(), u_score, u_exact, u_unc, s->sel_cnt.as<int32_t>(), st))
-    return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS merge of the sharded search (limit 16384 entries)");
-  static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();
-  if (repair_env != 0) {
-    if (repair_env != 2 && fpk_final_mark(u_score, u_unc, s->sel_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), st) == 0)
-      fpk_apply_marks(s->ms_marks.as<int32_t>(), s->ms_nmark.as<int32_t>(), B, R, u_exact, u_score, st);
-    else
-      HIPCHK(hipMemcpyAsync(u_score, u_exact, (size_t)B * R * 4, hipMemcpyDeviceToDevice, st));
+  // exchange 3: the union and its near-tie marking are identical on every rank; each rank repairs the marked documents it holds
+  // and ships their scores ([B][R] floats by union position)
+  HIPCHK(s->sh_x.ensure((size_t)B * R * 4));
+  HIPCHK(s->sh_xall.ensure((size_t)G * B * R * 4));
+  if (int rc = shard_mark_and_repair(ix, s, P.sh, s->sh_all.p, G, comm->rank, empty_local, K, s->sh_x.as<float>(), st)) return rc;
+  LAUNCHCHK("fp_shard_search (marking + repair)");
+  if (s->sh_marks_mode != 0) {
+    if (int rc = api->AllGather(s->sh_x.p, s->sh_xall.p, (size_t)B * R * 4, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+    LAUNCHCHK("fp_shard_search (third all-gather)");
   }
-  OutLayout ol(B, K);
-  HIPCHK(s->out_all.ensure(ol.total));
-  HIPCHK(s->h_out.ensure(ol.total));
-  char* od = s->out_all.as<char>();
-  fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->sel_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
-                 reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
-  LAUNCHCHK("fp_shard_search (merge)");
-  HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  ol.scatter(s->h_out.p, out_pids, out_scores, out_counts);
-  return FP_OK;
+  return shard_apply_and_rank(s, P.sh, s->sh_xall.as<float>(), K, out_pids, out_scores, out_counts, st);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -185,12 +185,19 @@ void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
                      hipStream_t st);
 void fpk_shard_pack2(const float* score, const float* unc /*nullable*/, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
-                     int64_t pid_offset, void* rec2, int phase, hipStream_t st);
+                     int64_t pid_offset, void* rec2, hipStream_t st);
 int fpk_shard_global_cut(const void* all_rec1 /*[G][B][R]*/, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
                          int32_t* sel_pid /*[B][R] local*/, int32_t* sel_cnt, hipStream_t st);
-int fpk_shard_union(const void* all_rec2 /*[G][B][R]*/, int G, int B, int64_t R, int64_t* u_pid, float* u_score, float* u_exact, float* u_unc,
+// union of the ranks' survivors in ascending id order; u_src = rank * R + slot in that rank's rerank list
+int fpk_shard_union(const void* all_rec2 /*[G][B][R]*/, int G, int B, int64_t R, int64_t* u_pid, float* u_score, int32_t* u_src, float* u_unc,
                     int32_t* u_cnt, hipStream_t st);
-void fpk_apply_marks(const int32_t* marks, const int32_t* nmark, int B, int64_t R, const float* u_exact, float* u_score, hipStream_t st);
+// third exchange (marks = union positions of the near-tied documents, nullptr = every flagged document)
+void fpk_shard_local_marks(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B,
+                           int64_t R, int rank, int32_t* lmarks, int32_t* lnmark, hipStream_t st);
+void fpk_shard_pack3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
+                     int rank, const float* exact_local, float* x /*[B][R]*/, hipStream_t st);
+void fpk_shard_apply3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
+                      const float* xall /*[G][B][R]*/, float* u_score, hipStream_t st);
 // misc
 void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
 // create.rs:148-184, :404-428 on device pointers: nearest centroid (MFMA narrowing + exact re-check of the near-ties, or the exact

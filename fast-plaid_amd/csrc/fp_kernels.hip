@@ -1636,11 +1636,11 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S8, int64_t C, int Q, int nch, float tail,
                                                    uint8_t* __restrict__ floors, uint32_t* __restrict__ Fsum, uint32_t* __restrict__ esc,
                                                    half_t* __restrict__ gfl /*nullable*/) {
-  extern __shared__ uint32_t l0h[];   // [nch*32][256]
+  extern __shared__ uint32_t l0h[];   // [nch*32][257]: a column's bins, rows padded by one word so that the per-column scans below hit 32 banks
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid < 64) esc[(int64_t)b * 64 + tid] = 0u;   // the query's escape slots (filled by whoever builds the table next)
   const int ncol = nch * 32;
-  for (int i = tid; i < ncol * 256; i += 1024) l0h[i] = 0u;
+  for (int i = tid; i < ncol * 257; i += 1024) l0h[i] = 0u;
   __syncthreads();
   const int64_t stride = C > L0_SAMPLE ? C / L0_SAMPLE : 1;
   const int64_t ns = (C + stride - 1) / stride;
@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
       for (int j0 = 0; j0 < 16; ++j0) {
         const int j = (j0 + rot) & 15;
         const uint32_t word = (j & 8) ? ((j & 4) ? v.w : v.z) : ((j & 4) ? v.y : v.x);
-        atomicAdd(&l0h[(colbase[u] + j) * 256 + ((word >> (8 * (j & 3))) & 0xFFu)], 1u);
+        atomicAdd(&l0h[(colbase[u] + j) * 257 + ((word >> (8 * (j & 3))) & 0xFFu)], 1u);
       }
     }
   }
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
       uint32_t above = 0;
       int k = 255;
       for (; k > 0; --k) {
-        above += l0h[tid * 256 + k];
+        above += l0h[tid * 257 + k];
         if (above > lim) break;
       }
       f = (uint32_t)k;
@@ -2244,7 +2244,7 @@ void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, 
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
   // n_rows <= L0_SAMPLE * 2: the kernel's own sampling stride over this table is 1 or (for 8192 < n_rows) still covers it
-  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum, esc,
+  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum, esc,
                      reinterpret_cast<half_t*>(gfl));
 }
 
@@ -2259,7 +2259,7 @@ void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
-  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 256 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum, w.esc,
+  hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum, w.esc,
                      (half_t*)nullptr);
   hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,
                      w.esc);
@@ -2882,29 +2882,23 @@ void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int3
                      static_cast<ShardRec1*>(rec1), total);
 }
 
-// phase 0: pid / score / unc (exact := score); phase 1: exact only (after the repair pass)
+// pid / MFMA score / uncertainty of the local survivors (the `exact` field is kept for layout compatibility: = score)
 __global__ void k_shard_pack2(const float* __restrict__ score, const float* __restrict__ unc, const int32_t* __restrict__ pid,
-                              const int32_t* __restrict__ cnt, int64_t R, int64_t pid_offset, ShardRec2* __restrict__ out, int64_t total,
-                              int phase) {
+                              const int32_t* __restrict__ cnt, int64_t R, int64_t pid_offset, ShardRec2* __restrict__ out, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / R), r = (int)(i % R);
-  const bool live = r < cnt[b];
-  if (phase == 0) {
-    ShardRec2 o;
-    o.pad = 0;
-    if (live) { o.pid = (long long)pid[i] + pid_offset; o.score = score[i]; o.exact = score[i]; o.unc = unc ? unc[i] : 0.f; }
-    else { o.pid = -1; o.score = -__builtin_inff(); o.exact = -__builtin_inff(); o.unc = 0.f; }
-    out[i] = o;
-  } else if (live) {
-    out[i].exact = score[i];
-  }
+  ShardRec2 o;
+  o.pad = 0;
+  if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.score = score[i]; o.exact = score[i]; o.unc = unc ? unc[i] : 0.f; }
+  else { o.pid = -1; o.score = -__builtin_inff(); o.exact = -__builtin_inff(); o.unc = 0.f; }
+  out[i] = o;
 }
 void fpk_shard_pack2(const float* score, const float* unc, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset,
-                     void* rec2, int phase, hipStream_t st) {
+                     void* rec2, hipStream_t st) {
   const int64_t total = (int64_t)B * R;
   hipLaunchKernelGGL(k_shard_pack2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, score, unc, sel_pid, sel_cnt, R, pid_offset,
-                     static_cast<ShardRec2*>(rec2), total, phase);
+                     static_cast<ShardRec2*>(rec2), total);
 }
 
 // global cut: sort the union of the G ranks' local top-R by (approx desc, id asc), keep the first R valid, and
@@ -2992,7 +2986,7 @@ int fpk_shard_global_cut(const void* all_rec1, int G, int B, int64_t R, int64_t 
 // union of the ranks' exact-scored documents of one query, in ascending doc id order (== the unsharded rerank list):
 // u_pid / u_score / u_exact / u_unc [B][R], u_cnt [B]
 __global__ __launch_bounds__(1024) void k_shard_union(const ShardRec2* __restrict__ all, int G, int B, int npow2, int64_t R,
-                                                      int64_t* __restrict__ u_pid, float* __restrict__ u_score, float* __restrict__ u_exact,
+                                                      int64_t* __restrict__ u_pid, float* __restrict__ u_score, int32_t* __restrict__ u_src,
                                                       float* __restrict__ u_unc, int32_t* __restrict__ u_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);   // id << 32 | index into the [G*R] union
@@ -3032,12 +3026,12 @@ __global__ __launch_bounds__(1024) void k_shard_union(const ShardRec2* __restric
     const int64_t o = (int64_t)b * R + i;
     u_pid[o] = e.pid;
     u_score[o] = e.score;
-    u_exact[o] = e.exact;
+    u_src[o] = idx;          // rank * R + slot in that rank's rerank list
     u_unc[o] = e.unc;
   }
   if (threadIdx.x == 0) u_cnt[b] = nv;
 }
-int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pid, float* u_score, float* u_exact, float* u_unc, int32_t* u_cnt,
+int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pid, float* u_score, int32_t* u_src, float* u_unc, int32_t* u_cnt,
                     hipStream_t st) {
   const int n = (int)(G * R);
   const int np2 = next_pow2(n < 2 ? 2 : n);
@@ -3045,22 +3039,70 @@ int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pi
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_shard_union, lds_ok, 160 * 1024);
   hipLaunchKernelGGL(k_shard_union, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8, st, static_cast<const ShardRec2*>(all_rec2), G, B, np2, R, u_pid,
-                     u_score, u_exact, u_unc, u_cnt);
+                     u_score, u_src, u_unc, u_cnt);
   return 0;
 }
 
-// marked documents take their repaired score
-__global__ void k_apply_marks(const int32_t* __restrict__ marks, const int32_t* __restrict__ nmark, int64_t R, const float* __restrict__ u_exact,
-                              float* __restrict__ u_score) {
+// ---- third exchange of the sharded search: only the near-tied documents are repaired, by the rank that holds them ----
+// marks = union positions (k_final_mark on the union, identical on every rank; marks == nullptr: every flagged document).
+// lmarks / lnmark: the marked documents of THIS rank as slots of its rerank list (the input of the repair kernel).
+__global__ __launch_bounds__(256) void k_shard_local_marks(const int32_t* __restrict__ marks, const int32_t* __restrict__ nmark,
+                                                           const float* __restrict__ u_unc, const int32_t* __restrict__ u_cnt,
+                                                           const int32_t* __restrict__ u_src, int64_t R, int rank,
+                                                           int32_t* __restrict__ lmarks, int32_t* __restrict__ lnmark) {
+  __shared__ int s_n;
   const int b = blockIdx.x;
-  const int n = nmark[b];
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int64_t o = (int64_t)b * R + marks[(int64_t)b * R + i];
-    u_score[o] = u_exact[o];
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int n = marks ? nmark[b] : u_cnt[b];
+  for (int m = threadIdx.x; m < n; m += 256) {
+    const int p = marks ? marks[(int64_t)b * R + m] : m;
+    if (!marks && !(u_unc[(int64_t)b * R + p] > 0.f)) continue;
+    const int src = u_src[(int64_t)b * R + p];
+    if (src / (int)R == rank) lmarks[(int64_t)b * R + atomicAdd(&s_n, 1)] = src % (int)R;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) lnmark[b] = s_n;
+}
+// x[b][p] = the repaired score of union position p, for the marked documents this rank holds (other entries are not read)
+__global__ __launch_bounds__(256) void k_shard_pack3(const int32_t* __restrict__ marks, const int32_t* __restrict__ nmark,
+                                                     const float* __restrict__ u_unc, const int32_t* __restrict__ u_cnt,
+                                                     const int32_t* __restrict__ u_src, int64_t R, int rank,
+                                                     const float* __restrict__ exact_local, float* __restrict__ x) {
+  const int b = blockIdx.x;
+  const int n = marks ? nmark[b] : u_cnt[b];
+  for (int m = threadIdx.x; m < n; m += 256) {
+    const int p = marks ? marks[(int64_t)b * R + m] : m;
+    if (!marks && !(u_unc[(int64_t)b * R + p] > 0.f)) continue;
+    const int src = u_src[(int64_t)b * R + p];
+    if (src / (int)R == rank) x[(int64_t)b * R + p] = exact_local[(int64_t)b * R + src % (int)R];
   }
 }
-void fpk_apply_marks(const int32_t* marks, const int32_t* nmark, int B, int64_t R, const float* u_exact, float* u_score, hipStream_t st) {
-  hipLaunchKernelGGL(k_apply_marks, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, R, u_exact, u_score);
+// marked documents take the repaired score from the rank that holds them
+__global__ __launch_bounds__(256) void k_shard_apply3(const int32_t* __restrict__ marks, const int32_t* __restrict__ nmark,
+                                                      const float* __restrict__ u_unc, const int32_t* __restrict__ u_cnt,
+                                                      const int32_t* __restrict__ u_src, int64_t R, int B,
+                                                      const float* __restrict__ xall /*[G][B][R]*/, float* __restrict__ u_score) {
+  const int b = blockIdx.x;
+  const int n = marks ? nmark[b] : u_cnt[b];
+  for (int m = threadIdx.x; m < n; m += 256) {
+    const int p = marks ? marks[(int64_t)b * R + m] : m;
+    if (!marks && !(u_unc[(int64_t)b * R + p] > 0.f)) continue;
+    const int g = u_src[(int64_t)b * R + p] / (int)R;
+    u_score[(int64_t)b * R + p] = xall[((int64_t)g * B + b) * R + p];
+  }
+}
+void fpk_shard_local_marks(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B,
+                           int64_t R, int rank, int32_t* lmarks, int32_t* lnmark, hipStream_t st) {
+  hipLaunchKernelGGL(k_shard_local_marks, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, u_unc, u_cnt, u_src, R, rank, lmarks, lnmark);
+}
+void fpk_shard_pack3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
+                     int rank, const float* exact_local, float* x, hipStream_t st) {
+  hipLaunchKernelGGL(k_shard_pack3, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, u_unc, u_cnt, u_src, R, rank, exact_local, x);
+}
+void fpk_shard_apply3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
+                      const float* xall, float* u_score, hipStream_t st) {
+  hipLaunchKernelGGL(k_shard_apply3, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, u_unc, u_cnt, u_src, R, B, xall, u_score);
 }
 
 // ============================================================================================

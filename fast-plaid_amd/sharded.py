@@ -9,10 +9,13 @@ and a contiguous, token-balanced range of documents.  Per batch of queries:
   all-gather        [B,R] records {i64 id, f32 approx} (16 B)                                  (R = max(n_full/4, 1))
   stage2  (local)   global top-R cut == search.rs:605-619 applied to the union, exact
                     MaxSim of the survivors that live here
-  all-gather        [B,R] records {i64 id, f32 score, f32 exact, f32 budget} (24 B)
-  stage3  (local)   union in id order, near-tie marking as in the unsharded search, global (score desc, id asc) sort, top_k
+  all-gather        [B,R] records {i64 id, f32 score, f32 -, f32 budget} (24 B)
+  stage3  (local)   union in id order, near-tie marking as in the unsharded search (identical on every rank); exact-order
+                    repair of the marked documents that live here
+  all-gather        [B,R] f32: the repaired scores, by union position
+  stage4  (local)   marked documents take their repaired score, global (score desc, id asc) sort, top_k
 
-Both messages are fixed-size byte buffers (B*R*16 and B*R*24 bytes per rank; 6 MB at B=256, R=1024): latency-bound on
+The messages are fixed-size buffers (B*R*16, B*R*24 and B*R*4 bytes per rank; 11 MB at B=256, R=1024): latency-bound on
 xGMI, so each is ONE all_gather_into_tensor call on a device buffer -- no host staging, no variable-length exchange, no
 repacking (the library writes and reads the record layout directly).  The result is identical to the unsharded search on
 the concatenated corpus, bit for bit (tests/test_hip_parity.py::test_sharded_equals_unsharded).
@@ -70,7 +73,7 @@ def shard_arrays(arrays: dict, begin: int, end: int) -> dict:
 REC1_BYTES = 16   # fp_shard_rec1 {i64 pid; f32 approx; i32 pad}
 REC2_BYTES = 24   # fp_shard_rec2 {i64 pid; f32 score; f32 exact; f32 unc; i32 pad}
 REC1_DTYPE = np.dtype([("pid", "<i8"), ("approx", "<f4"), ("pad", "<i4")])
-REC2_DTYPE = np.dtype([("pid", "<i8"), ("score", "<f4"), ("exact", "<f4"), ("unc", "<f4"), ("pad", "<i4")])
+REC2_DTYPE = np.dtype([("pid", "<i8"), ("score", "<f4"), ("reserved", "<f4"), ("unc", "<f4"), ("pad", "<i4")])
 
 
 class HipShardEngine:
@@ -108,12 +111,18 @@ class HipShardEngine:
         N.check(N.lib().fp_shard_stage2(st["ctx"], all_rec1.data_ptr(), world, rec.data_ptr()))
         return rec
 
-    def stage3(self, st, all_rec2, world):
+    def stage3(self, st, all_rec2, world, rank):
+        t = self.torch
+        x = t.zeros((st["B"], st["R"]), dtype=t.float32, device=self.device)
+        N.check(N.lib().fp_shard_stage3(st["ctx"], all_rec2.data_ptr(), world, rank, x.data_ptr()))
+        return x
+
+    def stage4(self, st, all_x, world):
         B, k = st["B"], max(st["top_k"], 1)
         pids = np.full((B, k), -1, np.int64)
         scores = np.zeros((B, k), np.float32)
         counts = np.zeros(B, np.int32)
-        N.check(N.lib().fp_shard_stage3(st["ctx"], all_rec2.data_ptr(), world, pids.ctypes.data_as(C.c_void_p),
+        N.check(N.lib().fp_shard_stage4(st["ctx"], all_x.data_ptr(), world, pids.ctypes.data_as(C.c_void_p),
                                         scores.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
         return pids[:, : st["top_k"]], scores[:, : st["top_k"]], counts
 
@@ -188,8 +197,8 @@ def _all_gather(torch, dist, x, world, group, force=False):
 
 
 def sharded_search(engine, queries_f16, params, dist=None, group=None, force_collectives=False):
-    """Runs one batch through the three stages with the two all-gathers in between.
-    `engine` implements begin/stage1/stage2/stage3/end (HipShardEngine in production).
+    """Runs one batch through the four stages with the three all-gathers in between.
+    `engine` implements begin/stage1/stage2/stage3/stage4/end (HipShardEngine in production).
     Returns (pids [B,top_k], scores, counts) -- identical on every rank."""
     import torch
     world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
@@ -203,7 +212,12 @@ def sharded_search(engine, queries_f16, params, dist=None, group=None, force_col
         all2 = _all_gather(torch, dist, rec2, world, group, force_collectives)
         if all2.is_cuda:
             torch.cuda.current_stream().synchronize()
-        return engine.stage3(st, all2, world)
+        rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+        x = engine.stage3(st, all2, world, rank)                     # [B, R] f32: repaired scores of this rank's near-tied documents
+        allx = _all_gather(torch, dist, x, world, group, force_collectives)
+        if allx.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return engine.stage4(st, allx, world)
     finally:
         engine.end(st)
 

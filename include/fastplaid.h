@@ -188,7 +188,7 @@ int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int
 /* ---- document-sharded search (one process per GPU; collectives stay with the caller) -
  * New relative to the reference, which only runs full replicas per device
  * (fast_plaid.py:893-928).  Every rank holds the full centroid table and a disjoint
- * document shard (fp_index_desc.pid_offset = first global id).  The three stages are
+ * document shard (fp_index_desc.pid_offset = first global id).  The four stages are
  * separated exactly where data must cross ranks; between them the caller all-gathers ONE
  * fixed-size device buffer of records per rank (RCCL: torch.distributed "nccl" on ROCm, or
  * ncclAllGather on bytes):
@@ -198,27 +198,31 @@ int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int
  *   (all-gather to [G,B,R])
  *   stage2: global top-R cut (reproduces search.rs:605-619 on the union), exact MaxSim of
  *           the survivors that live on this rank
- *           -> dev rec2 [B,R]  (fp_shard_rec2: the MFMA score, its uncertainty budget, and
- *              the score with every flagged column re-evaluated in the reference's order)
+ *           -> dev rec2 [B,R]  (fp_shard_rec2: the MFMA score and its uncertainty budget)
  *   (all-gather to [G,B,R])
  *   stage3: union in ascending id order, the unsharded search's near-tie marking on it
- *           (marked documents take `exact`), global sort + top_k -> host outputs as fp_search.
+ *           (identical on every rank); this rank repairs the marked documents it holds
+ *           -> dev x [B,R] f32 (by union position; only this rank's marked entries are meaningful)
+ *   (all-gather to [G,B,R])
+ *   stage4: marked documents take the repaired score of their rank, global sort + top_k
+ *           -> host outputs as fp_search.
  * R = max(n_full_scores/4, 1).  The result is identical to fp_search on the whole corpus,
  * bit for bit, for any G. */
 typedef struct fp_shard_rec1 { int64_t pid; float approx; int32_t pad; } fp_shard_rec1;                        /* 16 bytes */
-typedef struct fp_shard_rec2 { int64_t pid; float score; float exact; float unc; int32_t pad; } fp_shard_rec2; /* 24 bytes */
+typedef struct fp_shard_rec2 { int64_t pid; float score; float reserved; float unc; int32_t pad; } fp_shard_rec2; /* 24 bytes */
 int fp_shard_begin(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
                    const fp_search_params* params, fp_shard_ctx** out);
 int64_t fp_shard_R(const fp_shard_ctx* ctx);
 int fp_shard_stage1(fp_shard_ctx* ctx, void* dev_rec1 /*[B,R] fp_shard_rec1*/);
 int fp_shard_stage2(fp_shard_ctx* ctx, const void* dev_all_rec1 /*[G,B,R]*/, int32_t n_ranks, void* dev_rec2 /*[B,R] fp_shard_rec2*/);
-int fp_shard_stage3(fp_shard_ctx* ctx, const void* dev_all_rec2 /*[G,B,R]*/, int32_t n_ranks, int64_t* out_pids, float* out_scores,
+int fp_shard_stage3(fp_shard_ctx* ctx, const void* dev_all_rec2 /*[G,B,R]*/, int32_t n_ranks, int32_t rank, void* dev_x /*[B,R] f32*/);
+int fp_shard_stage4(fp_shard_ctx* ctx, const void* dev_all_x /*[G,B,R] f32*/, int32_t n_ranks, int64_t* out_pids, float* out_scores,
                     int32_t* out_counts);
 void fp_shard_end(fp_shard_ctx* ctx);
 
 /* The same sharded search with the collectives issued by the library (RCCL over xGMI, bound with dlopen at first use): both
  * all-gathers are enqueued on the search stream behind the kernels that fill their send buffers -- no host synchronisation
- * between the stages, no framework in the data path.  One communicator per process / GPU:
+ * between the stages, no framework in the data path (three all-gathers: 16 + 24 + 4 bytes per rerank slot).  One communicator per process / GPU:
  *   rank 0: fp_comm_unique_id(id) -> the caller ships the 128 bytes to every rank (any out-of-band channel)
  *   all   : fp_comm_create(device, n_ranks, rank, id, &comm)      (collective: ncclCommInitRank)
  *   all   : fp_shard_search(shard_index, comm, ...)                (collective; identical results on every rank, == fp_search

@@ -16,7 +16,7 @@ from fast_plaid_amd import sharded  # noqa: E402
 
 class OracleShardEngine:
     """Stand-in for HipShardEngine built on the CPU oracle (TEST ONLY): same stage contract
-    as include/fastplaid.h fp_shard_stage1/2/3."""
+    as include/fastplaid.h fp_shard_stage1/2/3/4."""
 
     def __init__(self, arr, begin, end):
         self.begin_, self.end_ = begin, end
@@ -48,7 +48,6 @@ class OracleShardEngine:
         rec = np.zeros((B, R), sharded.REC2_DTYPE)
         rec["pid"] = -1
         rec["score"] = -np.inf
-        rec["exact"] = -np.inf
         for b in range(B):
             a = all1[:, b, :]["approx"].reshape(-1)
             p = all1[:, b, :]["pid"].reshape(-1)
@@ -59,18 +58,23 @@ class OracleShardEngine:
             if len(mine):
                 ex = self.idx.exact_scores(st["q"][b], mine - self.begin_)   # the oracle's scores are exact: budget 0
                 rec[b, : len(mine)]["score"] = ex
-                rec[b, : len(mine)]["exact"] = ex
                 rec[b, : len(mine)]["pid"] = mine
         return torch.from_numpy(rec.view(np.uint8).reshape(B, R * sharded.REC2_BYTES))
 
-    def stage3(self, st, all_rec2, world):
-        B, k, R = st["B"], st["top_k"], st["R"]
-        all2 = all_rec2.numpy().reshape(world, B, R * sharded.REC2_BYTES).view(sharded.REC2_DTYPE).reshape(world, B, R)
+    def stage3(self, st, all_rec2, world, rank):
+        # the oracle's scores are exact (budget 0): nothing is marked, the third message carries no information
+        st["all2"] = all_rec2.numpy().reshape(world, st["B"], st["R"] * sharded.REC2_BYTES).view(sharded.REC2_DTYPE).reshape(world, st["B"], st["R"])
+        return torch.zeros((st["B"], st["R"]), dtype=torch.float32)
+
+    def stage4(self, st, all_x, world):
+        B, k = st["B"], st["top_k"]
+        assert tuple(all_x.shape) == (world, B, st["R"])
+        all2 = st["all2"]
         pids = np.full((B, k), -1, np.int64)
         scores = np.zeros((B, k), np.float32)
         counts = np.zeros(B, np.int32)
         for b in range(B):
-            s = all2[:, b, :]["exact"].reshape(-1)
+            s = all2[:, b, :]["score"].reshape(-1)
             p = all2[:, b, :]["pid"].reshape(-1)
             ok = p >= 0
             s, p = s[ok], p[ok]

@@ -34,8 +34,10 @@ def main():
     torch.cuda.synchronize()
     all2 = torch.stack([en.stage2(st, all1, G) for en, st in zip(engines, sts)]).contiguous()
     torch.cuda.synchronize()
+    allx = torch.stack([en.stage3(st, all2, G, r) for r, (en, st) in enumerate(zip(engines, sts))]).contiguous()   # [G, B, R] f32
+    torch.cuda.synchronize()
     for en, st in zip(engines, sts):
-        p3, s3, c3 = en.stage3(st, all2, G)
+        p3, s3, c3 = en.stage4(st, allx, G)
         assert np.array_equal(c3, counts), (c3, counts)
         for b in range(q.shape[0]):
             assert np.array_equal(p3[b, : c3[b]], pids[b, : counts[b]]), b
