@@ -116,7 +116,7 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -124,7 +124,7 @@ struct Scratch {
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
-                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
+                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
                       &ms_nmark, &sh_rec, &sh_all})
       b->release();
     h_out.release();
@@ -777,14 +777,15 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
   HIPCHK(s->ms_pref.ensure((size_t)(B + 1) * 8));
   const bool repair = repair_env != 0 && fpk_maxsim_fast_shape(D.dim, D.nbits);
   s->ms_repairable = repair;
-  FpMaxsimAux aux{nullptr, nullptr, nullptr};
+  FpMaxsimAux aux{nullptr, nullptr, nullptr, nullptr};
   if (repair) {
     HIPCHK(s->ms_cm16.ensure((size_t)B * R * sh.Qp * 2));
     HIPCHK(s->ms_unc.ensure((size_t)B * R * 4));
+    HIPCHK(s->ms_uncm.ensure((size_t)B * R * 4));
     HIPCHK(s->ms_flags.ensure((size_t)B * R * (sh.Qp / 32) * 4));
     HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
     HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
-    aux = FpMaxsimAux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>()};
+    aux = FpMaxsimAux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>(), s->ms_uncm.as<float>()};
   }
   if (mode != 2) {
     if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(),
@@ -795,7 +796,7 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
   if (stage_event) STAGE_DONE(ST_REPAIR);   // "S6+S7 maxsim" is the MaxSim kernel alone (+ the 4 us prefix kernel in front of it)
   if (repair && mode != 0) {
     const bool marked = mode == 1 && repair_env != 2 &&
-                        fpk_final_mark(s->exact.as<float>(), aux.unc, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
+                        fpk_final_mark(s->exact.as<float>(), aux.unc, aux.uncm, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
                                        s->ms_nmark.as<int32_t>(), st) == 0;
     s->ms_have_marks = false;
     if (marked && (size_t)B * 4 + 64 <= 4096) {   // marked documents per query -> pinned memory, summed for fp_last_search_counts after the final sync
@@ -1062,6 +1063,7 @@ extern "C" int fp_maxsim_columns(const fp_index* cix, const uint16_t* query, int
   HIPCHK(s->ms_pref.ensure(16));
   HIPCHK(s->ms_cm16.ensure((size_t)n * sh.Qp * 2));
   HIPCHK(s->ms_unc.ensure((size_t)n * 4));
+  HIPCHK(s->ms_uncm.ensure((size_t)n * 4));
   HIPCHK(s->ms_flags.ensure((size_t)n * nflag * 4));
   HIPCHK(hipMemcpyAsync(s->qin.p, query, (size_t)Q * dim * 2, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(s->sel_pid.p, loc.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1071,7 +1073,7 @@ extern "C" int fp_maxsim_columns(const fp_index* cix, const uint16_t* query, int
   HIPCHK(hipMemsetAsync(s->ms_cm16.p, 0, (size_t)n * sh.Qp * 2, st));
   fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), 1, Q, sh.Qp, dim, st);
   const bool fast = fpk_maxsim_fast_shape(D.dim, D.nbits);
-  FpMaxsimAux aux{fast ? s->ms_cm16.as<uint16_t>() : nullptr, s->ms_unc.as<float>(), fast ? s->ms_flags.as<uint32_t>() : nullptr};
+  FpMaxsimAux aux{fast ? s->ms_cm16.as<uint16_t>() : nullptr, s->ms_unc.as<float>(), fast ? s->ms_flags.as<uint32_t>() : nullptr, s->ms_uncm.as<float>()};
   if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), n, s->exact.as<float>(),
                  s->ms_pref.as<int64_t>(), aux, st))
     return fail(FP_EUNSUPPORTED, "dim/nbits");
@@ -1378,10 +1380,11 @@ extern "C" int fp_shard_stage2(fp_shard_ctx* c, const void* dev_all_rec1, int32_
     // MFMA scores + uncertainties (what the unsharded search ranks by); the near-tied documents are repaired in stage 3, once
     // the union of all ranks' survivors is known
     if (int rc = run_maxsim(c->ix, s, c->P.sh, R, c->params.top_k, /*mode*/ 0)) return rc;
-    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
+    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->ms_repairable ? s->ms_uncm.as<float>() : nullptr,
+                    s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
                     D.pid_offset, dev_rec2, s->st);
   } else {
-    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, s->st);
+    fpk_shard_pack2(s->exact.as<float>(), nullptr, nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, dev_rec2, s->st);
   }
   LAUNCHCHK("fp_shard_stage2");
   HIPCHK(hipStreamSynchronize(s->st));
@@ -1394,7 +1397,7 @@ static int shard_mark_and_repair(fp_index* ix, Scratch* s, const FpSearchShape& 
   const int B = sh.B;
   const int64_t R = sh.R;
   HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
-  HIPCHK(s->tmpf.ensure((size_t)3 * B * R * 4));
+  HIPCHK(s->tmpf.ensure((size_t)4 * B * R * 4));
   HIPCHK(s->u_cnt.ensure((size_t)B * 4));
   HIPCHK(s->ms_marks.ensure((size_t)B * R * 4));
   HIPCHK(s->ms_nmark.ensure((size_t)B * 4));
@@ -1403,18 +1406,19 @@ static int shard_mark_and_repair(fp_index* ix, Scratch* s, const FpSearchShape& 
   float* u_score = s->tmpf.as<float>();
   int32_t* u_src = reinterpret_cast<int32_t*>(u_score + (size_t)B * R);
   float* u_unc = u_score + (size_t)2 * B * R;
-  if (fpk_shard_union(all_rec2, G, B, R, s->tmpp.as<int64_t>(), u_score, u_src, u_unc, s->u_cnt.as<int32_t>(), st))
+  float* u_uncm = u_score + (size_t)3 * B * R;
+  if (fpk_shard_union(all_rec2, G, B, R, s->tmpp.as<int64_t>(), u_score, u_src, u_unc, u_uncm, s->u_cnt.as<int32_t>(), st))
     return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS merge of the sharded search (limit 16384 entries)");
   static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();
   s->sh_marks_mode = 0;   // 0 nothing to exchange, 1 near-tied documents (marks), 2 every flagged document
   if (repair_env != 0) {
-    s->sh_marks_mode = (repair_env != 2 && fpk_final_mark(u_score, u_unc, s->u_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(),
+    s->sh_marks_mode = (repair_env != 2 && fpk_final_mark(u_score, u_unc, u_uncm, s->u_cnt.as<int32_t>(), R, B, K, s->ms_marks.as<int32_t>(),
                                                           s->ms_nmark.as<int32_t>(), st) == 0) ? 1 : 2;
     const int32_t* marks = s->sh_marks_mode == 1 ? s->ms_marks.as<int32_t>() : nullptr;
     fpk_shard_local_marks(marks, s->ms_nmark.as<int32_t>(), u_unc, s->u_cnt.as<int32_t>(), u_src, B, R, rank, s->sh_lmarks.as<int32_t>(),
                           s->sh_lnmark.as<int32_t>(), st);
     if (!empty_local && s->ms_repairable) {
-      FpMaxsimAux aux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>()};
+      FpMaxsimAux aux{s->ms_cm16.as<uint16_t>(), s->ms_unc.as<float>(), s->ms_flags.as<uint32_t>(), s->ms_uncm.as<float>()};
       fpk_maxsim_repair(ix->d, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->sh_lmarks.as<int32_t>(),
                         s->sh_lnmark.as<int32_t>(), s->exact.as<float>(), aux, st);
     }
@@ -1594,10 +1598,11 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   // exchange 2: MFMA scores + uncertainties of the local survivors
   if (!empty_local) {
     if (int rc = run_maxsim(ix, s, P.sh, R, K, 0)) return rc;
-    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
+    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->ms_repairable ? s->ms_uncm.as<float>() : nullptr,
+                    s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
                     D.pid_offset, s->sh_rec.p, st);
   } else {
-    fpk_shard_pack2(s->exact.as<float>(), nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
+    fpk_shard_pack2(s->exact.as<float>(), nullptr, nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
   }
   LAUNCHCHK("fp_shard_search (cut + MaxSim)");
   if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);

@@ -165,13 +165,15 @@ struct FpMaxsimAux {
   uint16_t* cm16;    // [B][Rcap][Qp] per-column maxima (fp16 bits)
   float* unc;        // [B][Rcap]     uncertainty budget: sum of the fp16 ulps of the flagged columns (0 = certainly the reference's score)
   uint32_t* flags;   // [B][Rcap][Qp/32] flagged columns
+  float* uncm;       // [B][Rcap]     the part of `unc` by which the reference's score may be lower (it may be higher by unc - uncm)
 };
 bool fpk_maxsim_fast_shape(int dim, int nbits);
 // exact scores of the rerank lists; pref = [B+1] int64 scratch
 int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
                int64_t Rcap, float* exact /*[B][Rcap]*/, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st);
 // flagged documents that are near-tied in the final ranking -> marks [B][stride], nmark [B]; -1 when stride is too large for LDS
-int fpk_final_mark(const float* score, const float* unc, const int32_t* cnt, int64_t stride, int B, int64_t top_k, int32_t* marks, int32_t* nmark,
+int fpk_final_mark(const float* score, const float* unc, const float* uncm /*nullable: symmetric*/, const int32_t* cnt, int64_t stride, int B,
+                   int64_t top_k, int32_t* marks, int32_t* nmark,
                    hipStream_t st);
 // exact (ascending-k) re-evaluation of the flagged columns of the marked documents (marks == nullptr: of every flagged document)
 void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
@@ -184,13 +186,13 @@ void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local
 // sharded helpers (record layouts: include/fastplaid.h)
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
                      hipStream_t st);
-void fpk_shard_pack2(const float* score, const float* unc /*nullable*/, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
-                     int64_t pid_offset, void* rec2, hipStream_t st);
+void fpk_shard_pack2(const float* score, const float* unc /*nullable*/, const float* uncm /*nullable*/, const int32_t* sel_pid,
+                     const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec2, hipStream_t st);
 int fpk_shard_global_cut(const void* all_rec1 /*[G][B][R]*/, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
                          int32_t* sel_pid /*[B][R] local*/, int32_t* sel_cnt, hipStream_t st);
 // union of the ranks' survivors in ascending id order; u_src = rank * R + slot in that rank's rerank list
 int fpk_shard_union(const void* all_rec2 /*[G][B][R]*/, int G, int B, int64_t R, int64_t* u_pid, float* u_score, int32_t* u_src, float* u_unc,
-                    int32_t* u_cnt, hipStream_t st);
+                    float* u_uncm, int32_t* u_cnt, hipStream_t st);
 // third exchange (marks = union positions of the near-tied documents, nullptr = every flagged document)
 void fpk_shard_local_marks(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B,
                            int64_t R, int rank, int32_t* lmarks, int32_t* lnmark, hipStream_t st);

@@ -2861,7 +2861,7 @@ void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t*
 // as the unsharded search does on its rerank list and takes `exact` for them, `score` for the others: same result bit for bit.
 // ============================================================================================
 struct ShardRec1 { long long pid; float approx; int pad; };
-struct ShardRec2 { long long pid; float score; float exact; float unc; int pad; };
+struct ShardRec2 { long long pid; float score; float uncm; float unc; int pad; };
 static_assert(sizeof(ShardRec1) == 16 && sizeof(ShardRec2) == 24, "record layout is part of the C ABI");
 
 __global__ void k_shard_pack1(const float* __restrict__ approx, const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt, int64_t R,
@@ -2882,22 +2882,23 @@ void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int3
                      static_cast<ShardRec1*>(rec1), total);
 }
 
-// pid / MFMA score / uncertainty of the local survivors (the `exact` field is kept for layout compatibility: = score)
-__global__ void k_shard_pack2(const float* __restrict__ score, const float* __restrict__ unc, const int32_t* __restrict__ pid,
-                              const int32_t* __restrict__ cnt, int64_t R, int64_t pid_offset, ShardRec2* __restrict__ out, int64_t total) {
+// pid / MFMA score / uncertainty (total and downward part) of the local survivors
+__global__ void k_shard_pack2(const float* __restrict__ score, const float* __restrict__ unc, const float* __restrict__ uncm,
+                              const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt, int64_t R, int64_t pid_offset,
+                              ShardRec2* __restrict__ out, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / R), r = (int)(i % R);
   ShardRec2 o;
   o.pad = 0;
-  if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.score = score[i]; o.exact = score[i]; o.unc = unc ? unc[i] : 0.f; }
-  else { o.pid = -1; o.score = -__builtin_inff(); o.exact = -__builtin_inff(); o.unc = 0.f; }
+  if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.score = score[i]; o.uncm = uncm ? uncm[i] : 0.f; o.unc = unc ? unc[i] : 0.f; }
+  else { o.pid = -1; o.score = -__builtin_inff(); o.uncm = 0.f; o.unc = 0.f; }
   out[i] = o;
 }
-void fpk_shard_pack2(const float* score, const float* unc, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset,
-                     void* rec2, hipStream_t st) {
+void fpk_shard_pack2(const float* score, const float* unc, const float* uncm, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
+                     int64_t pid_offset, void* rec2, hipStream_t st) {
   const int64_t total = (int64_t)B * R;
-  hipLaunchKernelGGL(k_shard_pack2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, score, unc, sel_pid, sel_cnt, R, pid_offset,
+  hipLaunchKernelGGL(k_shard_pack2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, score, unc, uncm, sel_pid, sel_cnt, R, pid_offset,
                      static_cast<ShardRec2*>(rec2), total);
 }
 
@@ -2987,7 +2988,7 @@ int fpk_shard_global_cut(const void* all_rec1, int G, int B, int64_t R, int64_t 
 // u_pid / u_score / u_exact / u_unc [B][R], u_cnt [B]
 __global__ __launch_bounds__(1024) void k_shard_union(const ShardRec2* __restrict__ all, int G, int B, int npow2, int64_t R,
                                                       int64_t* __restrict__ u_pid, float* __restrict__ u_score, int32_t* __restrict__ u_src,
-                                                      float* __restrict__ u_unc, int32_t* __restrict__ u_cnt) {
+                                                      float* __restrict__ u_unc, float* __restrict__ u_uncm, int32_t* __restrict__ u_cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);   // id << 32 | index into the [G*R] union
   __shared__ int s_n;
@@ -3028,18 +3029,19 @@ __global__ __launch_bounds__(1024) void k_shard_union(const ShardRec2* __restric
     u_score[o] = e.score;
     u_src[o] = idx;          // rank * R + slot in that rank's rerank list
     u_unc[o] = e.unc;
+    u_uncm[o] = e.uncm;
   }
   if (threadIdx.x == 0) u_cnt[b] = nv;
 }
-int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pid, float* u_score, int32_t* u_src, float* u_unc, int32_t* u_cnt,
-                    hipStream_t st) {
+int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pid, float* u_score, int32_t* u_src, float* u_unc, float* u_uncm,
+                    int32_t* u_cnt, hipStream_t st) {
   const int n = (int)(G * R);
   const int np2 = next_pow2(n < 2 ? 2 : n);
   if ((size_t)np2 * 8 > 160 * 1024) return -1;
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_shard_union, lds_ok, 160 * 1024);
   hipLaunchKernelGGL(k_shard_union, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8, st, static_cast<const ShardRec2*>(all_rec2), G, B, np2, R, u_pid,
-                     u_score, u_src, u_unc, u_cnt);
+                     u_score, u_src, u_unc, u_uncm, u_cnt);
   return 0;
 }
 

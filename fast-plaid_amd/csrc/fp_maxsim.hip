@@ -196,6 +196,8 @@ struct MsArgs {
   float* exact;            // [B][Rcap]
   uint16_t* cm16;          // [B][Rcap][Qp] per-column maxima as fp16 bits (nullable)
   float* unc;              // [B][Rcap] sum of the fp16 ulps of the flagged columns (0 = certainly the reference's score; nullable)
+  float* uncm;             // [B][Rcap] the part of unc by which the reference's score may be LOWER (flagged columns whose fp32 maximum
+                           // sits just above a rounding boundary); the score may be higher by unc - uncm.  Nullable with unc.
   uint32_t* flags;         // [B][Rcap][Qp/32] flagged columns (nullable)
   int64_t Rcap;
   int B, Q, Qp, ch_begin, accumulate;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
       if (l31 == 0) {
         const float v = (float)nq * NEG_MASK_F;
         outp[r] = a.accumulate ? (outp[r] + v) : v;
-        if (a.unc && !a.accumulate) a.unc[(int64_t)b * a.Rcap + r] = 0.f;
+        if (a.unc && !a.accumulate) { a.unc[(int64_t)b * a.Rcap + r] = 0.f; a.uncm[(int64_t)b * a.Rcap + r] = 0.f; }
       }
       if (a.cm16) {
 #pragma unroll
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
         const bool s_last = __builtin_amdgcn_readlane((int)c_last, 32 * s) != 0;
         if (!s_valid) continue;
         const bool partial = (s_t0 + 32 > s_len);
-        float total = 0.f, ubud = 0.f;
+        float total = 0.f, ubud = 0.f, ubm = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           float v[16];
@@ -423,14 +425,19 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
             const float dist = halfulp - __builtin_fabsf(am - (float)hm);
             const bool flag = mine && !(dist > qn[c * 32 + l31]);         // NaN -> flagged (the repair reproduces it)
             float fu = flag ? 2.0f * halfulp : 0.f;
+            // the other candidate lies on ONE side: a maximum that was rounded up (am < hm) can only have been one ulp lower
+            float fm = (flag && !(am > (float)hm)) ? 2.0f * halfulp : 0.f;
+            if (flag && !(am < (float)hm) && !(am > (float)hm)) fu += 2.0f * halfulp;   // exactly on the value (or NaN): both sides
             const unsigned long long bal = __ballot(flag);
 #pragma unroll
             for (int sft = 32; sft > 0; sft >>= 1) {
               sv += __shfl_xor(sv, sft, 64);
               fu += __shfl_xor(fu, sft, 64);
+              fm += __shfl_xor(fm, sft, 64);
             }
             total += sv;
             ubud += fu;
+            ubm += fm;
             if (a.cm16 && hi == s && (a.ch_begin + c) * 32 < a.Qp)
               a.cm16[((int64_t)b * a.Rcap + s_r) * a.Qp + (a.ch_begin + c) * 32 + l31] = __builtin_bit_cast(uint16_t, hm);
             if (a.flags && lane == 0 && a.ch_begin + c < nflag)
@@ -443,6 +450,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
           if (a.unc) {
             float* up = a.unc + (int64_t)b * a.Rcap + s_r;
             *up = a.accumulate ? (*up + ubud) : ubud;
+            float* um = a.uncm + (int64_t)b * a.Rcap + s_r;
+            *um = a.accumulate ? (*um + ubm) : ubm;
           }
         }
       }
@@ -520,7 +529,8 @@ __global__ __launch_bounds__(64) void k_maxsim_generic(const uint16_t* __restric
 // suffix-max scan.  Flagged documents in such a conflict (with at least one of the two inside the emitted top_k) are marked;
 // every unmarked document's interval is disjoint from all others, so after the marked ones are re-scored exactly the order is
 // the reference's.  marks[b][0..nmark[b]) = rerank slots.
-__global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ score, const float* __restrict__ unc, const int32_t* __restrict__ cnt,
+__global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ score, const float* __restrict__ unc,
+                                                     const float* __restrict__ uncm /*nullable: symmetric intervals*/, const int32_t* __restrict__ cnt,
                                                      int64_t stride, int npow2, int64_t top_k, int32_t* __restrict__ marks,
                                                      int32_t* __restrict__ nmark) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -569,9 +579,11 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
       if (i < n) {
         const unsigned long long key = v[i];
         const float si = unmono32((uint32_t)(key >> 32));
-        const float u = unc[(int64_t)b * stride + (int)(0xFFFFFFFFu - (uint32_t)key)];
-        l = si - u;
-        h = si + u;
+        const int64_t o = (int64_t)b * stride + (int)(0xFFFFFFFFu - (uint32_t)key);
+        const float u = unc[o];
+        const float um = uncm ? uncm[o] : u;
+        l = si - um;
+        h = si + (uncm ? u - um : u);
       }
       lo[i] = l;
       hi[i] = h;
@@ -597,14 +609,16 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
       const int slot = (int)(0xFFFFFFFFu - (uint32_t)key);
       const float u = unc[(int64_t)b * stride + slot];
       if (!(u > 0.f)) continue;
+      const float um = uncm ? uncm[(int64_t)b * stride + slot] : u;
+      const float up = uncm ? u - um : u;
       const float si = unmono32((uint32_t)(key >> 32));
       bool conflict;
       if (i < kk) {
         const float lmin = i > 0 ? lo[i - 1] : inf;               // higher-ranked documents
         const float hmax = i + 1 < npow2 ? hi[i + 1] : -inf;      // lower-ranked documents (also those below the cut)
-        conflict = !(si + u < lmin) || !(si - u > hmax);
+        conflict = !(si + up < lmin) || !(si - um > hmax);
       } else {
-        conflict = !(si + u < lmin_top);                          // outside the emitted range: only a jump into it matters
+        conflict = !(si + up < lmin_top);                         // outside the emitted range: only a jump into it matters
       }
       if (conflict) marks[(int64_t)b * stride + atomicAdd(&s_n, 1)] = slot;
     }
@@ -759,7 +773,7 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
   int grid = ms_num_cus();
   if ((int64_t)grid * MS_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS_WAVES - 1) / MS_WAVES);
   static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
-  MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.flags,
+  MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
            Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel};
   static std::atomic<uint64_t> ok1{0}, ok2{0};
   fp_allow_big_lds((const void*)k_maxsim5<D, NBITS, 1>, ok1, 96 * 1024);
@@ -799,14 +813,15 @@ int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& 
 }
 
 // marks the flagged documents that are near-tied in the final ranking (marks / nmark), or nothing when npow2 keys do not fit LDS
-int fpk_final_mark(const float* score, const float* unc, const int32_t* cnt, int64_t stride, int B, int64_t top_k, int32_t* marks, int32_t* nmark,
+int fpk_final_mark(const float* score, const float* unc, const float* uncm, const int32_t* cnt, int64_t stride, int B, int64_t top_k, int32_t* marks,
+                   int32_t* nmark,
                    hipStream_t st) {
   int np2 = fp_next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
   if (np2 > 8192) return -1;   // 16 B of LDS per entry, 16 scan elements per thread
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_mark, lds_ok, 136 * 1024);
-  hipLaunchKernelGGL(k_final_mark, dim3((unsigned)B), dim3(1024), (size_t)np2 * 16, st, score, unc, cnt, stride, np2, top_k, marks, nmark);
+  hipLaunchKernelGGL(k_final_mark, dim3((unsigned)B), dim3(1024), (size_t)np2 * 16, st, score, unc, uncm, cnt, stride, np2, top_k, marks, nmark);
   return 0;
 }
 

@@ -73,7 +73,7 @@ def shard_arrays(arrays: dict, begin: int, end: int) -> dict:
 REC1_BYTES = 16   # fp_shard_rec1 {i64 pid; f32 approx; i32 pad}
 REC2_BYTES = 24   # fp_shard_rec2 {i64 pid; f32 score; f32 exact; f32 unc; i32 pad}
 REC1_DTYPE = np.dtype([("pid", "<i8"), ("approx", "<f4"), ("pad", "<i4")])
-REC2_DTYPE = np.dtype([("pid", "<i8"), ("score", "<f4"), ("reserved", "<f4"), ("unc", "<f4"), ("pad", "<i4")])
+REC2_DTYPE = np.dtype([("pid", "<i8"), ("score", "<f4"), ("unc_down", "<f4"), ("unc", "<f4"), ("pad", "<i4")])
 
 
 class HipShardEngine:

@@ -198,7 +198,8 @@ int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int
  *   (all-gather to [G,B,R])
  *   stage2: global top-R cut (reproduces search.rs:605-619 on the union), exact MaxSim of
  *           the survivors that live on this rank
- *           -> dev rec2 [B,R]  (fp_shard_rec2: the MFMA score and its uncertainty budget)
+ *           -> dev rec2 [B,R]  (fp_shard_rec2: the MFMA score, its uncertainty budget `unc` and the part of it
+ *              by which the reference's score may be lower, `unc_down`)
  *   (all-gather to [G,B,R])
  *   stage3: union in ascending id order, the unsharded search's near-tie marking on it
  *           (identical on every rank); this rank repairs the marked documents it holds
@@ -209,7 +210,7 @@ int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int
  * R = max(n_full_scores/4, 1).  The result is identical to fp_search on the whole corpus,
  * bit for bit, for any G. */
 typedef struct fp_shard_rec1 { int64_t pid; float approx; int32_t pad; } fp_shard_rec1;                        /* 16 bytes */
-typedef struct fp_shard_rec2 { int64_t pid; float score; float reserved; float unc; int32_t pad; } fp_shard_rec2; /* 24 bytes */
+typedef struct fp_shard_rec2 { int64_t pid; float score; float unc_down; float unc; int32_t pad; } fp_shard_rec2; /* 24 bytes */
 int fp_shard_begin(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
                    const fp_search_params* params, fp_shard_ctx** out);
 int64_t fp_shard_R(const fp_shard_ctx* ctx);
