@@ -8,11 +8,13 @@ n_full_scores=4096 (R=1024 exact-scored docs / query), n_ivf_probe=8.
 
     python bench.py                               # N=1, finishes in a few minutes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N         # document-sharded over N GPUs (RCCL)
+        --master-port P bench.py --gpus N         # N GPUs, one process each (RCCL)
 
-N>1: the SAME corpus and the SAME query batch, documents split into N contiguous
-token-balanced shards (one process per GPU), two fixed-size RCCL all-gathers per batch
-(fast-plaid_amd/sharded.py) -> "scaling": "strong".
+N>1: the SAME corpus and the SAME query batch -> "scaling": "strong".  Two modes (fast-plaid_amd/sharded.py), `--dist-mode`:
+"replica" = the reference's own multi-GPU mode (full index per GPU, the batch split across ranks, one result all-gather),
+chosen by "auto" when the index fits one GPU; "shard" = documents split into N contiguous token-balanced shards, three
+fixed-size all-gathers per batch issued by the library itself (fp_shard_search).  The mode that is not `value` is
+timed too and reported as `alt_mode` (unless --no-alt-mode).
 
 One JSON line on rank 0.  `value` is timed on the boundary call fp_search (host query buffer in, host
 results out -- what the reference's pysearch hands over, rust/lib.rs:195-223); the same steps with queries and

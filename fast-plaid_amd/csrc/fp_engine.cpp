@@ -297,7 +297,7 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     if (urc != 0) return fail(FP_EHIP, "unique-code build failed (hip error " + std::to_string(urc) + ")");
     D.ucodes = ucodes; D.uoff = uoff; D.U = U;
   }
-  // packed code lines for S4's level 0: one set per range of 2^17 centroids (17-bit codes relative to the range), up to 2^20
+  // packed code lines for S4's level 0: one set per range of 2^17 centroids (codes relative to the range), up to 2^20
   D.n_ranges = 0;
   D.n_lines = 0;
   if (D.C <= 8 * (1ll << 17)) {

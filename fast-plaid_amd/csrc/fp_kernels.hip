@@ -1616,13 +1616,13 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 // Since max_c S8[c][q] <= f_q + sum_c max(0, S8[c][q] - f_q), UB0(d) >= K(d) = sum_q max_c S8[c][q] for every document, and
 // with 128 A + 100 Q < K + Q (see above; a bin-255 entry makes e(c) infinite) a document can only reach an exact
 // approximate score A >= A_T if UB0(d) > 128 A_T + 99 Q.  e(c) is a BYTE table of C entries (128 KiB at C = 2^17) that
-// every workgroup copies into LDS; a candidate then costs its code list (a coalesced stream) and one LDS byte per code.
-// Values 0..191 are stored as they are, 192..254 name one of 63 escape slots (u32 values in LDS), 255 = infinite.
+// every workgroup copies into LDS; a candidate then costs its code line (128 B) and one LDS byte per code.  The table is
+// written by S1's epilogue (FpS1Excess; k_l0_table builds it from a full 8-bit table in the fallback form).
 //   A_T: the top-R' documents by UB0 (R' = 4 R) are scored exactly; A_T = the keep-th largest of THEIR exact scores, which
 //        is <= the keep-th largest exact score overall.  Survivors = { UB0 >= floor(128 A_T + 99 Q) + 1 }: they contain
 //        every document with A >= A_T, hence the exact top-keep with all its ties -> the selection that follows is
-//        identical to scoring every candidate exactly.  On the benchmark corpus 0.5-1.5 % of the candidates survive
-//        (tools/sim_s4_bounds.py reproduces the bound on the CPU).
+//        identical to scoring every candidate exactly.  On the benchmark corpus 1.9 % of the candidates are scored exactly
+//        (pilot group + survivors outside it; tools/sim_s4_bounds.py reproduces the bound on the CPU).
 // ============================================================================================
 // byte code of an excess e:  0..159 = e itself;  160..239 = 160 + ceil((e - 160) / 8), decoded as 160 + 8 (v - 160) >= e (at
 // most 7 looser; these are the query's own topic centroids, e = 200..600, one or two per document -- as escapes they cost a
@@ -1742,11 +1742,11 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
 
 // ub[cand] = min(F + sum e(c), 0xFFFE), or 0xFFFF when some code has an infinite excess.
 // The candidates' codes come from the packed lines (fp_synth.hip "packed unique codes"): one aligned 128-byte line per document
-// (more for documents with > 56 distinct codes), 8 lanes per line, one 16-byte piece = 7 codes per lane, nothing shared
-// between lanes but the final sum.  A lane group takes FOUR consecutive candidates per iteration and issues their four line
-// loads before it consumes any (the offsets of the next iteration's candidates and the ids of the one after are fetched in
-// the shadow).  Escape slots / infinite entries take a rare second pass over the candidate.  The histogram of (ub - F) >> 2
-// that the pilot cut needs is built here in LDS.
+// (more for documents with > 48 distinct codes), 8 lanes per line, one 16-byte piece = 6 codes per lane, nothing shared
+// between lanes but the final sum.  A lane group takes FOUR consecutive candidates per iteration; the line loads of the next
+// iteration, the line offsets of the one after and the ids of the one after that are in flight while it computes.  Escape
+// slots / infinite entries take a rare second pass over the candidate.  The histogram of (ub - F) >> 2 that the pilot cut
+// needs is built here in LDS.
 #define L0_HBINS 4096
 #define L0_UNROLL 4
 #define L0_PILOT_MAX 98304    // capacity of a query's pilot group

@@ -303,9 +303,10 @@ fail:
 // The level-0 kernel reads every candidate's unique-code list once per query; as int32 lists at arbitrary offsets (133 B on
 // the benchmark corpus) each candidate touched 2-3 128-byte lines, most of whose bytes belonged to non-candidates (6.7 GB
 // requested, 5.3 GB over the fabric for 2.8 GB of codes).  Here every document owns whole 128-byte LINES: a line is 8 pieces
-// of 16 bytes, a piece = 7 codes of up to 17 bits: bytes 0-13 the low 16 bits, byte 14 bit j = bit 16 of code j, byte 15 =
-// number of codes in the piece.  56 codes per line (one line per document on the benchmark corpus: 33 codes), any number of
-// lines per document; a lane reads ONE aligned 16-byte piece and needs nothing from its neighbours.  C <= 2^17 only.
+// of 16 bytes, a piece = 6 codes of 20 bits (bits 0..119) + the number of codes in the piece (bits 120..127).  48 codes per
+// line (one line per document on the benchmark corpus: 33 codes on average, 0.15 % of the documents need a second line), any
+// number of lines per document; a lane reads ONE aligned 16-byte piece and needs nothing from its neighbours.  Codes are
+// relative to a range of 2^17 centroids (one set of lines per range), so 17 of the 20 bits are used.
 #define PCODES_PER_PIECE 6
 #define PCODES_PER_LINE 48
 // sub-run of a document's ascending unique codes that falls in [lo, hi): rs[d] .. re[d] (positions in ucodes)
