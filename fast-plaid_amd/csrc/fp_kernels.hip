@@ -1630,7 +1630,8 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 // survivors);  240..254 = escape slot 0..14 (u32 values in LDS) for e >= 800;  255 = infinite.
 // decode of v <= 239:  max(v, 8 v - 1120)
 #define L0_INF 0xFFFFu
-#define L0_SAMPLE 8192          // centroids sampled for the column quantiles
+#define L0_SAMPLE 8192          // centroids sampled for the column quantiles (from a full 8-bit table)
+#define L0_SAMPLE_PRE 2048      // ... by S1's sampled pre-pass (FP_L0_SAMPLE; 8192 / 4096 / 2048 / 1024 rows: S1 stage 0.379 / 0.354 / 0.345 / 0.341 ms, same survivors)
 
 // floors[b][Qp] u8 (pad columns 0), Fsum[b]; one workgroup per query
 __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S8, int64_t C, int Q, int nch, float tail,
@@ -2234,7 +2235,8 @@ bool fpk_l0_fits(const FpIndexDev& ix) { return ix.n_ranges >= 1 && ix.pcodes !=
 // floors (+ their sum) from the bins of a centroid sample: S8s is [B][nch][ns][32], the bins of the centroids 0, stride, 2 stride, ...
 // (fpk_l0_sample_plan), exactly the sample k_l0_floor takes from a full table
 void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride) {
-  *stride = ix.C > L0_SAMPLE ? ix.C / L0_SAMPLE : 1;
+  static const int64_t want = [] { const char* e = getenv("FP_L0_SAMPLE"); const int64_t v = e ? atoll(e) : L0_SAMPLE_PRE; return v >= 256 && v <= L0_SAMPLE ? v : L0_SAMPLE_PRE; }();
+  *stride = ix.C > want ? ix.C / want : 1;
   *n_rows = (ix.C + *stride - 1) / *stride;
 }
 void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, uint16_t* gfl,
