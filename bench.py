@@ -13,8 +13,8 @@ n_full_scores=4096 (R=1024 exact-scored docs / query), n_ivf_probe=8.
 N>1: the SAME corpus and the SAME query batch -> "scaling": "strong".  Two modes (fast-plaid_amd/sharded.py), `--dist-mode`:
 "replica" = the reference's own multi-GPU mode (full index per GPU, the batch split across ranks, one result all-gather),
 chosen by "auto" when the index fits one GPU; "shard" = documents split into N contiguous token-balanced shards, three
-fixed-size all-gathers per batch issued by the library itself (fp_shard_search).  The mode that is not `value` is
-timed too and reported as `alt_mode` (unless --no-alt-mode).
+fixed-size all-gathers per batch issued by the library itself (fp_shard_search).  With --alt-mode the mode that is not
+`value` is timed too and reported as `alt_mode`.
 
 One JSON line on rank 0.  `value` is timed on the boundary call fp_search (host query buffer in, host
 results out -- what the reference's pysearch hands over, rust/lib.rs:195-223); the same steps with queries and
@@ -62,7 +62,8 @@ def parse():
     ap.add_argument("--dist-mode", choices=["auto", "replica", "shard"], default="auto",
                     help="N>1: replica = full index per GPU, batch split across ranks (the reference's multi-GPU mode); "
                          "shard = document shards + 2 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
-    ap.add_argument("--no-alt-mode", action="store_true", help="N>1: do not also time the other distribution mode")
+    ap.add_argument("--alt-mode", action="store_true", help="N>1: also time the other distribution mode and report it as alt_mode")
+    ap.add_argument("--no-alt-mode", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--dist-impl", choices=["native", "torch"], default="native",
                     help="shard mode: native = fp_shard_search (the library issues the RCCL all-gathers itself); torch = the three stage calls "
                          "with torch.distributed all-gathers in between (forced with --dist-backend gloo)")
@@ -223,7 +224,7 @@ def main():
         fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
         primary = a.dist_mode if a.dist_mode != "auto" else ("replica" if fits else "shard")
         other = "shard" if primary == "replica" else "replica"
-        run_other = (not a.no_alt_mode) and (other == "shard" or fits)
+        run_other = a.alt_mode and (not a.no_alt_mode) and (other == "shard" or fits)
     else:
         primary, run_other = "single", False
     res = run_mode(primary)
