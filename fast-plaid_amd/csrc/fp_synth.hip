@@ -399,7 +399,7 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   HCHK(hipMemcpyAsync(n_lines, loff + n_docs, 8, hipMemcpyDeviceToHost, st));
   HCHK(hipStreamSynchronize(st));
   if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
-  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 128 + 64));
+  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 128 + 256));   // a document without codes at the very end reads "its" line: one line of slack
   {
     const int64_t work = *n_lines * 8 + n_docs + 1;
     hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, rs, re, n_docs, (int32_t)code_lo, loff,
