@@ -74,6 +74,169 @@ __device__ __forceinline__ uint8_t l0_encode(uint32_t e, bool inf, uint32_t* __r
   return (uint8_t)(L0_ESC_BASE + slot);
 }
 #define S1_TILE 128
+#ifndef S1_ABL
+#define S1_ABL 0   // timing-only ablations of the S1 epilogue (tools/abl_run.sh): 1 no write-out, 2 direct 8-byte stores, 3 no excess math
+#endif
+// Epilogue of one 128 x 128 output tile (shared by the two S1 kernels): fp16 tile staged through LDS so that S leaves with
+// 16 B per lane, plus the by-products (column maxima, 8-bit bins or the level-0 excess byte).
+__device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][2], unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
+                                            const int tile_idx, uint16_t* __restrict__ S, const int64_t C, const int64_t Ntot, const int Qp,
+                                            uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, const int nch, const FpS1Excess& ex) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  __syncthreads();  // operand tiles are dead: the same LDS now stages the output
+  // D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi.
+  // Output tile in LDS: [group g = n/32 (4)][c (128)][32 q] halves = 64 B rows, the 16-byte chunk index
+  // XORed with (c>>2)&3 (lanes = consecutive c at a 64-byte stride would otherwise share banks).
+  unsigned char* Os = smem;                                           // 32 KiB
+  uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [2 (wc)][128 n] column maxima of each wave's 64 centroids
+  const uint32_t ninf2 = 0xFC00FC00u;  // packed fp16 -inf
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int g = wr * 2 + a;
+    uint32_t cm[8];  // packed column maxima: cm[2*q4 + h] = columns q = 8*q4 + 4*hi + 2*h + {0,1}
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cm[r] = ninf2;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int cl = wc * 64 + b * 32 + l31;       // centroid within the tile
+      const bool cok = (c0 + cl) < C;
+      unsigned char* orow = Os + ((size_t)(g * 128 + cl)) * 64;
+      const int f = (cl >> 2) & 3;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {             // q = 8*q4 + 4*hi + 0..3  -> chunk q4, half hi
+        h2 lo, hi2;
+        lo.x = (half_t)acc[a][b][4 * q4 + 0];
+        lo.y = (half_t)acc[a][b][4 * q4 + 1];
+        hi2.x = (half_t)acc[a][b][4 * q4 + 2];
+        hi2.y = (half_t)acc[a][b][4 * q4 + 3];
+#if S1_ABL == 2   // timing only: 8-byte pieces straight from the accumulators into a row-contiguous (column-permuted) layout
+        if (cok && n0 + g * 32 < Ntot)
+          *reinterpret_cast<uint2*>(S + (((n0 + g * 32) / Qp) * C + c0 + cl) * Qp + ((n0 + g * 32) % Qp) + hi * 16 + q4 * 4) =
+              make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
+#else
+        *reinterpret_cast<uint2*>(orow + ((q4 ^ f) * 16) + hi * 8) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
+#endif
+        if (cok) {
+          cm[2 * q4] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4]), lo));
+          cm[2 * q4 + 1] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4 + 1]), hi2));
+        }
+      }
+    }
+    if (cmax) {  // max over this wave's 64 centroids: DPP inside the 16-lane rows, one cross-row exchange
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint32_t v = cm[r];
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0xB1, 0xF, 0xF, false))));   // quad_perm [1,0,3,2]
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x4E, 0xF, 0xF, false))));   // quad_perm [2,3,0,1]
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x124, 0xF, 0xF, false))));  // row_ror:4
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x128, 0xF, 0xF, false))));  // row_ror:8
+        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2(shfl_xor_u32(v, 16))));                                                                  // the other row of this half
+        cm[r] = v;
+      }
+      if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int q = 8 * (r >> 1) + 4 * hi + 2 * (r & 1);
+          *reinterpret_cast<uint32_t*>(red + wc * 128 + g * 32 + q) = cm[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // write-out: 2048 16-byte pieces (g, c, chunk), 8 per thread, consecutive threads -> consecutive bytes of S when Qp == 32
+  uint32_t eacc[8];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (bit 31: a clamped bin), summed over the row's 4 lanes
+#if S1_ABL == 1 || S1_ABL == 2
+  if (Qp < 0)   // timing only: no write-out
+#endif
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    eacc[it] = 0u;
+    const int p = it * 256 + tid;
+    const int g = p >> 9, cl = (p >> 2) & 127, ch = p & 3;
+    const int64_t nb = n0 + g * 32;
+    const int64_t c = c0 + cl;
+    if (nb >= Ntot || c >= C) continue;
+    const int64_t bq = nb / Qp;
+    const int q0 = (int)(nb % Qp);
+    const uint4 v = *reinterpret_cast<const uint4*>(Os + ((size_t)(g * 128 + cl)) * 64 + ((ch ^ ((cl >> 2) & 3)) * 16));
+    *reinterpret_cast<uint4*>(S + (bq * C + c) * Qp + q0 + ch * 8) = v;
+    if (ex.e8 && S1_ABL != 3) {
+      // S4 level 0's table entry, straight from the tile (instead of writing the 8-bit bins and reading them back):
+      // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass
+      // packed fp16 throughout: 128 x, its floor, the clamp at bin 255 (floor = 155) and the difference to g = floor_q - 100
+      // are small integers, exact in fp16; pad columns carry g = 2000 (never positive) and score 0 (never clamped)
+      const uint4 gw = *reinterpret_cast<const uint4*>(ex.gfl + bq * Qp + q0 + ch * 8);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t gws[4] = {gw.x, gw.y, gw.z, gw.w};
+      const h2 k128 = {(half_t)128.f, (half_t)128.f}, k155 = {(half_t)155.f, (half_t)155.f}, kzero = {(half_t)0.f, (half_t)0.f};
+      h2 dsum = kzero, tmax = {(half_t)-1000.f, (half_t)-1000.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        h2 y = u32_as_h2(w[t]) * k128;
+        h2 fl;
+        fl.x = __builtin_floorf16(y.x);
+        fl.y = __builtin_floorf16(y.y);
+        tmax = __builtin_elementwise_max(tmax, fl);
+        const h2 d = __builtin_elementwise_min(fl, k155) - u32_as_h2(gws[t]);
+        dsum += __builtin_elementwise_max(d, kzero);
+      }
+      const uint32_t part = (uint32_t)(int)(float)dsum.x + (uint32_t)(int)(float)dsum.y;
+      const uint32_t inf = ((float)tmax.x >= 155.f || (float)tmax.y >= 155.f) ? 1u : 0u;
+      uint32_t acc = part | (inf << 31);   // (the sums stay far below 2^31: at most 64 columns x 255)
+      {
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        acc = ((acc & 0x7FFFFFFFu) + (o1 & 0x7FFFFFFFu)) | ((acc | o1) & 0x80000000u);
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        acc = ((acc & 0x7FFFFFFFu) + (o2 & 0x7FFFFFFFu)) | ((acc | o2) & 0x80000000u);
+      }
+      eacc[it] = acc;
+    }
+    if (S8) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t o[2] = {0u, 0u};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const h2 pr = u32_as_h2(w[t >> 1]);
+        const float x = (float)((t & 1) ? pr.y : pr.x);
+        int bin = (int)floorf(x * 128.0f) + 100;   // == Q8_OFFSET, see the bound stage of S4
+        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+        o[t >> 2] |= (uint32_t)bin << (8 * (t & 3));
+      }
+      // S8 is [b][Qp/32][c][32]: every 32-column chunk of a query is its own contiguous C x 32 B table
+      *reinterpret_cast<uint2*>(S8 + ((bq * (Qp / 32) + q0 / 32) * C + c) * 32 + ch * 8) = make_uint2(o[0], o[1]);
+    }
+  }
+  if (cmax && tid < 128) {
+    const int64_t n = n0 + tid;
+    if (n < Ntot) {
+      const uint16_t u0 = red[tid], u1 = red[128 + tid];
+      cmax[n * nch + tile_idx] = (mono16(u0) > mono16(u1)) ? u0 : u1;
+    }
+  }
+  if (ex.e8 && (tid & 3) == 0) {
+    // one byte per (query, centroid): with Qp == 64 a query's two 32-column groups (it = 2 g + half) belong together
+    const int per_q = Qp / 32;   // groups per query: 1 or 2
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int g = it >> 1;
+      if (per_q == 2 && (g & 1)) continue;
+      const int cl = (it & 1) * 64 + (tid >> 2);
+      const int64_t nb = n0 + g * 32;
+      const int64_t c = c0 + cl;
+      if (nb >= Ntot || c >= C) continue;
+      uint32_t acc = eacc[it];
+      if (per_q == 2) {
+        const uint32_t o = eacc[it + 2];
+        acc = ((acc & 0x7FFFFFFFu) + (o & 0x7FFFFFFFu)) | ((acc | o) & 0x80000000u);
+      }
+      const int64_t bq = nb / Qp;
+      ex.e8[bq * ex.Cpad + c] = l0_encode(acc & 0x7FFFFFFFu, (acc >> 31) != 0u, ex.esc + bq * 64);
+    }
+  }
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
@@ -132,146 +295,73 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  __syncthreads();  // operand tiles are dead: the same LDS now stages the output
-  // D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi.
-  // Output tile in LDS: [group g = n/32 (4)][c (128)][32 q] halves = 64 B rows, the 16-byte chunk index
-  // XORed with (c>>2)&3 (lanes = consecutive c at a 64-byte stride would otherwise share banks).
-  unsigned char* Os = smem;                                           // 32 KiB
-  uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [2 (wc)][128 n] column maxima of each wave's 64 centroids
-  const uint32_t ninf2 = 0xFC00FC00u;  // packed fp16 -inf
+  s1_epilogue(acc, smem, tid, n0, c0, (int)blockIdx.x, S, C, Ntot, Qp, S8, cmax, nch, ex);
+}
+
+// The same GEMM with the QUERY operand held in registers: a workgroup loads its 128 query columns' MFMA A fragments once
+// (all of K: DK / 16 k-steps x 2 row halves x 16 B per lane) and walks `nct` consecutive 128-centroid tiles, staging only the
+// centroid tile (128 x DK halves, 32 KiB at DK = 128) per tile.  The one-tile-per-workgroup kernel above moves 64 KB of
+// operands through L2 per tile and ran 201 us with its write-out removed (1 GB of operand traffic per batch); this one
+// moves 32 KB.  dim 128 / 64 (power-of-two 16-byte chunks per row for the XOR swizzle); other dims use the kernel above.
+template <int DK>
+__global__ __launch_bounds__(256) void k_centroid_scores_qreg(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
+                                                              uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
+                                                              uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, int nch, int nct,
+                                                              int64_t crow_stride, FpS1Excess ex) {
+  constexpr int CH = DK / 8;             // 16-byte chunks per row
+  constexpr int ROWB = DK * 2;           // bytes per row
+  constexpr int KSTEPS = DK / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Cs = smem;              // [128][ROWB]; the output staging of the epilogue reuses it
+  const int tid = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.y * 128;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
+  const int l31 = lane & 31, hi = lane >> 5;
+  h8 af[KSTEPS][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int g = wr * 2 + a;
-    uint32_t cm[8];  // packed column maxima: cm[2*q4 + h] = columns q = 8*q4 + 4*hi + 2*h + {0,1}
+  for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) cm[r] = ninf2;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int cl = wc * 64 + b * 32 + l31;       // centroid within the tile
-      const bool cok = (c0 + cl) < C;
-      unsigned char* orow = Os + ((size_t)(g * 128 + cl)) * 64;
-      const int f = (cl >> 2) & 3;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {             // q = 8*q4 + 4*hi + 0..3  -> chunk q4, half hi
-        h2 lo, hi2;
-        lo.x = (half_t)acc[a][b][4 * q4 + 0];
-        lo.y = (half_t)acc[a][b][4 * q4 + 1];
-        hi2.x = (half_t)acc[a][b][4 * q4 + 2];
-        hi2.y = (half_t)acc[a][b][4 * q4 + 3];
-        *reinterpret_cast<uint2*>(orow + ((q4 ^ f) * 16) + hi * 8) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
-        if (cok) {
-          cm[2 * q4] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4]), lo));
-          cm[2 * q4 + 1] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4 + 1]), hi2));
-        }
-      }
+    for (int t = 0; t < 2; ++t) {
+      const int64_t n = n0 + wr * 64 + t * 32 + l31;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < Ntot) v = *reinterpret_cast<const uint4*>(qpad + n * DK + (ks * 2 + hi) * 8);
+      af[ks][t] = __builtin_bit_cast(h8, v);
     }
-    if (cmax) {  // max over this wave's 64 centroids: DPP inside the 16-lane rows, one cross-row exchange
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        uint32_t v = cm[r];
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0xB1, 0xF, 0xF, false))));   // quad_perm [1,0,3,2]
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x4E, 0xF, 0xF, false))));   // quad_perm [2,3,0,1]
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x124, 0xF, 0xF, false))));  // row_ror:4
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x128, 0xF, 0xF, false))));  // row_ror:8
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2(shfl_xor_u32(v, 16))));                                                                  // the other row of this half
-        cm[r] = v;
-      }
-      if (l31 == 0) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int q = 8 * (r >> 1) + 4 * hi + 2 * (r & 1);
-          *reinterpret_cast<uint32_t*>(red + wc * 128 + g * 32 + q) = cm[r];
-        }
-      }
+  for (int ct = 0; ct < nct; ++ct) {
+    const int tile_idx = (int)blockIdx.x * nct + ct;
+    if (tile_idx >= nch) break;   // (uniform)
+    const int64_t c0 = (int64_t)tile_idx * 128;
+    if (ct > 0) __syncthreads();   // the previous tile's output staging is no longer read
+    for (int i = tid; i < 128 * CH; i += 256) {
+      const int row = i / CH, j = i % CH;
+      uint4 vc = make_uint4(0, 0, 0, 0);
+      if (c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * crow_stride * DK + j * 8);
+      *reinterpret_cast<uint4*>(Cs + row * ROWB + ((j ^ (row & (CH - 1))) * 16)) = vc;
     }
-  }
-  __syncthreads();
-  // write-out: 2048 16-byte pieces (g, c, chunk), 8 per thread, consecutive threads -> consecutive bytes of S when Qp == 32
-  uint32_t eacc[8];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (bit 31: a clamped bin), summed over the row's 4 lanes
+    __syncthreads();
+    f16v acc[2][2];
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    eacc[it] = 0u;
-    const int p = it * 256 + tid;
-    const int g = p >> 9, cl = (p >> 2) & 127, ch = p & 3;
-    const int64_t nb = n0 + g * 32;
-    const int64_t c = c0 + cl;
-    if (nb >= Ntot || c >= C) continue;
-    const int64_t bq = nb / Qp;
-    const int q0 = (int)(nb % Qp);
-    const uint4 v = *reinterpret_cast<const uint4*>(Os + ((size_t)(g * 128 + cl)) * 64 + ((ch ^ ((cl >> 2) & 3)) * 16));
-    *reinterpret_cast<uint4*>(S + (bq * C + c) * Qp + q0 + ch * 8) = v;
-    if (ex.e8) {
-      // S4 level 0's table entry, straight from the tile (instead of writing the 8-bit bins and reading them back):
-      // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass
-      // packed fp16 throughout: 128 x, its floor, the clamp at bin 255 (floor = 155) and the difference to g = floor_q - 100
-      // are small integers, exact in fp16; pad columns carry g = 2000 (never positive) and score 0 (never clamped)
-      const uint4 gw = *reinterpret_cast<const uint4*>(ex.gfl + bq * Qp + q0 + ch * 8);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      const uint32_t gws[4] = {gw.x, gw.y, gw.z, gw.w};
-      const h2 k128 = {(half_t)128.f, (half_t)128.f}, k155 = {(half_t)155.f, (half_t)155.f}, kzero = {(half_t)0.f, (half_t)0.f};
-      h2 dsum = kzero, tmax = {(half_t)-1000.f, (half_t)-1000.f};
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        h2 y = u32_as_h2(w[t]) * k128;
-        h2 fl;
-        fl.x = __builtin_floorf16(y.x);
-        fl.y = __builtin_floorf16(y.y);
-        tmax = __builtin_elementwise_max(tmax, fl);
-        const h2 d = __builtin_elementwise_min(fl, k155) - u32_as_h2(gws[t]);
-        dsum += __builtin_elementwise_max(d, kzero);
-      }
-      const uint32_t part = (uint32_t)(int)(float)dsum.x + (uint32_t)(int)(float)dsum.y;
-      const uint32_t inf = ((float)tmax.x >= 155.f || (float)tmax.y >= 155.f) ? 1u : 0u;
-      uint32_t acc = part | (inf << 31);   // (the sums stay far below 2^31: at most 64 columns x 255)
-      {
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-        acc = ((acc & 0x7FFFFFFFu) + (o1 & 0x7FFFFFFFu)) | ((acc | o1) & 0x80000000u);
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-        acc = ((acc & 0x7FFFFFFFu) + (o2 & 0x7FFFFFFFu)) | ((acc | o2) & 0x80000000u);
-      }
-      eacc[it] = acc;
-    }
-    if (S8) {
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      uint32_t o[2] = {0u, 0u};
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const h2 pr = u32_as_h2(w[t >> 1]);
-        const float x = (float)((t & 1) ? pr.y : pr.x);
-        int bin = (int)floorf(x * 128.0f) + 100;   // == Q8_OFFSET, see the bound stage of S4
-        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
-        o[t >> 2] |= (uint32_t)bin << (8 * (t & 3));
-      }
-      // S8 is [b][Qp/32][c][32]: every 32-column chunk of a query is its own contiguous C x 32 B table
-      *reinterpret_cast<uint2*>(S8 + ((bq * (Qp / 32) + q0 / 32) * C + c) * 32 + ch * 8) = make_uint2(o[0], o[1]);
-    }
-  }
-  if (cmax && tid < 128) {
-    const int64_t n = n0 + tid;
-    if (n < Ntot) {
-      const uint16_t u0 = red[tid], u1 = red[128 + tid];
-      cmax[n * nch + blockIdx.x] = (mono16(u0) > mono16(u1)) ? u0 : u1;
-    }
-  }
-  if (ex.e8 && (tid & 3) == 0) {
-    // one byte per (query, centroid): with Qp == 64 a query's two 32-column groups (it = 2 g + half) belong together
-    const int per_q = Qp / 32;   // groups per query: 1 or 2
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int g = it >> 1;
-      if (per_q == 2 && (g & 1)) continue;
-      const int cl = (it & 1) * 64 + (tid >> 2);
-      const int64_t nb = n0 + g * 32;
-      const int64_t c = c0 + cl;
-      if (nb >= Ntot || c >= C) continue;
-      uint32_t acc = eacc[it];
-      if (per_q == 2) {
-        const uint32_t o = eacc[it + 2];
-        acc = ((acc & 0x7FFFFFFFu) + (o & 0x7FFFFFFFu)) | ((acc | o) & 0x80000000u);
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      h8 bf[2];
+      const int j = ks * 2 + hi;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rc = wc * 64 + t * 32 + l31;
+        bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
       }
-      const int64_t bq = nb / Qp;
-      ex.e8[bq * ex.Cpad + c] = l0_encode(acc & 0x7FFFFFFFu, (acc >> 31) != 0u, ex.esc + bq * 64);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[b], acc[a][b], 0, 0, 0);
     }
+    s1_epilogue(acc, smem, tid, n0, c0, tile_idx, S, C, Ntot, Qp, S8, cmax, nch, ex);
   }
 }
 
@@ -289,6 +379,23 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
   const int D = ix.dim;
   if (D % 8 != 0 || D < 8) return -1;
+  // (measured at cfg2: 0.394 ms for the S1 stage against 0.343 ms with one tile per workgroup -- 232 registers leave two
+  // workgroups per CU instead of three, and a workgroup's stage / MFMA / epilogue phases do not overlap with each other.
+  // Kept as an experiment: FP_S1_QREG=1.)
+  static const int qreg_env = [] { const char* e = getenv("FP_S1_QREG"); return e ? atoi(e) : 0; }();
+  if ((D == 128 || D == 64) && qreg_env) {
+    // query operand in registers, several centroid tiles per workgroup: enough workgroups to fill the chip a few times over
+    const int64_t tiles = (int64_t)nch * grid.y;
+    int nct = (int)(tiles / (256 * 8));
+    nct = nct < 1 ? 1 : (nct > 8 ? 8 : nct);
+    dim3 g2((unsigned)((nch + nct - 1) / nct), grid.y);
+    const size_t lds = std::max<size_t>((size_t)128 * D * 2, out_lds);
+    if (D == 128)
+      hipLaunchKernelGGL(k_centroid_scores_qreg<128>, g2, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, rs, ex);
+    else
+      hipLaunchKernelGGL(k_centroid_scores_qreg<64>, g2, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, rs, ex);
+    return 0;
+  }
   if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
     hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
