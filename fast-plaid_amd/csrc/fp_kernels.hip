@@ -1883,17 +1883,31 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ poff,
                                                   const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist,
-                                                  int first, int last) {
+                                                  int first, int last, int bxn, int xcd_affine) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)l0s != 0u) __builtin_trap();   // the table must sit at LDS address 0
   uint8_t* tab = l0s;                                                  // [tab_bytes + 16]
   uint32_t* es = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [64]
   uint32_t* hl = es + 64;                                              // [L0_HBINS]
-  const int b = blockIdx.y, tid = threadIdx.x;
+  // XCD affinity (experiment, off by default: slower, see fpk_l0_scan): workgroups are dealt to the 8 XCDs round-robin by
+  // linear id, and every workgroup starts by copying its query's table (up to 128 KiB) out of L2.  With the plain (chunk,
+  // query) grid a query's workgroups land on all 8 XCDs and every L2 sees all B tables; with xcd_affine query b is served by
+  // XCD b % 8 only.  bxn = chunks per query; needs B % 8 == 0.
+  const int tid = threadIdx.x;
+  int b, bxi;
+  if (xcd_affine) {
+    const int lin = blockIdx.x;                 // 1-D launch of bxn * B workgroups
+    const int xcd = lin & 7, slot = lin >> 3;   // slot-th workgroup of this XCD
+    b = (slot / bxn) * 8 + xcd;
+    bxi = slot % bxn;
+  } else {
+    b = blockIdx.y;
+    bxi = blockIdx.x;
+  }
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   constexpr int CPI = 128 * L0_UNROLL;   // candidates per workgroup iteration
-  if ((int64_t)blockIdx.x * CPI >= n) return;
+  if ((int64_t)bxi * CPI >= n) return;
   {
     const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad + tab_off);
     uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -1906,11 +1920,11 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   const uint32_t F = Fsum[b];
   const int sub = tid & 7;
   const int kq = sub & 3;                      // the candidate of the group's four whose id / line offsets this lane fetches
-  const int64_t stride = (int64_t)gridDim.x * CPI;
+  const int64_t stride = (int64_t)bxn * CPI;
   const int32_t* cpids = cand_pid + beg;
   const uint2* pmeta = reinterpret_cast<const uint2*>(poff);
   uint16_t* ubrow = ub + l0_row(cand_off, b);
-  int64_t i = (int64_t)blockIdx.x * CPI + (tid >> 3) * L0_UNROLL;
+  int64_t i = (int64_t)bxi * CPI + (tid >> 3) * L0_UNROLL;
   // Software pipeline over the dependent chain  id -> {first line, line count} -> code line(s):  while iteration t is
   // computed, the code lines of t+1, the offsets of t+2 and the ids of t+3 are in flight (one workgroup per CU -- the table
   // takes the LDS -- leaves only 4 waves per SIMD to hide latency otherwise).  Ids and offsets are fetched cooperatively: each
@@ -2393,12 +2407,18 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
     fp_allow_big_lds((const void*)k_l0_scan<2>, ok2b, 160 * 1024);
     fp_allow_big_lds((const void*)k_l0_scan<3>, ok2c, 160 * 1024);
   }
+  // measured at cfg2: XCD-affine 0.674 ms, plain (chunk, query) grid 0.565 ms -- the table copies are the smaller effect; with
+  // the plain grid the workgroups of ~4 queries sweep the corpus together on all XCDs and share the code lines in the
+  // memory-side cache.  Experiment only: FP_L0_XCD=1.
+  static const int affine_env = [] { const char* e = getenv("FP_L0_XCD"); return e ? atoi(e) : 0; }();
+  const int affine = (affine_env && B % 8 == 0 && bx * (int64_t)B < (1ll << 31)) ? 1 : 0;
+  const dim3 grid = affine ? dim3((unsigned)(bx * B)) : dim3((unsigned)bx, (unsigned)B);
   for (int r = 0; r < ix.n_ranges; ++r) {
     const int64_t off = (int64_t)r * FP_L0_RANGE;
     const int tb = (int)std::min<int64_t>(FP_L0_RANGE, Cpad - off);
 #define L0_LAUNCH(A_) \
-    hipLaunchKernelGGL(k_l0_scan<A_>, dim3((unsigned)bx, (unsigned)B), dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
-                       cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0)
+    hipLaunchKernelGGL(k_l0_scan<A_>, grid, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
+                       cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, (int)bx, affine)
     switch (abl & 3) {
       case 1: L0_LAUNCH(1); break;
       case 2: L0_LAUNCH(2); break;
