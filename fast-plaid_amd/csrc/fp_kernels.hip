@@ -1908,15 +1908,6 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   const int64_t n = cand_off[b + 1] - beg;
   constexpr int CPI = 128 * L0_UNROLL;   // candidates per workgroup iteration
   if ((int64_t)bxi * CPI >= n) return;
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad + tab_off);
-    uint4* dst = reinterpret_cast<uint4*>(tab);
-    for (int i = tid; i < tab_bytes / 16; i += 1024) dst[i] = src[i];
-    if (tid < 4) reinterpret_cast<uint32_t*>(tab + tab_bytes)[tid] = 0u;
-    if (tid < 64) es[tid] = esc[(int64_t)b * 64 + tid];
-    for (int i = tid; i < L0_HBINS; i += 1024) hl[i] = 0u;
-  }
-  __syncthreads();
   const uint32_t F = Fsum[b];
   const int sub = tid & 7;
   const int kq = sub & 3;                      // the candidate of the group's four whose id / line offsets this lane fetches
@@ -1954,6 +1945,16 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   uint4 pcA[L0_UNROLL], pcB[L0_UNROLL];                // first code lines of t / t+1, roles swapped every iteration
 #pragma unroll
   for (int k = 0; k < L0_UNROLL; ++k) pcA[k] = load_line(qb(m0.x, k));
+  // the query's table -> LDS, behind the pipeline's first loads (nothing above touches LDS): the copy's latency overlaps theirs
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad + tab_off);
+    uint4* dst = reinterpret_cast<uint4*>(tab);
+    for (int j = tid; j < tab_bytes / 16; j += 1024) dst[j] = src[j];
+    if (tid < 4) reinterpret_cast<uint32_t*>(tab + tab_bytes)[tid] = 0u;
+    if (tid < 64) es[tid] = esc[(int64_t)b * 64 + tid];
+    for (int j = tid; j < L0_HBINS; j += 1024) hl[j] = 0u;
+  }
+  __syncthreads();
   // sum of the 6 table entries of one piece (6 codes of 20 bits + the count in the top byte; 48 codes per line: 0.15 % of the
   // benchmark corpus' documents need a second line, against 6 % with 40 -- the second line is not prefetched).  Slots past the
   // piece's count repeat its last code (fp_synth.hip): all six are summed and (6 - count) x the last taken off again (an empty
