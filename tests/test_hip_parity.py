@@ -119,6 +119,45 @@ def test_decompress_reconstruct_matches_oracle(fp):
         assert np.array_equal(out, ref), f"{name}: max diff {np.abs(out - ref).max()}"
 
 
+@pytest.mark.parametrize("impl", ["auto", "l0"])
+def test_non_finite_queries_do_not_break_the_pipeline(fp, impl):
+    """NaN / Inf / huge query components (the reference has no check either: ATen propagates them): the call returns, the counts
+    stay within top_k, finite queries of the same batch are unaffected, and the index keeps answering afterwards."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import fast_plaid_amd as fp
+R = fp.fast_plaid_rust
+spec = fp.synth.SynthSpec(n_docs=20000, doc_len=40, n_centroids=2048, variable_len=True, seed=5)
+arr = fp.synth.host_index_arrays(spec)
+idx = R.construct_index(arr["nbits"], arr["centroids"], None, None, arr["bucket_weights"], arr["ivf"], arr["ivf_lengths"],
+                        arr["doc_codes"], arr["doc_residuals"], arr["doc_lengths"], "cuda:0", False)
+q = fp.synth.make_queries(spec, arr["centroids"], 6, 32).astype(np.float16)
+params = R.SearchParameters(2000, 256, 20, 8)
+good = R.search_arrays(idx, q, params)
+bad = q.copy()
+bad[1, 3, 7] = np.nan
+bad[2, :, :] = np.inf
+bad[3, 0, :] = 60000.0
+bad[4, 5, 1] = -np.inf
+p, s, c = R.search_arrays(idx, bad, params)
+assert np.all(c <= 20) and np.all(c >= 0)
+for b in (0, 5):
+    assert c[b] == good[2][b] and np.array_equal(p[b], good[0][b]) and np.array_equal(s[b], good[1][b]), b
+again = R.search_arrays(idx, q, params)
+assert all(np.array_equal(x, y) for x, y in zip(good, again))
+print("NONFINITE_OK")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if impl != "auto":
+        env["FP_APPROX_IMPL"] = impl
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "NONFINITE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_api_level_behaviour(fp):
     """behaviours pinned by the reference's tests/test.py at the FastPlaid level."""
     z, arr = _load_golden("base_d128_nb4")
