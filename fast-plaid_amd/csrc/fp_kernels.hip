@@ -79,18 +79,22 @@ __device__ __forceinline__ uint8_t l0_encode(uint32_t e, bool inf, uint32_t* __r
 #endif
 // Epilogue of one 128 x 128 output tile (shared by the two S1 kernels): fp16 tile staged through LDS so that S leaves with
 // 16 B per lane, plus the by-products (column maxima, 8-bit bins or the level-0 excess byte).
-__device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][2], unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
+template <int NWC /*wave columns: 2 (256 threads, 64 x 64 per wave) or 4 (512 threads, 64 x 32 per wave)*/>
+__device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
                                             const int tile_idx, uint16_t* __restrict__ S, const int64_t C, const int64_t Ntot, const int Qp,
                                             uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, const int nch, const FpS1Excess& ex) {
   const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;
+  constexpr int NB = 4 / NWC;          // 32-centroid MFMA tiles per wave
+  constexpr int NT = 128 * NWC;        // threads
+  constexpr int NIT = 2048 / NT;       // 16-byte pieces of the output tile per thread
+  const int wr = wave / NWC, wc = wave % NWC;
   const int l31 = lane & 31, hi = lane >> 5;
   __syncthreads();  // operand tiles are dead: the same LDS now stages the output
   // D[row = n (query col)][col = c]; lane: col = lane&31, rows (r&3)+8*(r>>2)+4*hi.
   // Output tile in LDS: [group g = n/32 (4)][c (128)][32 q] halves = 64 B rows, the 16-byte chunk index
   // XORed with (c>>2)&3 (lanes = consecutive c at a 64-byte stride would otherwise share banks).
   unsigned char* Os = smem;                                           // 32 KiB
-  uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [2 (wc)][128 n] column maxima of each wave's 64 centroids
+  uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [NWC][128 n] column maxima of each wave's centroids
   const uint32_t ninf2 = 0xFC00FC00u;  // packed fp16 -inf
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -99,8 +103,8 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][2], unsigned char* sm
 #pragma unroll
     for (int r = 0; r < 8; ++r) cm[r] = ninf2;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int cl = wc * 64 + b * 32 + l31;       // centroid within the tile
+    for (int b = 0; b < NB; ++b) {
+      const int cl = wc * (32 * NB) + b * 32 + l31;       // centroid within the tile
       const bool cok = (c0 + cl) < C;
       unsigned char* orow = Os + ((size_t)(g * 128 + cl)) * 64;
       const int f = (cl >> 2) & 3;
@@ -146,14 +150,14 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][2], unsigned char* sm
   }
   __syncthreads();
   // write-out: 2048 16-byte pieces (g, c, chunk), 8 per thread, consecutive threads -> consecutive bytes of S when Qp == 32
-  uint32_t eacc[8];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (bit 31: a clamped bin), summed over the row's 4 lanes
+  uint32_t eacc[NIT];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (bit 31: a clamped bin), summed over the row's 4 lanes
 #if S1_ABL == 1 || S1_ABL == 2
   if (Qp < 0)   // timing only: no write-out
 #endif
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     eacc[it] = 0u;
-    const int p = it * 256 + tid;
+    const int p = it * NT + tid;
     const int g = p >> 9, cl = (p >> 2) & 127, ch = p & 3;
     const int64_t nb = n0 + g * 32;
     const int64_t c = c0 + cl;
@@ -211,24 +215,29 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][2], unsigned char* sm
   if (cmax && tid < 128) {
     const int64_t n = n0 + tid;
     if (n < Ntot) {
-      const uint16_t u0 = red[tid], u1 = red[128 + tid];
-      cmax[n * nch + tile_idx] = (mono16(u0) > mono16(u1)) ? u0 : u1;
+      uint16_t best = red[tid];
+#pragma unroll
+      for (int w = 1; w < NWC; ++w) {
+        const uint16_t u = red[w * 128 + tid];
+        best = (mono16(u) > mono16(best)) ? u : best;
+      }
+      cmax[n * nch + tile_idx] = best;
     }
   }
   if (ex.e8 && (tid & 3) == 0) {
-    // one byte per (query, centroid): with Qp == 64 a query's two 32-column groups (it = 2 g + half) belong together
+    // one byte per (query, centroid): with Qp == 64 a query's two 32-column groups (pieces 512 apart) belong together
     const int per_q = Qp / 32;   // groups per query: 1 or 2
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int g = it >> 1;
+    for (int it = 0; it < NIT; ++it) {
+      const int p = it * NT + tid;
+      const int g = p >> 9, cl = (p >> 2) & 127;
       if (per_q == 2 && (g & 1)) continue;
-      const int cl = (it & 1) * 64 + (tid >> 2);
       const int64_t nb = n0 + g * 32;
       const int64_t c = c0 + cl;
       if (nb >= Ntot || c >= C) continue;
       uint32_t acc = eacc[it];
       if (per_q == 2) {
-        const uint32_t o = eacc[it + 2];
+        const uint32_t o = eacc[(it + 512 / NT) % NIT];   // (index always < NIT here: g is even)
         acc = ((acc & 0x7FFFFFFFu) + (o & 0x7FFFFFFFu)) | ((acc | o) & 0x80000000u);
       }
       const int64_t bq = nb / Qp;
@@ -237,8 +246,8 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][2], unsigned char* sm
   }
 }
 
-template <int KS>
-__global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
+template <int KS, int NWC>
+__global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
                                                          uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
                                                          int nch, int D, int64_t crow_stride, FpS1Excess ex) {
@@ -255,19 +264,21 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
   const int64_t n0 = (int64_t)blockIdx.y * 128;
   const int64_t c0 = (int64_t)blockIdx.x * 128;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
+  constexpr int NB = 4 / NWC;               // 32-centroid MFMA tiles per wave
+  constexpr int NT = 128 * NWC;
+  const int wr = wave / NWC, wc = wave % NWC;  // 2 x NWC waves, 64 (n) x 32 NB (c) each
   const int l31 = lane & 31, hi = lane >> 5;
-  f16v acc[2][2];
+  f16v acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   for (int k0 = 0; k0 < D; k0 += KS) {
     if (k0 > 0) __syncthreads();   // the previous slice is no longer read
     // stage both tiles (coalesced 16 B per thread), swizzled
-    for (int i = tid; i < 128 * CH; i += 256) {
+    for (int i = tid; i < 128 * CH; i += NT) {
       int row = i / CH, j = i % CH;
       int js = j ^ (row & (CH - 1));
       uint4 vq = make_uint4(0, 0, 0, 0), vc = make_uint4(0, 0, 0, 0);
@@ -280,22 +291,25 @@ __global__ __launch_bounds__(256) void k_centroid_scores(const uint16_t* __restr
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KS / 16; ++ks) {
-      h8 af[2], bf[2];
+      h8 af[2], bf[NB];
       const int j = ks * 2 + hi;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        int rq = wr * 64 + t * 32 + l31;
-        int rc = wc * 64 + t * 32 + l31;
+        const int rq = wr * 64 + t * 32 + l31;
         af[t] = *reinterpret_cast<const h8*>(Qs + rq * ROWB + ((j ^ (rq & (CH - 1))) * 16));
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int rc = wc * (32 * NB) + t * 32 + l31;
         bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  s1_epilogue(acc, smem, tid, n0, c0, (int)blockIdx.x, S, C, Ntot, Qp, S8, cmax, nch, ex);
+  s1_epilogue<NWC>(acc, smem, tid, n0, c0, (int)blockIdx.x, S, C, Ntot, Qp, S8, cmax, nch, ex);
 }
 
 // The same GEMM with the QUERY operand held in registers: a workgroup loads its 128 query columns' MFMA A fragments once
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(256) void k_centroid_scores_qreg(const uint16_t* __
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[b], acc[a][b], 0, 0, 0);
     }
-    s1_epilogue(acc, smem, tid, n0, c0, tile_idx, S, C, Ntot, Qp, S8, cmax, nch, ex);
+    s1_epilogue<2>(acc, smem, tid, n0, c0, tile_idx, S, C, Ntot, Qp, S8, cmax, nch, ex);
   }
 }
 
@@ -376,7 +390,7 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   const int nch = (int)((C + S1_TILE - 1) / S1_TILE);
   dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
   if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
-  const size_t out_lds = 4 * 128 * 64 + 2 * 128 * 2;
+  const size_t out_lds = 4 * 128 * 64 + 4 * 128 * 2;
   const int D = ix.dim;
   if (D % 8 != 0 || D < 8) return -1;
   // (measured at cfg2: 0.394 ms for the S1 stage against 0.343 ms with one tile per workgroup -- 232 registers leave two
@@ -396,15 +410,19 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
       hipLaunchKernelGGL(k_centroid_scores_qreg<64>, g2, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, rs, ex);
     return 0;
   }
+  static const int nwc = [] { const char* e = getenv("FP_S1_WAVES"); return (e && atoi(e) == 4) ? 2 : 4; }();   // FP_S1_WAVES=4: 2 x 2 waves (round 1)
   if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<64>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<64, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    else hipLaunchKernelGGL((k_centroid_scores<64, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
   } else if (D % 32 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 32 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<32>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<32, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    else hipLaunchKernelGGL((k_centroid_scores<32, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
   } else {
     const size_t lds = std::max<size_t>(2 * 128 * 16 * 2, out_lds);
-    hipLaunchKernelGGL(k_centroid_scores<16>, grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<16, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    else hipLaunchKernelGGL((k_centroid_scores<16, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
   }
   return 0;
 }
