@@ -843,11 +843,12 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
   struct Rel { fp_index* ix; Scratch* s; ~Rel() { release(ix, s); } } rel{ix, s};
   const int Qp = (Q + 31) & ~31;
   // sub-batch so that the centroid-score table stays within a budget
-  size_t free_b = 0, total_b = 0;
-  (void)hipMemGetInfo(&free_b, &total_b);
   static const size_t budget_env = getenv("FP_S_BUDGET_KB") ? (size_t)atoll(getenv("FP_S_BUDGET_KB")) << 10 : 0;   // tests: force sub-batching
-  const size_t budget = budget_env ? budget_env : std::max<size_t>((size_t)1 << 30, std::min<size_t>((size_t)24 << 30, free_b / 3));
   const size_t perq = (size_t)D.C * Qp * 2;
+  size_t free_b = 0, total_b = 0;
+  if (!budget_env && (size_t)nq * perq > ((size_t)1 << 30))   // the driver call costs tens of microseconds: only when the table can exceed the floor of the budget
+    (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t budget = budget_env ? budget_env : std::max<size_t>((size_t)1 << 30, std::min<size_t>((size_t)24 << 30, free_b / 3));
   int maxB = (int)std::max<size_t>(1, budget / perq);
   if (tr) maxB = 1;
   std::vector<int64_t> sub_off_local;
