@@ -120,6 +120,8 @@ struct Scratch {
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
+  bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
+  bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
   void destroy() {
     out_all.release();
@@ -157,13 +159,14 @@ static thread_local int64_t g_last_counts[4];  // candidates, exact-scored docs,
 
 // results of one (sub-)batch in one device block: ids | scores | counts
 struct OutLayout {
-  size_t score_off, cnt_off, total, nk, n;
+  size_t score_off, cnt_off, stat_off, total, nk, n;
   OutLayout(int B, int64_t K) {
     n = (size_t)B;
     nk = (size_t)B * (size_t)K;
     score_off = (nk * 8 + 255) & ~(size_t)255;
     cnt_off = (score_off + nk * 4 + 255) & ~(size_t)255;
-    total = cnt_off + n * 4;
+    stat_off = (cnt_off + n * 4 + 255) & ~(size_t)255;   // [1 + B] int64 statistics (survivor total, marked documents per query)
+    total = stat_off + (n + 1) * 8;
   }
   void scatter(const void* host, int64_t* pids, float* scores, int32_t* counts) const {
     const char* h = static_cast<const char*>(host);
@@ -737,7 +740,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     sel_off = s->surv_off.as<int64_t>();
     sel_src = s->surv_pid.as<int32_t>();
     // survivor total for fp_last_search_counts: lands in pinned memory by the time the caller's final sync returns
-    HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 8, s->surv_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
+    if (!s->fold_stats)
+      HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 8, s->surv_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
     // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2 after the 8-bit bounds); the kernel walks a
     // grid-stride loop if there are more
     if (P.approx_impl != 2)
@@ -799,7 +803,8 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
                         fpk_final_mark(s->exact.as<float>(), aux.unc, aux.uncm, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
                                        s->ms_nmark.as<int32_t>(), st) == 0;
     s->ms_have_marks = false;
-    if (marked && (size_t)B * 4 + 64 <= 4096) {   // marked documents per query -> pinned memory, summed for fp_last_search_counts after the final sync
+    s->ms_marked_now = marked;
+    if (marked && !s->fold_stats && (size_t)B * 4 + 64 <= 4096) {   // marked documents per query -> pinned memory, summed for fp_last_search_counts after the final sync
       HIPCHK(s->h_small.ensure(4096));
       HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 64, s->ms_nmark.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
       s->ms_have_marks = true;
@@ -868,6 +873,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       for (int i = 0; i <= B; ++i) sub_off_local[i] = subset_off[b0 + i] - subset_off[b0];
       sids = subset_ids + subset_off[b0];
     }
+    s->fold_stats = !dev_io;
+    s->ms_marked_now = false;
     if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
     if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
     g_last_counts[0] += P.M;
@@ -883,7 +890,10 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     HIPCHK(s->h_out.ensure(ol.total));
     char* od = s->out_all.as<char>();
     fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
-                   reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
+                   reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st,
+                   (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
+                   (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
+                   s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr);
     if (dev_io) {
       HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, od, ol.nk * 8, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, od + ol.score_off, ol.nk * 4, hipMemcpyDeviceToDevice, st));
@@ -896,8 +906,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       HIPCHK(hipStreamSynchronize(st));
       ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     }
+    if (s->fold_stats) {   // the statistics came down with the results
+      const int64_t* stv = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
+      g_last_counts[1] += P.used_q8 ? stv[0] : P.M;
+      for (int i = 0; i < B; ++i) g_last_counts[2] += stv[1 + i];
+    } else
     g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : P.M;
-    if (s->ms_have_marks) {
+    if (!s->fold_stats && s->ms_have_marks) {
       const int32_t* nm = reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 64);
       for (int i = 0; i < B; ++i) g_last_counts[2] += nm[i];
       s->ms_have_marks = false;
@@ -1359,6 +1374,7 @@ extern "C" int fp_shard_stage1(fp_shard_ctx* c, void* dev_rec1) {
     HIPCHK(s->sel_approx.ensure((size_t)B * R * 4));
     HIPCHK(hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, s->st));
   } else {
+    s->fold_stats = false;
     if (int rc = run_front(c->P, nullptr, nullptr, false)) return rc;
   }
   fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, c->ix->d.pid_offset, dev_rec1, s->st);
@@ -1587,6 +1603,7 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
     HIPCHK(s->exact.ensure((size_t)B * R * 4));
     HIPCHK(hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, st));
   } else {
+    s->fold_stats = false;
     if (int rc = run_front(P, nullptr, nullptr, false)) return rc;
   }
   // exchange 1: local top-R by approximate score

@@ -182,7 +182,8 @@ void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* q_pad, const FpSear
 void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local /*[B][stride] or null*/,
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,
                     int64_t stride, int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid /*[B][top_k]*/,
-                    float* out_score, int32_t* out_cnt, hipStream_t st);
+                    float* out_score, int32_t* out_cnt, hipStream_t st, const int64_t* stat_total = nullptr, const int32_t* stat_per_query = nullptr,
+                    int64_t* stat_out /*[1 + B]: statistics copied next to the results*/ = nullptr);
 // sharded helpers (record layouts: include/fastplaid.h)
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
                      hipStream_t st);

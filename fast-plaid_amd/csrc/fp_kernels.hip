@@ -2932,8 +2932,15 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
                                                      const int64_t* __restrict__ pid_global, const int32_t* __restrict__ cnt,
                                                      int64_t stride, int npow2, int64_t top_k, int64_t pid_offset,
                                                      int64_t* __restrict__ out_pid, float* __restrict__ out_score,
-                                                     int32_t* __restrict__ out_cnt) {
+                                                     int32_t* __restrict__ out_cnt, const int64_t* __restrict__ stat_total,
+                                                     const int32_t* __restrict__ stat_per_query, int64_t* __restrict__ stat_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // statistics of the search that travel with the results (one copy to the host instead of three): [0] = *stat_total,
+  // [1 + b] = stat_per_query[b]
+  if (stat_out && threadIdx.x == 0) {
+    stat_out[1 + blockIdx.x] = stat_per_query ? (int64_t)stat_per_query[blockIdx.x] : 0;
+    if (blockIdx.x == 0) stat_out[0] = stat_total ? *stat_total : 0;
+  }
   // all LDS in the dynamic region (a static __shared__ in front would mis-align the 8-byte keys)
   int* s_validp = reinterpret_cast<int*>(smem);
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem + 16);
@@ -2991,13 +2998,13 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
 
 void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
                     int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
-                    hipStream_t st) {
+                    hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out) {
   int np2 = next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_topk, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,
-                     top_k, pid_offset, out_pid, out_score, out_cnt);
+                     top_k, pid_offset, out_pid, out_score, out_cnt, stat_total, stat_per_query, stat_out);
 }
 
 // ============================================================================================
