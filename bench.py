@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
     ap.add_argument("--dist-mode", choices=["auto", "replica", "shard"], default="auto",
                     help="N>1: replica = full index per GPU, batch split across ranks (the reference's multi-GPU mode); "
-                         "shard = document shards + 2 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
+                         "shard = document shards + 3 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
     ap.add_argument("--alt-mode", action="store_true", help="N>1: also time the other distribution mode and report it as alt_mode")
     ap.add_argument("--no-alt-mode", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--dist-impl", choices=["native", "torch"], default="native",

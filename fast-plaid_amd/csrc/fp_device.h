@@ -14,6 +14,27 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ uint32_t h2_as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ h2 u32_as_h2(uint32_t v) { return __builtin_bit_cast(h2, v); }
 __device__ __forceinline__ h2 pk_max(h2 a, h2 b) { return __builtin_elementwise_max(a, b); }
+// The bare instructions: __builtin_elementwise_max / min first canonicalise both operands (v_pk_max_f16 x, x, x) because the
+// kernels run in IEEE mode, tripling the count.  Only for values that cannot be signalling NaNs (everything the kernels produce).
+__device__ __forceinline__ uint32_t pk_max_raw(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_min_raw(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// floor of both halves in two instructions: the second one writes the upper half only (the compiler's form is floor, floor
+// into another register, pack).  The trailing s_nop covers the wait state a sub-dword write needs before a VALU reads it.
+__device__ __forceinline__ uint32_t pk_floor_raw(uint32_t y) {
+  uint32_t r;
+  asm("v_floor_f16_e32 %0, %1\n\tv_floor_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"
+      : "=&v"(r)
+      : "v"(y));
+  return r;
+}
 __device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
 // order-preserving maps (larger float <-> larger unsigned)

@@ -116,17 +116,21 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
+  // Candidate-buffer capacity learnt from earlier batches of the same shape (0: none): with it, fp_search does not wait for the
+  // candidate total in the middle of the pipeline (see run_front)
+  int64_t spec_cap = 0;
+  int64_t spec_key[4] = {0, 0, 0, 0};   // {B, Q, n_ivf_probe, subset?}
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
-                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
+                      &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
                       &ms_nmark, &sh_rec, &sh_all})
       b->release();
     h_out.release();
@@ -545,6 +549,8 @@ struct Pipe {
   bool used_q8 = false;   // a bound stage pruned the candidates (8-bit bounds or level 0)
   int approx_impl = 0;    // 0 exact for all, 1 8-bit bounds, 2 level 0
   bool l0_ready = false;  // S1 produced level 0's floors and excess table (instead of the 8-bit table)
+  bool allow_spec = false;   // fp_search / fp_search_device: M may be the learnt capacity instead of this batch's total (no mid-pipeline sync)
+  bool spec = false;         // ... and it was
 };
 
 // stages S1..S5 for one sub-batch whose fp16 queries are already in s->qin
@@ -644,13 +650,32 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->blkcnt.ensure((size_t)B * P.nblk * 4));
   HIPCHK(s->ncand.ensure((size_t)B * 4));
   HIPCHK(s->cand_off.ensure((size_t)(B + 1) * 8));
+  // The candidate total sizes the buffers and grids of S4 / S5.  The first batch of a shape waits for it (the one mid-pipeline
+  // host sync, ~30 us of idle GPU); later batches of the same shape run on with the capacity learnt so far (125 % of the largest
+  // total seen) as M -- every kernel below takes its ranges from cand_off, M only sizes things.  A batch that exceeds the
+  // capacity is emptied on the device (k_cand_offsets) and run again by the caller once the true total is known.
+  static const bool spec_env = [] { const char* e = getenv("FP_SPECULATE"); return !e || atoi(e) != 0; }();
+  const int64_t key[4] = {B, sh.Q, sh.n_probe, has_subset ? 1 : 0};
+  if (P.allow_spec && (s->spec_key[0] != key[0] || s->spec_key[1] != key[1] || s->spec_key[2] != key[2] || s->spec_key[3] != key[3])) {
+    s->spec_cap = 0;
+    for (int i = 0; i < 4; ++i) s->spec_key[i] = key[i];
+  }
+  P.spec = P.allow_spec && spec_env && s->spec_cap > 0;
+  HIPCHK(s->spec_total.ensure(8));
+  int64_t* d_total = s->spec_total.as<int64_t>();
   fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
-                 s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st);
+                 s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st, P.spec ? s->spec_cap : 0,
+                 s->invalid.as<int32_t>(), d_total);
   HIPCHK(s->h_small.ensure(4096));
-  HIPCHK(hipMemcpyAsync(s->h_small.p, s->cand_off.as<int64_t>() + B, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(s->h_small.p, d_total, 8, hipMemcpyDeviceToHost, st));
   STAGE_DONE(ST_COMPACT);
-  HIPCHK(hipStreamSynchronize(st));  // the one mid-pipeline host sync: candidate total sizes the buffers
-  const int64_t M = *reinterpret_cast<const int64_t*>(s->h_small.p);
+  int64_t M;
+  if (P.spec) {
+    M = s->spec_cap;
+  } else {
+    HIPCHK(hipStreamSynchronize(st));
+    M = *reinterpret_cast<const int64_t*>(s->h_small.p);
+  }
   P.M = M;
   HIPCHK(s->cand_pid.ensure((size_t)std::max<int64_t>(M, 1) * 4));
   HIPCHK(s->approx.ensure((size_t)std::max<int64_t>(M, 1) * 4));
@@ -875,10 +900,9 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     }
     s->fold_stats = !dev_io;
     s->ms_marked_now = false;
+    P.allow_spec = tr == nullptr && !has_subset;   // (subset searches: the candidate total follows the subset sizes, not the shape)
     if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
     if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
-    g_last_counts[0] += P.M;
-    g_last_counts[3] += 1;
     // S6+S7
     const int64_t R = P.sh.R;
     if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true)) return rc;
@@ -906,12 +930,28 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       HIPCHK(hipStreamSynchronize(st));
       ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     }
+    // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
+    const int64_t M_true = *reinterpret_cast<const int64_t*>(s->h_small.p);
+    if (P.spec && M_true > P.M) {
+      // more candidates than the capacity learnt from earlier batches: the device emptied the batch (k_cand_offsets); run it again,
+      // this time waiting for the total
+      s->spec_cap = 0;
+      b0 -= maxB;
+      continue;
+    }
+    {
+      static const int pct = [] { const char* e = getenv("FP_SPEC_CAP_PCT"); const int v = e ? atoi(e) : 125; return v > 0 ? v : 125; }();   // tests: < 100 forces the re-run
+      const int64_t want = M_true * pct / 100 + 1024;
+      if (want > s->spec_cap || pct < 100) s->spec_cap = want;
+    }
+    g_last_counts[0] += M_true;
+    g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
       const int64_t* stv = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
-      g_last_counts[1] += P.used_q8 ? stv[0] : P.M;
+      g_last_counts[1] += P.used_q8 ? stv[0] : M_true;
       for (int i = 0; i < B; ++i) g_last_counts[2] += stv[1 + i];
     } else
-    g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : P.M;
+    g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : M_true;
     if (!s->fold_stats && s->ms_have_marks) {
       const int32_t* nm = reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 64);
       for (int i = 0; i < B; ++i) g_last_counts[2] += nm[i];

@@ -103,7 +103,8 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
                   uint32_t* bitmap, int64_t W, hipStream_t st);
 // candidate compaction: count -> scan -> offsets -> compact (ascending doc ids)
 void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
-                    int32_t* blkcnt, int nblk, int32_t* ncand, int64_t* cand_off /*[B+1]*/, hipStream_t st);
+                    int32_t* blkcnt, int nblk, int32_t* ncand, int64_t* cand_off /*[B+1]*/, hipStream_t st,
+                    int64_t cap /*0: none*/, int32_t* invalid_rw, int64_t* total_out);
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkcnt /*exclusive-scanned*/, int nblk, const int64_t* cand_off, int32_t* cand_pid,
                       hipStream_t st);

@@ -64,6 +64,7 @@ void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, i
 #define L0_LIN 160
 #define L0_ESC_BASE 240
 #define L0_ESC_SLOTS 15
+#define L0_EINF 0x100000u   // S1's epilogue: added to an excess sum for every clamped bin (the sums themselves stay below it)
 __device__ __forceinline__ uint8_t l0_encode(uint32_t e, bool inf, uint32_t* __restrict__ esc) {
   if (inf) return 255u;
   if (e < L0_LIN) return (uint8_t)e;
@@ -79,13 +80,31 @@ __device__ __forceinline__ uint8_t l0_encode(uint32_t e, bool inf, uint32_t* __r
 #endif
 // Epilogue of one 128 x 128 output tile (shared by the two S1 kernels): fp16 tile staged through LDS so that S leaves with
 // 16 B per lane, plus the by-products (column maxima, 8-bit bins or the level-0 excess byte).
-template <int NWC /*wave columns: 2 (256 threads, 64 x 64 per wave) or 4 (512 threads, 64 x 32 per wave)*/>
-__device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
+// query index and first column of the four 32-column groups of a 128-column tile (wave-uniform; Qp is a multiple of 32, so a
+// group never straddles two queries): one division per tile instead of one per 16-byte piece
+struct S1Groups { uint32_t bq[4]; uint32_t q0[4]; };
+__device__ __forceinline__ S1Groups s1_groups(int64_t n0, int Qp) {
+  S1Groups G;
+  uint32_t bq = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)n0 / (uint32_t)Qp));   // (B * Qp < 2^31; the divide runs on the vector unit)
+  uint32_t q = (uint32_t)n0 - bq * (uint32_t)Qp;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    G.bq[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bq);   // (uniform already; this pins the values to scalar registers)
+    G.q0[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    q += 32u;
+    if (q >= (uint32_t)Qp) { q = 0u; ++bq; }
+  }
+  return G;
+}
+template <int NWC /*wave columns: 2 (256 threads, 64 x 64 per wave) or 4 (512 threads, 64 x 32 per wave)*/, bool DMA_WAIT = false,
+          int NWR = 2 /*wave rows: 2, or 4 (32 query columns per wave)*/>
+__device__ __forceinline__ void s1_epilogue(f16v (&acc)[4 / NWR][4 / NWC], unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
                                             const int tile_idx, uint16_t* __restrict__ S, const int64_t C, const int64_t Ntot, const int Qp,
-                                            uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, const int nch, const FpS1Excess& ex) {
+                                            uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, const int nch, const FpS1Excess& ex, const S1Groups& G) {
   const int wave = tid >> 6, lane = tid & 63;
   constexpr int NB = 4 / NWC;          // 32-centroid MFMA tiles per wave
-  constexpr int NT = 128 * NWC;        // threads
+  constexpr int NA = 4 / NWR;          // 32-column query groups per wave
+  constexpr int NT = 64 * NWR * NWC;   // threads
   constexpr int NIT = 2048 / NT;       // 16-byte pieces of the output tile per thread
   const int wr = wave / NWC, wc = wave % NWC;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -97,8 +116,8 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned ch
   uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [NWC][128 n] column maxima of each wave's centroids
   const uint32_t ninf2 = 0xFC00FC00u;  // packed fp16 -inf
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int g = wr * 2 + a;
+  for (int a = 0; a < NA; ++a) {
+    const int g = wr * NA + a;
     uint32_t cm[8];  // packed column maxima: cm[2*q4 + h] = columns q = 8*q4 + 4*hi + 2*h + {0,1}
 #pragma unroll
     for (int r = 0; r < 8; ++r) cm[r] = ninf2;
@@ -123,8 +142,8 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned ch
         *reinterpret_cast<uint2*>(orow + ((q4 ^ f) * 16) + hi * 8) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
 #endif
         if (cok) {
-          cm[2 * q4] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4]), lo));
-          cm[2 * q4 + 1] = h2_as_u32(pk_max(u32_as_h2(cm[2 * q4 + 1]), hi2));
+          cm[2 * q4] = pk_max_raw(cm[2 * q4], h2_as_u32(lo));
+          cm[2 * q4 + 1] = pk_max_raw(cm[2 * q4 + 1], h2_as_u32(hi2));
         }
       }
     }
@@ -132,11 +151,11 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned ch
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         uint32_t v = cm[r];
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0xB1, 0xF, 0xF, false))));   // quad_perm [1,0,3,2]
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x4E, 0xF, 0xF, false))));   // quad_perm [2,3,0,1]
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x124, 0xF, 0xF, false))));  // row_ror:4
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2((uint32_t)__builtin_amdgcn_update_dpp((int)ninf2, (int)v, 0x128, 0xF, 0xF, false))));  // row_ror:8
-        v = h2_as_u32(pk_max(u32_as_h2(v), u32_as_h2(shfl_xor_u32(v, 16))));                                                                  // the other row of this half
+        v = pk_max_raw(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+        v = pk_max_raw(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+        v = pk_max_raw(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, false));   // row_ror:4
+        v = pk_max_raw(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, false));   // row_ror:8
+        v = pk_max_raw(v, shfl_xor_u32(v, 16));                                                   // the other row of this half
         cm[r] = v;
       }
       if (l31 == 0) {
@@ -149,52 +168,63 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned ch
     }
   }
   __syncthreads();
-  // write-out: 2048 16-byte pieces (g, c, chunk), 8 per thread, consecutive threads -> consecutive bytes of S when Qp == 32
-  uint32_t eacc[NIT];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (bit 31: a clamped bin), summed over the row's 4 lanes
+  // k_centroid_scores_stream: the next tile's operand loads (straight into the other LDS buffer) were issued before this
+  // tile's MFMAs; waiting for them here, in front of this tile's stores, keeps the wait from covering the stores' latency too
+  if (DMA_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (a builtin, so that the compiler's own wait insertion sees it)
+  // write-out: 2048 16-byte pieces (g, c, chunk), NIT per thread, consecutive threads -> consecutive bytes of S when Qp == 32.
+  // Piece p = it * NT + tid: the group g and the first centroid row of the pass depend on `it` only (compile time), the
+  // lane's row / chunk within the pass on tid only -- so every address below is a wave-uniform base (scalar registers) plus a
+  // 32-bit per-lane offset that does not change with `it`.
+  uint32_t eacc[NIT];   // ex.e8 != nullptr: excess of row (g, cl) over the column floors (+ L0_EINF per clamped bin), summed over the row's 4 lanes
+  const int clt = tid >> 2, ch = tid & 3;
+  const uint32_t lane_s = (uint32_t)(clt * Qp + ch * 8);                        // halves, within the pass's block of S
+  const uint32_t lane_o = (uint32_t)(clt * 64 + ((ch ^ ((clt >> 2) & 3)) * 16));       // bytes, within the pass's block of the staged tile
 #if S1_ABL == 1 || S1_ABL == 2
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) eacc[it] = 0u;
   if (Qp < 0)   // timing only: no write-out
 #endif
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     eacc[it] = 0u;
-    const int p = it * NT + tid;
-    const int g = p >> 9, cl = (p >> 2) & 127, ch = p & 3;
+    const int g = (it * NT) >> 9, cl0 = ((it * NT) >> 2) & 127;   // (cl0 is a multiple of 64: the staging swizzle (cl >> 2) & 3 sees clt only)
     const int64_t nb = n0 + g * 32;
-    const int64_t c = c0 + cl;
-    if (nb >= Ntot || c >= C) continue;
-    const int64_t bq = nb / Qp;
-    const int q0 = (int)(nb % Qp);
-    const uint4 v = *reinterpret_cast<const uint4*>(Os + ((size_t)(g * 128 + cl)) * 64 + ((ch ^ ((cl >> 2) & 3)) * 16));
-    *reinterpret_cast<uint4*>(S + (bq * C + c) * Qp + q0 + ch * 8) = v;
+    if (nb >= Ntot || c0 + cl0 + clt >= C) continue;
+    const int64_t bq = G.bq[g];
+    const int q0 = (int)G.q0[g];
+    // (the floors are fetched before the store is issued: the memory counter is in order, so a load behind the store would make
+    // its consumer wait for the store's acknowledgement)
+    uint4 gw = make_uint4(0, 0, 0, 0);
+    if (ex.e8 && S1_ABL != 3) gw = *reinterpret_cast<const uint4*>(ex.gfl + (bq * Qp + q0) + (uint32_t)(ch * 8));
+    const uint4 v = *reinterpret_cast<const uint4*>(Os + (g * 128 + cl0) * 64 + lane_o);
+    uint16_t* Sblk = S + ((bq * C + c0 + cl0) * Qp + q0);   // (uniform)
+    *reinterpret_cast<uint4*>(Sblk + lane_s) = v;
     if (ex.e8 && S1_ABL != 3) {
       // S4 level 0's table entry, straight from the tile (instead of writing the 8-bit bins and reading them back):
-      // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass
-      // packed fp16 throughout: 128 x, its floor, the clamp at bin 255 (floor = 155) and the difference to g = floor_q - 100
-      // are small integers, exact in fp16; pad columns carry g = 2000 (never positive) and score 0 (never clamped)
-      const uint4 gw = *reinterpret_cast<const uint4*>(ex.gfl + bq * Qp + q0 + ch * 8);
+      // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass.
+      // Packed fp16 throughout: 128 x, its floor, the clamp at bin 255 (floor = 155) and the difference to g = floor_q - 100
+      // are small integers, exact in fp16; pad columns carry g = 2000 (never positive) and score 0 (never clamped).
+      // (The floor has to be exact: rounding 128 x to nearest instead -- one packed fma with the constant 1280, still an upper
+      // bound -- loosened the table enough to let 503 k instead of 391 k documents per batch through to the exact rescoring.)
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       const uint32_t gws[4] = {gw.x, gw.y, gw.z, gw.w};
       const h2 k128 = {(half_t)128.f, (half_t)128.f}, k155 = {(half_t)155.f, (half_t)155.f}, kzero = {(half_t)0.f, (half_t)0.f};
-      h2 dsum = kzero, tmax = {(half_t)-1000.f, (half_t)-1000.f};
+      h2 dsum = kzero;
+      uint32_t tmax = 0xE400E400u;   // packed -1024
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        h2 y = u32_as_h2(w[t]) * k128;
-        h2 fl;
-        fl.x = __builtin_floorf16(y.x);
-        fl.y = __builtin_floorf16(y.y);
-        tmax = __builtin_elementwise_max(tmax, fl);
-        const h2 d = __builtin_elementwise_min(fl, k155) - u32_as_h2(gws[t]);
-        dsum += __builtin_elementwise_max(d, kzero);
+        const uint32_t fl = pk_floor_raw(h2_as_u32(u32_as_h2(w[t]) * k128));
+        tmax = pk_max_raw(tmax, fl);
+        const h2 d = u32_as_h2(pk_min_raw(fl, h2_as_u32(k155))) - u32_as_h2(gws[t]);
+        dsum += u32_as_h2(pk_max_raw(h2_as_u32(d), 0u));
       }
-      const uint32_t part = (uint32_t)(int)(float)dsum.x + (uint32_t)(int)(float)dsum.y;
-      const uint32_t inf = ((float)tmax.x >= 155.f || (float)tmax.y >= 155.f) ? 1u : 0u;
-      uint32_t acc = part | (inf << 31);   // (the sums stay far below 2^31: at most 64 columns x 255)
-      {
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-        acc = ((acc & 0x7FFFFFFFu) + (o1 & 0x7FFFFFFFu)) | ((acc | o1) & 0x80000000u);
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-        acc = ((acc & 0x7FFFFFFFu) + (o2 & 0x7FFFFFFFu)) | ((acc | o2) & 0x80000000u);
-      }
+      // four integer terms of at most 255 per half: their total stays below 2048, exact in fp16
+      const uint32_t part = (uint32_t)(int)(float)(half_t)(dsum.x + dsum.y);
+      const h2 tm = u32_as_h2(tmax);
+      const uint32_t inf = (tm.x >= (half_t)155.f || tm.y >= (half_t)155.f) ? L0_EINF : 0u;
+      uint32_t acc = part + inf;   // (the sums stay far below L0_EINF: at most 64 columns x 255)
+      acc += (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+      acc += (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
       eacc[it] = acc;
     }
     if (S8) {
@@ -209,7 +239,8 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned ch
         o[t >> 2] |= (uint32_t)bin << (8 * (t & 3));
       }
       // S8 is [b][Qp/32][c][32]: every 32-column chunk of a query is its own contiguous C x 32 B table
-      *reinterpret_cast<uint2*>(S8 + ((bq * (Qp / 32) + q0 / 32) * C + c) * 32 + ch * 8) = make_uint2(o[0], o[1]);
+      uint8_t* S8blk = S8 + ((bq * (Qp / 32) + q0 / 32) * C + c0 + cl0) * 32;   // (uniform)
+      *reinterpret_cast<uint2*>(S8blk + (uint32_t)(clt * 32 + ch * 8)) = make_uint2(o[0], o[1]);
     }
   }
   if (cmax && tid < 128) {
@@ -229,19 +260,15 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[2][4 / NWC], unsigned ch
     const int per_q = Qp / 32;   // groups per query: 1 or 2
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int p = it * NT + tid;
-      const int g = p >> 9, cl = (p >> 2) & 127;
+      const int g = (it * NT) >> 9, cl0 = ((it * NT) >> 2) & 127;
       if (per_q == 2 && (g & 1)) continue;
       const int64_t nb = n0 + g * 32;
-      const int64_t c = c0 + cl;
+      const int64_t c = c0 + cl0 + clt;
       if (nb >= Ntot || c >= C) continue;
       uint32_t acc = eacc[it];
-      if (per_q == 2) {
-        const uint32_t o = eacc[(it + 512 / NT) % NIT];   // (index always < NIT here: g is even)
-        acc = ((acc & 0x7FFFFFFFu) + (o & 0x7FFFFFFFu)) | ((acc | o) & 0x80000000u);
-      }
-      const int64_t bq = nb / Qp;
-      ex.e8[bq * ex.Cpad + c] = l0_encode(acc & 0x7FFFFFFFu, (acc >> 31) != 0u, ex.esc + bq * 64);
+      if (per_q == 2) acc += eacc[(it + 512 / NT) % NIT];   // (index always < NIT here: g is even)
+      const int64_t bq = G.bq[g];
+      ex.e8[bq * ex.Cpad + c] = l0_encode(acc & (L0_EINF - 1u), acc >= L0_EINF, ex.esc + bq * 64);
     }
   }
 }
@@ -250,7 +277,7 @@ template <int KS, int NWC>
 __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
                                                          uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
-                                                         int nch, int D, int64_t crow_stride, FpS1Excess ex) {
+                                                         int nch, int D, int64_t crow_stride, FpS1Excess ex, int nrt_xcd) {
   // K is consumed in slices of KS dims: the operand tiles take 2 x 128 x KS x 2 B of LDS (32 KiB at KS = 64) instead of
   // 64 KiB for the whole K = 128, which lifts the kernel from 2 to 3 workgroups per CU (VGPR limit) so that one
   // workgroup's store phase overlaps another's MFMA phase.  Any dim that is a multiple of 8 (one 16-byte piece): KS = 64 /
@@ -261,8 +288,18 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
   unsigned char* Qs = smem;              // [128][ROWB]
   unsigned char* Cs = smem + 128 * ROWB; // [128][ROWB]
   const int tid = threadIdx.x;
-  const int64_t n0 = (int64_t)blockIdx.y * 128;
-  const int64_t c0 = (int64_t)blockIdx.x * 128;
+  // Workgroups go round-robin over the 8 XCDs in launch order.  nrt_xcd > 0 (1-D grid): the nrt_xcd query tiles of one
+  // centroid tile run back to back on ONE XCD, so the centroid tile crosses the fabric once (32 MB per batch at cfg2) instead
+  // of once per query tile from the memory-side cache (512 MB); the 512 KB of queries stay in every XCD's L2 either way.
+  int tile_c = (int)blockIdx.x, tile_n = (int)blockIdx.y;
+  if (nrt_xcd > 0) {
+    const uint32_t w = blockIdx.x, seq = w >> 3;
+    tile_n = (int)(seq % (uint32_t)nrt_xcd);
+    tile_c = (int)(seq / (uint32_t)nrt_xcd) * 8 + (int)(w & 7u);
+    if (tile_c >= nch) return;   // (uniform)
+  }
+  const int64_t n0 = (int64_t)tile_n * 128;
+  const int64_t c0 = (int64_t)tile_c * 128;
   const int wave = tid >> 6, lane = tid & 63;
   constexpr int NB = 4 / NWC;               // 32-centroid MFMA tiles per wave
   constexpr int NT = 128 * NWC;
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  s1_epilogue<NWC>(acc, smem, tid, n0, c0, (int)blockIdx.x, S, C, Ntot, Qp, S8, cmax, nch, ex);
+  s1_epilogue<NWC>(acc, smem, tid, n0, c0, tile_c, S, C, Ntot, Qp, S8, cmax, nch, ex, s1_groups(n0, Qp));
 }
 
 // The same GEMM with the QUERY operand held in registers: a workgroup loads its 128 query columns' MFMA A fragments once
@@ -375,7 +412,111 @@ __global__ __launch_bounds__(256) void k_centroid_scores_qreg(const uint16_t* __
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[b], acc[a][b], 0, 0, 0);
     }
-    s1_epilogue<2>(acc, smem, tid, n0, c0, tile_idx, S, C, Ntot, Qp, S8, cmax, nch, ex);
+    s1_epilogue<2>(acc, smem, tid, n0, c0, tile_idx, S, C, Ntot, Qp, S8, cmax, nch, ex, s1_groups(n0, Qp));
+  }
+}
+
+
+// The streaming form of the same GEMM (dim 128 / 64, main pass): a workgroup of 8 waves (4 x 2: 32 query columns x 64 centroids
+// each) keeps its query columns' MFMA A fragments in registers (32 VGPRs at dim 128) and walks `nct` consecutive 128-centroid
+// tiles.  The centroid tile is the only operand that moves: `global_load_lds_dwordx4` writes it straight into one of two LDS
+// buffers (no VGPR staging, so the loads of tile t+1 are in flight while tile t's MFMAs and epilogue run), swizzled on the
+// global-address side (LDS piece p = row * CH + js receives the row's 16-byte piece js ^ (row % CH)).  The epilogue stages tile
+// t's output in tile t's own operand buffer.  The loads are issued from inline assembly: the compiler orders every LDS access
+// after an LDS-writing load it knows of with vmcnt(0), which would serialise the prefetch with the MFMA phase; here the one wait
+// sits in the epilogue in front of the tile's stores and the barrier at the top of the loop publishes the buffer.
+// (One-tile-per-workgroup form above: 64 KB of operands per tile in two serialised round trips, 201 us without its write-out.)
+#ifndef S1_LAUNDER
+#define S1_LAUNDER 1
+#endif
+#define S1_BUF (4 * 128 * 64 + 4 * 128 * 2)   // operand tile / output staging (32 KiB) + the epilogue's column-maximum scratch
+template <int DK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, uint16_t* __restrict__ S, int64_t C,
+                              int64_t Ntot, int Qp, uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, int nch, int nct, int nrt,
+                              FpS1Excess ex) {
+  constexpr int CH = DK / 8;             // 16-byte chunks per row
+  constexpr int ROWB = DK * 2;           // bytes per row
+  constexpr int KSTEPS = DK / 16;
+  constexpr int NLD = 128 * CH / 512;    // 16-byte pieces of a centroid tile per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;  // 4 x 2 waves, 32 (n) x 64 (c) each
+  const int l31 = lane & 31, hi = lane >> 5;
+  // (the divide runs on the vector unit: readfirstlane puts the wave-uniform results back into scalar registers)
+  const int tile_n = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nrt));
+  const int t_first = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)nrt)) * nct;
+  const int t_end = (t_first + nct < nch) ? t_first + nct : nch;
+  if (t_first >= nch) return;   // (uniform)
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+  // piece i of this lane: centroid row i * (512 / CH) + rbase of the tile, 16-byte chunk j16 / 16 of it (the swizzle does not
+  // depend on i: the row advances by a multiple of CH)
+  const uint32_t rbase = (uint32_t)(tid / CH);
+  const uint32_t j16 = (uint32_t)(((tid % CH) ^ ((tid / CH) & (CH - 1))) * 16);
+  auto prefetch = [&](int tile, uint32_t buf_off) {
+    const int64_t c0 = (int64_t)tile * 128;
+    const uint16_t* tile_base = cent + c0 * DK;                        // (scalar)
+    const uint32_t rows_valid = (uint32_t)(C - c0 < 128 ? C - c0 : 128);   // rows past the end read row 0 of the tile (never stored)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const uint32_t row = rbase + (uint32_t)(i * (512 / CH));
+      const uint32_t voff = (row < rows_valid ? row : 0u) * (uint32_t)ROWB + j16;
+      // lane l's 16 bytes land at LDS address M0 + 16 l
+      const uint32_t m0v = lds0 + buf_off + ((uint32_t)i * 8u + wave_s) * 1024u;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // "m0 is reserved": nothing else in this kernel uses it
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(tile_base), "s"(m0v) : "memory", "m0");
+#pragma clang diagnostic pop
+    }
+  };
+  prefetch(t_first, 0u);
+  h8 af[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const int64_t n = (int64_t)tile_n * 128 + wr * 32 + l31;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < Ntot) v = *reinterpret_cast<const uint4*>(qpad + n * DK + (ks * 2 + hi) * 8);
+    af[ks] = __builtin_bit_cast(h8, v);
+  }
+  const S1Groups G0 = s1_groups((int64_t)tile_n * 128, Qp);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first tile and the A fragments (a builtin: the compiler's wait insertion then knows that nothing is pending at the loop head)
+  for (int t = t_first; t < t_end; ++t) {
+    const uint32_t cur_off = (uint32_t)((t - t_first) & 1) * (uint32_t)S1_BUF;
+    unsigned char* cur = smem + cur_off;
+    __syncthreads();   // every wave's pieces of tile t have landed; nobody still reads the other buffer (tile t-1's staging)
+    if (t + 1 < t_end) prefetch(t + 1, (uint32_t)S1_BUF - cur_off);
+    f16v acc[1][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int j = ks * 2 + hi;
+      h8 bf[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int rc = wc * 64 + b * 32 + l31;
+        bf[b] = *reinterpret_cast<const h8*>(cur + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[b], acc[0][b], 0, 0, 0);
+    }
+    // (tile_n is laundered so that the epilogue's per-lane addresses are recomputed per tile instead of living in registers
+    // across the loop: with them hoisted the kernel spills, and a scratch reload's vmcnt(0) would wait for the prefetch)
+    int tn = tile_n;
+    S1Groups G = G0;
+#if S1_LAUNDER
+    asm volatile("" : "+s"(tn));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      asm volatile("" : "+s"(G.bq[g]));
+      asm volatile("" : "+s"(G.q0[g]));
+    }
+#endif
+    s1_epilogue<2, true, 4>(acc, cur, tid, (int64_t)tn * 128, (int64_t)t * 128, t, S, C, Ntot, Qp, S8, cmax, nch, ex, G);
   }
 }
 
@@ -410,19 +551,41 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
       hipLaunchKernelGGL(k_centroid_scores_qreg<64>, g2, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, rs, ex);
     return 0;
   }
+  // streaming form: main pass only (the sampled pre-pass has too few tiles to walk), dim 128 / 64
+  static const int stream_env = [] { const char* e = getenv("FP_S1_STREAM"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup; n > 1: tiles per workgroup
+  if ((D == 128 || D == 64) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= 2048) {
+    const int nrt = (int)grid.y;
+    const int nct = stream_env > 1 ? stream_env : 8;
+    const unsigned nwg = (unsigned)((nch + nct - 1) / nct) * (unsigned)nrt;
+    const size_t lds = 2 * (size_t)S1_BUF;   // 66 KiB: above the 64 KiB that need no opt-in
+    static std::atomic<uint64_t> ok128{0}, ok64{0};
+    if (D == 128) fp_allow_big_lds((const void*)k_centroid_scores_stream<128>, ok128, 80 * 1024);
+    else fp_allow_big_lds((const void*)k_centroid_scores_stream<64>, ok64, 80 * 1024);
+    if (D == 128)
+      hipLaunchKernelGGL(k_centroid_scores_stream<128>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex);
+    else
+      hipLaunchKernelGGL(k_centroid_scores_stream<64>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex);
+    return 0;
+  }
   static const int nwc = [] { const char* e = getenv("FP_S1_WAVES"); return (e && atoi(e) == 4) ? 2 : 4; }();   // FP_S1_WAVES=4: 2 x 2 waves (round 1)
+  static const int xcd_env = [] { const char* e = getenv("FP_S1_XCD"); return e ? atoi(e) : 0; }();   // 1: XCD-aware tile order (measured 315 vs 297 us: the memory-side cache already serves the re-reads)
+  int nrt = 0;
+  if (xcd_env && grid.y > 1 && (int64_t)((nch + 7) / 8) * 8 * grid.y < (1ll << 31)) {
+    nrt = (int)grid.y;
+    grid = dim3((unsigned)(((nch + 7) / 8) * 8 * nrt), 1);
+  }
   if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
-    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<64, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
-    else hipLaunchKernelGGL((k_centroid_scores<64, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<64, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
+    else hipLaunchKernelGGL((k_centroid_scores<64, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
   } else if (D % 32 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 32 * 2, out_lds);
-    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<32, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
-    else hipLaunchKernelGGL((k_centroid_scores<32, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<32, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
+    else hipLaunchKernelGGL((k_centroid_scores<32, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
   } else {
     const size_t lds = std::max<size_t>(2 * 128 * 16 * 2, out_lds);
-    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<16, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
-    else hipLaunchKernelGGL((k_centroid_scores<16, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<16, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
+    else hipLaunchKernelGGL((k_centroid_scores<16, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
   }
   return 0;
 }
@@ -1127,19 +1290,28 @@ __global__ __launch_bounds__(256) void k_cand_scan(int32_t* __restrict__ blkcnt,
   if (threadIdx.x == 0) ncand[b] = base;
 }
 
-__global__ void k_cand_offsets(const int32_t* __restrict__ ncand, int B, int64_t* __restrict__ cand_off) {
+// cap > 0 (the host sized the candidate buffers from earlier batches instead of waiting for this total): a total above the
+// capacity empties every list and marks every query invalid, so that nothing downstream writes; the host sees the true total
+// in *total_out after the call's final sync and runs the batch again with buffers of the right size.
+__global__ void k_cand_offsets(const int32_t* __restrict__ ncand, int B, int64_t* __restrict__ cand_off, int64_t cap = 0,
+                               int32_t* __restrict__ invalid = nullptr, int64_t* __restrict__ total_out = nullptr) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     int64_t a = 0;
     for (int b = 0; b < B; ++b) { cand_off[b] = a; a += ncand[b]; }
     cand_off[B] = a;
+    if (total_out) *total_out = a;
+    if (cap > 0 && a > cap) {
+      for (int b = 0; b <= B; ++b) cand_off[b] = 0;
+      for (int b = 0; b < B; ++b) invalid[b] = 1;
+    }
   }
 }
 
 void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W, int32_t* blkcnt,
-                    int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st) {
+                    int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st, int64_t cap, int32_t* invalid_rw, int64_t* total_out) {
   hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, ncand, B, cand_off);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, ncand, B, cand_off, cap, invalid_rw, total_out);
 }
 
 __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
@@ -1727,7 +1899,7 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
   hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut, bins);
   hipLaunchKernelGGL(k_surv_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cut, blkcnt, nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, nsurv);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr);
   hipLaunchKernelGGL(k_surv_compact, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cand_pid, cut, blkcnt, nblk, surv_off,
                      surv_pid);
 }
@@ -2472,7 +2644,7 @@ void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const in
                      w.blkcntx, w.nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcntx, w.nblk, w.nextra);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr);
   hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.thr, w.cut, w.npilot,
                      w.cand_approx, w.blkcnt, w.blkcntx, w.nblk, surv_off, surv_pid, surv_approx, w.xpid, w.xdst);
 }

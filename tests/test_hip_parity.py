@@ -353,6 +353,23 @@ def test_index_build_with_capped_grids(fp):
     assert r.returncode == 0 and "GRID_CAP_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("cap_pct,impl", [("", ""), ("50", ""), ("50", "l0"), ("", "l0")])
+def test_candidate_capacity_speculation(fp, cap_pct, impl):
+    """fp_search sizes S4 / S5 from the candidate totals of earlier batches of the same shape instead of waiting for the
+    current total in the middle of the pipeline; a batch above the learnt capacity is emptied on the device and run again.
+    FP_SPEC_CAP_PCT=50 makes the capacity half of the last total, so every batch after a shape's first takes the re-run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if cap_pct:
+        env["FP_SPEC_CAP_PCT"] = cap_pct
+    if impl:
+        env["FP_APPROX_IMPL"] = impl
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "spec_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "SPEC_OK" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("ppd", ["auto", "1", "2", "4", "8"])
 def test_bound_and_refine_forced(fp, ppd):
     """S4's bound-and-refine form (8-bit bins of S -> per-candidate bounds -> exact rescoring of
