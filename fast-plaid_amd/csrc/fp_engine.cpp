@@ -123,6 +123,7 @@ struct Scratch {
   // Candidate-buffer capacity learnt from earlier batches of the same shape (0: none): with it, fp_search does not wait for the
   // candidate total in the middle of the pipeline (see run_front)
   int64_t spec_cap = 0;
+  int64_t spec_last = 0;   // the previous batch's total: sizes the grids (the capacity would over-provision them by a quarter)
   int64_t spec_key[4] = {0, 0, 0, 0};   // {B, Q, n_ivf_probe, subset?}
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
@@ -739,7 +740,9 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                     s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>()};
       fpk_l0_prepare(D, nullptr, sh, w, st);   // floors and table came with S1
       STAGE_DONE(ST_APPROX);
-      fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
+      // (grid: from the previous batch's total when M is the learnt capacity -- every extra workgroup copies the table into LDS;
+      // the kernel strides if this batch has more)
+      fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), P.spec && s->spec_last > 0 ? std::min(M, s->spec_last) : M, w, st);
       STAGE_DONE(ST_REFINE);
       fpk_l0_pilot(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
       // exact scores of the pilot group (about FP_L0_PILOT x keep documents per query; ties of UB0 at the cut can add more)
@@ -944,6 +947,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       const int64_t want = M_true * pct / 100 + 1024;
       if (want > s->spec_cap || pct < 100) s->spec_cap = want;
     }
+    s->spec_last = M_true;
     g_last_counts[0] += M_true;
     g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
