@@ -10,11 +10,14 @@ n_full_scores=4096 (R=1024 exact-scored docs / query), n_ivf_probe=8.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N         # N GPUs, one process each (RCCL)
 
-N>1: the SAME corpus and the SAME query batch -> "scaling": "strong".  Two modes (fast-plaid_amd/sharded.py), `--dist-mode`:
-"replica" = the reference's own multi-GPU mode (full index per GPU, the batch split across ranks, one result all-gather),
-chosen by "auto" when the index fits one GPU; "shard" = documents split into N contiguous token-balanced shards, three
-fixed-size all-gathers per batch issued by the library itself (fp_shard_search).  With --alt-mode the mode that is not
-`value` is timed too and reported as `alt_mode`.
+N>1, `--dist-mode` (fast-plaid_amd/sharded.py):
+"replica" (chosen by "auto" when the index fits one GPU) = the reference's multi-GPU layout -- a full index per GPU, one
+process per GPU -- with every rank searching its OWN batch of 64 per step through fp_search: queries are independent units,
+so there is no data-path collective; `value` = N x 64 queries per step / max-over-ranks time, "scaling": "weak".
+"split" = the same replicas with ONE batch of 64 split across the ranks and a result all-gather ("strong");
+"shard" = the corpus split into N contiguous token-balanced document shards, the SAME batch on every rank, three fixed-size
+all-gathers per batch issued by the library itself (fp_shard_search; "strong"; what "auto" picks for an index that does not
+fit one GPU).  With --alt-mode a second mode is timed too and reported as `alt_mode`.
 
 One JSON line on rank 0.  `value` is timed on the boundary call fp_search (host query buffer in, host
 results out -- what the reference's pysearch hands over, rust/lib.rs:195-223); the same steps with queries and
@@ -59,9 +62,11 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
     ap.add_argument("--workload", type=str, default="", help="label override")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
-    ap.add_argument("--dist-mode", choices=["auto", "replica", "shard"], default="auto",
-                    help="N>1: replica = full index per GPU, batch split across ranks (the reference's multi-GPU mode); "
-                         "shard = document shards + 3 RCCL all-gathers per batch; auto = replica when the index fits one GPU")
+    ap.add_argument("--dist-mode", choices=["auto", "replica", "split", "shard"], default="auto",
+                    help="N>1: replica = full index per GPU, every rank searches its OWN batch of --batch queries per step, no "
+                         "data-path collective (weak scaling: the reference's replicas, one client stream per GPU); split = "
+                         "full index per GPU, ONE batch split across the ranks + a result all-gather (strong); shard = document "
+                         "shards + 3 RCCL all-gathers per batch (strong); auto = replica when the index fits one GPU, else shard")
     ap.add_argument("--alt-mode", action="store_true", help="N>1: also time the other distribution mode and report it as alt_mode")
     ap.add_argument("--no-alt-mode", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--dist-impl", choices=["native", "torch"], default="native",
@@ -135,6 +140,9 @@ def main():
     params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
     n_batches = a.steps + a.warmup   # a distinct query batch for every step (no cache-warm repeats)
     batches = [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i) for i in range(n_batches)]
+    # "replica" mode: every rank has its own stream of batches (rank 0's is the single-GPU stream)
+    own_batches = batches if rank == 0 else [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i + 7919 * rank)
+                                             for i in range(n_batches)]
 
     def sync():
         if use_dist:
@@ -169,9 +177,11 @@ def main():
                 if native_comm is not None:
                     return sharded.native_sharded_search(index, native_comm, q, params)
                 return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
-            if mode == "replica":
+            if mode == "split":
                 return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist,
                                                  device=("cpu" if a.dist_backend == "gloo" else dev), force_collectives=True)
+            if mode == "replica":   # this rank's own batch on its own replica: the fp_search boundary, nothing else
+                return R.search_arrays(index, own_batches[i % n_batches], params)
             return R.search_arrays(index, q, params)
 
         for i in range(a.warmup):
@@ -187,7 +197,7 @@ def main():
             ts = time.perf_counter()
             step(a.warmup + i)
             lat.append(time.perf_counter() - ts)
-            if mode == "single":
+            if mode in ("single", "replica"):
                 for k, v in R.last_search_timings().items():
                     stage_acc[k] = stage_acc.get(k, 0.0) + v
                 cnts = R.last_search_counts()
@@ -223,7 +233,7 @@ def main():
         hbm = torch.cuda.get_device_properties(local_rank).total_memory
         fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
         primary = a.dist_mode if a.dist_mode != "auto" else ("replica" if fits else "shard")
-        other = "shard" if primary == "replica" else "replica"
+        other = "shard" if primary in ("replica", "split") else "split"
         run_other = a.alt_mode and (not a.no_alt_mode) and (other == "shard" or fits)
     else:
         primary, run_other = "single", False
@@ -232,7 +242,9 @@ def main():
     exact_total = res["exact_total"]
     dev_elapsed = res["dev_elapsed"]
     ms_per_step = elapsed / a.steps * 1e3
-    qps = a.batch * a.steps / elapsed
+    weak = primary == "replica"
+    global_batch = a.batch * (world if weak else 1)   # replica: every rank searched its own batch in each step
+    qps = global_batch * a.steps / elapsed
     index_bytes = index.device_bytes
     alt = None
     if run_other:
@@ -242,7 +254,9 @@ def main():
         alt = {"mode": other, "value": a.batch * a.steps / r2["elapsed"], "ms_per_step": r2["elapsed"] / a.steps * 1e3}
         del r2
     par = {"single": "1 GPU",
-           "replica": "full index replica per GPU, batch split %d-way, result all-gather over %s" % (
+           "replica": "%d full-index replicas, one process per GPU, each searching its own batch of %d queries per step through "
+                      "fp_search; no data-path collective (barrier + max-over-ranks timing only)" % (world, a.batch),
+           "split": "full index replica per GPU, batch split %d-way, result all-gather over %s" % (
                world, "RCCL" if a.dist_backend == "nccl" else "gloo (test mode: ranks share the visible GPUs)"),
            "shard": "document-sharded x%d, 3 RCCL all-gathers/batch (%s)" % (
                world, "issued by the library on the search stream" if (a.dist_impl == "native" and a.dist_backend == "nccl") else "torch.distributed between four stage calls")}[primary]
@@ -250,13 +264,14 @@ def main():
     out = {
         "metric": "queries/sec @ top_k=%d (batch=%d, dim=%d); p50 search latency" % (a.topk, a.batch, a.dim),
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": ("strong" if primary in ("shard", "split") else "weak"),
+        "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {
             "workload": a.workload or ("BASELINE cfg2: %d docs x %d tok x dim%d, nbits=%d, %d centroids, batch=%d x %d tok, "
                                        "top_k=%d, n_full_scores=%d, n_ivf_probe=%d" % (
                                            a.docs, a.doc_len, a.dim, a.nbits, C, a.batch, a.qlen, a.topk, a.nfull, a.nprobe)),
-            "parallelism": par,
+            "parallelism": par, "global_batch": global_batch,
             "index_bytes_per_gpu": index_bytes, "index_build_s": round(t_build, 2),
         },
         "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
@@ -268,7 +283,7 @@ def main():
             a.batch * a.qlen * a.dim * 2 // 1024, a.batch * a.topk * 12 // 1024)
         out["value_device_io"] = {"value": a.batch * a.steps / dev_elapsed, "ms_per_step": dev_elapsed / a.steps * 1e3,
                                   "note": "fp_search_device: queries uploaded before the timed region, results left in HBM"}
-    if not use_dist and rank == 0:
+    if primary in ("single", "replica") and rank == 0:   # (replica: rank 0's own kernels; every rank runs the same pipeline)
         stages = {k: v / a.steps for k, v in stage_acc.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
         out["docs_repaired_per_batch"] = res["repaired_total"] / a.steps
@@ -337,7 +352,7 @@ def main():
                                   "frac": (fl_s1 / (t_s1 * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS) if t_s1 > 0 else 0.0},
         }
         # ---- CPU baseline: the plain-C oracle ("port"), all host cores, same corpus, bounded sample
-        ncpu = a.cpu_queries
+        ncpu = a.cpu_queries if not use_dist else 0   # rank 0 at N=1 only
         if ncpu != 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import plaid_oracle as OC
