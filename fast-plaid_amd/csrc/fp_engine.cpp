@@ -554,6 +554,14 @@ struct Pipe {
   bool spec = false;         // ... and it was
 };
 
+// after a batch: the candidate capacity the next batch of this shape runs on (see run_front)
+static void learn_capacity(Scratch* s, int64_t M_true) {
+  static const int pct = [] { const char* e = getenv("FP_SPEC_CAP_PCT"); const int v = e ? atoi(e) : 125; return v > 0 ? v : 125; }();   // tests: < 100 forces the re-run
+  const int64_t want = M_true * pct / 100 + 1024;
+  if (want > s->spec_cap || pct < 100) s->spec_cap = want;
+  s->spec_last = M_true;
+}
+
 // stages S1..S5 for one sub-batch whose fp16 queries are already in s->qin
 static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off /*B+1 rebased*/, bool has_subset) {
   fp_index* ix = P.ix;
@@ -662,7 +670,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     for (int i = 0; i < 4; ++i) s->spec_key[i] = key[i];
   }
   P.spec = P.allow_spec && spec_env && s->spec_cap > 0;
-  HIPCHK(s->spec_total.ensure(8));
+  HIPCHK(s->spec_total.ensure(16));   // {candidate total, fp_shard_search's overflow mark}
   int64_t* d_total = s->spec_total.as<int64_t>();
   fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                  s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st, P.spec ? s->spec_cap : 0,
@@ -942,12 +950,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       b0 -= maxB;
       continue;
     }
-    {
-      static const int pct = [] { const char* e = getenv("FP_SPEC_CAP_PCT"); const int v = e ? atoi(e) : 125; return v > 0 ? v : 125; }();   // tests: < 100 forces the re-run
-      const int64_t want = M_true * pct / 100 + 1024;
-      if (want > s->spec_cap || pct < 100) s->spec_cap = want;
-    }
-    s->spec_last = M_true;
+    learn_capacity(s, M_true);
     g_last_counts[0] += M_true;
     g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
@@ -1630,8 +1633,13 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   struct Rel { fp_index* ix; Scratch* s; ~Rel() { (void)hipStreamSynchronize(s->st); release(ix, s); } } rel{ix, s};
   hipStream_t st = s->st;
   const int B = nq;
+  // Like fp_search, the front half runs on the candidate capacity learnt from earlier batches instead of waiting for this
+  // batch's total.  A rank whose batch outgrows its capacity has emptied its lists; it says so in record 0 of the first
+  // exchange, every rank sees the mark after its final sync, and every rank runs the batch again -- this time waiting.
+  for (int attempt = 0; attempt < 2; ++attempt) {
   Pipe P{};
   P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
+  P.allow_spec = attempt == 0;
   const int64_t R = P.sh.R;
   const int64_t K = p->top_k;
   // every rank must issue both collectives whatever its shard holds (an empty shard contributes only padding records)
@@ -1651,10 +1659,16 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
     if (int rc = run_front(P, nullptr, nullptr, false)) return rc;
   }
   // exchange 1: local top-R by approximate score
-  fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
+  fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st,
+                  P.spec ? s->spec_total.as<int64_t>() : nullptr, P.spec ? P.M : 0);
   LAUNCHCHK("fp_shard_search (front half)");
   if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
   LAUNCHCHK("fp_shard_search (first all-gather)");
+  HIPCHK(s->h_small.ensure(4096));
+  HIPCHK(s->spec_total.ensure(16));
+  int32_t* d_over = s->spec_total.as<int32_t>() + 2;   // (behind the 8 bytes of the candidate total)
+  fpk_shard_any_overflow(s->sh_all.p, G, B, R, d_over, st);
+  HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, d_over, 4, hipMemcpyDeviceToHost, st));
   if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st))
     return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
   // exchange 2: MFMA scores + uncertainties of the local survivors
@@ -1679,8 +1693,20 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
     if (int rc = api->AllGather(s->sh_x.p, s->sh_xall.p, (size_t)B * R * 4, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
     LAUNCHCHK("fp_shard_search (third all-gather)");
   }
-  return shard_apply_and_rank(s, P.sh, s->sh_xall.as<float>(), K, out_pids, out_scores, out_counts, st);
+  if (int rc = shard_apply_and_rank(s, P.sh, s->sh_xall.as<float>(), K, out_pids, out_scores, out_counts, st)) return rc;
+  HIPCHK(hipStreamSynchronize(st));
+  if (attempt == 0 && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 40) != 0) {
+    s->spec_cap = 0;   // (the rank that overflowed; harmless on the others: the second attempt waits everywhere)
+    continue;
+  }
+  if (!empty_local) {
+    learn_capacity(s, *reinterpret_cast<const int64_t*>(s->h_small.p));
+  }
+  return FP_OK;
+  }
+  return fail(FP_EHIP, "fp_shard_search: the candidate capacity overflowed twice");
 }
+
 
 // ------------------------------------------------------------------------------------------
 // exhaustive arithmetic self-test (see fp_kernels.hip k_selftest_arith)

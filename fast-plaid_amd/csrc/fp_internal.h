@@ -187,7 +187,8 @@ void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local
                     int64_t* stat_out /*[1 + B]: statistics copied next to the results*/ = nullptr);
 // sharded helpers (record layouts: include/fastplaid.h)
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
-                     hipStream_t st);
+                     hipStream_t st, const int64_t* cand_total = nullptr, int64_t cand_cap = 0);
+void fpk_shard_any_overflow(const void* all_rec1, int G, int B, int64_t R, int32_t* flag, hipStream_t st);
 void fpk_shard_pack2(const float* score, const float* unc /*nullable*/, const float* uncm /*nullable*/, const int32_t* sel_pid,
                      const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec2, hipStream_t st);
 int fpk_shard_global_cut(const void* all_rec1 /*[G][B][R]*/, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,

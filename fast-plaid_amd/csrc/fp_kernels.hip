@@ -3192,21 +3192,36 @@ struct ShardRec2 { long long pid; float score; float uncm; float unc; int pad; }
 static_assert(sizeof(ShardRec1) == 16 && sizeof(ShardRec2) == 24, "record layout is part of the C ABI");
 
 __global__ void k_shard_pack1(const float* __restrict__ approx, const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt, int64_t R,
-                              int64_t pid_offset, ShardRec1* __restrict__ out, int64_t total) {
+                              int64_t pid_offset, ShardRec1* __restrict__ out, int64_t total,
+                              const int64_t* __restrict__ cand_total /*nullable*/, int64_t cand_cap) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / R), r = (int)(i % R);
   ShardRec1 o;
-  o.pad = 0;
+  // record 0 tells the other ranks whether this rank's batch outgrew its learnt candidate capacity (its lists are then empty and
+  // every rank runs the batch again: fp_shard_search)
+  o.pad = (i == 0 && cand_total && cand_cap > 0 && *cand_total > cand_cap) ? 1 : 0;
   if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.approx = approx[i]; }
   else { o.pid = -1; o.approx = -__builtin_inff(); }
   out[i] = o;
 }
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
-                     hipStream_t st) {
+                     hipStream_t st, const int64_t* cand_total, int64_t cand_cap) {
   const int64_t total = (int64_t)B * R;
   hipLaunchKernelGGL(k_shard_pack1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sel_approx, sel_pid, sel_cnt, R, pid_offset,
-                     static_cast<ShardRec1*>(rec1), total);
+                     static_cast<ShardRec1*>(rec1), total, cand_total, cand_cap);
+}
+
+// OR of the ranks' overflow marks (record 0 of each rank's block of the gathered first exchange)
+__global__ void k_shard_any_overflow(const ShardRec1* __restrict__ all, int G, int64_t per_rank, int32_t* __restrict__ flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int f = 0;
+    for (int g = 0; g < G; ++g) f |= all[(int64_t)g * per_rank].pad;
+    *flag = f;
+  }
+}
+void fpk_shard_any_overflow(const void* all_rec1, int G, int B, int64_t R, int32_t* flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_shard_any_overflow, dim3(1), dim3(64), 0, st, static_cast<const ShardRec1*>(all_rec1), G, (int64_t)B * R, flag);
 }
 
 // pid / MFMA score / uncertainty (total and downward part) of the local survivors

@@ -228,7 +228,11 @@ void fp_shard_end(fp_shard_ctx* ctx);
  *   all   : fp_comm_create(device, n_ranks, rank, id, &comm)      (collective: ncclCommInitRank)
  *   all   : fp_shard_search(shard_index, comm, ...)                (collective; identical results on every rank, == fp_search
  *                                                                   on the whole corpus)
- * Every rank passes the same queries / parameters.  Not re-entrant on one communicator. */
+ * Every rank passes the same queries / parameters.  Not re-entrant on one communicator.
+ * From a shape's second batch on, a rank sizes its candidate buffers from earlier batches instead of waiting for the current
+ * total (as fp_search does).  A rank whose batch outgrows that capacity marks record 0 of its first-exchange block
+ * (fp_shard_rec1.pad = 1); every rank sees the mark and the whole call is run once more inside the library -- callers of
+ * fp_shard_search notice nothing, callers of the staged entry points (which always wait) always see pad = 0. */
 typedef struct fp_comm fp_comm;
 int fp_comm_unique_id(void* out_id_128_bytes);
 int fp_comm_create(int device_id, int n_ranks, int rank, const void* unique_id_128_bytes, fp_comm** out);

@@ -909,6 +909,25 @@ def test_sharded_equals_unsharded(fp):
     assert r.returncode == 0 and "SHARDED_GPU_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("cap_pct", ["", "50"])
+def test_native_rccl_shard_search_one_rank(fp, cap_pct):
+    """fp_shard_search with one rank over RCCL (a single-GPU box allows no more) reproduces fp_search exactly, also when the
+    learnt candidate capacity is forced too small and the batch is run again after the overflow mark of the first exchange."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if cap_pct:
+        env["FP_SPEC_CAP_PCT"] = cap_pct
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "native_shard_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "NATIVE_SHARD_OK" in r.stdout, r.stdout + r.stderr
+
+
 FULL_SIZE = {
     # BASELINE.json configs at full size (SURVEY 8d config table); centroids = 2^floor(log2(16*sqrt(tokens)))
     "cfg2": dict(n_docs=1_000_000, doc_len=128, n_centroids=131072, B=64, Q=32, top_k=1000, n_full=4096, n_probe=8),
