@@ -349,74 +349,6 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
   s1_epilogue<NWC>(acc, smem, tid, n0, c0, tile_c, S, C, Ntot, Qp, S8, cmax, nch, ex, s1_groups(n0, Qp));
 }
 
-// The same GEMM with the QUERY operand held in registers: a workgroup loads its 128 query columns' MFMA A fragments once
-// (all of K: DK / 16 k-steps x 2 row halves x 16 B per lane) and walks `nct` consecutive 128-centroid tiles, staging only the
-// centroid tile (128 x DK halves, 32 KiB at DK = 128) per tile.  The one-tile-per-workgroup kernel above moves 64 KB of
-// operands through L2 per tile and ran 201 us with its write-out removed (1 GB of operand traffic per batch); this one
-// moves 32 KB.  dim 128 / 64 (power-of-two 16-byte chunks per row for the XOR swizzle); other dims use the kernel above.
-template <int DK>
-__global__ __launch_bounds__(256) void k_centroid_scores_qreg(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
-                                                              uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
-                                                              uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, int nch, int nct,
-                                                              int64_t crow_stride, FpS1Excess ex) {
-  constexpr int CH = DK / 8;             // 16-byte chunks per row
-  constexpr int ROWB = DK * 2;           // bytes per row
-  constexpr int KSTEPS = DK / 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Cs = smem;              // [128][ROWB]; the output staging of the epilogue reuses it
-  const int tid = threadIdx.x;
-  const int64_t n0 = (int64_t)blockIdx.y * 128;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;  // 2x2 waves, 64x64 each
-  const int l31 = lane & 31, hi = lane >> 5;
-  h8 af[KSTEPS][2];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int64_t n = n0 + wr * 64 + t * 32 + l31;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < Ntot) v = *reinterpret_cast<const uint4*>(qpad + n * DK + (ks * 2 + hi) * 8);
-      af[ks][t] = __builtin_bit_cast(h8, v);
-    }
-  for (int ct = 0; ct < nct; ++ct) {
-    const int tile_idx = (int)blockIdx.x * nct + ct;
-    if (tile_idx >= nch) break;   // (uniform)
-    const int64_t c0 = (int64_t)tile_idx * 128;
-    if (ct > 0) __syncthreads();   // the previous tile's output staging is no longer read
-    for (int i = tid; i < 128 * CH; i += 256) {
-      const int row = i / CH, j = i % CH;
-      uint4 vc = make_uint4(0, 0, 0, 0);
-      if (c0 + row < C) vc = *reinterpret_cast<const uint4*>(cent + (c0 + row) * crow_stride * DK + j * 8);
-      *reinterpret_cast<uint4*>(Cs + row * ROWB + ((j ^ (row & (CH - 1))) * 16)) = vc;
-    }
-    __syncthreads();
-    f16v acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      h8 bf[2];
-      const int j = ks * 2 + hi;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int rc = wc * 64 + t * 32 + l31;
-        bf[t] = *reinterpret_cast<const h8*>(Cs + rc * ROWB + ((j ^ (rc & (CH - 1))) * 16));
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[b], acc[a][b], 0, 0, 0);
-    }
-    s1_epilogue<2>(acc, smem, tid, n0, c0, tile_idx, S, C, Ntot, Qp, S8, cmax, nch, ex, s1_groups(n0, Qp));
-  }
-}
-
-
 // The streaming form of the same GEMM (dim 128 / 64, main pass): a workgroup of 8 waves (4 x 2: 32 query columns x 64 centroids
 // each) keeps its query columns' MFMA A fragments in registers (32 VGPRs at dim 128) and walks `nct` consecutive 128-centroid
 // tiles.  The centroid tile is the only operand that moves: `global_load_lds_dwordx4` writes it straight into one of two LDS
@@ -534,23 +466,6 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   const size_t out_lds = 4 * 128 * 64 + 4 * 128 * 2;
   const int D = ix.dim;
   if (D % 8 != 0 || D < 8) return -1;
-  // (measured at cfg2: 0.394 ms for the S1 stage against 0.343 ms with one tile per workgroup -- 232 registers leave two
-  // workgroups per CU instead of three, and a workgroup's stage / MFMA / epilogue phases do not overlap with each other.
-  // Kept as an experiment: FP_S1_QREG=1.)
-  static const int qreg_env = [] { const char* e = getenv("FP_S1_QREG"); return e ? atoi(e) : 0; }();
-  if ((D == 128 || D == 64) && qreg_env) {
-    // query operand in registers, several centroid tiles per workgroup: enough workgroups to fill the chip a few times over
-    const int64_t tiles = (int64_t)nch * grid.y;
-    int nct = (int)(tiles / (256 * 8));
-    nct = nct < 1 ? 1 : (nct > 8 ? 8 : nct);
-    dim3 g2((unsigned)((nch + nct - 1) / nct), grid.y);
-    const size_t lds = std::max<size_t>((size_t)128 * D * 2, out_lds);
-    if (D == 128)
-      hipLaunchKernelGGL(k_centroid_scores_qreg<128>, g2, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, rs, ex);
-    else
-      hipLaunchKernelGGL(k_centroid_scores_qreg<64>, g2, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, rs, ex);
-    return 0;
-  }
   // streaming form: main pass only (the sampled pre-pass has too few tiles to walk), dim 128 / 64
   static const int stream_env = [] { const char* e = getenv("FP_S1_STREAM"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup; n > 1: tiles per workgroup
   if ((D == 128 || D == 64) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= 2048) {
