@@ -3,6 +3,7 @@
 // rust/utils/residual_codec.rs of the reference: index construction = upload + re-layout,
 // search_many = one batched, stream-ordered pipeline of HIP kernels (fp_kernels.hip).
 // No torch / tch; only the HIP runtime.
+#include <atomic>
 #include "../../include/fastplaid.h"
 
 #include <algorithm>
@@ -37,7 +38,7 @@ static int fail(int code, const std::string& msg) {
     hipError_t l_ = hipGetLastError();                                                                 \
     if (l_ != hipSuccess)                                                                              \
       return fail(FP_EHIP, std::string("HIP launch error: ") + hipGetErrorString(l_) + " before the end of stage " #X); \
-    HIPCHK(hipEventRecord(s->ev[X], st));                                                              \
+    if (!s->capturing) HIPCHK(hipEventRecord(s->ev[X], st));                                           \
   } while (0)
 #define LAUNCHCHK(where)                                                                               \
   do {                                                                                                 \
@@ -56,11 +57,15 @@ extern "C" int fp_device_count(void) {
 // ------------------------------------------------------------------------------------------
 // grow-only device buffer
 // ------------------------------------------------------------------------------------------
+// bumped by every (re)allocation of a scratch buffer: a captured graph (FP_GRAPH) holds raw pointers and is only replayed while
+// the count it was captured under still stands
+static std::atomic<uint64_t> g_alloc_gen{0};
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   hipError_t ensure(size_t need) {
     if (need <= cap) return hipSuccess;
+    g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -85,6 +90,7 @@ struct HostBuf {
   size_t cap = 0;
   hipError_t ensure(size_t need) {
     if (need <= cap) return hipSuccess;
+    g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
@@ -125,6 +131,18 @@ struct Scratch {
   int64_t spec_cap = 0;
   int64_t spec_last = 0;   // the previous batch's total: sizes the grids (the capacity would over-provision them by a quarter)
   int64_t spec_key[4] = {0, 0, 0, 0};   // {B, Q, n_ivf_probe, subset?}
+  // FP_GRAPH=1 (opt-in): once fp_search runs on the learnt capacity there is no host decision left inside the pipeline, so the
+  // whole call -- query upload from a pinned staging buffer, ~55 launches and fills, result download -- is captured once per
+  // {shape, parameters, capacity, allocation generation} and replayed with one hipGraphLaunch
+  struct GraphCache {
+    hipGraphExec_t exec = nullptr;
+    int64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // key of the last speculative call (a capture needs one such call before it: every buffer sized)
+    int warm = 0, fails = 0;
+    bool valid = false, used_q8 = false, marked = false;
+  } graph;
+  bool capturing = false;
+  HostBuf h_qin;
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
@@ -136,6 +154,8 @@ struct Scratch {
       b->release();
     h_out.release();
     h_small.release();
+    h_qin.release();
+    if (graph.exec) { (void)hipGraphExecDestroy(graph.exec); graph.exec = nullptr; graph.valid = false; }
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
                      &sub_off,  &bitmap,   &blkcnt,   &ncand,   &cand_off, &cand_pid,  &approx,  &hist,     &selstate, &sel_pid, &tie_pid,
                      &sel_approx, &sel_cnt, &exact,   &out_pid, &out_score, &out_cnt,  &tmpf,    &tmpp,     &tok_idx, &recon};
@@ -881,7 +901,21 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
   if (D.N == 0) return FP_OK;
   Scratch* s = acquire(ix);
   if (!s) return fail(FP_EHIP, "could not create a HIP stream");
-  struct Rel { fp_index* ix; Scratch* s; ~Rel() { release(ix, s); } } rel{ix, s};
+  struct Rel {
+    fp_index* ix; Scratch* s;
+    ~Rel() {
+      if (s->capturing) {   // an error return in the middle of a capture: close it, or the stream stays unusable
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(s->st, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        s->capturing = false;
+        s->graph.fails = 1000;
+      }
+      release(ix, s);
+    }
+  } rel{ix, s};
+  static const bool graph_env = [] { const char* e = getenv("FP_GRAPH"); return e && atoi(e) != 0; }();
   const int Qp = (Q + 31) & ~31;
   // sub-batch so that the centroid-score table stays within a budget
   static const size_t budget_env = getenv("FP_S_BUDGET_KB") ? (size_t)atoll(getenv("FP_S_BUDGET_KB")) << 10 : 0;   // tests: force sub-batching
@@ -899,9 +933,42 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
     P.exact_all = tr != nullptr;   // the trace reports the approximate score of every candidate
     hipStream_t st = s->st;
+    const int64_t K = p->top_k;
+    OutLayout ol(B, K);
+    // ---- FP_GRAPH: replay / capture (host-buffer calls of one sub-batch, no subset, no trace)
+    const bool graph_ok = graph_env && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3;
+    const size_t qbytes = (size_t)B * Q * D.dim * 2;
+    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)g_alloc_gen.load(std::memory_order_relaxed), 1};
+    bool replayed = false;
+    if (graph_ok && s->graph.valid && std::equal(gkey, gkey + 8, s->graph.key)) {
+      memcpy(s->h_qin.p, queries, qbytes);
+      HIPCHK(hipGraphLaunch(s->graph.exec, st));
+      HIPCHK(hipStreamSynchronize(st));
+      P.spec = true;
+      P.M = s->spec_cap;
+      P.used_q8 = s->graph.used_q8;
+      s->fold_stats = true;
+      s->ms_marked_now = s->graph.marked;
+      replayed = true;
+    }
+    bool capture = false;
+    if (graph_ok && !replayed) {
+      // capture when the previous call was a speculative one with the same key (so that no buffer grows inside the capture)
+      capture = s->spec_cap > 0 && s->graph.warm >= 1 && std::equal(gkey, gkey + 8, s->graph.last);
+      if (capture) {
+        HIPCHK(s->h_qin.ensure(qbytes));
+        gkey[6] = (int64_t)g_alloc_gen.load(std::memory_order_relaxed);
+        memcpy(s->h_qin.p, queries, qbytes);
+        if (s->graph.exec) { (void)hipGraphExecDestroy(s->graph.exec); s->graph.exec = nullptr; }
+        s->graph.valid = false;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        s->capturing = true;
+      }
+    }
+    if (!replayed) {
     STAGE_DONE(ST_UPLOAD);
-    HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
-    HIPCHK(hipMemcpyAsync(s->qin.p, queries + (size_t)b0 * Q * D.dim, (size_t)B * Q * D.dim * 2,
+    HIPCHK(s->qin.ensure(qbytes));
+    HIPCHK(hipMemcpyAsync(s->qin.p, capture ? static_cast<const uint16_t*>(s->h_qin.p) : queries + (size_t)b0 * Q * D.dim, qbytes,
                           dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     const int64_t* sids = nullptr;
     if (has_subset) {
@@ -913,14 +980,11 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     s->ms_marked_now = false;
     P.allow_spec = tr == nullptr && !has_subset;   // (subset searches: the candidate total follows the subset sizes, not the shape)
     if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
-    if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
     // S6+S7
     const int64_t R = P.sh.R;
     if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true)) return rc;
     STAGE_DONE(ST_TOPK);
     // S8
-    const int64_t K = p->top_k;
-    OutLayout ol(B, K);
     HIPCHK(s->out_all.ensure(ol.total));
     HIPCHK(s->h_out.ensure(ol.total));
     char* od = s->out_all.as<char>();
@@ -937,10 +1001,36 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       HIPCHK(hipStreamSynchronize(st));   // results are complete in HBM when the call returns
     } else {
       HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
+      if (capture) {
+        // nothing has run yet: close the capture, keep the executable graph if the call was what a replay needs (speculative, no
+        // buffer moved), and launch it -- or fall back to the plain path for this batch
+        hipGraph_t g = nullptr;
+        const hipError_t ce = hipStreamEndCapture(st, &g);
+        s->capturing = false;
+        hipGraphExec_t ex = nullptr;
+        const bool usable = ce == hipSuccess && g && P.spec && gkey[6] == (int64_t)g_alloc_gen.load(std::memory_order_relaxed) &&
+                            hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex;
+        if (g) (void)hipGraphDestroy(g);
+        if (!usable) {
+          (void)hipGetLastError();
+          if (ex) (void)hipGraphExecDestroy(ex);
+          s->graph.fails++;
+          s->graph.warm = 0;
+          b0 -= maxB;
+          continue;
+        }
+        s->graph.exec = ex;
+        std::copy(gkey, gkey + 8, s->graph.key);
+        s->graph.used_q8 = P.used_q8;
+        s->graph.marked = s->ms_marked_now;
+        s->graph.valid = true;
+        HIPCHK(hipGraphLaunch(ex, st));
+      }
       STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));
-      ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     }
+    }   // !replayed
+    if (!dev_io) ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
     const int64_t M_true = *reinterpret_cast<const int64_t*>(s->h_small.p);
     if (P.spec && M_true > P.M) {
@@ -951,6 +1041,16 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       continue;
     }
     learn_capacity(s, M_true);
+    if (graph_ok) {
+      // remember what this call ran on: the next call may capture if it has the same shape, the capacity is still the one THIS
+      // call sized every buffer for, and nothing was (re)allocated since
+      if (P.spec && std::equal(gkey, gkey + 5, s->graph.last)) s->graph.warm++;
+      else s->graph.warm = P.spec ? 1 : 0;
+      std::copy(gkey, gkey + 8, s->graph.last);
+      s->graph.last[5] = P.spec ? P.M : 0;
+      s->graph.last[6] = (int64_t)g_alloc_gen.load(std::memory_order_relaxed);
+    }
+    if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
     g_last_counts[0] += M_true;
     g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
@@ -964,7 +1064,10 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       for (int i = 0; i < B; ++i) g_last_counts[2] += nm[i];
       s->ms_have_marks = false;
     }
-    if (b0 == 0) {
+    if (replayed || capture) {   // a graph launch records no stage events
+      for (int i = 0; i < ST_N; ++i) g_last_ms[i] = 0.f;
+      g_have_ms = true;
+    } else if (b0 == 0) {
       for (int i = 0; i < ST_N; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) != hipSuccess) ms = 0.f;

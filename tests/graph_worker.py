@@ -1,0 +1,40 @@
+"""GPU worker for tests/test_zz_graph_replay.py: FP_GRAPH=1 (set by the test).  From the third batch of a shape on, fp_search
+replays one captured HIP graph (query upload from a pinned staging buffer, every launch and fill of S1..S8, result download)
+instead of enqueuing ~55 launches.  Every batch -- waited-for, speculative, captured, replayed, and after a switch to another
+shape and back -- must equal fp_search_trace, which never speculates and never replays."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import fast_plaid_amd as fp  # noqa: E402
+
+
+def main():
+    assert os.environ.get("FP_GRAPH") == "1"
+    R = fp.fast_plaid_rust
+    spec = fp.synth.SynthSpec(n_docs=20000, doc_len=32, n_centroids=1024, variable_len=True, seed=5)
+    host = fp.synth.host_index_arrays(spec)
+    dev = R.construct_synthetic_index(spec, "cuda:0", centroids=host["centroids"])
+    shapes = [(6, 4, 512, 50), (1, 8, 1024, 100), (6, 4, 512, 50), (3, 16, 1024, 20)]   # (batch, n_ivf_probe, n_full_scores, top_k)
+    runs = []
+    for si, (nb, n_probe, n_full, top_k) in enumerate(shapes):
+        params = R.SearchParameters(2000, n_full, top_k, n_probe)
+        for rep in range(7):
+            q = fp.synth.make_queries(spec, host["centroids"], nb, 32, seed=500 + 10 * si + (rep % 5))
+            pids, scores, counts = R.search_arrays(dev, q, params)
+            runs.append((params, q, pids.copy(), scores.copy(), counts.copy(), R.last_search_counts()))
+    for params, q, pids, scores, counts, cnt in runs:
+        assert cnt["candidates"] > 0
+        for b in range(q.shape[0]):
+            t = R.search_trace(dev, q[b], params)
+            assert counts[b] == len(t["pids"]), (b, counts[b], len(t["pids"]))
+            assert np.array_equal(pids[b, : counts[b]], t["pids"])
+            assert np.array_equal(scores[b, : counts[b]], t["scores"])
+    print("GRAPH_OK")
+
+
+if __name__ == "__main__":
+    main()
