@@ -197,15 +197,23 @@ def main():
             ts = time.perf_counter()
             step(a.warmup + i)
             lat.append(time.perf_counter() - ts)
-            if mode in ("single", "replica"):
+        sync()
+        elapsed = time.perf_counter() - t_start
+        if mode in ("single", "replica"):
+            # per-stage HIP-event times and work counters: the SAME K steps once more with graph replay off -- in the timed loop
+            # above every step is one hipGraphLaunch, which records no per-stage events (same kernels, same launch parameters)
+            was = R.set_graph_replay(False)
+            step(a.warmup)   # (the first call after the switch re-learns nothing, but keep it out of the averages)
+            for i in range(a.steps):
+                step(a.warmup + i)
                 for k, v in R.last_search_timings().items():
                     stage_acc[k] = stage_acc.get(k, 0.0) + v
                 cnts = R.last_search_counts()
                 cand_total += cnts["candidates"]
                 exact_total += cnts["approx_exact"]
                 repaired_total += cnts.get("repaired", 0)
-        sync()
-        elapsed = time.perf_counter() - t_start
+            R.set_graph_replay(was)
+            sync()
         if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if a.dist_backend == "gloo" else dev))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -286,6 +294,8 @@ def main():
     if primary in ("single", "replica") and rank == 0:   # (replica: rank 0's own kernels; every rank runs the same pipeline)
         stages = {k: v / a.steps for k, v in stage_acc.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in stages.items()}
+        out["stages_note"] = ("HIP-event stage times of the same K steps repeated with graph replay off (in the timed loop a step is "
+                              "one hipGraphLaunch, which records no per-stage events)")
         out["docs_repaired_per_batch"] = res["repaired_total"] / a.steps
         Rr = max(a.nfull // 4, 1)
         rer_docs = a.batch * min(Rr, a.docs)

@@ -60,6 +60,8 @@ extern "C" int fp_device_count(void) {
 // bumped by every (re)allocation of a scratch buffer: a captured graph (FP_GRAPH) holds raw pointers and is only replayed while
 // the count it was captured under still stands
 static std::atomic<uint64_t> g_alloc_gen{0};
+// fp_set_graph_replay / FP_GRAPH: on unless the environment says 0
+static std::atomic<int> g_graph_replay{[] { const char* e = getenv("FP_GRAPH"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -131,7 +133,7 @@ struct Scratch {
   int64_t spec_cap = 0;
   int64_t spec_last = 0;   // the previous batch's total: sizes the grids (the capacity would over-provision them by a quarter)
   int64_t spec_key[4] = {0, 0, 0, 0};   // {B, Q, n_ivf_probe, subset?}
-  // FP_GRAPH=1 (opt-in): once fp_search runs on the learnt capacity there is no host decision left inside the pipeline, so the
+  // Graph replay (fp_set_graph_replay; FP_GRAPH=0 switches it off): once fp_search runs on the learnt capacity there is no host decision left inside the pipeline, so the
   // whole call -- query upload from a pinned staging buffer, ~55 launches and fills, result download -- is captured once per
   // {shape, parameters, capacity, allocation generation} and replayed with one hipGraphLaunch
   struct GraphCache {
@@ -915,7 +917,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       release(ix, s);
     }
   } rel{ix, s};
-  static const bool graph_env = [] { const char* e = getenv("FP_GRAPH"); return e && atoi(e) != 0; }();
+  const bool graph_env = g_graph_replay.load(std::memory_order_relaxed) != 0;
   const int Qp = (Q + 31) & ~31;
   // sub-batch so that the centroid-score table stays within a budget
   static const size_t budget_env = getenv("FP_S_BUDGET_KB") ? (size_t)atoll(getenv("FP_S_BUDGET_KB")) << 10 : 0;   // tests: force sub-batching
@@ -1184,6 +1186,8 @@ extern "C" int fp_last_search_counts(int64_t* out, int cap) {
   for (int i = 0; i < n; ++i) out[i] = g_last_counts[i];
   return n;
 }
+
+extern "C" int fp_set_graph_replay(int enabled) { return g_graph_replay.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int fp_last_search_timings(const char** names, float* ms, int cap) {
   if (!g_have_ms) return 0;

@@ -306,6 +306,11 @@ def last_search_timings() -> dict:
     return {names[i].decode(): float(ms[i]) for i in range(n)}
 
 
+def set_graph_replay(enabled: bool) -> bool:
+    """fp_set_graph_replay: HIP-graph replay of fp_search on / off (process-wide); returns the previous setting."""
+    return bool(N.lib().fp_set_graph_replay(1 if enabled else 0))
+
+
 def maxsim_columns(index: PyLoadedIndex, query_f16, pids) -> dict:
     """fp_maxsim_columns: the exact stage's MFMA pass on `pids` for one query [q_len, dim], before the exact-order repair."""
     q = np.ascontiguousarray(query_f16, dtype=np.float16)

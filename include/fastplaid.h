@@ -133,6 +133,13 @@ int fp_search_trace(const fp_index* index, const uint16_t* query, int32_t q_len,
  * of stages written (<= cap). */
 int fp_last_search_timings(const char** names, float* ms, int cap);
 
+/* fp_search replays one captured HIP graph per batch from a shape's third batch on (query upload from a pinned staging buffer,
+ * every launch and fill, result download: one hipGraphLaunch instead of ~55 enqueues).  A graph launch records no per-stage
+ * events, so fp_last_search_timings reports zeros for such a call; a profiler or benchmark that wants stage times switches the
+ * replay off for the calls it measures.  enabled: 0 / 1; returns the previous setting.  Process-wide; default 1 (FP_GRAPH=0 in
+ * the environment starts with 0). */
+int fp_set_graph_replay(int enabled);
+
 /* Work counters of the most recent fp_search on this thread: out[0] = candidate documents
  * summed over queries (S3 output), out[1] = candidates that reached the exact approximate-score
  * kernel (== out[0] unless a bound stage pruned), out[2] = documents whose near-tied final score was re-evaluated in the
