@@ -944,14 +944,19 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     bool replayed = false;
     if (graph_ok && s->graph.valid && std::equal(gkey, gkey + 8, s->graph.key)) {
       memcpy(s->h_qin.p, queries, qbytes);
-      HIPCHK(hipGraphLaunch(s->graph.exec, st));
-      HIPCHK(hipStreamSynchronize(st));
-      P.spec = true;
-      P.M = s->spec_cap;
-      P.used_q8 = s->graph.used_q8;
-      s->fold_stats = true;
-      s->ms_marked_now = s->graph.marked;
-      replayed = true;
+      if (hipGraphLaunch(s->graph.exec, st) == hipSuccess) {
+        HIPCHK(hipStreamSynchronize(st));
+        P.spec = true;
+        P.M = s->spec_cap;
+        P.used_q8 = s->graph.used_q8;
+        s->fold_stats = true;
+        s->ms_marked_now = s->graph.marked;
+        replayed = true;
+      } else {   // a runtime that will not launch the graph: plain path from here on
+        (void)hipGetLastError();
+        s->graph.valid = false;
+        s->graph.fails = 1000;
+      }
     }
     bool capture = false;
     if (graph_ok && !replayed) {
@@ -963,8 +968,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         memcpy(s->h_qin.p, queries, qbytes);
         if (s->graph.exec) { (void)hipGraphExecDestroy(s->graph.exec); s->graph.exec = nullptr; }
         s->graph.valid = false;
-        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        s->capturing = true;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+          s->capturing = true;
+        } else {   // no capture on this runtime / stream: plain path from here on
+          (void)hipGetLastError();
+          s->graph.fails = 1000;
+          capture = false;
+        }
       }
     }
     if (!replayed) {
@@ -1026,7 +1036,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         s->graph.used_q8 = P.used_q8;
         s->graph.marked = s->ms_marked_now;
         s->graph.valid = true;
-        HIPCHK(hipGraphLaunch(ex, st));
+        if (hipGraphLaunch(ex, st) != hipSuccess) {   // nothing of this batch has run: take the plain path, for good
+          (void)hipGetLastError();
+          s->graph.valid = false;
+          s->graph.fails = 1000;
+          b0 -= maxB;
+          continue;
+        }
       }
       STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));
