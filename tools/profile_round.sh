@@ -15,6 +15,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_
 python $R/tools/summarize_prof.py $(ls $OUT/${TAG}_prof/*/run_kernel_stats.csv $OUT/${TAG}_prof/run_kernel_stats.csv 2>/dev/null | head -1) \
     $OUT/${TAG}_kernel_stats.csv "bench.py --steps 20 --warmup 5 (cfg2: 1M docs, 64 queries/batch), MI355X"
 CMD3="python $R/bench.py --steps 3 --warmup 1 --cpu-queries 0"
+# counter passes: per-dispatch counters of graph-launched kernels are unchecked on this pool -> plain launches (the kernels and
+# their launch parameters are the same; the kernel-trace summary above stays on the default, graph-replayed path)
+export FP_GRAPH=0
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_fetch -o run -- $CMD3 > $OUT/${TAG}_pmc.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/${TAG}_pmc_write -o run -- $CMD3 >> $OUT/${TAG}_pmc.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_mfma -o run -- $CMD3 >> $OUT/${TAG}_pmc.log 2>&1
