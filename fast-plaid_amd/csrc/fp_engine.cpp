@@ -1657,7 +1657,7 @@ extern "C" int fp_shard_stage4(fp_shard_ctx* c, const void* dev_all_x, int32_t G
 }
 
 // ------------------------------------------------------------------------------------------
-// document-sharded search with the collectives issued by the library itself (RCCL over xGMI): the two all-gathers go on the
+// document-sharded search with the collectives issued by the library itself (RCCL over xGMI): the three all-gathers go on the
 // search stream right behind the kernels that fill their send buffers -- no host synchronisation between the stages, no
 // framework in the data path.  librccl is bound at run time (dlopen), so single-GPU users never need it.
 // ------------------------------------------------------------------------------------------
@@ -1765,7 +1765,7 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   P.allow_spec = attempt == 0;
   const int64_t R = P.sh.R;
   const int64_t K = p->top_k;
-  // every rank must issue both collectives whatever its shard holds (an empty shard contributes only padding records)
+  // every rank must issue every collective whatever its shard holds (an empty shard contributes only padding records)
   const bool empty_local = (p->n_ivf_probe > D.C) || D.N == 0;
   HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
   HIPCHK(hipMemcpyAsync(s->qin.p, queries, (size_t)B * Q * D.dim * 2, hipMemcpyHostToDevice, st));

@@ -228,7 +228,7 @@ int fp_shard_stage4(fp_shard_ctx* ctx, const void* dev_all_x /*[G,B,R] f32*/, in
                     int32_t* out_counts);
 void fp_shard_end(fp_shard_ctx* ctx);
 
-/* The same sharded search with the collectives issued by the library (RCCL over xGMI, bound with dlopen at first use): both
+/* The same sharded search with the collectives issued by the library (RCCL over xGMI, bound with dlopen at first use): the
  * all-gathers are enqueued on the search stream behind the kernels that fill their send buffers -- no host synchronisation
  * between the stages, no framework in the data path (three all-gathers: 16 + 24 + 4 bytes per rerank slot).  One communicator per process / GPU:
  *   rank 0: fp_comm_unique_id(id) -> the caller ships the 128 bytes to every rank (any out-of-band channel)
