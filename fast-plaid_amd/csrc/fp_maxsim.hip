@@ -333,7 +333,11 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
       uint32_t e[NE];
       uint32_t rw[RW];
       // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
+#if defined(FP_MS_ABL) && (FP_MS_ABL == 1 || FP_MS_ABL == 5)
+      ms_load_token<D, NBITS>(a.resid, a.cent, valid ? tok_row() : 0, 0, rw, e);   // timing-only ablation: no scattered centroid gather
+#else
       ms_load_token<D, NBITS>(a.resid, a.cent, valid ? tok_row() : 0, valid ? code : 0, rw, e);
+#endif
       const float nf = (float)__builtin_bit_cast(half_t, nrm);
       // ---- this chunk's bookkeeping, then step the stream and prefetch the next code / norm ----
       const int c_t0 = t0, c_len = len, c_r = r;
@@ -348,11 +352,24 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
         if (valid) { const long long rr = tok_row(); code = a.codes[rr]; nrm = a.norms[rr]; }
       }
       // ---- e = h(cent + w);  e^ = h(fl32(e / n)) through the compensated reciprocal product (fp_selftest_arith out[0]) ----
+#if !defined(FP_MS_ABL) || FP_MS_ABL != 3
       ms_decode<D, NBITS>(laneoff, rw, e);
+#else
+#pragma unroll
+      for (int i = 0; i < RW; ++i) e[i] ^= rw[i];
+#endif
       float r_hi, r_lo;
       recip2(nf, r_hi, r_lo);
+#if !defined(FP_MS_ABL) || FP_MS_ABL == 1 || FP_MS_ABL == 3
 #pragma unroll
       for (int i = 0; i < NE; i += 2) norm_pair2(e[i], e[i + 1], r_hi, r_lo);
+#elif FP_MS_ABL == 4 || FP_MS_ABL == 5   // timing-only: one v_fma_mixlo/hi per element
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        asm volatile("v_fma_mixlo_f16 %0, %0, %1, 0 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %0, %1, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(e[i]) : "v"(r_hi + r_lo));
+#else
+      e[0] ^= __float_as_uint(r_hi + r_lo);
+#endif
       // ---- MFMA: acc0 rows = lower stream's tokens, acc1 rows = upper stream's tokens ----
       f16v acc0[NCH], acc1[NCH];
 #pragma unroll

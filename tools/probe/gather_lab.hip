@@ -1,0 +1,276 @@
+// What does the MaxSim kernel's memory side cost on its own?  8.39 M tokens (64 queries x 1024 documents x 128 tokens, the cfg2
+// rerank set): per token a 256-byte centroid row (gathered by code; codes sorted inside a document, 8 Zipf topics + 20 % uniform
+// like fp_synth) and 64 contiguous residual bytes.  Variants differ in which lane fetches which 16-byte piece:
+//   M0  token per lane, 64 tokens per step: 16 x dwordx4 of the lane's own row (k_maxsim5's pattern) + 4 x dwordx4 residual
+//   M1  half row per lane, 32 tokens per step: lane (t, h) fetches the 128-byte line h of row t (8 x dwordx4) + 2 x dwordx4
+//   M2  16 lanes per row, 32 tokens per step: instruction j fetches rows 4j..4j+3 whole (coalesced) + coalesced residuals
+//   M3  M2 through global_load_lds_dwordx4 (no VGPR round trip) + ds_read_b128 in M1's lane order (the transposition)
+//   M4  M2 + ds_write_b128 + ds_read_b128 (transposition through registers)
+// Every variant xors what it fetched into a per-lane accumulator.  16 waves per CU, one workgroup per CU, contiguous documents per wave.
+//   hipcc -O3 --offload-arch=gfx950 gather_lab.hip -o gather_lab.bin && ./gather_lab.bin
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+struct Args {
+  const uint4* tab;       // [C][16]
+  const int32_t* codes;   // [T]
+  const uint4* resid;     // [T][4]
+  const int32_t* docs;    // [ND] document ids of the batch
+  int nd, doclen;
+  uint4* out;
+  int part;   // M2 only: 1 = centroid rows, 2 = residuals, 3 = both
+};
+
+__device__ __forceinline__ void xacc(uint4& a, const uint4 v) { a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(const Args a, const int nwaves) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = gridDim.x * nwaves;
+  const int gw = blockIdx.x * nwaves + wave;
+  const int d0 = (int)((long long)a.nd * gw / nw), d1 = (int)((long long)a.nd * (gw + 1) / nw);
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  uint4* wl = reinterpret_cast<uint4*>(smem) + wave * 512;   // 8 KiB per wave (M3 / M4)
+  for (int d = d0; d < d1; ++d) {
+    const long long off = (long long)a.docs[d] * a.doclen;
+    if constexpr (MODE == 6) {
+      const int r = lane & 15, g = lane >> 4;
+      for (int t0 = 0; t0 < a.doclen; t0 += 16) {
+        const long long row = off + t0 + r;
+        const int code = a.codes[row];
+        uint4 v[4];
+        uint32_t rs[4];
+        uint4 rq = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) v[s2] = a.tab[(long long)code * 16 + s2 * 4 + g];
+        if (a.part & 8) rq = a.resid[row * 4 + g];
+        else {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) rs[s2] = reinterpret_cast<const uint32_t*>(a.resid)[row * 16 + s2 * 4 + g];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) xacc(acc, v[s2]);
+        if (a.part & 8) xacc(acc, rq);
+        else {
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc.x ^= rs[s2];
+        }
+      }
+    } else if constexpr (MODE == 5) {   // M2's pattern with register prefetch: codes two steps ahead, data one step ahead (vmcnt is in order:
+                                 // a step's codes must be older than the previous step's data loads or waiting for them drains everything)
+      uint4 v[2][8], r[2][2];
+      auto codes_of = [&](int t0) { return a.codes[off + (t0 < a.doclen ? t0 : 0) + (lane & 31)]; };
+      auto issue = [&](int t0, int mycode, uint4 (&vv)[8], uint4 (&rr)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rr[j] = a.resid[(off + t0) * 4 + j * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int code = __shfl(mycode, 4 * j + (lane >> 4), 64);
+          vv[j] = a.tab[(long long)code * 16 + (lane & 15)];
+        }
+      };
+      auto consume = [&](uint4 (&vv)[8], uint4 (&rr)[2]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xacc(acc, vv[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xacc(acc, rr[j]);
+      };
+      int c0 = codes_of(0);
+      int c1 = codes_of(32);
+      issue(0, c0, v[0], r[0]);
+      for (int t0 = 0; t0 < a.doclen; t0 += 64) {
+        c0 = codes_of(t0 + 64);
+        issue(t0 + 32, c1, v[1], r[1]);
+        consume(v[0], r[0]);
+        c1 = codes_of(t0 + 96);
+        if (t0 + 64 < a.doclen) issue(t0 + 64, c0, v[0], r[0]);
+        consume(v[1], r[1]);
+      }
+    } else if constexpr (MODE == 0) {
+      for (int t0 = 0; t0 < a.doclen; t0 += 64) {
+        const long long row = off + t0 + lane;
+        const int code = a.codes[row];
+        uint4 v[16], r[4];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = a.tab[(long long)code * 16 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = a.resid[row * 4 + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xacc(acc, v[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xacc(acc, r[j]);
+      }
+    } else if constexpr (MODE == 1) {
+      for (int t0 = 0; t0 < a.doclen; t0 += 32) {
+        const long long row = off + t0 + (lane & 31);
+        const int h = lane >> 5;
+        const int code = a.codes[row];
+        uint4 v[8], r[2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = a.tab[(long long)code * 16 + h * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) r[j] = a.resid[row * 4 + h * 2 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xacc(acc, v[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xacc(acc, r[j]);
+      }
+    } else {
+      for (int t0 = 0; t0 < a.doclen; t0 += 32) {
+        // codes of the 32 tokens: lane l holds token l & 31; instruction j needs the code of token 4j + l/16
+        const int mycode = a.codes[off + t0 + (lane & 31)];
+        uint4 r[2];
+        r[0] = r[1] = make_uint4(0, 0, 0, 0);
+        if (MODE == 2 && (a.part & 4)) {   // residual stream with the non-temporal hint
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { typedef uint32_t u4v __attribute__((ext_vector_type(4))); const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(&a.resid[(off + t0) * 4 + j * 64 + lane])); r[j] = make_uint4(t.x, t.y, t.z, t.w); }
+        } else if (MODE != 2 || (a.part & 2)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) r[j] = a.resid[(off + t0) * 4 + j * 64 + lane];
+        }
+        if constexpr (MODE == 2) {
+          uint4 v[8];
+          if (a.part & 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int code = __shfl(mycode, 4 * j + (lane >> 4), 64);
+            v[j] = a.tab[(long long)code * 16 + (lane & 15)];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xacc(acc, v[j]);
+          }
+        } else if constexpr (MODE == 3) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int code = __shfl(mycode, 4 * j + (lane >> 4), 64);
+            const int trow = 4 * j + (lane >> 4);
+            // LDS piece p of row t holds global piece p ^ (t & 7): the reader's 8 consecutive rows hit 8 different bank groups
+            const uint4* src = a.tab + (long long)code * 16 + ((lane & 15) ^ (trow & 7));
+            const uint32_t m0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(wl + j * 64);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(__builtin_amdgcn_readfirstlane(m0)), "v"(src) : "memory");
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xacc(acc, wl[t * 16 + ((h * 8 + j) ^ (t & 7))]);
+        } else {
+          uint4 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int code = __shfl(mycode, 4 * j + (lane >> 4), 64);
+            v[j] = a.tab[(long long)code * 16 + (lane & 15)];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int trow = 4 * j + (lane >> 4);
+            wl[trow * 16 + ((lane & 15) ^ (trow & 7))] = v[j];
+          }
+          const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xacc(acc, wl[t * 16 + ((h * 8 + j) ^ (t & 7))]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xacc(acc, r[j]);
+      }
+    }
+  }
+  a.out[(long long)blockIdx.x * blockDim.x + tid] = acc;
+}
+
+static uint64_t rng_s = 88172645463325252ull;
+static inline uint64_t rnd() { rng_s ^= rng_s << 13; rng_s ^= rng_s >> 7; rng_s ^= rng_s << 17; return rng_s; }
+
+int main(int argc, char** argv) {
+  const int C = 131072, NDOCS = 1000000, L = 128, ND = 65536;
+  const long long T = (long long)NDOCS * L;
+  std::vector<int32_t> codes((size_t)T);
+  for (int d = 0; d < NDOCS; ++d) {
+    int topic[8];
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t r = rnd();
+      const int e = (int)(r % 17);
+      const uint64_t rank = ((1ull << e) - 1) + ((r >> 8) & ((1ull << e) - 1));
+      topic[i] = (int)((rank * 0x9E3779B1ull + 12345) & (C - 1));
+    }
+    int32_t* c = &codes[(size_t)d * L];
+    for (int t = 0; t < L; ++t) {
+      const uint64_t r = rnd();
+      c[t] = ((r & 0xFF) < 205) ? topic[(r >> 8) & 7] : (int)((r >> 16) & (C - 1));
+    }
+    std::sort(c, c + L);
+  }
+  // the rerank set: 64 queries x 1024 documents; a query's documents share one of its 4 "query topics" half of the time is
+  // not modelled -- documents are uniform random (less row sharing between documents than a real rerank list: pessimistic)
+  std::vector<int32_t> docs(ND);
+  for (int q = 0; q < 64; ++q) {
+    std::vector<int32_t> l(1024);
+    for (auto& x : l) x = (int32_t)(rnd() % NDOCS);
+    std::sort(l.begin(), l.end());
+    std::copy(l.begin(), l.end(), docs.begin() + q * 1024);
+  }
+  Args a{};
+  uint4* tab; int32_t* dcodes; uint4* resid; int32_t* ddocs; uint4* out;
+  CHK(hipMalloc(&tab, (size_t)C * 256)); CHK(hipMemset(tab, 1, (size_t)C * 256));
+  CHK(hipMalloc(&dcodes, (size_t)T * 4)); CHK(hipMemcpy(dcodes, codes.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+  CHK(hipMalloc(&resid, (size_t)T * 64)); CHK(hipMemset(resid, 2, (size_t)T * 64));
+  CHK(hipMalloc(&ddocs, ND * 4)); CHK(hipMemcpy(ddocs, docs.data(), ND * 4, hipMemcpyHostToDevice));
+  CHK(hipMalloc(&out, (size_t)256 * 1024 * 16));
+  a.part = 3; a.tab = tab; a.codes = dcodes; a.resid = resid; a.docs = ddocs; a.nd = ND; a.doclen = L; a.out = out;
+  const char* names[6] = {"M0 token/lane 64-step", "M1 half row/lane 32-step", "M2 16 lanes/row coalesced", "M3 M2 via LDS DMA + transposed read", "M4 M2 + ds_write/ds_read transpose", "M5 M2 with 2 steps in flight"};
+  CHK(hipFuncSetAttribute((const void*)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  CHK(hipFuncSetAttribute((const void*)k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  for (int part : {3}) {
+    a.part = part;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+      CHK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k<2>, dim3(256), dim3(1024), 0, 0, a, 16);
+      CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+      float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("M2 part=%d (1 centroid rows, 2 residuals, 3 both, 4 nt residuals, 5 rows + nt residuals), 16 waves: %.1f us\n", part, ms * 1e3);
+    }
+  }
+  for (int part : {3, 11}) {
+    a.part = part;
+    for (int nwaves : {16, 12, 8})
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+      CHK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k<6>, dim3(256), dim3(nwaves * 64), 0, 0, a, nwaves);
+      CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+      float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep) printf("M6 16x16-native (16-token steps, 64 B of a row per instruction), residual %s, %d waves: %.1f us\n", (part & 8) ? "1 x dwordx4 (permuted layout)" : "4 x dword strided", nwaves, ms * 1e3);
+    }
+  }
+  a.part = 3;
+  for (int nwaves : {16, 16})
+  if (nwaves < 0)
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int mode = 0; mode < 6; ++mode) {
+      hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+      CHK(hipEventRecord(e0));
+      const size_t lds = mode >= 3 ? 128 * 1024 : 0;
+      switch (mode) {
+        case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves); break;
+        case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves); break;
+        case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves); break;
+        case 3: hipLaunchKernelGGL(k<3>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves); break;
+        case 4: hipLaunchKernelGGL(k<4>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves); break;
+        case 5: hipLaunchKernelGGL(k<5>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves); break;
+      }
+      CHK(hipGetLastError());
+      CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+      float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+      const double tok = (double)ND * L;
+      if (rep) printf("w%-2d %-40s %8.1f us   %6.1f tokens/us/CU   %.2f TB/s of (256+64+4) B/token\n", nwaves, names[mode], ms * 1e3, tok / (ms * 1e3) / 256, tok * 324 / (ms * 1e-3) / 1e12);
+    }
+  }
+  return 0;
+}
