@@ -85,6 +85,29 @@ __device__ __forceinline__ void norm_pair2(uint32_t& a, uint32_t& b, float r_hi,
   b = db;
 }
 
+// h(fl32(e * r)) for two packed fp16 pairs: the one-multiply normalisation of k_maxsim6.  r is the token's stored reciprocal
+// (k_token_rinv picked it so that the result equals norm_pair2's for EVERY dim of the token, i.e. the reference's e^ bits).
+__device__ __forceinline__ void norm_mul2(uint32_t& a, uint32_t& b, float r) {
+  uint32_t da, db;
+  float t0, t1, t2, t3;
+  asm("v_fma_mix_f32 %2, %6, %8, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %3, %6, %8, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %4, %7, %8, 0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %5, %7, %8, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_cvt_pk_f16_f32 %1, %4, %5"
+      : "=&v"(da), "=&v"(db), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(a), "v"(b), "v"(r));
+  a = da;
+  b = db;
+}
+// max(a, b, c) without the canonicalisation __builtin_fmaxf adds in IEEE mode (a NaN operand is ignored, as by fmaxf)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // More than 64 KiB of dynamic LDS needs an opt-in per kernel AND per device (gfx950: 160 KiB per workgroup); one process
 // may drive several GPUs (FastPlaid(device=[...])), so the "done" flag is a bit per device.
 static inline void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done, int bytes) {

@@ -178,6 +178,7 @@ struct fp_index {
   std::mutex mu;
   std::vector<Scratch*> pool;
   bool synthetic = false;
+  int64_t n_hard_tokens = 0;   // tokens without a one-multiply reciprocal (k_token_rinv)
 };
 
 static thread_local float g_last_ms[ST_N];
@@ -316,6 +317,39 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token norms)");
     D.norms = norms;
   }
+  D.resid_nat = nullptr;
+  D.rinv = nullptr;
+  if (fpk_maxsim6_shape(D.dim, D.nbits)) {
+    uint8_t* rn = nullptr;
+    hipError_t e = hipMalloc((void**)&rn, (size_t)std::max<int64_t>(D.T, 1) * D.pr + 64);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (native residual order)");
+    ix->owned.push_back(rn);
+    ix->bytes += D.T * D.pr;
+    fpk_resid_native(D, rn, st);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (native residual order)");
+    D.resid_nat = rn;
+    static const bool use_rinv = [] { const char* e2 = getenv("FP_MS_RINV"); return !(e2 && atoi(e2) == 0); }();
+    if (use_rinv) {
+      uint32_t* rv = nullptr;
+      unsigned long long* nh = nullptr;
+      e = hipMalloc((void**)&rv, (size_t)std::max<int64_t>(D.T, 1) * 4 + 64);
+      if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token reciprocals)");
+      ix->owned.push_back(rv);
+      ix->bytes += D.T * 4;
+      e = hipMalloc((void**)&nh, 8);
+      if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token reciprocals)");
+      ix->owned.push_back(nh);
+      (void)hipMemsetAsync(nh, 0, 8, st);
+      fpk_token_rinv(D, rv, nh, st);
+      unsigned long long hard = 0;
+      e = hipMemcpyAsync(&hard, nh, 8, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token reciprocals)");
+      D.rinv = rv;
+      ix->n_hard_tokens = (int64_t)hard;
+    }
+  }
   {
     int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
     hipError_t e = hipMalloc((void**)&uoff, ((size_t)D.N + 1) * 8 + 64);
@@ -437,6 +471,7 @@ extern "C" int32_t fp_index_nbits(const fp_index* ix) { return ix ? ix->d.nbits 
 extern "C" int64_t fp_index_device_bytes(const fp_index* ix) { return ix ? ix->bytes : 0; }
 extern "C" int64_t fp_index_num_unique_codes(const fp_index* ix) { return ix ? ix->d.U : 0; }
 extern "C" int64_t fp_index_num_code_lines(const fp_index* ix) { return ix ? ix->d.n_lines : 0; }
+extern "C" int64_t fp_index_num_hard_tokens(const fp_index* ix) { return ix ? ix->n_hard_tokens : 0; }
 
 // ------------------------------------------------------------------------------------------
 // synthetic device-resident corpora

@@ -160,6 +160,81 @@ void fpk_token_norms(const FpIndexDev& ix, uint16_t* norms, hipStream_t st) {
                      ix.dim, ix.nbits, ix.T, norms);
 }
 
+// ---- per-token reciprocals (k_maxsim6) -----------------------------------------------------------------------------------
+// e^ = h(fl32(e / n)) costs the search two fp32 FMAs per value through the compensated reciprocal (norm_pair2).  h(fl32(e * r))
+// with ONE fp32 multiplier r gives the same bits for all dims of a token for nearly every r in a window around 1/n about
+// 2^-18 wide, i.e. for dozens of fp32 values: this kernel tries r = fl32(1/n) and its neighbours (+-1 .. +-4 ulp) against
+// norm_pair2's result on every dim -- the very instruction sequences the search runs -- and stores the first that matches
+// everywhere.  A token with no such r (about 1 in 10^4: two dims pinch the window from both sides; also n = 0 / inf / nan) is
+// stored with bit 31 set and the search takes the compensated path for the 16-token step that contains it.  +-0 count as
+// equal (a zero operand contributes nothing to the contraction); NaNs likewise.
+__global__ __launch_bounds__(256) void k_token_rinv(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut,
+                                                    const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
+                                                    const uint16_t* __restrict__ norms, int D, int nbits, int64_t T, uint32_t* __restrict__ rinv,
+                                                    unsigned long long* __restrict__ n_hard) {
+  const int pb = 8 / nbits, pr = D * nbits / 8;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+    const uint16_t* cp = cent + (int64_t)codes[t] * D;
+    const uint8_t* rp = resid + t * pr;
+    const float nf = (float)__builtin_bit_cast(half_t, norms[t]);
+    float r_hi, r_lo;
+    recip2(nf, r_hi, r_lo);
+    const uint32_t r0 = __float_as_uint(r_hi);
+    const bool searchable = (r0 & 0x80000000u) == 0u && ((r0 >> 23) & 0xFFu) != 0u && ((r0 >> 23) & 0xFFu) != 0xFFu;   // positive, normal, finite
+    uint32_t found = r0 | 0x80000000u;
+    bool ok_any = false;
+    if (searchable) {
+      for (int ci = 0; ci < 9 && !ok_any; ++ci) {
+        const int j = (ci + 1) / 2 * ((ci & 1) ? 1 : -1);   // 0, +1, -1, +2, -2, ...
+        const uint32_t rb = r0 + (uint32_t)j;
+        if (((rb >> 23) & 0xFFu) == 0u || ((rb >> 23) & 0xFFu) == 0xFFu) continue;
+        const float r = __uint_as_float(rb);
+        bool ok = true;
+        for (int d = 0; d < D && ok; d += 4) {   // D is a multiple of 8: two packed pairs per round
+          uint32_t pk[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint32_t two = 0;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+              const int dd = d + 2 * h + x;
+              const int byte = rp[dd / pb];
+              const half_t w = __builtin_bit_cast(half_t, lut[byte * pb + dd % pb]);
+              const half_t c = __builtin_bit_cast(half_t, cp[dd]);
+              const half_t e = (half_t)((float)w + (float)c);
+              two |= (uint32_t)__builtin_bit_cast(uint16_t, e) << (16 * x);
+            }
+            pk[h] = two;
+          }
+          uint32_t a0 = pk[0], a1 = pk[1], b0 = pk[0], b1 = pk[1];
+          norm_pair2(a0, a1, r_hi, r_lo);
+          norm_mul2(b0, b1, r);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t x = h ? a1 : a0, y = h ? b1 : b0;
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+              const uint32_t u = (x >> (16 * z)) & 0xFFFFu, v = (y >> (16 * z)) & 0xFFFFu;
+              const bool both_zero = ((u | v) & 0x7FFFu) == 0u;
+              const bool both_nan = (u & 0x7FFFu) > 0x7C00u && (v & 0x7FFFu) > 0x7C00u;
+              if (u != v && !both_zero && !both_nan) ok = false;
+            }
+          }
+        }
+        if (ok) { ok_any = true; found = rb; }
+      }
+    }
+    rinv[t] = found;
+    if (!ok_any && n_hard) atomicAdd(n_hard, 1ull);
+  }
+}
+
+void fpk_token_rinv(const FpIndexDev& ix, uint32_t* rinv, unsigned long long* n_hard_dev, hipStream_t st) {
+  if (ix.T <= 0) return;
+  hipLaunchKernelGGL(k_token_rinv, dim3(fp_grid_cap((ix.T + 255) / 256, 256)), dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals,
+                     ix.norms, ix.dim, ix.nbits, ix.T, rinv, n_hard_dev);
+}
+
 // inclusive prefix of the per-query rerank counts: pref[0] = 0, pref[b+1] = sum_{i<=b} cnt[i]
 __global__ __launch_bounds__(256) void k_cnt_prefix(const int32_t* __restrict__ cnt, int B, int64_t* __restrict__ pref) {
   __shared__ long long s[256];
@@ -202,6 +277,9 @@ struct MsArgs {
   int64_t Rcap;
   int B, Q, Qp, ch_begin, accumulate;
   float eps_rel;           // a column is flagged when its fp32 maximum lies within eps_rel * |q_col| of an fp16 rounding boundary
+  const uint8_t* resid_nat;   // k_maxsim6: residual rows in the MFMA-native unit order (fp_resid_native_pos); nullptr = not built
+  const uint32_t* rinv;       // k_maxsim6: per-token reciprocal bits for the one-multiply normalisation (bit 31: take the exact path); nullable
+  int xcd;                    // k_maxsim6: 1 = workgroup -> share mapping that keeps a query's documents on one XCD
 };
 
 // Layout (v5).  ONE TOKEN PER LANE: a wave carries two independent 32-token streams (lanes 0-31 and 32-63), each walking its
@@ -472,6 +550,420 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
           }
         }
       }
+    }
+  }
+}
+
+// ======================================================================================================================
+// k_maxsim6 -- the MFMA-native layout (round 3).
+//
+// What bounded k_maxsim5 (profiles/r03_gather_lab.txt, r03_maxsim5_ablations.txt): its token-per-lane gather -- 16 dwordx4
+// loads per 64 tokens, every one of them touching 64 different cache lines -- takes 246 us for the cfg2 rerank set WITHOUT any
+// arithmetic (the texture path pays per instruction and line), and the kernel ran at exactly that; dropping the normalisation
+// or the decode from it changed nothing.  The same bytes fetched as 64-byte chunks of a row per instruction take ~150 us.
+//
+// Layout: v_mfma_f32_16x16x32_f16 wants from lane (r = lane % 16, g = lane / 16) eight consecutive k values of row r.  A step
+// is 16 tokens (rows); k-step s of the lane covers dims 32 s + 8 g .. + 8, so that
+//   * one dwordx4 per k-step fetches the lane's 16 bytes of its token's centroid row, the four lanes of a row reading 64
+//     contiguous bytes (4 instructions x 16 lines per 16 tokens instead of 16 x 64 per 64);
+//   * the decompressed, normalised values ARE the A operand: no lane swaps, no transposition through LDS;
+//   * the residual bytes of the lane's 8-dim units sit next to each other in the index ("native unit order",
+//     fp_resid_native_pos: unit 4 s + g is stored at g * KS4 + s), so the lane's residuals are ONE load and the 16 tokens of
+//     a step one contiguous kilobyte;
+//   * the norm / reciprocal of the token is the same for every value the lane holds.
+// A lane holds 20 registers of loads per step, so three steps are kept in flight (codes one step further ahead): 16 waves x
+// 2 x 5 KiB of loads outstanding per CU while a step is being computed.
+// Everything downstream of the fp32 accumulators (fp32 column maximum, rounding, certification window, flags, budgets, the
+// per-document sum) is k_maxsim5's.
+template <int KS4, int NBITS>
+struct Ms6Cfg {
+  static constexpr int D = KS4 * 32;                  // dims (multiple of 32)
+  static constexpr int PR = D * NBITS / 8;            // residual bytes per token
+  static constexpr int LB = KS4 * NBITS;              // residual bytes per lane: its KS4 units of 8 dims
+  static constexpr int RW = (LB + 3) / 4;             // ... as 32-bit words
+  static constexpr int PB = 8 / NBITS;                // dims per byte
+  static constexpr int NE = KS4 * 4;                  // half2 registers per lane (8 dims per k-step)
+  static constexpr int EW = PB >= 2 ? PB / 2 : 1;     // 32-bit words per LUT entry
+  static constexpr int COPIES = 64 / EW;
+  static_assert(LB % 4 == 0, "lane residual chunk must be whole words");
+};
+
+template <int NBITS>
+__device__ __forceinline__ void ms6_fill_lut(unsigned char* lds, const uint16_t* __restrict__ lut_g, int tid, int nthreads) {
+  constexpr int PB = 8 / NBITS, EW = PB >= 2 ? PB / 2 : 1, COPIES = 64 / EW;
+  uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
+  for (int i = tid; i < 256 * COPIES; i += nthreads) {
+    const int entry = i / COPIES, copy = i % COPIES;
+#pragma unroll
+    for (int w = 0; w < EW; ++w) {
+      uint32_t word;
+      if constexpr (NBITS == 8) word = (uint32_t)lut_g[entry];
+      else word = reinterpret_cast<const uint32_t*>(lut_g)[entry * EW + w];
+      l32[(entry * 256 + copy * EW * 4) / 4 + w] = word;
+    }
+  }
+}
+
+// e += weights of the lane's residual bytes (same table addressing as ms_decode: one v_perm per byte)
+template <int NBITS, int RW, int NE>
+__device__ __forceinline__ void ms6_decode(uint32_t laneoff, const uint32_t (&rw)[RW], uint32_t (&e)[NE]) {
+#pragma unroll
+  for (int w = 0; w < RW; ++w) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int bi = w * 4 + kk;
+      const uint32_t addr = __builtin_amdgcn_perm(rw[w], laneoff, 0x0C0C0400u | ((uint32_t)kk << 8));
+      if constexpr (NBITS == 4) {
+        e[bi] = h2_as_u32(u32_as_h2(e[bi]) + u32_as_h2(*(ms_lds_u32*)(uintptr_t)addr));
+      } else if constexpr (NBITS == 2) {
+        const ms_u32x2 wv = *(ms_lds_u64*)(uintptr_t)addr;
+        e[2 * bi] = h2_as_u32(u32_as_h2(e[2 * bi]) + u32_as_h2(wv.x));
+        e[2 * bi + 1] = h2_as_u32(u32_as_h2(e[2 * bi + 1]) + u32_as_h2(wv.y));
+      } else if constexpr (NBITS == 1) {
+        const ms_u32x4 wv = *(ms_lds_u128*)(uintptr_t)addr;
+        e[4 * bi] = h2_as_u32(u32_as_h2(e[4 * bi]) + u32_as_h2(wv.x));
+        e[4 * bi + 1] = h2_as_u32(u32_as_h2(e[4 * bi + 1]) + u32_as_h2(wv.y));
+        e[4 * bi + 2] = h2_as_u32(u32_as_h2(e[4 * bi + 2]) + u32_as_h2(wv.z));
+        e[4 * bi + 3] = h2_as_u32(u32_as_h2(e[4 * bi + 3]) + u32_as_h2(wv.w));
+      } else {   // NBITS == 8
+        if ((kk & 1) == 0) {
+          const uint32_t addr1 = __builtin_amdgcn_perm(rw[w], laneoff, 0x0C0C0400u | ((uint32_t)(kk + 1) << 8));
+          const uint32_t lo = *(ms_lds_u32*)(uintptr_t)addr;
+          const uint32_t hi = *(ms_lds_u32*)(uintptr_t)addr1;
+          e[bi / 2] = h2_as_u32(u32_as_h2(e[bi / 2]) + u32_as_h2(__builtin_amdgcn_perm(hi, lo, 0x05040100u)));
+        }
+      }
+    }
+  }
+}
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int KS4, int NBITS>
+struct Ms6Buf {
+  uint32_t e[Ms6Cfg<KS4, NBITS>::NE];    // centroid half2 pairs of the lane's dims, k-step major (decoded in place)
+  uint32_t rw[Ms6Cfg<KS4, NBITS>::RW];   // the lane's residual bytes
+};
+
+struct Ms6Step {   // one 16-token step of one document; wave-uniform
+  long long off;   // first token row of the document
+  int t0, len, r;  // first token of the step, document length, rerank slot
+  int valid;
+};
+
+#define MS6_WAVES 16
+#define MS6_THREADS (MS6_WAVES * 64)
+
+template <int KS4, int NBITS, int NCH>
+__global__ __launch_bounds__(MS6_THREADS) void k_maxsim6(const MsArgs a) {
+  using Cf = Ms6Cfg<KS4, NBITS>;
+  constexpr int D = Cf::D, NE = Cf::NE, RW = Cf::RW, PR = Cf::PR, LB = Cf::LB;
+  constexpr int NC16 = NCH * 2;   // 16-column groups per launch
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lut = smem;                                                          // 64 KiB
+  uint4* qs = reinterpret_cast<uint4*>(smem + MS_LUT_BYTES);                         // B fragments: [NC16][KS4][64] x 16 B
+  float* qn = reinterpret_cast<float*>(smem + MS_LUT_BYTES + NC16 * KS4 * 64 * 16);  // [NCH * 32] certification window per column
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r16 = lane & 15, g = lane >> 4;
+  ms_lds_base_is_zero(smem);
+  ms6_fill_lut<NBITS>(lut, a.lut_g, tid, MS6_THREADS);
+  const uint32_t laneoff = (uint32_t)((lane & (Cf::COPIES - 1)) * Cf::EW * 4);
+  const half_t negm = (half_t)NEG_MASK_F;
+  int nq = a.Q - a.ch_begin * 32;
+  nq = nq < 0 ? 0 : (nq > NCH * 32 ? NCH * 32 : nq);
+  const int nflag = a.Qp / 32;
+
+  // this workgroup's share of the flattened (query, rerank slot) space.  xcd: workgroup i runs on XCD i % 8; giving XCD x the
+  // x-th eighth of the space keeps a query's documents (and the centroid rows they share) in ONE L2
+  int bid = blockIdx.x;
+  if (a.xcd && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const long long tot = a.pref[a.B];
+  const long long lo = tot * (long long)bid / (long long)gridDim.x;
+  const long long hi_end = tot * (long long)(bid + 1) / (long long)gridDim.x;
+  int b = 0;
+  {
+    int l = 0, h = a.B;
+    while (h - l > 1) { const int m = (l + h) >> 1; if (a.pref[m] <= lo) l = m; else h = m; }
+    b = l;
+  }
+  for (; b < a.B && a.pref[b] < hi_end; ++b) {
+    const long long pb0 = a.pref[b], pb1 = a.pref[b + 1];
+    const int ra = (int)((lo > pb0 ? lo : pb0) - pb0);
+    const int rb = (int)((hi_end < pb1 ? hi_end : pb1) - pb0);
+    if (rb <= ra) continue;
+    __syncthreads();
+    // B fragment of (16-column group c, k-step s), lane (n, gq): q[col = 16 c + n][dims 32 s + 8 gq .. + 8]
+    for (int i = tid; i < NC16 * KS4 * 64; i += MS6_THREADS) {
+      const int ln = i & 63, s = (i >> 6) % KS4, c = (i >> 6) / KS4;
+      const int col = a.ch_begin * 32 + c * 16 + (ln & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (col < a.Qp) v = *reinterpret_cast<const uint4*>(a.qpad + ((int64_t)b * a.Qp + col) * D + 32 * s + 8 * (ln >> 4));
+      qs[i] = v;
+    }
+    if (tid < NCH * 32) {
+      const int col = a.ch_begin * 32 + tid;
+      float ss = 0.f;
+      if (col < a.Qp) {
+        const uint16_t* qp = a.qpad + ((int64_t)b * a.Qp + col) * D;
+        for (int k = 0; k < D; ++k) { const float x = (float)__builtin_bit_cast(half_t, qp[k]); ss = __builtin_fmaf(x, x, ss); }
+      }
+      qn[tid] = a.eps_rel * __builtin_sqrtf(ss);
+    }
+    __syncthreads();
+    const int per = (rb - ra + MS6_WAVES - 1) / MS6_WAVES;
+    const int r0 = ra + wave * per;
+    if (r0 >= rb) continue;
+    const int rend = (r0 + per < rb) ? (r0 + per) : rb;
+    const int32_t* selp = a.sel_pid + (int64_t)b * a.Rcap;
+    float* outp = a.exact + (int64_t)b * a.Rcap;
+
+    // ---- the stream of 16-token steps of documents r0 .. rend-1 (all wave-uniform).  The document metadata comes through the
+    // scalar cache (constant address space: the lists were written by earlier kernels), so that no vector load -- and with it no
+    // vmcnt(0) -- sits between the pipelined row loads ----
+    typedef const __attribute__((address_space(4))) int32_t* ms_cptr_i32;
+    typedef const __attribute__((address_space(4))) int64_t* ms_cptr_i64;
+    const ms_cptr_i32 selc = (ms_cptr_i32)(uintptr_t)selp;
+    const ms_cptr_i64 doffc = (ms_cptr_i64)(uintptr_t)a.doc_off;
+    auto meta = [&](int rr, long long& o, int& l) {
+      const int32_t pid = selc[rr];
+      o = doffc[pid];
+      l = (int)(doffc[pid + 1] - o);
+    };
+    // empty documents first (every column keeps the masked value, nothing to flag); the stream below skips them
+    for (int rr = r0; rr < rend; ++rr) {
+      long long o; int l;
+      meta(rr, o, l);
+      if (l != 0) continue;
+      if (lane == 0) {
+        const float v = (float)nq * NEG_MASK_F;
+        outp[rr] = a.accumulate ? (outp[rr] + v) : v;
+        if (a.unc && !a.accumulate) { a.unc[(int64_t)b * a.Rcap + rr] = 0.f; a.uncm[(int64_t)b * a.Rcap + rr] = 0.f; }
+      }
+      if (a.cm16 && lane < 32) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if ((a.ch_begin + c) * 32 < a.Qp) a.cm16[((int64_t)b * a.Rcap + rr) * a.Qp + (a.ch_begin + c) * 32 + lane] = __builtin_bit_cast(uint16_t, negm);
+      }
+      if (a.flags && lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (a.ch_begin + c < nflag) a.flags[((int64_t)b * a.Rcap + rr) * nflag + a.ch_begin + c] = 0u;
+      }
+    }
+    int it_r = r0, it_t0 = 0, it_len = 0, n_len = 0;
+    long long it_off = 0, n_off = 0;
+    if (it_r < rend) meta(it_r, it_off, it_len);
+    if (it_r + 1 < rend) meta(it_r + 1, n_off, n_len);
+    auto next_doc = [&]() {
+      ++it_r;
+      it_off = n_off;
+      it_len = n_len;
+      it_t0 = 0;
+      if (it_r + 1 < rend) meta(it_r + 1, n_off, n_len);
+    };
+    while (it_r < rend && it_len == 0) next_doc();
+    auto next_step = [&]() -> Ms6Step {   // the iterator's current step, then advance
+      Ms6Step st{it_off, it_t0, it_len, it_r, it_r < rend ? 1 : 0};
+      if (st.valid) {
+        it_t0 += 16;
+        if (it_t0 >= it_len) {
+          next_doc();
+          while (it_r < rend && it_len == 0) next_doc();
+        }
+      }
+      return st;
+    };
+    // the lane's token inside the step's document (clamped: loads stay in bounds, rows beyond the document are masked at the maximum)
+    auto tok_of = [&](const Ms6Step& st) -> int {
+      const int tok = st.t0 + r16;
+      return st.valid ? (tok < st.len ? tok : st.len - 1) : 0;
+    };
+    auto load_tok = [&](Ms6Buf<KS4, NBITS>& bf, const Ms6Step& st, int32_t code) {
+      const long long row = (st.valid ? st.off : 0) + tok_of(st);
+      const uint8_t* rp = a.resid_nat + row * (long long)PR + g * LB;
+      if constexpr (LB % 16 == 0) {
+#pragma unroll
+        for (int i = 0; i < LB / 16; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
+          bf.rw[4 * i] = v.x; bf.rw[4 * i + 1] = v.y; bf.rw[4 * i + 2] = v.z; bf.rw[4 * i + 3] = v.w;
+        }
+      } else if constexpr (LB % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < LB / 8; ++i) {
+          const uint2 v = *reinterpret_cast<const uint2*>(rp + 8 * i);
+          bf.rw[2 * i] = v.x; bf.rw[2 * i + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < LB / 4; ++i) bf.rw[i] = *reinterpret_cast<const uint32_t*>(rp + 4 * i);
+      }
+      const uint16_t* cp = a.cent + (long long)code * D + 8 * g;
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) {
+        const uint4 v = *reinterpret_cast<const uint4*>(cp + 32 * s);
+        bf.e[4 * s] = v.x; bf.e[4 * s + 1] = v.y; bf.e[4 * s + 2] = v.z; bf.e[4 * s + 3] = v.w;
+      }
+    };
+    auto load_cn = [&](const Ms6Step& st, int32_t& code, uint32_t& nrm) {   // nrm: reciprocal bits (a.rinv) or the fp16 norm
+      const long long row = (st.valid ? st.off : 0) + tok_of(st);
+      code = a.codes[row];
+      nrm = a.rinv ? a.rinv[row] : (uint32_t)a.norms[row];
+    };
+
+    float mx[NC16];
+#pragma unroll
+    for (int c = 0; c < NC16; ++c) mx[c] = NEG_MASK_F;
+
+    auto compute = [&](const Ms6Step& st, Ms6Buf<KS4, NBITS>& bf, uint32_t nrm) {
+      // e = h(cent + w);  e^ = h(fl32(e / n))
+#if !defined(FP_MS6_ABL) || (FP_MS6_ABL != 2 && FP_MS6_ABL != 4)
+      ms6_decode<NBITS, RW, NE>(laneoff, bf.rw, bf.e);
+#else
+#pragma unroll
+      for (int i = 0; i < RW; ++i) bf.e[i] ^= bf.rw[i];   // timing-only ablation: no decode
+#endif
+#if !defined(FP_MS6_ABL) || FP_MS6_ABL == 3
+      if (a.rinv && !__any((int)(nrm >> 31))) {   // one multiply per value by the token's stored reciprocal
+        const float r = __uint_as_float(nrm);
+#pragma unroll
+        for (int i = 0; i < NE; i += 2) norm_mul2(bf.e[i], bf.e[i + 1], r);
+      } else {   // no reciprocals in the index, or a token of the step has none: the compensated quotient
+        uint16_t n16 = (uint16_t)nrm;
+        if (a.rinv) n16 = a.norms[(st.valid ? st.off : 0) + tok_of(st)];
+        float r_hi, r_lo;
+        recip2((float)__builtin_bit_cast(half_t, n16), r_hi, r_lo);
+#pragma unroll
+        for (int i = 0; i < NE; i += 2) norm_pair2(bf.e[i], bf.e[i + 1], r_hi, r_lo);
+      }
+#else
+      bf.e[0] ^= nrm;   // timing-only ablation: no normalisation
+#endif
+      // MFMA: D[row = token][col], this lane's rows 4 g + i
+      f4v acc[NC16];
+#if defined(FP_MS6_ABL) && (FP_MS6_ABL == 3 || FP_MS6_ABL == 4)
+#pragma unroll
+      for (int c = 0; c < NC16; ++c) acc[c] = f4v{__uint_as_float(bf.e[c]), __uint_as_float(bf.e[4 + c]), __uint_as_float(bf.e[8 + c]), __uint_as_float(bf.e[12 + c])};   // timing-only: no MFMA / fragment reads
+#else
+#pragma unroll
+      for (int c = 0; c < NC16; ++c) {
+#pragma unroll
+        for (int s = 0; s < KS4; ++s) {
+          const h8 av = __builtin_bit_cast(h8, make_uint4(bf.e[4 * s], bf.e[4 * s + 1], bf.e[4 * s + 2], bf.e[4 * s + 3]));
+          const h8 bq = __builtin_bit_cast(h8, qs[(c * KS4 + s) * 64 + lane]);
+          if (s == 0) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq, f4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq, acc[c], 0, 0, 0);
+        }
+      }
+#endif
+      const bool partial = st.t0 + 16 > st.len;
+#pragma unroll
+      for (int c = 0; c < NC16; ++c) {
+        float v0 = acc[c][0], v1 = acc[c][1], v2 = acc[c][2], v3 = acc[c][3];
+        if (partial) {
+          const int rowb = st.t0 + 4 * g;
+          if (rowb + 0 >= st.len) v0 = NEG_MASK_F;
+          if (rowb + 1 >= st.len) v1 = NEG_MASK_F;
+          if (rowb + 2 >= st.len) v2 = NEG_MASK_F;
+          if (rowb + 3 >= st.len) v3 = NEG_MASK_F;
+        }
+        mx[c] = max3_raw(v2, v3, max3_raw(v0, v1, mx[c]));
+      }
+      if (st.t0 + 16 >= st.len) {   // the document's last step: combine the four row groups, round, certify, sum
+        float total = 0.f, ubud = 0.f, ubm = 0.f;
+        const unsigned long long upper16 = 0xFFFF0000FFFF0000ull;   // lanes with (lane & 16)
+#pragma unroll
+        for (int c = 0; c < NC16; ++c) {
+          {  // maximum over lanes l, l^16, l^32, l^48 (the same column, other row groups)
+            auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx[c]), __float_as_uint(mx[c]), false, false);
+            float m = __builtin_fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+            auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            mx[c] = __builtin_fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          // lane l < 32 takes column 32 c + l: lanes 0-15 from group 2c, lanes 16-31 from group 2c + 1 (every row group holds both)
+          float am;   // (a plain ?: over two array elements becomes an indexed scratch access; spell the select)
+          asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(am) : "v"(mx[2 * c]), "v"(mx[2 * c + 1]), "s"(upper16));
+          const int q = (a.ch_begin + c) * 32 + (lane & 31);
+          const bool mine = (lane < 32) && (q < a.Q);
+          const half_t hm = (half_t)am;
+          float sv = mine ? (float)hm : 0.f;
+          uint32_t ef = (__float_as_uint(am) >> 23) & 0xFFu;
+          ef = ef < 113u ? 113u : ef;
+          const float halfulp = __uint_as_float((ef - 11u) << 23);
+          const float dist = halfulp - __builtin_fabsf(am - (float)hm);
+          const bool flag = mine && !(dist > qn[c * 32 + (lane & 31)]);
+          float fu = flag ? 2.0f * halfulp : 0.f;
+          float fm = (flag && !(am > (float)hm)) ? 2.0f * halfulp : 0.f;
+          if (flag && !(am < (float)hm) && !(am > (float)hm)) fu += 2.0f * halfulp;
+          const unsigned long long bal = __ballot(flag);
+#pragma unroll
+          for (int sft = 32; sft > 0; sft >>= 1) sv += __shfl_xor(sv, sft, 64);
+          if (bal) {
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+              fu += __shfl_xor(fu, sft, 64);
+              fm += __shfl_xor(fm, sft, 64);
+            }
+          }
+          total += sv;
+          ubud += fu;
+          ubm += fm;
+          if (a.cm16 && lane < 32 && (a.ch_begin + c) * 32 < a.Qp)
+            a.cm16[((int64_t)b * a.Rcap + st.r) * a.Qp + (a.ch_begin + c) * 32 + lane] = __builtin_bit_cast(uint16_t, hm);
+          if (a.flags && lane == 0 && a.ch_begin + c < nflag) a.flags[((int64_t)b * a.Rcap + st.r) * nflag + a.ch_begin + c] = (uint32_t)bal;
+        }
+        if (lane == 0) {
+          outp[st.r] = a.accumulate ? (outp[st.r] + total) : total;
+          if (a.unc) {
+            float* up = a.unc + (int64_t)b * a.Rcap + st.r;
+            *up = a.accumulate ? (*up + ubud) : ubud;
+            float* um = a.uncm + (int64_t)b * a.Rcap + st.r;
+            *um = a.accumulate ? (*um + ubm) : ubm;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NC16; ++c) mx[c] = NEG_MASK_F;
+      }
+    };
+
+    // ---- software pipeline: step k is computed while the loads of steps k+1, k+2 are in flight and the code / norm of
+    // step k+3 are being fetched.  vmcnt retires in order, so a step's code load must be OLDER than the previous step's
+    // row loads (or waiting for it would drain them): order per iteration = codes(k+3), rows(k+2), compute(k). ----
+    Ms6Buf<KS4, NBITS> B0, B1, B2;
+    Ms6Step d0 = next_step(), d1 = next_step(), d2 = next_step(), d3{};
+    int32_t code0, code1, code2, code3 = 0;
+    uint32_t nrm0, nrm1, nrm2, nrm3 = 0;
+    load_cn(d0, code0, nrm0);
+    load_cn(d1, code1, nrm1);
+    load_cn(d2, code2, nrm2);
+    asm volatile("" ::: "memory");
+    load_tok(B0, d0, code0);   // (unconditional: an exhausted stream reads row 0 -- every path then has the same number of
+    load_tok(B1, d1, code1);   //  loads in flight, which is what lets the compiler wait with vmcnt(n) instead of vmcnt(0))
+    asm volatile("" ::: "memory");
+    // (the empty asm statements with a memory clobber pin the ORDER in which the loads are issued: without them the compiler
+    // sinks a step's code load next to its first use, one iteration later, and then has to drain every load in front of it)
+    auto body = [&](Ms6Buf<KS4, NBITS>& cur, Ms6Buf<KS4, NBITS>& ld) {
+      d3 = next_step();
+      load_cn(d3, code3, nrm3);
+      asm volatile("" ::: "memory");
+      load_tok(ld, d2, code2);
+      asm volatile("" ::: "memory");
+      compute(d0, cur, nrm0);
+      asm volatile("" ::: "memory");
+      d0 = d1; d1 = d2; d2 = d3;
+      nrm0 = nrm1; nrm1 = nrm2; nrm2 = nrm3;
+      code2 = code3;
+    };
+    while (true) {
+      if (!d0.valid) break;
+      body(B0, B2);
+      if (!d0.valid) break;
+      body(B1, B0);
+      if (!d0.valid) break;
+      body(B2, B1);
     }
   }
 }
@@ -778,7 +1270,58 @@ static int ms_num_cus() {
 }
 
 bool fpk_maxsim_fast_shape(int dim, int nbits) {
-  return (dim == 128 || dim == 96 || dim == 64 || dim == 48) && (nbits == 4 || nbits == 2);
+  return ((dim == 128 || dim == 96 || dim == 64 || dim == 48) && (nbits == 4 || nbits == 2)) || fpk_maxsim6_shape(dim, nbits);
+}
+bool fpk_maxsim6_shape(int dim, int nbits) {
+  return (dim == 128 && nbits == 4) || (dim == 64 && nbits == 4) || (dim == 128 && nbits == 2);
+}
+
+__global__ __launch_bounds__(256) void k_resid_native(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int64_t T, int pr, int nbits, int nu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T * nu; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / nu;
+    const int u = (int)(i - t * nu);
+    const int pos = fp_resid_native_unit(u, nu);
+    for (int w = 0; w < nbits; ++w) dst[t * pr + pos * nbits + w] = src[t * pr + u * nbits + w];
+  }
+}
+void fpk_resid_native(const FpIndexDev& ix, uint8_t* dst, hipStream_t st) {
+  if (ix.T <= 0) return;
+  const int nu = ix.dim / 8;
+  hipLaunchKernelGGL(k_resid_native, dim3(fp_grid_cap((ix.T * nu + 255) / 256, 256)), dim3(256), 0, st, ix.residuals, dst, ix.T, ix.pr, ix.nbits, nu);
+}
+
+static int ms_impl() {   // FP_MAXSIM_IMPL=5: the round-2 kernel everywhere (A/B runs)
+  static const int v = [] { const char* e = getenv("FP_MAXSIM_IMPL"); return e ? atoi(e) : 6; }();
+  return v;
+}
+
+template <int KS4, int NBITS>
+static void launch_maxsim6(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int64_t* pref,
+                           int64_t Rcap, float* exact, const FpMaxsimAux& aux, hipStream_t st) {
+  const int nch = sh.Qp / 32;
+  const int64_t tot_max = (int64_t)sh.B * Rcap;
+  int grid = ms_num_cus();
+  if ((int64_t)grid * MS6_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS6_WAVES - 1) / MS6_WAVES);
+  static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  static const int xcd = [] { const char* e = getenv("FP_MS_XCD"); return e ? atoi(e) : 0; }();
+  MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
+           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, ix.resid_nat, ix.rinv, xcd};
+  static std::atomic<uint64_t> ok1{0}, ok2{0};
+  fp_allow_big_lds((const void*)k_maxsim6<KS4, NBITS, 1>, ok1, 96 * 1024);
+  fp_allow_big_lds((const void*)k_maxsim6<KS4, NBITS, 2>, ok2, 112 * 1024);
+  for (int ch = 0; ch < nch;) {
+    a.ch_begin = ch;
+    if (nch - ch >= 2) {
+      const size_t lds = MS_LUT_BYTES + (size_t)4 * KS4 * 64 * 16 + 2 * 32 * 4;
+      hipLaunchKernelGGL((k_maxsim6<KS4, NBITS, 2>), dim3((unsigned)grid), dim3(MS6_THREADS), lds, st, a);
+      ch += 2;
+    } else {
+      const size_t lds = MS_LUT_BYTES + (size_t)2 * KS4 * 64 * 16 + 1 * 32 * 4;
+      hipLaunchKernelGGL((k_maxsim6<KS4, NBITS, 1>), dim3((unsigned)grid), dim3(MS6_THREADS), lds, st, a);
+      ch += 1;
+    }
+    a.accumulate = 1;
+  }
 }
 
 template <int D, int NBITS>
@@ -791,7 +1334,7 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
   if ((int64_t)grid * MS_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS_WAVES - 1) / MS_WAVES);
   static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
-           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel};
+           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, nullptr, nullptr, 0};
   static std::atomic<uint64_t> ok1{0}, ok2{0};
   fp_allow_big_lds((const void*)k_maxsim5<D, NBITS, 1>, ok1, 96 * 1024);
   fp_allow_big_lds((const void*)k_maxsim5<D, NBITS, 2>, ok2, 96 * 1024);
@@ -814,6 +1357,16 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
 // budgets and flag masks for the exact-order repair.  Returns 0, or -1 when q_len is too large for the generic kernel.
 int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
                int64_t Rcap, float* exact, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st) {
+#define MS6_CASE(KS4_, NB_) \
+  if (ix.dim == KS4_ * 32 && ix.nbits == NB_) { \
+    hipLaunchKernelGGL(k_cnt_prefix, dim3(1), dim3(256), 0, st, sel_cnt, sh.B, pref); \
+    launch_maxsim6<KS4_, NB_>(ix, qpad, sh, sel_pid, pref, Rcap, exact, aux, st); \
+    return 0; \
+  }
+  if (ix.resid_nat && ms_impl() != 5) {
+    MS6_CASE(4, 4) MS6_CASE(2, 4) MS6_CASE(4, 2)
+  }
+#undef MS6_CASE
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
     hipLaunchKernelGGL(k_cnt_prefix, dim3(1), dim3(256), 0, st, sel_cnt, sh.B, pref); \

@@ -119,6 +119,11 @@ class PyLoadedIndex:
         """128-byte lines of packed unique codes that S4's level-0 stage streams (all centroid ranges)."""
         return int(N.lib().fp_index_num_code_lines(self._h))
 
+    @property
+    def n_hard_tokens(self):
+        """tokens whose normalisation has no one-multiply reciprocal (k_token_rinv): their steps take the compensated path"""
+        return int(N.lib().fp_index_num_hard_tokens(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib().fp_index_destroy(self._h)

@@ -93,6 +93,8 @@ int64_t fp_index_device_bytes(const fp_index* index);
 int64_t fp_index_num_unique_codes(const fp_index* index);
 /* 128-byte lines of the packed per-document unique codes that S4's level-0 stage streams (0 when the index has none) */
 int64_t fp_index_num_code_lines(const fp_index* index);
+/* tokens whose normalisation has no one-multiply reciprocal (the MaxSim kernel takes the compensated path for their steps) */
+int64_t fp_index_num_hard_tokens(const fp_index* index);
 
 /* ---- search: `pysearch` (rust/lib.rs:195-223) -> search_many (search.rs:219-288) ----- */
 /* queries: host [n_queries, q_len, dim] f16.  subset_offsets NULL = no subset; otherwise

@@ -48,8 +48,25 @@ __global__ __launch_bounds__(1024) void k(const Args a, const int nwaves) {
         uint4 v[4];
         uint32_t rs[4];
         uint4 rq = make_uint4(0, 0, 0, 0);
+        {
+          typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+          u4v t[4];
+          const uint4* p0 = &a.tab[(long long)code * 16 + g];
+          const int pol = a.part >> 4;   // cache policy of the centroid-row loads
+          if (pol == 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) v[s2] = a.tab[(long long)code * 16 + s2 * 4 + g];
+            for (int s2 = 0; s2 < 4; ++s2) v[s2] = p0[s2 * 4];
+          } else {
+#define LD4(POL) asm volatile("global_load_dwordx4 %0, %4, off " POL "\n\tglobal_load_dwordx4 %1, %4, off offset:64 " POL "\n\tglobal_load_dwordx4 %2, %4, off offset:128 " POL "\n\tglobal_load_dwordx4 %3, %4, off offset:192 " POL "\n\ts_waitcnt vmcnt(0)" : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(p0) : "memory")
+            if (pol == 1) LD4("sc0");
+            else if (pol == 2) LD4("sc1");
+            else if (pol == 3) LD4("sc0 sc1");
+            else if (pol == 4) LD4("nt");
+            else LD4("");
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) v[s2] = make_uint4(t[s2].x, t[s2].y, t[s2].z, t[s2].w);
+          }
+        }
         if (a.part & 8) rq = a.resid[row * 4 + g];
         else {
 #pragma unroll
@@ -237,16 +254,16 @@ int main(int argc, char** argv) {
       if (rep) printf("M2 part=%d (1 centroid rows, 2 residuals, 3 both, 4 nt residuals, 5 rows + nt residuals), 16 waves: %.1f us\n", part, ms * 1e3);
     }
   }
-  for (int part : {3, 11}) {
+  for (int part : {11, 11 + 16, 11 + 32, 11 + 48, 11 + 64, 11 + 80}) {
     a.part = part;
-    for (int nwaves : {16, 12, 8})
+    for (int nwaves : {16})
     for (int rep = 0; rep < 2; ++rep) {
       hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
       CHK(hipEventRecord(e0));
       hipLaunchKernelGGL(k<6>, dim3(256), dim3(nwaves * 64), 0, 0, a, nwaves);
       CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
       float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-      if (rep) printf("M6 16x16-native (16-token steps, 64 B of a row per instruction), residual %s, %d waves: %.1f us\n", (part & 8) ? "1 x dwordx4 (permuted layout)" : "4 x dword strided", nwaves, ms * 1e3);
+      if (rep) printf("M6 16x16-native, policy %d (0 plain C++ loads, 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt, 5 asm loads without a policy), %d waves: %.1f us\n", part >> 4, nwaves, ms * 1e3);
     }
   }
   a.part = 3;
