@@ -317,19 +317,13 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token norms)");
     D.norms = norms;
   }
-  D.resid_nat = nullptr;
+  D.resid_native = 0;
   D.rinv = nullptr;
   if (fpk_maxsim6_shape(D.dim, D.nbits)) {
-    uint8_t* rn = nullptr;
-    hipError_t e = hipMalloc((void**)&rn, (size_t)std::max<int64_t>(D.T, 1) * D.pr + 64);
-    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (native residual order)");
-    ix->owned.push_back(rn);
-    ix->bytes += D.T * D.pr;
-    fpk_resid_native(D, rn, st);
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (native residual order)");
-    D.resid_nat = rn;
+    // per-token reciprocals (from the rows still in the reference's byte order), then every row rewritten in the MaxSim kernel's
+    // unit order IN PLACE, a slab of rows at a time through a bounded temporary
     static const bool use_rinv = [] { const char* e2 = getenv("FP_MS_RINV"); return !(e2 && atoi(e2) == 0); }();
+    hipError_t e = hipSuccess;
     if (use_rinv) {
       uint32_t* rv = nullptr;
       unsigned long long* nh = nullptr;
@@ -349,6 +343,17 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
       D.rinv = rv;
       ix->n_hard_tokens = (int64_t)hard;
     }
+    if (D.T > 0) {
+      const int64_t slab = std::max<int64_t>(1, std::min<int64_t>(D.T, (512ll << 20) / D.pr));
+      uint8_t* tmp = nullptr;
+      e = hipMalloc((void**)&tmp, (size_t)slab * D.pr);
+      if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (native residual order)");
+      for (int64_t t0 = 0; t0 < D.T; t0 += slab) fpk_resid_native(D, t0, std::min<int64_t>(slab, D.T - t0), tmp, st);
+      e = hipStreamSynchronize(st);
+      (void)hipFree(tmp);
+      if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (native residual order)");
+    }
+    D.resid_native = 1;
   }
   {
     int64_t* uoff = nullptr; int32_t* ucodes = nullptr; int64_t U = 0;
@@ -538,6 +543,14 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   return FP_OK;
 }
 
+// one stored residual row -> the reference's byte order (identity unless the index keeps k_maxsim6's unit order)
+static inline void row_to_reference_order(const fp_index* ix, const uint8_t* stored, uint8_t* out) {
+  const int pr = ix->d.pr;
+  if (!ix->d.resid_native) { memcpy(out, stored, (size_t)pr); return; }
+  const int nbits = ix->d.nbits, nu = ix->d.dim / 8;
+  for (int b = 0; b < pr; ++b) out[b] = stored[fp_resid_pos(b, nbits, nu, 1)];
+}
+
 extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* codes, uint8_t* residuals, int64_t cap) {
   if (!ix || doc < 0 || doc >= ix->d.N) return fail(FP_EINVAL, "bad document id");
   (void)hipSetDevice(ix->device);
@@ -555,7 +568,7 @@ extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* c
   for (int64_t i = 0; i < len; ++i) {  // stored position i holds original token perm[i]
     const int64_t p = ix->d.perm ? perm[i] : i;
     codes[p] = tmp[i];
-    memcpy(residuals + p * pr, rtmp.data() + i * pr, (size_t)pr);
+    row_to_reference_order(ix, rtmp.data() + i * pr, residuals + p * pr);
   }
   return len;
 }
@@ -1916,7 +1929,7 @@ extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* 
       for (int64_t i = ix->h_doc_off[d0]; i < ix->h_doc_off[d0 + 1]; ++i) doc_codes[orig_row(d0, i)] = tmp[i];
   }
   if (doc_residuals && D.T > 0) {
-    if (hperm.empty()) {
+    if (hperm.empty() && !D.resid_native) {
       HIPCHK(hipMemcpy(doc_residuals, D.residuals, (size_t)D.T * D.pr, hipMemcpyDeviceToHost));
     } else {
       std::vector<uint8_t> rt((size_t)std::min<int64_t>(chunk, D.T) * D.pr);
@@ -1926,7 +1939,7 @@ extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* 
         HIPCHK(hipMemcpy(rt.data(), D.residuals + s0 * D.pr, (size_t)m * D.pr, hipMemcpyDeviceToHost));
         for (int64_t i = s0; i < s0 + m; ++i) {
           while (ix->h_doc_off[d0 + 1] <= i) ++d0;
-          memcpy(doc_residuals + orig_row(d0, i) * D.pr, rt.data() + (i - s0) * D.pr, (size_t)D.pr);
+          row_to_reference_order(ix, rt.data() + (i - s0) * D.pr, doc_residuals + orig_row(d0, i) * D.pr);
         }
       }
     }

@@ -53,19 +53,35 @@ struct FpIndexDev {
   const uint4* pcodes_r[8];
   const int32_t* poff_r[8];
   const uint16_t* norms;   // [T]   fp16 bits of h(sqrt(sum_fp32 e_k^2)) per stored token (ascending-k sum; computed at index creation)
-  const uint8_t* resid_nat;   // [T][PR] the residual rows again with each token's 8-dim units in k_maxsim6's order (fp_resid_native_pos);
-                              //         nullptr when the shape has no k_maxsim6 instantiation
+  int resid_native;           // 1: every token's residual row is stored in k_maxsim6's unit order (fp_resid_native_unit); the arrays
+                              //    handed over by the caller and everything exported are in the reference's order
   const uint32_t* rinv;       // [T]   fp32 bits of a reciprocal r with h(fl32(e_k * r)) == h(fl32(e_k / n)) for every dim of the token
                               //         (bit 31 set: no such r within the search range -> the kernel takes the exact path for the step); nullable
 };
 
 // Native unit order of a token's residual bytes (k_maxsim6): a unit = 8 dims = nbits bytes; unit u = 4 s + g (k-step s of 32 dims,
-// lane group g) is stored at position g * ceil-share + s, so that the units one lane decodes are contiguous.  nu = dim / 8.
-static inline __host__ __device__ int fp_resid_native_unit(int u, int nu) {
+// lane group g) is stored at position start(g) + s, so that the units one lane decodes are contiguous.  nu = dim / 8.
+static inline __host__ __device__ constexpr int fp_resid_native_unit(int u, int nu) {
   const int s = u >> 2, g = u & 3;
   int start = 0;
   for (int i = 0; i < g; ++i) start += (nu - i + 3) >> 2;
   return start + s;
+}
+// stored position of the reference-order residual byte b of a token (identity when the index is not in native order)
+static inline __host__ __device__ constexpr int fp_resid_pos(int b, int nbits, int nu, int native) {
+  return native ? fp_resid_native_unit(b / nbits, nu) * nbits + b % nbits : b;
+}
+// the inverse: reference-order byte held at stored position p
+static inline __host__ __device__ constexpr int fp_resid_logical(int p, int nbits, int nu, int native) {
+  if (!native) return p;
+  const int pu = p / nbits;
+  int start = 0, g = 0;
+  for (; g < 4; ++g) {
+    const int cnt = (nu - g + 3) >> 2;
+    if (pu < start + cnt) break;
+    start += cnt;
+  }
+  return (4 * (pu - start) + g) * nbits + p % nbits;
 }
 
 // A HIP dispatch carries its grid size in work-items as a 32-bit number: blocks * block_size must
@@ -183,8 +199,8 @@ struct FpMaxsimAux {
 };
 bool fpk_maxsim_fast_shape(int dim, int nbits);
 bool fpk_maxsim6_shape(int dim, int nbits);   // shapes k_maxsim6 is instantiated for
-// residual rows in k_maxsim6's unit order (dst [T][PR]; src = ix.residuals)
-void fpk_resid_native(const FpIndexDev& ix, uint8_t* dst, hipStream_t st);
+// rows [t0, t0 + n) of ix.residuals rewritten in k_maxsim6's unit order through tmp (n * pr bytes)
+void fpk_resid_native(const FpIndexDev& ix, int64_t t0, int64_t n, uint8_t* tmp, hipStream_t st);
 // per-token reciprocals for k_maxsim6's one-multiply normalisation (needs ix.norms); n_hard_dev (nullable): device counter of the
 // tokens that keep the exact path
 void fpk_token_rinv(const FpIndexDev& ix, uint32_t* rinv, unsigned long long* n_hard_dev, hipStream_t st);

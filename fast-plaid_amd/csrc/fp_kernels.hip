@@ -3381,14 +3381,14 @@ void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add,
 // the result is bit-identical to the CPU reference order.
 __global__ __launch_bounds__(64) void k_reconstruct(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut,
                                                     const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid, int D,
-                                                    int nbits, const int64_t* __restrict__ tok_idx, float* __restrict__ out) {
+                                                    int nbits, const int64_t* __restrict__ tok_idx, float* __restrict__ out, int native) {
   __shared__ float e[512];
   __shared__ float nrm;
   const int64_t t = tok_idx[blockIdx.x];
   const int pb = 8 / nbits, pr = D * nbits / 8;
   const int32_t code = codes[t];
   for (int d = threadIdx.x; d < D; d += 64) {
-    const int byte = resid[t * pr + d / pb];
+    const int byte = resid[t * pr + fp_resid_pos(d / pb, nbits, D / 8, native)];
     const half_t w = __builtin_bit_cast(half_t, lut[byte * pb + d % pb]);
     const half_t c = __builtin_bit_cast(half_t, cent[(int64_t)code * D + d]);
     e[d] = (float)(half_t)((float)w + (float)c);
@@ -3406,7 +3406,7 @@ __global__ __launch_bounds__(64) void k_reconstruct(const uint16_t* __restrict__
 void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx, int64_t n, float* out, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_reconstruct, dim3((unsigned)n), dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.dim, ix.nbits,
-                     tok_idx, out);
+                     tok_idx, out, ix.resid_native);
 }
 
 // token-score matrices (search.rs:651-653, :668-686): one 64-thread block per hit.  Per token: decompress exactly like
@@ -3417,7 +3417,7 @@ __global__ __launch_bounds__(64) void k_token_scores(const uint16_t* __restrict_
                                                      const int64_t* __restrict__ doc_off, const uint16_t* __restrict__ perm, int D, int nbits,
                                                      const uint16_t* __restrict__ queries /*[nq][Q][D]*/, int Q,
                                                      const int32_t* __restrict__ hit_query, const int32_t* __restrict__ hit_pid,
-                                                     const int64_t* __restrict__ out_off, uint16_t* __restrict__ out) {
+                                                     const int64_t* __restrict__ out_off, uint16_t* __restrict__ out, int native) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* qs = reinterpret_cast<float*>(smem);          // [Q][D] the hit's query as fp32
   float* e = qs + (size_t)Q * D;                       // [D]
@@ -3435,7 +3435,7 @@ __global__ __launch_bounds__(64) void k_token_scores(const uint16_t* __restrict_
     const int32_t code = codes[t];
     __syncthreads();  // e / nrm of the previous token are no longer read
     for (int d = threadIdx.x; d < D; d += 64) {
-      const int byte = resid[t * pr + d / pb];
+      const int byte = resid[t * pr + fp_resid_pos(d / pb, nbits, D / 8, native)];
       const half_t w = __builtin_bit_cast(half_t, lut[byte * pb + d % pb]);
       const half_t c = __builtin_bit_cast(half_t, cent[(int64_t)code * D + d]);
       e[d] = (float)(half_t)((float)w + (float)c);
@@ -3469,7 +3469,7 @@ int fpk_token_scores(const FpIndexDev& ix, const uint16_t* queries, int Q, const
   for (int64_t h0 = 0; h0 < n_hits; h0 += 0x7FFFFF00ll / 64) {   // grid.x * 64 threads must stay below 2^32
     const int64_t nh = std::min<int64_t>(n_hits - h0, 0x7FFFFF00ll / 64);
     hipLaunchKernelGGL(k_token_scores, dim3((unsigned)nh), dim3(64), lds, st, ix.centroids, ix.lut, ix.codes, ix.residuals, ix.doc_off, ix.perm,
-                       ix.dim, ix.nbits, queries, Q, hit_query + h0, hit_pid + h0, out_off + h0, out);
+                       ix.dim, ix.nbits, queries, Q, hit_query + h0, hit_pid + h0, out_off + h0, out, ix.resid_native);
   }
   return 0;
 }

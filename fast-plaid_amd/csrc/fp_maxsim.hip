@@ -34,6 +34,12 @@ struct MsCfg {
 };
 #define MS_LUT_BYTES (256 * 256)   // byte -> weights table, 64 KiB of LDS whatever nbits is
 
+// shapes k_maxsim6 is instantiated for (MS6_SHAPES below); an index of such a shape keeps its residual rows in native unit order
+static constexpr bool ms6_shape(int dim, int nbits) {
+  return (dim == 128 && (nbits == 4 || nbits == 2 || nbits == 8 || nbits == 1)) || (dim == 64 && (nbits == 4 || nbits == 2)) ||
+         (dim == 96 && nbits == 4) || (dim == 256 && (nbits == 4 || nbits == 2));
+}
+
 // ---- byte -> bucket weights table in LDS -----------------------------------------------------------------------------
 // entry (byte v, copy c) at byte offset v * 256 + c * EW * 4: the LDS address of a lane's entry is {0, 0, v, laneoff} as
 // bytes, i.e. ONE v_perm_b32 of the residual word and a per-lane constant (no shift / mask / add per byte).
@@ -277,7 +283,6 @@ struct MsArgs {
   int64_t Rcap;
   int B, Q, Qp, ch_begin, accumulate;
   float eps_rel;           // a column is flagged when its fp32 maximum lies within eps_rel * |q_col| of an fp16 rounding boundary
-  const uint8_t* resid_nat;   // k_maxsim6: residual rows in the MFMA-native unit order (fp_resid_native_pos); nullptr = not built
   const uint32_t* rinv;       // k_maxsim6: per-token reciprocal bits for the one-multiply normalisation (bit 31: take the exact path); nullable
   int xcd;                    // k_maxsim6: 1 = workgroup -> share mapping that keeps a query's documents on one XCD
 };
@@ -651,12 +656,13 @@ struct Ms6Step {   // one 16-token step of one document; wave-uniform
   int valid;
 };
 
-#define MS6_WAVES 16
-#define MS6_THREADS (MS6_WAVES * 64)
+// waves per workgroup (one workgroup per CU): 16 where three steps of loads fit 128 registers, fewer for wide rows / two column chunks
+static constexpr int ms6_waves(int ks4, int nch, int nbits = 4) { return ks4 >= 8 ? 8 : ((ks4 >= 4 && (nch == 2 || nbits == 8)) ? 12 : 16); }
 
 template <int KS4, int NBITS, int NCH>
-__global__ __launch_bounds__(MS6_THREADS) void k_maxsim6(const MsArgs a) {
+__global__ __launch_bounds__(ms6_waves(KS4, NCH, NBITS) * 64) __attribute__((amdgpu_waves_per_eu(ms6_waves(KS4, NCH, NBITS) / 4, ms6_waves(KS4, NCH, NBITS) / 4))) void k_maxsim6(const MsArgs a) {
   using Cf = Ms6Cfg<KS4, NBITS>;
+  constexpr int MS6_WAVES = ms6_waves(KS4, NCH, NBITS), MS6_THREADS = MS6_WAVES * 64;
   constexpr int D = Cf::D, NE = Cf::NE, RW = Cf::RW, PR = Cf::PR, LB = Cf::LB;
   constexpr int NC16 = NCH * 2;   // 16-column groups per launch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(MS6_THREADS) void k_maxsim6(const MsArgs a) {
     };
     auto load_tok = [&](Ms6Buf<KS4, NBITS>& bf, const Ms6Step& st, int32_t code) {
       const long long row = (st.valid ? st.off : 0) + tok_of(st);
-      const uint8_t* rp = a.resid_nat + row * (long long)PR + g * LB;
+      const uint8_t* rp = a.resid + row * (long long)PR + g * LB;
       if constexpr (LB % 16 == 0) {
 #pragma unroll
         for (int i = 0; i < LB / 16; ++i) {
@@ -1150,6 +1156,7 @@ __global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict
                                                       const int32_t* __restrict__ nmark, float* __restrict__ exact, float* __restrict__ unc,
                                                       uint16_t* __restrict__ cm16, uint32_t* __restrict__ flags) {
   using Cf = MsCfg<D, NBITS>;
+  constexpr int native = ms6_shape(D, NBITS) ? 1 : 0;   // the stored unit order of this shape's residual rows
   constexpr int NE = Cf::NE, RW = Cf::RW, PB = Cf::PB;
   __shared__ uint16_t slut[256 * PB];
   const int b = blockIdx.y;
@@ -1188,7 +1195,7 @@ __global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict
           for (int w = 0; w < RW; ++w) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-              const int bi = w * 4 + kk;
+              const int bi = fp_resid_logical(w * 4 + kk, NBITS, D / 8, native);   // (a constant after unrolling)
               const uint32_t byte = (rw[w] >> (8 * kk)) & 0xFFu;
               if constexpr (PB >= 2) {
 #pragma unroll
@@ -1196,7 +1203,7 @@ __global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict
                   const uint32_t wv = *reinterpret_cast<const uint32_t*>(&slut[byte * PB + 2 * j]);
                   e[bi * (PB / 2) + j] = h2_as_u32(u32_as_h2(e[bi * (PB / 2) + j]) + u32_as_h2(wv));
                 }
-              } else if ((kk & 1) == 0) {   // nbits 8: two bytes make one packed register
+              } else if ((kk & 1) == 0) {   // nbits 8: two bytes make one packed register (a unit is 8 bytes: pairs stay together)
                 const uint32_t byte1 = (rw[w] >> (8 * (kk + 1))) & 0xFFu;
                 const uint32_t wv = (uint32_t)slut[byte] | ((uint32_t)slut[byte1] << 16);
                 e[bi / 2] = h2_as_u32(u32_as_h2(e[bi / 2]) + u32_as_h2(wv));
@@ -1270,29 +1277,24 @@ static int ms_num_cus() {
 }
 
 bool fpk_maxsim_fast_shape(int dim, int nbits) {
-  return ((dim == 128 || dim == 96 || dim == 64 || dim == 48) && (nbits == 4 || nbits == 2)) || fpk_maxsim6_shape(dim, nbits);
+  return ((dim == 96 || dim == 48) && (nbits == 4 || nbits == 2)) || ms6_shape(dim, nbits);
 }
-bool fpk_maxsim6_shape(int dim, int nbits) {
-  return (dim == 128 && nbits == 4) || (dim == 64 && nbits == 4) || (dim == 128 && nbits == 2);
-}
+bool fpk_maxsim6_shape(int dim, int nbits) { return ms6_shape(dim, nbits); }
 
-__global__ __launch_bounds__(256) void k_resid_native(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int64_t T, int pr, int nbits, int nu) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T * nu; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void k_resid_native(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int64_t n, int pr, int nbits, int nu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * nu; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / nu;
     const int u = (int)(i - t * nu);
     const int pos = fp_resid_native_unit(u, nu);
     for (int w = 0; w < nbits; ++w) dst[t * pr + pos * nbits + w] = src[t * pr + u * nbits + w];
   }
 }
-void fpk_resid_native(const FpIndexDev& ix, uint8_t* dst, hipStream_t st) {
-  if (ix.T <= 0) return;
+void fpk_resid_native(const FpIndexDev& ix, int64_t t0, int64_t n, uint8_t* tmp, hipStream_t st) {
+  if (n <= 0) return;
   const int nu = ix.dim / 8;
-  hipLaunchKernelGGL(k_resid_native, dim3(fp_grid_cap((ix.T * nu + 255) / 256, 256)), dim3(256), 0, st, ix.residuals, dst, ix.T, ix.pr, ix.nbits, nu);
-}
-
-static int ms_impl() {   // FP_MAXSIM_IMPL=5: the round-2 kernel everywhere (A/B runs)
-  static const int v = [] { const char* e = getenv("FP_MAXSIM_IMPL"); return e ? atoi(e) : 6; }();
-  return v;
+  uint8_t* rows = const_cast<uint8_t*>(ix.residuals) + t0 * ix.pr;
+  hipLaunchKernelGGL(k_resid_native, dim3(fp_grid_cap((n * nu + 255) / 256, 256)), dim3(256), 0, st, rows, tmp, n, ix.pr, ix.nbits, nu);
+  (void)hipMemcpyAsync(rows, tmp, (size_t)n * ix.pr, hipMemcpyDeviceToDevice, st);
 }
 
 template <int KS4, int NBITS>
@@ -1300,12 +1302,15 @@ static void launch_maxsim6(const FpIndexDev& ix, const uint16_t* qpad, const FpS
                            int64_t Rcap, float* exact, const FpMaxsimAux& aux, hipStream_t st) {
   const int nch = sh.Qp / 32;
   const int64_t tot_max = (int64_t)sh.B * Rcap;
-  int grid = ms_num_cus();
-  if ((int64_t)grid * MS6_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS6_WAVES - 1) / MS6_WAVES);
+  auto grid_for = [&](int waves) {
+    int g = ms_num_cus();
+    if ((int64_t)g * waves > tot_max) g = (int)std::max<int64_t>(1, (tot_max + waves - 1) / waves);
+    return g;
+  };
   static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
   static const int xcd = [] { const char* e = getenv("FP_MS_XCD"); return e ? atoi(e) : 0; }();
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
-           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, ix.resid_nat, ix.rinv, xcd};
+           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, ix.rinv, xcd};
   static std::atomic<uint64_t> ok1{0}, ok2{0};
   fp_allow_big_lds((const void*)k_maxsim6<KS4, NBITS, 1>, ok1, 96 * 1024);
   fp_allow_big_lds((const void*)k_maxsim6<KS4, NBITS, 2>, ok2, 112 * 1024);
@@ -1313,11 +1318,11 @@ static void launch_maxsim6(const FpIndexDev& ix, const uint16_t* qpad, const FpS
     a.ch_begin = ch;
     if (nch - ch >= 2) {
       const size_t lds = MS_LUT_BYTES + (size_t)4 * KS4 * 64 * 16 + 2 * 32 * 4;
-      hipLaunchKernelGGL((k_maxsim6<KS4, NBITS, 2>), dim3((unsigned)grid), dim3(MS6_THREADS), lds, st, a);
+      hipLaunchKernelGGL((k_maxsim6<KS4, NBITS, 2>), dim3((unsigned)grid_for(ms6_waves(KS4, 2, NBITS))), dim3(ms6_waves(KS4, 2, NBITS) * 64), lds, st, a);
       ch += 2;
     } else {
       const size_t lds = MS_LUT_BYTES + (size_t)2 * KS4 * 64 * 16 + 1 * 32 * 4;
-      hipLaunchKernelGGL((k_maxsim6<KS4, NBITS, 1>), dim3((unsigned)grid), dim3(MS6_THREADS), lds, st, a);
+      hipLaunchKernelGGL((k_maxsim6<KS4, NBITS, 1>), dim3((unsigned)grid_for(ms6_waves(KS4, 1, NBITS))), dim3(ms6_waves(KS4, 1, NBITS) * 64), lds, st, a);
       ch += 1;
     }
     a.accumulate = 1;
@@ -1334,7 +1339,7 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
   if ((int64_t)grid * MS_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS_WAVES - 1) / MS_WAVES);
   static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
-           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, nullptr, nullptr, 0};
+           Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, nullptr, 0};
   static std::atomic<uint64_t> ok1{0}, ok2{0};
   fp_allow_big_lds((const void*)k_maxsim5<D, NBITS, 1>, ok1, 96 * 1024);
   fp_allow_big_lds((const void*)k_maxsim5<D, NBITS, 2>, ok2, 96 * 1024);
@@ -1363,8 +1368,8 @@ int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& 
     launch_maxsim6<KS4_, NB_>(ix, qpad, sh, sel_pid, pref, Rcap, exact, aux, st); \
     return 0; \
   }
-  if (ix.resid_nat && ms_impl() != 5) {
-    MS6_CASE(4, 4) MS6_CASE(2, 4) MS6_CASE(4, 2)
+  if (ix.resid_native) {
+    MS6_CASE(4, 4) MS6_CASE(4, 2) MS6_CASE(4, 8) MS6_CASE(4, 1) MS6_CASE(2, 4) MS6_CASE(2, 2) MS6_CASE(3, 4) MS6_CASE(8, 4) MS6_CASE(8, 2)
   }
 #undef MS6_CASE
 #define MS_CASE(D_, NB_) \
@@ -1373,7 +1378,7 @@ int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& 
     launch_maxsim5<D_, NB_>(ix, qpad, sh, sel_pid, pref, Rcap, exact, aux, st); \
     return 0; \
   }
-  MS_CASE(128, 4) MS_CASE(128, 2) MS_CASE(96, 4) MS_CASE(96, 2) MS_CASE(64, 4) MS_CASE(64, 2) MS_CASE(48, 4) MS_CASE(48, 2)
+  MS_CASE(96, 2) MS_CASE(48, 4) MS_CASE(48, 2)   // k_maxsim5: the fast shapes k_maxsim6 has no instantiation for (dim not a multiple of 32, 6-byte lane chunks)
 #undef MS_CASE
   const int qcap = (sh.Q + 63) / 64 > 8 ? 8 : (sh.Q + 63) / 64;
   hipLaunchKernelGGL(k_maxsim_generic, dim3((unsigned)Rcap, (unsigned)sh.B), dim3(64), (size_t)ix.dim * 4, st, ix.centroids, ix.lut, ix.codes,
@@ -1407,6 +1412,7 @@ void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* qpad, const FpSearc
                        ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags); \
     return; \
   }
-  MS_CASE(128, 4) MS_CASE(128, 2) MS_CASE(96, 4) MS_CASE(96, 2) MS_CASE(64, 4) MS_CASE(64, 2) MS_CASE(48, 4) MS_CASE(48, 2)
+  MS_CASE(128, 4) MS_CASE(128, 2) MS_CASE(128, 8) MS_CASE(128, 1) MS_CASE(96, 4) MS_CASE(96, 2) MS_CASE(64, 4) MS_CASE(64, 2) MS_CASE(48, 4) MS_CASE(48, 2)
+  MS_CASE(256, 4) MS_CASE(256, 2)
 #undef MS_CASE
 }
