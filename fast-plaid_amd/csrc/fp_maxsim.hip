@@ -177,7 +177,7 @@ void fpk_token_norms(const FpIndexDev& ix, uint16_t* norms, hipStream_t st) {
 __global__ __launch_bounds__(256) void k_token_rinv(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ lut,
                                                     const int32_t* __restrict__ codes, const uint8_t* __restrict__ resid,
                                                     const uint16_t* __restrict__ norms, int D, int nbits, int64_t T, uint32_t* __restrict__ rinv,
-                                                    unsigned long long* __restrict__ n_hard) {
+                                                    unsigned long long* __restrict__ n_hard, int hard_every /*testing: every n-th token takes the exact path*/) {
   const int pb = 8 / nbits, pr = D * nbits / 8;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
     const uint16_t* cp = cent + (int64_t)codes[t] * D;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void k_token_rinv(const uint16_t* __restrict__
         if (ok) { ok_any = true; found = rb; }
       }
     }
+    if (hard_every > 0 && t % hard_every == 0) { ok_any = false; found |= 0x80000000u; }
     rinv[t] = found;
     if (!ok_any && n_hard) atomicAdd(n_hard, 1ull);
   }
@@ -237,8 +238,9 @@ __global__ __launch_bounds__(256) void k_token_rinv(const uint16_t* __restrict__
 
 void fpk_token_rinv(const FpIndexDev& ix, uint32_t* rinv, unsigned long long* n_hard_dev, hipStream_t st) {
   if (ix.T <= 0) return;
+  static const int hard_every = [] { const char* e = getenv("FP_MS_RINV_HARD_EVERY"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(k_token_rinv, dim3(fp_grid_cap((ix.T + 255) / 256, 256)), dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals,
-                     ix.norms, ix.dim, ix.nbits, ix.T, rinv, n_hard_dev);
+                     ix.norms, ix.dim, ix.nbits, ix.T, rinv, n_hard_dev, hard_every);
 }
 
 // inclusive prefix of the per-query rerank counts: pref[0] = 0, pref[b+1] = sum_{i<=b} cnt[i]

@@ -40,7 +40,10 @@ def main():
     for (dim, nbits, n_docs, C, Q, n_full, n_probe, top_k, seed) in (
             (128, 4, 20000, 2048, 32, 4096, 8, 500, 1), (128, 2, 20000, 2048, 32, 2048, 8, 300, 2), (64, 4, 20000, 1024, 32, 2048, 8, 300, 3),
             (64, 2, 12000, 1024, 20, 1024, 4, 200, 4), (96, 4, 12000, 1024, 32, 2048, 8, 300, 5), (48, 2, 12000, 512, 32, 1024, 8, 200, 6),
-            (128, 4, 12000, 1024, 50, 1024, 8, 200, 7), (48, 4, 8000, 512, 7, 512, 4, 100, 8), (96, 2, 8000, 512, 64, 1024, 8, 200, 9)):
+            (128, 4, 12000, 1024, 50, 1024, 8, 200, 7), (48, 4, 8000, 512, 7, 512, 4, 100, 8), (96, 2, 8000, 512, 64, 1024, 8, 200, 9),
+            # round 3: shapes that moved from the exact-chain kernel to the MFMA kernel (k_maxsim6)
+            (128, 8, 8000, 512, 32, 1024, 8, 200, 10), (128, 1, 8000, 512, 32, 1024, 8, 200, 11), (256, 4, 6000, 512, 32, 1024, 8, 200, 12),
+            (256, 2, 6000, 512, 40, 512, 4, 100, 13)):
         spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=40, n_centroids=C, dim=dim, nbits=nbits, variable_len=True, seed=seed)
         arr = fp.synth.host_index_arrays(spec)
         idx, orc = mk(arr), oracle(arr)
@@ -58,6 +61,8 @@ def main():
                 n_scores += n
             _same_order_modulo_ref_ties(pids[b, :n], ref[b][0], dict(zip(np.asarray(ref[b][0]).tolist(), np.asarray(ref[b][1]).tolist())))
             n_lists += 1
+        if os.environ.get("FP_MS_RINV_HARD_EVERY") and fp.fast_plaid_rust is R and dim % 32 == 0 and not (dim == 96 and nbits == 2):
+            assert idx.n_hard_tokens > 0, (dim, nbits)   # the forced exact-path tokens were really marked
     print("REPAIR_OK mode", mode, "scores", n_scores, "lists", n_lists)
 
 

@@ -401,15 +401,16 @@ def test_level0_forced(fp, tail, pilot):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("mode", ["2", "1"])
-def test_maxsim_repair_vs_oracle(fp, mode):
+@pytest.mark.parametrize("mode,extra", [("2", {}), ("1", {}), ("2", {"FP_MS_RINV_HARD_EVERY": "5"}), ("2", {"FP_MS_RINV": "0"})])
+def test_maxsim_repair_vs_oracle(fp, mode, extra):
     """exact-order repair of the MFMA MaxSim pass (tests/repair_worker.py): with every flagged document repaired
-    (FP_MAXSIM_REPAIR=2) every returned score equals the oracle's bit for bit over nine dim/nbits/q_len shapes; with the default
-    near-tied repair (1) the id lists are the oracle's."""
+    (FP_MAXSIM_REPAIR=2) every returned score equals the oracle's bit for bit over thirteen dim/nbits/q_len shapes; with the
+    default near-tied repair (1) the id lists are the oracle's.  Also with every fifth token forced onto k_maxsim6's
+    compensated-quotient path (the path of tokens that have no one-multiply reciprocal) and with the reciprocals switched off."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FP_MAXSIM_REPAIR=mode)
+    env = dict(os.environ, FP_MAXSIM_REPAIR=mode, **extra)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "repair_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "REPAIR_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
