@@ -10,14 +10,14 @@ n_full_scores=4096 (R=1024 exact-scored docs / query), n_ivf_probe=8.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N         # N GPUs, one process each (RCCL)
 
-N>1, `--dist-mode` (fast-plaid_amd/sharded.py):
-"replica" (chosen by "auto" when the index fits one GPU) = the reference's multi-GPU layout -- a full index per GPU, one
-process per GPU -- with every rank searching its OWN batch of 64 per step through fp_search: queries are independent units,
-so there is no data-path collective; `value` = N x 64 queries per step / max-over-ranks time, "scaling": "weak".
-"split" = the same replicas with ONE batch of 64 split across the ranks and a result all-gather ("strong");
-"shard" = the corpus split into N contiguous token-balanced document shards, the SAME batch on every rank, three fixed-size
-all-gathers per batch issued by the library itself (fp_shard_search; "strong"; what "auto" picks for an index that does not
-fit one GPU).  With --alt-mode a second mode is timed too and reported as `alt_mode`.
+N>1 defaults to BASELINE.json configs[2] (`--config cfg3`): 10M docs x 128 tok, 2^19 centroids, batch 256, top_k 1000, the corpus
+split into N contiguous token-balanced DOCUMENT SHARDS, the SAME batch on every rank, three fixed-size RCCL all-gathers per batch
+issued by the library itself on its search stream (fp_shard_search) -- "scaling": "strong"; `python bench.py --gpus 1 --config cfg3`
+is the one-GPU anchor of that series (the newest committed measurement of it is echoed as `n1_anchor`).
+Other `--dist-mode`s (fast-plaid_amd/sharded.py), one flag away: "replica" = the reference's multi-GPU layout -- a full index per
+GPU, one process per GPU -- with every rank searching its OWN batch per step through fp_search and no data-path collective
+("weak"); "split" = the same replicas with ONE batch split across the ranks and a result all-gather ("strong").
+With --alt-mode a second mode is timed too and reported as `alt_mode`.
 
 One JSON line on rank 0.  `value` is timed on the boundary call fp_search (host query buffer in, host
 results out -- what the reference's pysearch hands over, rust/lib.rs:195-223); the same steps with queries and
@@ -49,10 +49,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3"], default="auto",
+                    help="BASELINE.json configs[1] (cfg2: 1M docs, batch 64; the single-GPU metric) or configs[2] (cfg3: 10M docs, batch 256, "
+                         "document-sharded over the ranks: the multi-GPU configuration); auto = cfg2 on one GPU, cfg3 on several.  "
+                         "`--gpus 1 --config cfg3` is the one-GPU anchor of the strong-scaling series")
+    ap.add_argument("--docs", type=int, default=0, help="0 = the config's (1M / 10M)")
     ap.add_argument("--doc-len", type=int, default=128)
     ap.add_argument("--centroids", type=int, default=0, help="0 = 2^floor(log2(16*sqrt(tokens)))")
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=0, help="0 = the config's (64 / 256)")
     ap.add_argument("--qlen", type=int, default=32)
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--nfull", type=int, default=4096)
@@ -75,7 +79,14 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = result gather through CPU tensors, ranks wrapped onto the visible GPUs (testing the multi-process "
                          "path on a box with fewer GPUs than ranks)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    a.cfg = a.config if a.config != "auto" else ("cfg3" if max(world, a.gpus) > 1 else "cfg2")
+    if a.docs == 0:
+        a.docs = 10_000_000 if a.cfg == "cfg3" else 1_000_000
+    if a.batch == 0:
+        a.batch = 256 if a.cfg == "cfg3" else 64
+    return a
 
 
 def _pmc_traffic(kernel_prefix, applicable):
@@ -107,7 +118,7 @@ def main():
     sys.stdout.flush()
     _real_stdout = os.dup(1)
     os.dup2(2, 1)
-    default_cfg = (a.docs == 1_000_000 and a.doc_len == 128 and a.centroids == 0 and a.batch == 64 and a.qlen == 32 and
+    default_cfg = (a.cfg == "cfg2" and a.docs == 1_000_000 and a.doc_len == 128 and a.centroids == 0 and a.batch == 64 and a.qlen == 32 and
                    a.topk == 1000 and a.nfull == 4096 and a.nprobe == 8 and a.dim == 128 and a.nbits == 4)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,7 +251,9 @@ def main():
         est_bytes = a.docs * a.doc_len * (a.dim * a.nbits // 8 + 4 + 2 + 4) + C * a.dim * 2
         hbm = torch.cuda.get_device_properties(local_rank).total_memory
         fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
-        primary = a.dist_mode if a.dist_mode != "auto" else ("replica" if fits else "shard")
+        # auto: BASELINE configs[2] is the SHARDED index (documents split over the ranks, RCCL all-gathers in the data path, strong
+        # scaling against `--gpus 1 --config cfg3`); replicas only for an explicitly requested single-GPU-sized workload
+        primary = a.dist_mode if a.dist_mode != "auto" else ("shard" if (a.cfg == "cfg3" or not fits) else "replica")
         other = "shard" if primary in ("replica", "split") else "split"
         run_other = a.alt_mode and (not a.no_alt_mode) and (other == "shard" or fits)
     else:
@@ -276,14 +289,25 @@ def main():
         "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {
-            "workload": a.workload or ("BASELINE cfg2: %d docs x %d tok x dim%d, nbits=%d, %d centroids, batch=%d x %d tok, "
+            "workload": a.workload or ("BASELINE %s: %d docs x %d tok x dim%d, nbits=%d, %d centroids, batch=%d x %d tok, "
                                        "top_k=%d, n_full_scores=%d, n_ivf_probe=%d" % (
-                                           a.docs, a.doc_len, a.dim, a.nbits, C, a.batch, a.qlen, a.topk, a.nfull, a.nprobe)),
+                                           a.cfg, a.docs, a.doc_len, a.dim, a.nbits, C, a.batch, a.qlen, a.topk, a.nfull, a.nprobe)),
             "parallelism": par, "global_batch": global_batch,
             "index_bytes_per_gpu": index_bytes, "index_build_s": round(t_build, 2),
         },
         "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
     }
+    if primary in ("shard", "split") or (a.cfg == "cfg3" and world == 1):
+        # the one-GPU anchor of the strong-scaling series: `python bench.py --gpus 1 --config cfg3` (the newest committed measurement of it)
+        import glob
+        anchors = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cfg3_1gpu.json")))
+        if anchors and world > 1:
+            try:
+                an = json.loads(open(anchors[-1]).read().strip().splitlines()[-1])
+                out["n1_anchor"] = {"value": an["value"], "ms_per_step": an["ms_per_step"], "source": "profiles/" + os.path.basename(anchors[-1]),
+                                    "command": "python bench.py --gpus 1 --config cfg3", "speedup_vs_n1": qps / an["value"] if an["value"] else None}
+            except Exception:
+                pass
     if alt is not None:
         out["alt_mode"] = alt
     if dev_elapsed:
@@ -363,6 +387,8 @@ def main():
         }
         # ---- CPU baseline: the plain-C oracle ("port"), all host cores, same corpus, bounded sample
         ncpu = a.cpu_queries if not use_dist else 0   # rank 0 at N=1 only
+        if ncpu < 0 and a.docs * a.doc_len > 400_000_000:
+            ncpu = 0   # the C oracle runs on a host copy of the corpus: not for the 10M-document anchor run (97 GB)
         if ncpu != 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import plaid_oracle as OC

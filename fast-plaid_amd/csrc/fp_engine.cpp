@@ -1626,11 +1626,22 @@ extern "C" int fp_shard_stage2(fp_shard_ctx* c, const void* dev_all_rec1, int32_
   return FP_OK;
 }
 
+// whether the third exchange of the sharded search happens, as a pure function of the environment and R (every rank must agree
+// without looking at what its own stages did): 0 no repair at all, 1 near-tied documents, 2 every flagged document (also when R
+// is beyond the LDS of the marking kernel)
+static int shard_marks_mode(int64_t R) {
+  static const int repair_env = [] { const char* e = getenv("FP_MAXSIM_REPAIR"); return e ? atoi(e) : 1; }();
+  if (repair_env == 0) return 0;
+  int np2 = 2;
+  while (np2 < R) np2 <<= 1;
+  return (repair_env != 2 && np2 <= 8192) ? 1 : 2;
+}
 // union + near-tie marking (identical on every rank) + repair of the marked documents this rank holds -> dev_x [B][R] f32
 static int shard_mark_and_repair(fp_index* ix, Scratch* s, const FpSearchShape& sh, const void* all_rec2, int G, int rank, bool empty_local,
                                  int64_t K, float* x, hipStream_t st) {
   const int B = sh.B;
   const int64_t R = sh.R;
+  s->sh_marks_mode = 0;   // (set again below; a failure before that point must not leave the previous call's value behind)
   HIPCHK(s->tmpp.ensure((size_t)B * R * 8));
   HIPCHK(s->tmpf.ensure((size_t)4 * B * R * 4));
   HIPCHK(s->u_cnt.ensure((size_t)B * 4));
@@ -1663,7 +1674,7 @@ static int shard_mark_and_repair(fp_index* ix, Scratch* s, const FpSearchShape& 
 }
 
 static int shard_apply_and_rank(Scratch* s, const FpSearchShape& sh, const float* xall, int64_t K, int64_t* out_pids, float* out_scores,
-                                int32_t* out_counts, hipStream_t st) {
+                                int32_t* out_counts, hipStream_t st, int64_t xstride = 0) {
   const int B = sh.B;
   const int64_t R = sh.R;
   float* u_score = s->tmpf.as<float>();
@@ -1671,7 +1682,7 @@ static int shard_apply_and_rank(Scratch* s, const FpSearchShape& sh, const float
   float* u_unc = u_score + (size_t)2 * B * R;
   if (s->sh_marks_mode != 0)
     fpk_shard_apply3(s->sh_marks_mode == 1 ? s->ms_marks.as<int32_t>() : nullptr, s->ms_nmark.as<int32_t>(), u_unc, s->u_cnt.as<int32_t>(), u_src, B,
-                     R, xall, u_score, st);
+                     R, xall, u_score, st, xstride);
   OutLayout ol(B, K);
   HIPCHK(s->out_all.ensure(ol.total));
   HIPCHK(s->h_out.ensure(ol.total));
@@ -1717,6 +1728,7 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, FpNcclUid, int) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string why;
 };
@@ -1736,6 +1748,7 @@ static RcclApi* rccl_api() {
     api.CommInitRank = reinterpret_cast<int (*)(void**, int, FpNcclUid, int)>(dlsym(api.h, "ncclCommInitRank"));
     api.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(api.h, "ncclAllGather"));
     api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.h, "ncclCommDestroy"));
+    api.CommAbort = reinterpret_cast<int (*)(void*)>(dlsym(api.h, "ncclCommAbort"));
     api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.h, "ncclGetErrorString"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) { api.why = "librccl lacks the expected symbols"; api.h = nullptr; }
   });
@@ -1785,97 +1798,162 @@ extern "C" void fp_comm_destroy(fp_comm* c) {
 extern "C" int fp_comm_n_ranks(const fp_comm* c) { return c ? c->n_ranks : 0; }
 extern "C" int fp_comm_rank(const fp_comm* c) { return c ? c->rank : -1; }
 
+// One batch (<= the S budget) of the document-sharded search.  COLLECTIVE SAFETY: between the first and the last all-gather
+// nothing returns.  Every buffer the protocol itself needs is allocated before the first collective; a stage that fails locally
+// (a kernel launch, an allocation inside the front half, ...) only records its error, empties this rank's contribution, and
+// raises bit 1 of the status word that travels in record 0 of the rank's block of the next exchange (bit 0: the learnt candidate
+// capacity overflowed).  Every rank reads the OR of all status words after its final sync: any failure -> every rank returns an
+// error for the batch; an overflow -> every rank runs the batch again, waiting for its candidate total this time.
+enum { SH_OVERFLOW = 1, SH_FAILED = 2 };
+static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* api, const uint16_t* queries, int B, int32_t Q,
+                              const fp_search_params* p, int64_t* out_pids, float* out_scores, int32_t* out_counts) {
+  const FpIndexDev& D = ix->d;
+  const int G = comm->n_ranks;
+  hipStream_t st = s->st;
+  const int64_t K = p->top_k;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    Pipe P{};
+    P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
+    P.allow_spec = attempt == 0;
+    const int64_t R = P.sh.R;
+    const int64_t xstride = (int64_t)B * R + 16;   // floats per rank in the third exchange: [B][R] scores + a status tail
+    // every rank must issue every collective whatever its shard holds (an empty shard contributes only padding records)
+    const bool empty_local = (p->n_ivf_probe > D.C) || D.N == 0;
+    // ---- everything the protocol needs, before the first collective (a failure here leaves no peer inside a collective of
+    // THIS call; the communicator is aborted so that peers already waiting for this rank get an error instead of a hang) ----
+    int status = 0;
+    std::string first_err;
+    auto note = [&](int rc) {   // a local failure: remember the first message, keep going with an empty contribution
+      if (rc != FP_OK && !(status & SH_FAILED)) { status |= SH_FAILED; first_err = g_err; }
+    };
+    {
+      hipError_t e = hipSuccess;
+      auto need = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+      need(s->qin.ensure((size_t)B * Q * D.dim * 2));
+      need(s->sh_rec.ensure((size_t)B * R * 24));
+      need(s->sh_all.ensure((size_t)G * B * R * 24));
+      need(s->sh_x.ensure((size_t)xstride * 4));
+      need(s->sh_xall.ensure((size_t)G * xstride * 4));
+      need(s->sel_cnt.ensure((size_t)B * 4));
+      need(s->sel_pid.ensure((size_t)B * R * 4));
+      need(s->sel_approx.ensure((size_t)B * R * 4));
+      need(s->exact.ensure((size_t)B * R * 4));
+      need(s->h_small.ensure(4096));
+      need(s->spec_total.ensure(16));
+      need(s->tmpp.ensure((size_t)B * R * 8));
+      need(s->tmpf.ensure((size_t)4 * B * R * 4));
+      need(s->u_cnt.ensure((size_t)B * 4));
+      need(s->ms_marks.ensure((size_t)B * R * 4));
+      need(s->ms_nmark.ensure((size_t)B * 4));
+      need(s->sh_lmarks.ensure((size_t)B * R * 4));
+      need(s->sh_lnmark.ensure((size_t)B * 4));
+      OutLayout ol(B, K);
+      need(s->out_all.ensure(ol.total));
+      need(s->h_out.ensure(ol.total));
+      if (e == hipSuccess) e = hipMemcpyAsync(s->qin.p, queries, (size_t)B * Q * D.dim * 2, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) {
+        if (api->CommAbort && comm->comm) { (void)api->CommAbort(comm->comm); comm->comm = nullptr; }
+        return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (sharded search buffers; the communicator was aborted)");
+      }
+    }
+    int32_t* d_flags = s->spec_total.as<int32_t>() + 2;   // (behind the 8 bytes of the candidate total)
+    (void)hipMemsetAsync(d_flags, 0, 4, st);
+    static const int fail_at = [] { const char* e = getenv("FP_SHARD_FAIL_AT"); return e ? atoi(e) : 0; }();   // testing: a local failure in stage n
+    // ---- front half (S1..S5 on the shard) ----
+    bool have_front = false;
+    if (fail_at == 1) note(fail(FP_EHIP, "injected failure in the front half (FP_SHARD_FAIL_AT=1)"));
+    else if (!empty_local) {
+      s->fold_stats = false;
+      const int rc = run_front(P, nullptr, nullptr, false);
+      note(rc);
+      have_front = rc == FP_OK;
+    }
+    if (!have_front) (void)hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, st);   // nothing to offer: padding records only
+    // exchange 1: local top-R by approximate score
+    fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st,
+                    (have_front && P.spec) ? s->spec_total.as<int64_t>() : nullptr, (have_front && P.spec) ? P.M : 0, status);
+    if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+    fpk_shard_status(s->sh_all.p, G, (int64_t)B * R * 16, 12, d_flags, st);
+    // global cut on the union (sort in LDS, or select + ordered compaction when n_ranks * R is beyond it)
+    if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st)) {
+      note(fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) does not fit a 32-bit union index"));
+      (void)hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, st);
+    }
+    // exchange 2: MFMA scores + uncertainties of the local survivors
+    bool have_scores = false;
+    if (fail_at == 2) note(fail(FP_EHIP, "injected failure before the MaxSim pass (FP_SHARD_FAIL_AT=2)"));
+    if (have_front && !(status & SH_FAILED)) {
+      const int rc = run_maxsim(ix, s, P.sh, R, K, 0);
+      note(rc);
+      have_scores = rc == FP_OK;
+    }
+    if (!have_scores) (void)hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, st);
+    fpk_shard_pack2(s->exact.as<float>(), (have_scores && s->ms_repairable) ? s->ms_unc.as<float>() : nullptr,
+                    (have_scores && s->ms_repairable) ? s->ms_uncm.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
+                    D.pid_offset, s->sh_rec.p, st, status);
+    if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+    fpk_shard_status(s->sh_all.p, G, (int64_t)B * R * 24, 20, d_flags, st);
+    // exchange 3: the union and its near-tie marking are identical on every rank; each rank repairs the marked documents it holds
+    // and ships their scores ([B][R] floats by union position)
+    (void)hipMemsetAsync(s->sh_x.p, 0, (size_t)xstride * 4, st);
+    if (fail_at == 3) note(fail(FP_EHIP, "injected failure before the marking (FP_SHARD_FAIL_AT=3)"));
+    note(shard_mark_and_repair(ix, s, P.sh, s->sh_all.p, G, comm->rank, !have_scores, K, s->sh_x.as<float>(), st));
+    if (shard_marks_mode(R) != 0) {   // (the same on every rank whatever happened locally: a function of the environment and R)
+      (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->sh_x.as<int32_t>() + (int64_t)B * R), status, 1, st);
+      if (int rc = api->AllGather(s->sh_x.p, s->sh_xall.p, (size_t)xstride * 4, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+      fpk_shard_status(s->sh_xall.p, G, xstride * 4, (int64_t)B * R * 4, d_flags, st);
+    }
+    // ---- past the last collective: the merge, the download, and the verdict of all ranks ----
+    (void)hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, d_flags, 4, hipMemcpyDeviceToHost, st);
+    const int mrc = (status & SH_FAILED) ? FP_OK : shard_apply_and_rank(s, P.sh, s->sh_xall.as<float>(), K, out_pids, out_scores, out_counts, st, xstride);
+    HIPCHK(hipStreamSynchronize(st));
+    if (hipError_t le = hipGetLastError(); le != hipSuccess) note(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(le) + " (sharded search)"));
+    const int flags = *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 40);
+    if (status & SH_FAILED) return fail(FP_EHIP, "fp_shard_search failed on this rank (every rank reports the batch as failed): " + first_err);
+    if (flags & SH_FAILED) {
+      for (int i = 0; i < B; ++i) out_counts[i] = 0;
+      return fail(FP_EHIP, "fp_shard_search: another rank failed during this batch (its error is reported there); no rank returns results");
+    }
+    if (mrc) return mrc;
+    if (attempt == 0 && (flags & SH_OVERFLOW)) {
+      s->spec_cap = 0;   // (the rank that overflowed; harmless on the others: the second attempt waits everywhere)
+      continue;
+    }
+    if (have_front) learn_capacity(s, *reinterpret_cast<const int64_t*>(s->h_small.p));
+    return FP_OK;
+  }
+  return fail(FP_EHIP, "fp_shard_search: the candidate capacity overflowed twice");
+}
+
 extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_t* queries, int32_t nq, int32_t Q, int32_t dim,
                                const fp_search_params* p, int64_t* out_pids, float* out_scores, int32_t* out_counts) {
-  if (!comm || !comm->comm) return fail(FP_EINVAL, "null communicator");
+  if (!comm || !comm->comm) return fail(FP_EINVAL, "null (or aborted) communicator");
   if (int rc = validate_search(cix, nq, Q, dim, p)) return rc;
   if (nq < 1 || !queries || !out_counts || (p->top_k > 0 && (!out_pids || !out_scores))) return fail(FP_EINVAL, "bad argument");
   RcclApi* api = rccl_api();
   if (!api) return fail(FP_EUNSUPPORTED, "RCCL unavailable");
   fp_index* ix = const_cast<fp_index*>(cix);
   if (ix->device != comm->device) return fail(FP_EINVAL, "index and communicator live on different devices");
-  const FpIndexDev& D = ix->d;
-  const int G = comm->n_ranks;
   HIPCHK(hipSetDevice(ix->device));
   for (int i = 0; i < nq; ++i) out_counts[i] = 0;
   if (p->top_k == 0) return FP_OK;
   Scratch* s = acquire(ix);
   if (!s) return fail(FP_EHIP, "could not create a HIP stream");
   struct Rel { fp_index* ix; Scratch* s; ~Rel() { (void)hipStreamSynchronize(s->st); release(ix, s); } } rel{ix, s};
-  hipStream_t st = s->st;
-  const int B = nq;
-  // Like fp_search, the front half runs on the candidate capacity learnt from earlier batches instead of waiting for this
-  // batch's total.  A rank whose batch outgrows its capacity has emptied its lists; it says so in record 0 of the first
-  // exchange, every rank sees the mark after its final sync, and every rank runs the batch again -- this time waiting.
-  for (int attempt = 0; attempt < 2; ++attempt) {
-  Pipe P{};
-  P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
-  P.allow_spec = attempt == 0;
-  const int64_t R = P.sh.R;
+  // Sub-batches against a FIXED budget of the centroid-score table (every rank must split the batch identically, so the budget
+  // may not depend on a rank's free memory as fp_search's does): 16 GiB, FP_SHARD_S_BUDGET_KB for tests
+  static const int64_t budget = [] { const char* e = getenv("FP_SHARD_S_BUDGET_KB"); return e ? atoll(e) * 1024 : (16ll << 30); }();
+  const int Qp = (Q + 31) & ~31;
+  const int64_t per_query = (int64_t)ix->d.C * Qp * 2;
+  const int maxB = (int)std::max<int64_t>(1, std::min<int64_t>(nq, budget / std::max<int64_t>(per_query, 1)));
   const int64_t K = p->top_k;
-  // every rank must issue every collective whatever its shard holds (an empty shard contributes only padding records)
-  const bool empty_local = (p->n_ivf_probe > D.C) || D.N == 0;
-  HIPCHK(s->qin.ensure((size_t)B * Q * D.dim * 2));
-  HIPCHK(hipMemcpyAsync(s->qin.p, queries, (size_t)B * Q * D.dim * 2, hipMemcpyHostToDevice, st));
-  HIPCHK(s->sh_rec.ensure((size_t)B * R * 24));
-  HIPCHK(s->sh_all.ensure((size_t)G * B * R * 24));
-  if (empty_local) {
-    HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
-    HIPCHK(s->sel_pid.ensure((size_t)B * R * 4));
-    HIPCHK(s->sel_approx.ensure((size_t)B * R * 4));
-    HIPCHK(s->exact.ensure((size_t)B * R * 4));
-    HIPCHK(hipMemsetAsync(s->sel_cnt.p, 0, (size_t)B * 4, st));
-  } else {
-    s->fold_stats = false;
-    if (int rc = run_front(P, nullptr, nullptr, false)) return rc;
-  }
-  // exchange 1: local top-R by approximate score
-  fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st,
-                  P.spec ? s->spec_total.as<int64_t>() : nullptr, P.spec ? P.M : 0);
-  LAUNCHCHK("fp_shard_search (front half)");
-  if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
-  LAUNCHCHK("fp_shard_search (first all-gather)");
-  HIPCHK(s->h_small.ensure(4096));
-  HIPCHK(s->spec_total.ensure(16));
-  int32_t* d_over = s->spec_total.as<int32_t>() + 2;   // (behind the 8 bytes of the candidate total)
-  fpk_shard_any_overflow(s->sh_all.p, G, B, R, d_over, st);
-  HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, d_over, 4, hipMemcpyDeviceToHost, st));
-  if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st))
-    return fail(FP_EUNSUPPORTED, "n_ranks * max(n_full_scores/4, 1) is too large for the LDS cut of the sharded search (limit 16384 entries)");
-  // exchange 2: MFMA scores + uncertainties of the local survivors
-  if (!empty_local) {
-    if (int rc = run_maxsim(ix, s, P.sh, R, K, 0)) return rc;
-    fpk_shard_pack2(s->exact.as<float>(), s->ms_repairable ? s->ms_unc.as<float>() : nullptr, s->ms_repairable ? s->ms_uncm.as<float>() : nullptr,
-                    s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
-                    D.pid_offset, s->sh_rec.p, st);
-  } else {
-    fpk_shard_pack2(s->exact.as<float>(), nullptr, nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st);
-  }
-  LAUNCHCHK("fp_shard_search (cut + MaxSim)");
-  if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
-  LAUNCHCHK("fp_shard_search (second all-gather)");
-  // exchange 3: the union and its near-tie marking are identical on every rank; each rank repairs the marked documents it holds
-  // and ships their scores ([B][R] floats by union position)
-  HIPCHK(s->sh_x.ensure((size_t)B * R * 4));
-  HIPCHK(s->sh_xall.ensure((size_t)G * B * R * 4));
-  if (int rc = shard_mark_and_repair(ix, s, P.sh, s->sh_all.p, G, comm->rank, empty_local, K, s->sh_x.as<float>(), st)) return rc;
-  LAUNCHCHK("fp_shard_search (marking + repair)");
-  if (s->sh_marks_mode != 0) {
-    if (int rc = api->AllGather(s->sh_x.p, s->sh_xall.p, (size_t)B * R * 4, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
-    LAUNCHCHK("fp_shard_search (third all-gather)");
-  }
-  if (int rc = shard_apply_and_rank(s, P.sh, s->sh_xall.as<float>(), K, out_pids, out_scores, out_counts, st)) return rc;
-  HIPCHK(hipStreamSynchronize(st));
-  if (attempt == 0 && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 40) != 0) {
-    s->spec_cap = 0;   // (the rank that overflowed; harmless on the others: the second attempt waits everywhere)
-    continue;
-  }
-  if (!empty_local) {
-    learn_capacity(s, *reinterpret_cast<const int64_t*>(s->h_small.p));
+  for (int b0 = 0; b0 < nq; b0 += maxB) {
+    const int B = std::min(maxB, nq - b0);
+    if (int rc = shard_search_batch(ix, s, comm, api, queries + (size_t)b0 * Q * dim, B, Q, p, out_pids ? out_pids + (size_t)b0 * K : nullptr,
+                                    out_scores ? out_scores + (size_t)b0 * K : nullptr, out_counts + b0))
+      return rc;
   }
   return FP_OK;
-  }
-  return fail(FP_EHIP, "fp_shard_search: the candidate capacity overflowed twice");
 }
 
 

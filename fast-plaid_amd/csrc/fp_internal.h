@@ -222,10 +222,12 @@ void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local
                     int64_t* stat_out /*[1 + B]: statistics copied next to the results*/ = nullptr);
 // sharded helpers (record layouts: include/fastplaid.h)
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
-                     hipStream_t st, const int64_t* cand_total = nullptr, int64_t cand_cap = 0);
+                     hipStream_t st, const int64_t* cand_total = nullptr, int64_t cand_cap = 0, int status = 0);
 void fpk_shard_any_overflow(const void* all_rec1, int G, int B, int64_t R, int32_t* flag, hipStream_t st);
+// *flag |= OR over the ranks' blocks (stride_bytes apart) of the 32-bit status word at byte word_off (bit 0 overflow, bit 1 failure)
+void fpk_shard_status(const void* all, int G, int64_t stride_bytes, int64_t word_off, int32_t* flag, hipStream_t st);
 void fpk_shard_pack2(const float* score, const float* unc /*nullable*/, const float* uncm /*nullable*/, const int32_t* sel_pid,
-                     const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec2, hipStream_t st);
+                     const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec2, hipStream_t st, int status = 0);
 int fpk_shard_global_cut(const void* all_rec1 /*[G][B][R]*/, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
                          int32_t* sel_pid /*[B][R] local*/, int32_t* sel_cnt, hipStream_t st);
 // union of the ranks' survivors in ascending id order; u_src = rank * R + slot in that rank's rerank list
@@ -237,7 +239,7 @@ void fpk_shard_local_marks(const int32_t* marks, const int32_t* nmark, const flo
 void fpk_shard_pack3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
                      int rank, const float* exact_local, float* x /*[B][R]*/, hipStream_t st);
 void fpk_shard_apply3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
-                      const float* xall /*[G][B][R]*/, float* u_score, hipStream_t st);
+                      const float* xall /*[G][xstride]; xstride 0 = B * R*/, float* u_score, hipStream_t st, int64_t xstride = 0);
 // misc
 void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
 // create.rs:148-184, :404-428 on device pointers: nearest centroid (MFMA narrowing + exact re-check of the near-ties, or the exact

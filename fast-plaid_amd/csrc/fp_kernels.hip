@@ -3108,55 +3108,182 @@ static_assert(sizeof(ShardRec1) == 16 && sizeof(ShardRec2) == 24, "record layout
 
 __global__ void k_shard_pack1(const float* __restrict__ approx, const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt, int64_t R,
                               int64_t pid_offset, ShardRec1* __restrict__ out, int64_t total,
-                              const int64_t* __restrict__ cand_total /*nullable*/, int64_t cand_cap) {
+                              const int64_t* __restrict__ cand_total /*nullable*/, int64_t cand_cap, int status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / R), r = (int)(i % R);
   ShardRec1 o;
   // record 0 tells the other ranks whether this rank's batch outgrew its learnt candidate capacity (its lists are then empty and
   // every rank runs the batch again: fp_shard_search)
-  o.pad = (i == 0 && cand_total && cand_cap > 0 && *cand_total > cand_cap) ? 1 : 0;
+  // ... and (bit 1, `status`) whether it failed before this exchange: a failing rank keeps issuing every collective with empty
+  // records instead of leaving its peers blocked in the next one, and every rank returns the error after its final sync
+  o.pad = (i == 0) ? (((cand_total && cand_cap > 0 && *cand_total > cand_cap) ? 1 : 0) | status) : 0;
   if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.approx = approx[i]; }
   else { o.pid = -1; o.approx = -__builtin_inff(); }
   out[i] = o;
 }
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
-                     hipStream_t st, const int64_t* cand_total, int64_t cand_cap) {
+                     hipStream_t st, const int64_t* cand_total, int64_t cand_cap, int status) {
   const int64_t total = (int64_t)B * R;
   hipLaunchKernelGGL(k_shard_pack1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sel_approx, sel_pid, sel_cnt, R, pid_offset,
-                     static_cast<ShardRec1*>(rec1), total, cand_total, cand_cap);
+                     static_cast<ShardRec1*>(rec1), total, cand_total, cand_cap, status);
 }
 
-// OR of the ranks' overflow marks (record 0 of each rank's block of the gathered first exchange)
-__global__ void k_shard_any_overflow(const ShardRec1* __restrict__ all, int G, int64_t per_rank, int32_t* __restrict__ flag) {
+// flag |= OR over the ranks of the 32-bit status word at byte `word_off` of each rank's block of a gathered buffer (block stride
+// `stride` bytes): bit 0 = that rank's candidate capacity overflowed, bit 1 = it failed
+__global__ void k_shard_status(const unsigned char* __restrict__ all, int G, int64_t stride, int64_t word_off, int32_t* __restrict__ flag) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int f = 0;
-    for (int g = 0; g < G; ++g) f |= all[(int64_t)g * per_rank].pad;
+    int f = *flag;
+    for (int g = 0; g < G; ++g) f |= *reinterpret_cast<const int32_t*>(all + (int64_t)g * stride + word_off);
     *flag = f;
   }
 }
+void fpk_shard_status(const void* all, int G, int64_t stride_bytes, int64_t word_off, int32_t* flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_shard_status, dim3(1), dim3(64), 0, st, static_cast<const unsigned char*>(all), G, stride_bytes, word_off, flag);
+}
 void fpk_shard_any_overflow(const void* all_rec1, int G, int B, int64_t R, int32_t* flag, hipStream_t st) {
-  hipLaunchKernelGGL(k_shard_any_overflow, dim3(1), dim3(64), 0, st, static_cast<const ShardRec1*>(all_rec1), G, (int64_t)B * R, flag);
+  (void)hipMemsetAsync(flag, 0, 4, st);
+  fpk_shard_status(all_rec1, G, (int64_t)B * R * 16, 12, flag, st);
 }
 
 // pid / MFMA score / uncertainty (total and downward part) of the local survivors
 __global__ void k_shard_pack2(const float* __restrict__ score, const float* __restrict__ unc, const float* __restrict__ uncm,
                               const int32_t* __restrict__ pid, const int32_t* __restrict__ cnt, int64_t R, int64_t pid_offset,
-                              ShardRec2* __restrict__ out, int64_t total) {
+                              ShardRec2* __restrict__ out, int64_t total, int status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / R), r = (int)(i % R);
   ShardRec2 o;
-  o.pad = 0;
+  o.pad = i == 0 ? status : 0;
   if (r < cnt[b]) { o.pid = (long long)pid[i] + pid_offset; o.score = score[i]; o.uncm = uncm ? uncm[i] : 0.f; o.unc = unc ? unc[i] : 0.f; }
   else { o.pid = -1; o.score = -__builtin_inff(); o.uncm = 0.f; o.unc = 0.f; }
   out[i] = o;
 }
 void fpk_shard_pack2(const float* score, const float* unc, const float* uncm, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R,
-                     int64_t pid_offset, void* rec2, hipStream_t st) {
+                     int64_t pid_offset, void* rec2, hipStream_t st, int status) {
   const int64_t total = (int64_t)B * R;
   hipLaunchKernelGGL(k_shard_pack2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, score, unc, uncm, sel_pid, sel_cnt, R, pid_offset,
-                     static_cast<ShardRec2*>(rec2), total);
+                     static_cast<ShardRec2*>(rec2), total, status);
+}
+
+// ---- the same two steps for unions that do not fit the LDS sorts (n_ranks * R > 16384): no sort at all.  The ranks' lists are
+// in ascending id order and the shards are contiguous id ranges in rank order, so (rank, slot) order IS id order: the cut is a
+// radix select of the R-th largest approximate score (ties at the threshold taken in id order, like the sort's secondary key)
+// followed by an ordered compaction, the union an ordered compaction.
+__device__ __forceinline__ int shard_block_exscan(int v, int* lds /*[1025]*/) {   // exclusive prefix over the 1024 threads; lds[1024] = total
+  const int t = threadIdx.x;
+  lds[t] = v;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int add = t >= off ? lds[t - off] : 0;
+    __syncthreads();
+    lds[t] += add;
+    __syncthreads();
+  }
+  const int incl = lds[t];
+  if (t == 1023) lds[1024] = incl;
+  __syncthreads();
+  return incl - v;
+}
+__global__ __launch_bounds__(1024) void k_shard_cut_big(const ShardRec1* __restrict__ all, int G, int B, int64_t R, int64_t pid_lo, int64_t pid_hi,
+                                                        int32_t* __restrict__ sel_pid, int32_t* __restrict__ sel_cnt) {
+  __shared__ int hist[256];
+  __shared__ int scan[1025];
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_want;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int64_t n = (int64_t)G * R;
+  auto rec = [&](int64_t i) -> ShardRec1 { return all[((i / R) * B + b) * R + (i % R)]; };
+  auto key_of = [&](const ShardRec1& e) -> uint32_t { return e.pid >= 0 ? mono32(e.approx) : 0u; };   // 0 = padding (every valid key is > 0)
+  // T = the R-th largest key (0 when fewer than R valid entries): 4 rounds of 8 bits from the top
+  if (t == 0) { s_prefix = 0u; s_want = (int)R; }
+  __syncthreads();
+  for (int round = 0; round < 4; ++round) {
+    const int shift = 24 - 8 * round;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    const uint32_t himask = round == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int64_t i = t; i < n; i += 1024) {
+      const uint32_t k = key_of(rec(i));
+      if (k != 0u && (k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 0xFFu], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+      int want = s_want, d = 255;
+      for (; d > 0; --d) {
+        if (hist[d] >= want) break;
+        want -= hist[d];
+      }
+      // d == 0 also covers "fewer than `want` entries left": everything under the prefix is taken
+      s_prefix = prefix | ((uint32_t)d << shift);
+      s_want = want;
+    }
+    __syncthreads();
+  }
+  const uint32_t T = s_prefix;
+  // ties at T are taken in (rank, slot) order until R entries are selected
+  int64_t per = (n + 1023) / 1024;
+  const int64_t i0 = (int64_t)t * per, i1 = i0 + per < n ? i0 + per : n;
+  int gt = 0, eq = 0;
+  for (int64_t i = i0; i < i1; ++i) {
+    const uint32_t k = key_of(rec(i));
+    gt += (k != 0u && k > T) ? 1 : 0;
+    eq += (k != 0u && k == T) ? 1 : 0;
+  }
+  const int eq_before = shard_block_exscan(eq, scan);
+  const int gt_before = shard_block_exscan(gt, scan);
+  const int gt_total = scan[1024];
+  __syncthreads();
+  const int need = (int)R - gt_total;   // ties to take (>= 1 when R or more valid entries exist; all of them otherwise)
+  (void)gt_before;
+  int mine = 0, seen_eq = eq_before;
+  for (int64_t i = i0; i < i1; ++i) {
+    const ShardRec1 e = rec(i);
+    const uint32_t k = key_of(e);
+    bool take = k != 0u && k > T;
+    if (k != 0u && k == T) { take = seen_eq < need; ++seen_eq; }
+    if (take && e.pid >= pid_lo && e.pid < pid_hi) ++mine;
+  }
+  const int out0 = shard_block_exscan(mine, scan);
+  const int total = scan[1024];
+  int o = out0;
+  seen_eq = eq_before;
+  for (int64_t i = i0; i < i1; ++i) {
+    const ShardRec1 e = rec(i);
+    const uint32_t k = key_of(e);
+    bool take = k != 0u && k > T;
+    if (k != 0u && k == T) { take = seen_eq < need; ++seen_eq; }
+    if (take && e.pid >= pid_lo && e.pid < pid_hi) sel_pid[(int64_t)b * R + o++] = (int32_t)(e.pid - pid_lo);
+  }
+  if (t == 0) sel_cnt[b] = total;
+}
+__global__ __launch_bounds__(1024) void k_shard_union_big(const ShardRec2* __restrict__ all, int G, int B, int64_t R, int64_t* __restrict__ u_pid,
+                                                          float* __restrict__ u_score, int32_t* __restrict__ u_src, float* __restrict__ u_unc,
+                                                          float* __restrict__ u_uncm, int32_t* __restrict__ u_cnt) {
+  __shared__ int scan[1025];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int64_t n = (int64_t)G * R;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t i0 = (int64_t)t * per, i1 = i0 + per < n ? i0 + per : n;
+  int mine = 0;
+  for (int64_t i = i0; i < i1; ++i) mine += all[((i / R) * B + b) * R + (i % R)].pid >= 0 ? 1 : 0;
+  int o = shard_block_exscan(mine, scan);
+  const int total = scan[1024];
+  for (int64_t i = i0; i < i1; ++i) {
+    const ShardRec2 e = all[((i / R) * B + b) * R + (i % R)];
+    if (e.pid < 0) continue;
+    if (o < R) {
+      const int64_t d = (int64_t)b * R + o;
+      u_pid[d] = e.pid;
+      u_score[d] = e.score;
+      u_src[d] = (int32_t)i;
+      u_unc[d] = e.unc;
+      u_uncm[d] = e.uncm;
+    }
+    ++o;
+  }
+  if (t == 0) u_cnt[b] = total < (int)R ? total : (int)R;
 }
 
 // global cut: sort the union of the G ranks' local top-R by (approx desc, id asc), keep the first R valid, and
@@ -3233,7 +3360,13 @@ int fpk_shard_global_cut(const void* all_rec1, int G, int B, int64_t R, int64_t 
   const int np2 = next_pow2(n < 2 ? 2 : n);
   const int rp2 = next_pow2((int)(R < 2 ? 2 : R));
   const size_t lds = (size_t)np2 * 8 + (size_t)rp2 * 4 + 16;
-  if (lds > 160 * 1024) return -1;
+  static const bool force_big = getenv("FP_SHARD_BIG") && atoi(getenv("FP_SHARD_BIG")) != 0;   // testing: the sort-free paths for every size
+  if (lds > 160 * 1024 || force_big) {
+    if ((int64_t)G * R >= 0x7FFFFFFFll) return -1;
+    hipLaunchKernelGGL(k_shard_cut_big, dim3((unsigned)B), dim3(1024), 0, st, static_cast<const ShardRec1*>(all_rec1), G, B, R, pid_lo, pid_hi, sel_pid,
+                       sel_cnt);
+    return 0;
+  }
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_shard_cut, lds_ok, 160 * 1024);
   hipLaunchKernelGGL(k_shard_cut, dim3((unsigned)B), dim3(1024), lds, st, static_cast<const ShardRec1*>(all_rec1), G, B, np2, R, pid_lo, pid_hi,
@@ -3294,7 +3427,13 @@ int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pi
                     int32_t* u_cnt, hipStream_t st) {
   const int n = (int)(G * R);
   const int np2 = next_pow2(n < 2 ? 2 : n);
-  if ((size_t)np2 * 8 > 160 * 1024) return -1;
+  static const bool force_big = getenv("FP_SHARD_BIG") && atoi(getenv("FP_SHARD_BIG")) != 0;
+  if ((size_t)np2 * 8 > 160 * 1024 || force_big) {
+    if ((int64_t)G * R >= 0x7FFFFFFFll) return -1;
+    hipLaunchKernelGGL(k_shard_union_big, dim3((unsigned)B), dim3(1024), 0, st, static_cast<const ShardRec2*>(all_rec2), G, B, R, u_pid, u_score, u_src,
+                       u_unc, u_uncm, u_cnt);
+    return 0;
+  }
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_shard_union, lds_ok, 160 * 1024);
   hipLaunchKernelGGL(k_shard_union, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8, st, static_cast<const ShardRec2*>(all_rec2), G, B, np2, R, u_pid,
@@ -3340,15 +3479,15 @@ __global__ __launch_bounds__(256) void k_shard_pack3(const int32_t* __restrict__
 // marked documents take the repaired score from the rank that holds them
 __global__ __launch_bounds__(256) void k_shard_apply3(const int32_t* __restrict__ marks, const int32_t* __restrict__ nmark,
                                                       const float* __restrict__ u_unc, const int32_t* __restrict__ u_cnt,
-                                                      const int32_t* __restrict__ u_src, int64_t R, int B,
-                                                      const float* __restrict__ xall /*[G][B][R]*/, float* __restrict__ u_score) {
+                                                      const int32_t* __restrict__ u_src, int64_t R, int64_t xstride /*floats per rank*/,
+                                                      const float* __restrict__ xall /*[G][xstride]*/, float* __restrict__ u_score) {
   const int b = blockIdx.x;
   const int n = marks ? nmark[b] : u_cnt[b];
   for (int m = threadIdx.x; m < n; m += 256) {
     const int p = marks ? marks[(int64_t)b * R + m] : m;
     if (!marks && !(u_unc[(int64_t)b * R + p] > 0.f)) continue;
     const int g = u_src[(int64_t)b * R + p] / (int)R;
-    u_score[(int64_t)b * R + p] = xall[((int64_t)g * B + b) * R + p];
+    u_score[(int64_t)b * R + p] = xall[(int64_t)g * xstride + (int64_t)b * R + p];
   }
 }
 void fpk_shard_local_marks(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B,
@@ -3360,8 +3499,9 @@ void fpk_shard_pack3(const int32_t* marks, const int32_t* nmark, const float* u_
   hipLaunchKernelGGL(k_shard_pack3, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, u_unc, u_cnt, u_src, R, rank, exact_local, x);
 }
 void fpk_shard_apply3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
-                      const float* xall, float* u_score, hipStream_t st) {
-  hipLaunchKernelGGL(k_shard_apply3, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, u_unc, u_cnt, u_src, R, B, xall, u_score);
+                      const float* xall, float* u_score, hipStream_t st, int64_t xstride) {
+  hipLaunchKernelGGL(k_shard_apply3, dim3((unsigned)B), dim3(256), 0, st, marks, nmark, u_unc, u_cnt, u_src, R, xstride > 0 ? xstride : (int64_t)B * R,
+                     xall, u_score);
 }
 
 // ============================================================================================

@@ -26,6 +26,23 @@ def main():
     host = fp.synth.host_index_arrays(spec)
     index = R.construct_synthetic_index(spec, "cuda:0", centroids=host["centroids"])
     comm = sharded.NativeComm.from_torch_dist(index.device_id, dist)
+    if os.environ.get("FP_SHARD_FAIL_AT"):
+        # a stage that fails locally must neither hang nor return results: every collective is still issued, the failure travels in
+        # the status word of the next exchange, and the call raises after its final sync; the communicator stays usable
+        params = R.SearchParameters(2000, 512, 50, 4)
+        q = fp.synth.make_queries(spec, host["centroids"], 5, 32, seed=300)
+        for rep in range(2):
+            try:
+                sharded.native_sharded_search(index, comm, q, params)
+            except ValueError as e:
+                assert "failed on this rank" in str(e) and "injected failure" in str(e), str(e)
+            else:
+                raise AssertionError("the injected failure did not surface")
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        print("NATIVE_SHARD_OK")
+        return
     for n_probe, n_full, top_k in ((4, 512, 50), (16, 1024, 100)):
         params = R.SearchParameters(2000, n_full, top_k, n_probe)
         for rep in range(4):

@@ -897,23 +897,28 @@ def test_device_memory_is_returned(fp):
     assert before - after < (64 << 20), f"device memory shrank by {(before - after) >> 20} MiB over 10 create/search/close cycles"
 
 
-def test_sharded_equals_unsharded(fp):
+@pytest.mark.parametrize("big", ["0", "1"])
+def test_sharded_equals_unsharded(fp, big):
     """3 document shards on one GPU, the two exchanges done by concatenation: result must be
     IDENTICAL (ids and scores) to the unsharded search.  Runs in a subprocess that imports
     torch BEFORE the HIP library: torch wheels bundle their own libamdhip64.so.7, and the first
-    HIP runtime loaded into a process is the one every later library binds to."""
+    HIP runtime loaded into a process is the one every later library binds to.  big = 1: the sort-free global cut and
+    union that take over when n_ranks * R does not fit the LDS sorts (select + ordered compaction), forced for every size."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_gpu_worker.py")], capture_output=True, text=True,
-                       timeout=600)
+                       timeout=600, env=dict(os.environ, FP_SHARD_BIG=big))
     assert r.returncode == 0 and "SHARDED_GPU_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("cap_pct", ["", "50"])
-def test_native_rccl_shard_search_one_rank(fp, cap_pct):
+@pytest.mark.parametrize("cap_pct,extra", [("", {}), ("50", {}), ("", {"FP_SHARD_BIG": "1"}), ("50", {"FP_SHARD_S_BUDGET_KB": "128"}),
+                                           ("", {"FP_SHARD_FAIL_AT": "1"}), ("", {"FP_SHARD_FAIL_AT": "2"}), ("", {"FP_SHARD_FAIL_AT": "3"})])
+def test_native_rccl_shard_search_one_rank(fp, cap_pct, extra):
     """fp_shard_search with one rank over RCCL (a single-GPU box allows no more) reproduces fp_search exactly, also when the
-    learnt candidate capacity is forced too small and the batch is run again after the overflow mark of the first exchange."""
+    learnt candidate capacity is forced too small and the batch is run again after the overflow mark of the first exchange;
+    with the sort-free cut / union of large unions forced (FP_SHARD_BIG); split into sub-batches by a tiny budget of the
+    centroid-score table; and with a failure injected into each stage (the call raises, no collective is skipped)."""
     import socket
     import subprocess
     import sys
@@ -925,6 +930,7 @@ def test_native_rccl_shard_search_one_rank(fp, cap_pct):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if cap_pct:
         env["FP_SPEC_CAP_PCT"] = cap_pct
+    env.update(extra)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "native_shard_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NATIVE_SHARD_OK" in r.stdout, r.stdout + r.stderr
 
