@@ -369,13 +369,21 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   // packed code lines for S4's level 0: one set per range of 2^17 centroids (codes relative to the range), up to 2^20
   D.n_ranges = 0;
   D.n_lines = 0;
-  if (D.C <= 8 * (1ll << 17)) {
+  D.l0_ppl = 8;
+  // the static part of run_front's level-0 predicate (table of >= 32768 centroids, documents of <= 64 distinct codes on average;
+  // FP_APPROX_IMPL=l0 forces level 0 in tests): an index that can never take level 0 does not carry the packed lines
+  static const bool l0_forced = [] { const char* e2 = getenv("FP_APPROX_IMPL"); return e2 && e2[0] == 'l'; }();
+  if (D.C <= 8 * (1ll << 17) && (l0_forced || (D.C * 64 >= (2ll << 20) && D.U <= 64 * D.N))) {
     const int nr = (int)((D.C + (1ll << 17) - 1) >> 17);
+    // lines of 4 pieces (24 codes) when a document has few codes per range: half the lanes, half the bytes per candidate and range
+    static const int ppl_env = [] { const char* e2 = getenv("FP_L0_PPL"); return e2 ? atoi(e2) : 0; }();
+    if (ppl_env == 4 || ppl_env == 8) D.l0_ppl = ppl_env;
+    else if (nr > 1 && D.N > 0 && (double)D.U / ((double)D.N * nr) <= 14.0) D.l0_ppl = 4;
     for (int r = 0; r < nr; ++r) {
       void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
       const int64_t lo = (int64_t)r << 17, hi = std::min<int64_t>(D.C, lo + (1ll << 17));
-      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st);
-      if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 128; D.n_lines += nl; }
+      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st, D.l0_ppl);
+      if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 16 * D.l0_ppl; D.n_lines += nl; }
       if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
       if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
       D.pcodes_r[r] = static_cast<const uint4*>(lines); D.poff_r[r] = poff;
@@ -475,7 +483,7 @@ extern "C" int32_t fp_index_dim(const fp_index* ix) { return ix ? ix->d.dim : 0;
 extern "C" int32_t fp_index_nbits(const fp_index* ix) { return ix ? ix->d.nbits : 0; }
 extern "C" int64_t fp_index_device_bytes(const fp_index* ix) { return ix ? ix->bytes : 0; }
 extern "C" int64_t fp_index_num_unique_codes(const fp_index* ix) { return ix ? ix->d.U : 0; }
-extern "C" int64_t fp_index_num_code_lines(const fp_index* ix) { return ix ? ix->d.n_lines : 0; }
+extern "C" int64_t fp_index_num_code_lines(const fp_index* ix) { return ix ? ix->d.n_lines * ix->d.l0_ppl / 8 : 0; }   // in 128-byte units
 extern "C" int64_t fp_index_num_hard_tokens(const fp_index* ix) { return ix ? ix->n_hard_tokens : 0; }
 
 // ------------------------------------------------------------------------------------------

@@ -49,7 +49,8 @@ struct FpIndexDev {
   // centroid ranges of 2^17 (FP_L0_RANGE) for tables beyond 2^17 centroids: range r has its own lines / offsets with codes
   // relative to r * 2^17; [0] aliases pcodes / poff
   int n_ranges;
-  int64_t n_lines;         // 128-byte code lines over all ranges
+  int l0_ppl;              // 16-byte pieces per code line: 8 (128-byte lines) or 4 (64-byte lines; tables of several ranges)
+  int64_t n_lines;         // code lines over all ranges
   const uint4* pcodes_r[8];
   const int32_t* poff_r[8];
   const uint16_t* norms;   // [T]   fp16 bits of h(sqrt(sum_fp32 e_k^2)) per stored token (ascending-k sum; computed at index creation)
@@ -286,7 +287,7 @@ int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n
                      int64_t* uoff_dev, hipStream_t st);
 // The unique codes in [code_lo, code_hi) of every document packed into 128-byte lines (S4 level 0).  Allocates *lines and *poff [N][2].
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
-                     int32_t** poff, int64_t* n_lines, hipStream_t st);
+                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl = 8 /*16-byte pieces (6 codes each) per line: 8 or 4*/);
 // Builds the IVF (per-cell ascending unique local doc ids) from the per-document unique codes.
 // Allocates *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
 int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t U, int64_t P, int32_t** ivf_pids,

@@ -1966,23 +1966,28 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
 // the bounds of query b live at ub[l0_row(cand_off, b) + i], i = position in the query's candidate list: rows start on 16-byte
 // boundaries (ub holds M + 8 B + 16 entries) so that the passes over them use 16-byte loads
 __device__ __forceinline__ int64_t l0_row(const int64_t* __restrict__ cand_off, int b) { return ((cand_off[b] + 7) & ~(int64_t)7) + 8 * (int64_t)b; }
-__device__ __forceinline__ uint32_t l0_red8(uint32_t v) {   // sum over the 8 lanes of a group, in all of them (no lane outside the group is read)
+template <int LPC>
+__device__ __forceinline__ uint32_t l0_red(uint32_t v) {   // sum over the LPC (8 or 4) lanes of a group, in all of them (no lane outside the group is read)
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the group
+  if constexpr (LPC == 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror: the other quad of the group
   return v;
 }
-__device__ __forceinline__ uint32_t l0_max8(uint32_t v) {
+template <int LPC>
+__device__ __forceinline__ uint32_t l0_maxg(uint32_t v) {
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
   v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  if constexpr (LPC == 8) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
   return v;
 }
 // Tables beyond 2^17 centroids are walked in ranges of 2^17 (one launch each, the range's slice of the table in LDS and the
 // index's per-range code lines): the first launch writes F + its sum, the later ones add theirs (saturating, infinite stays
 // infinite), the last one builds the histogram from the final values.
 typedef __attribute__((address_space(3))) const uint8_t l0_lds_u8;
-template <int ABL /*timing experiments only: 1 no table lookups, 2 no line loads*/>
+// LPC = lanes per candidate = 16-byte pieces per code line: 8 (128-byte lines, 48 codes: one line per document for tables of one
+// range) or 4 (64-byte lines, 24 codes: tables of several ranges, where a document has ~8 codes per range and 8 lanes per
+// candidate would spend three quarters of their lookups on empty pieces).
+template <int ABL /*timing experiments only: 1 no table lookups, 2 no line loads*/, int LPC>
 __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, int64_t tab_off, int tab_bytes,
                                                   const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
@@ -2011,16 +2016,16 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   }
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
-  constexpr int CPI = 128 * L0_UNROLL;   // candidates per workgroup iteration
+  constexpr int CPI = (1024 / LPC) * L0_UNROLL;   // candidates per workgroup iteration
   if ((int64_t)bxi * CPI >= n) return;
   const uint32_t F = Fsum[b];
-  const int sub = tid & 7;
+  const int sub = tid & (LPC - 1);
   const int kq = sub & 3;                      // the candidate of the group's four whose id / line offsets this lane fetches
   const int64_t stride = (int64_t)bxn * CPI;
   const int32_t* cpids = cand_pid + beg;
   const uint2* pmeta = reinterpret_cast<const uint2*>(poff);
   uint16_t* ubrow = ub + l0_row(cand_off, b);
-  int64_t i = (int64_t)bxi * CPI + (tid >> 3) * L0_UNROLL;
+  int64_t i = (int64_t)bxi * CPI + (tid / LPC) * L0_UNROLL;
   // Software pipeline over the dependent chain  id -> {first line, line count} -> code line(s):  while iteration t is
   // computed, the code lines of t+1, the offsets of t+2 and the ids of t+3 are in flight (one workgroup per CU -- the table
   // takes the LDS -- leaves only 4 waves per SIMD to hide latency otherwise).  Ids and offsets are fetched cooperatively: each
@@ -2041,7 +2046,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   auto pos = [&](int64_t at) -> int64_t { return at + kq < nlast ? at + kq : nlast; };
   auto load_line = [&](uint32_t line) -> uint4 {
     if (ABL & 2) return make_uint4(line * 2654435761u & 0x1FFFFu, line * 40503u & 0x1FFFFu, line * 7919u & 0x1FFFFu, 0x06000000u | (line & 0xFFFFu));
-    return pcodes[(int64_t)line * 8 + sub];
+    return pcodes[(int64_t)line * LPC + sub];
   };
   uint2 m0 = pmeta[cpids[pos(i)]];                     // iteration t
   uint2 m1 = pmeta[cpids[pos(i + stride)]];            // t+1
@@ -2116,16 +2121,16 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       const uint32_t l0k = qb(m0.x, k), nlk = qb(m0.y, k);
       uint32_t sum = sums[k];
       for (uint32_t t = 1; t < nlk; ++t) {   // documents with more than 48 distinct codes
-        const uint4 more = pcodes[((int64_t)l0k + t) * 8 + sub];
+        const uint4 more = pcodes[((int64_t)l0k + t) * LPC + sub];
         sum += piece(more);
       }
-      sum = l0_red8(sum);   // bits 24.. count the pieces that hold an escaped / infinite code (at most 8 x lines, far below 2^8)
+      sum = l0_red<LPC>(sum);   // bits 24.. count the pieces that hold an escaped / infinite code (at most 8 x lines, far below 2^8)
       if (sum >> 24) {
         // some code of this candidate has an escaped (e >= 800) or infinite excess: a second pass that takes the escape values
         // from LDS.  The group branches as one (the sum is the same in its 8 lanes); the first line is still in registers.
         uint32_t s2 = 0, inf = 0;
         for (uint32_t t = 0; t < nlk; ++t) {
-          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)l0k + t) * 8 + sub];
+          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)l0k + t) * LPC + sub];
           const uint32_t cnt = q.w >> 24;
           uint32_t c[6];
           codes6(q, c);
@@ -2141,8 +2146,8 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
           s2 += s6 - (6u - cnt) * last;
           inf |= cnt ? i6 : 0u;
         }
-        sum = l0_red8(s2);
-        sum = l0_max8(inf) ? 0xFFFFFFu : sum;
+        sum = l0_red<LPC>(s2);
+        sum = l0_maxg<LPC>(inf) ? 0xFFFFFFu : sum;
       }
       uint32_t v = (first ? F : (uint32_t)prev[k]) + sum;
       v = (sum >= 0xFFFFFFu || (!first && prev[k] == L0_INF)) ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
@@ -2498,8 +2503,9 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
                  hipStream_t st) {
   const int B = sh.B;
   const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
-  static std::atomic<uint64_t> ok2{0}, ok2a{0}, ok2b{0}, ok2c{0};
-  fp_allow_big_lds((const void*)k_l0_scan<0>, ok2, 160 * 1024);
+  static std::atomic<uint64_t> ok8{0}, ok4{0};
+  fp_allow_big_lds((const void*)k_l0_scan<0, 8>, ok8, 160 * 1024);
+  fp_allow_big_lds((const void*)k_l0_scan<0, 4>, ok4, 160 * 1024);
   const int64_t per_q = (M + B - 1) / B;
   // each workgroup copies the table (up to 128 KiB) into LDS first: candidates per workgroup (measured at cfg2: 256 / 512 / 1024 /
   // 2048 / 4096 -> 1.99 / 1.76 / 1.60 / 1.51 / 1.51 ms with the first version of the kernel)
@@ -2507,30 +2513,39 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   int64_t bx = (per_q + cpw - 1) / cpw;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
-  static const int abl = [] { const char* e = getenv("FP_L0_ABL"); return e ? atoi(e) : 0; }();   // timing experiments only (results are wrong)
-  if (abl & 3) {
-    fp_allow_big_lds((const void*)k_l0_scan<1>, ok2a, 160 * 1024);
-    fp_allow_big_lds((const void*)k_l0_scan<2>, ok2b, 160 * 1024);
-    fp_allow_big_lds((const void*)k_l0_scan<3>, ok2c, 160 * 1024);
-  }
   // measured at cfg2: XCD-affine 0.674 ms, plain (chunk, query) grid 0.565 ms -- the table copies are the smaller effect; with
   // the plain grid the workgroups of ~4 queries sweep the corpus together on all XCDs and share the code lines in the
   // memory-side cache.  Experiment only: FP_L0_XCD=1.
   static const int affine_env = [] { const char* e = getenv("FP_L0_XCD"); return e ? atoi(e) : 0; }();
   const int affine = (affine_env && B % 8 == 0 && bx * (int64_t)B < (1ll << 31)) ? 1 : 0;
   const dim3 grid = affine ? dim3((unsigned)(bx * B)) : dim3((unsigned)bx, (unsigned)B);
+#ifdef FP_ABLATIONS   // timing-only variants of the scan (results are wrong): built only with -DFP_ABLATIONS, never in the shipped library
+  static const int abl = [] { const char* e = getenv("FP_L0_ABL"); return e ? atoi(e) : 0; }();
+  static std::atomic<uint64_t> ok2a{0}, ok2b{0}, ok2c{0};
+  if (abl & 3) {
+    fp_allow_big_lds((const void*)k_l0_scan<1, 8>, ok2a, 160 * 1024);
+    fp_allow_big_lds((const void*)k_l0_scan<2, 8>, ok2b, 160 * 1024);
+    fp_allow_big_lds((const void*)k_l0_scan<3, 8>, ok2c, 160 * 1024);
+  }
+#endif
   for (int r = 0; r < ix.n_ranges; ++r) {
     const int64_t off = (int64_t)r * FP_L0_RANGE;
     const int tb = (int)std::min<int64_t>(FP_L0_RANGE, Cpad - off);
-#define L0_LAUNCH(A_) \
-    hipLaunchKernelGGL(k_l0_scan<A_>, grid, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
+#define L0_LAUNCH(A_, L_) \
+    hipLaunchKernelGGL((k_l0_scan<A_, L_>), grid, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
                        cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, (int)bx, affine)
-    switch (abl & 3) {
-      case 1: L0_LAUNCH(1); break;
-      case 2: L0_LAUNCH(2); break;
-      case 3: L0_LAUNCH(3); break;
-      default: L0_LAUNCH(0); break;
+#ifdef FP_ABLATIONS
+    if (ix.l0_ppl == 8 && (abl & 3)) {
+      switch (abl & 3) {
+        case 1: L0_LAUNCH(1, 8); break;
+        case 2: L0_LAUNCH(2, 8); break;
+        default: L0_LAUNCH(3, 8); break;
+      }
+      continue;
     }
+#endif
+    if (ix.l0_ppl == 4) L0_LAUNCH(0, 4);
+    else L0_LAUNCH(0, 8);
 #undef L0_LAUNCH
   }
 }

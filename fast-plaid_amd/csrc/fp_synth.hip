@@ -322,26 +322,27 @@ __global__ void k_pcode_range(const int32_t* __restrict__ ucodes, const int64_t*
     re[d] = z0;
   }
 }
-__global__ void k_pcode_lines(const int64_t* __restrict__ rs, const int64_t* __restrict__ re, int64_t n_docs, int64_t* __restrict__ nlines) {
+__global__ void k_pcode_lines(const int64_t* __restrict__ rs, const int64_t* __restrict__ re, int64_t n_docs, int64_t* __restrict__ nlines, int cpl /*codes per line*/) {
   for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= n_docs; d += (int64_t)gridDim.x * blockDim.x)
-    nlines[d] = d < n_docs ? (re[d] - rs[d] + PCODES_PER_LINE - 1) / PCODES_PER_LINE : 0;
+    nlines[d] = d < n_docs ? (re[d] - rs[d] + cpl - 1) / cpl : 0;
 }
 __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ rs,
                                                     const int64_t* __restrict__ re, int64_t n_docs, int32_t code_base,
-                                                    const int64_t* __restrict__ loff, int32_t* __restrict__ poff, uint4* __restrict__ lines) {
+                                                    const int64_t* __restrict__ loff, int32_t* __restrict__ poff, uint4* __restrict__ lines,
+                                                    int ppl /*pieces per line: 8 or 4*/) {
   // one thread per piece
   const int64_t nl = loff[n_docs];
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nl * 8 + n_docs + 1; g += (int64_t)gridDim.x * blockDim.x) {
-    if (g >= nl * 8) {   // per document {first line, line count}
-      const int64_t d = g - nl * 8;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nl * ppl + n_docs + 1; g += (int64_t)gridDim.x * blockDim.x) {
+    if (g >= nl * ppl) {   // per document {first line, line count}
+      const int64_t d = g - nl * ppl;
       if (d < n_docs) {
         poff[2 * d] = (int32_t)loff[d];
         poff[2 * d + 1] = (int32_t)(loff[d + 1] - loff[d]);
       }
       continue;
     }
-    const int64_t line = g >> 3;
-    const int piece = (int)(g & 7);
+    const int64_t line = g / ppl;
+    const int piece = (int)(g % ppl);
     // document of `line`: last d with loff[d] <= line
     int64_t lo = 0, hi = n_docs;
     while (hi - lo > 1) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
       if (loff[mid] <= line) lo = mid; else hi = mid;
     }
     const int64_t u0 = rs[lo], n = re[lo] - u0;
-    const int64_t first = (line - loff[lo]) * PCODES_PER_LINE + (int64_t)piece * PCODES_PER_PIECE;
+    const int64_t first = (line - loff[lo]) * (PCODES_PER_PIECE * ppl) + (int64_t)piece * PCODES_PER_PIECE;
     // piece = 6 codes of 20 bits (bits 0..119) + the count in bits 120..127.  Slots past the piece's last code repeat that code
     // (an empty piece holds code 0 six times): the scan sums all six table entries and takes (6 - count) x the last one off
     // again, instead of predicating every lookup
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
 // The unique codes in [code_lo, code_hi) (at most 2^17 values) of every document, packed into 128-byte lines.  Allocates
 // *lines ([NL] x 128 B) and *poff ([N] x {first line, line count} i32 pairs); returns 0 or a hipError
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
-                     int32_t** poff, int64_t* n_lines, hipStream_t st) {
+                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl) {
   int rc = 0;
   int64_t* nlines = nullptr;
   int64_t* loff = nullptr;
@@ -392,18 +393,18 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   HCHK(hipMalloc((void**)&re, (size_t)(n_docs + 1) * 8));
   hipLaunchKernelGGL(k_pcode_range, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, ucodes, uoff_dev, n_docs, (int32_t)code_lo,
                      (int32_t)code_hi, rs, re);
-  hipLaunchKernelGGL(k_pcode_lines, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, rs, re, n_docs, nlines);
+  hipLaunchKernelGGL(k_pcode_lines, dim3(fp_grid_cap((n_docs + 256) / 256, 256)), dim3(256), 0, st, rs, re, n_docs, nlines, PCODES_PER_PIECE * ppl);
   HCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, nlines, loff, (int)(n_docs + 1), st));
   HCHK(hipMalloc(&tmp, tb ? tb : 16));
   HCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, nlines, loff, (int)(n_docs + 1), st));
   HCHK(hipMemcpyAsync(n_lines, loff + n_docs, 8, hipMemcpyDeviceToHost, st));
   HCHK(hipStreamSynchronize(st));
   if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
-  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 128 + 256));   // a document without codes at the very end reads "its" line: one line of slack
+  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 16 * ppl + 256));   // a document without codes at the very end reads "its" line: one line of slack
   {
-    const int64_t work = *n_lines * 8 + n_docs + 1;
+    const int64_t work = *n_lines * ppl + n_docs + 1;
     hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, rs, re, n_docs, (int32_t)code_lo, loff,
-                       *poff, static_cast<uint4*>(*lines));
+                       *poff, static_cast<uint4*>(*lines), ppl);
   }
   HCHK(hipStreamSynchronize(st));
 fail:

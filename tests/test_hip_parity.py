@@ -387,8 +387,8 @@ def test_bound_and_refine_forced(fp, ppd):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("tail,pilot", [("0.025", "4"), ("0.3", "1"), ("0.002", "2"), ("0.1", "16")])
-def test_level0_forced(fp, tail, pilot):
+@pytest.mark.parametrize("tail,pilot,ppl", [("0.025", "4", ""), ("0.3", "1", ""), ("0.002", "2", ""), ("0.1", "16", ""), ("0.025", "4", "4"), ("0.1", "2", "8")])
+def test_level0_forced(fp, tail, pilot, ppl):
     """S4's level-0 form (per-centroid excess table in LDS -> upper bound of every candidate from its code list alone ->
     pilot group scored exactly -> threshold -> survivors scored exactly) forced on small corpora via FP_APPROX_IMPL=l0, for
     several floor quantiles (FP_L0_TAIL) and pilot-group sizes (FP_L0_PILOT): fp_search must equal fp_search_trace (which
@@ -397,6 +397,8 @@ def test_level0_forced(fp, tail, pilot):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FP_APPROX_IMPL="l0", FP_L0_TAIL=tail, FP_L0_PILOT=pilot)
+    if ppl:   # code lines of 4 / 8 pieces whatever the table size (4: documents of more than 24 codes take the multi-line path)
+        env["FP_L0_PPL"] = ppl
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
