@@ -60,6 +60,7 @@ SYMBOLS = {
     "fp_search_trace": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(FpSearchParams), _vp, _i64, _i32] + [_vp] * 10),
     "fp_last_search_timings": (C.c_int, [_vp, _vp, C.c_int]),
     "fp_set_graph_replay": (C.c_int, [C.c_int]),
+    "fp_graph_replay_count": (C.c_uint64, []),
     "fp_reconstruct_embeddings": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "fp_compress": (C.c_int, [C.c_int, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "fp_assign_l2": (C.c_int, [C.c_int, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),

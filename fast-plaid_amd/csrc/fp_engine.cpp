@@ -60,6 +60,14 @@ extern "C" int fp_device_count(void) {
 // bumped by every (re)allocation of a scratch buffer: a captured graph (FP_GRAPH) holds raw pointers and is only replayed while
 // the count it was captured under still stands
 static std::atomic<uint64_t> g_alloc_gen{0};
+// ... counted per scratch: the thread that holds a scratch points this at the scratch's own counter (search_impl), so that a
+// (re)allocation in another thread / index / scratch does not invalidate this scratch's graphs
+static thread_local uint64_t* t_alloc_gen = nullptr;
+static inline void bump_alloc_gen() {
+  if (t_alloc_gen) ++*t_alloc_gen;
+  else g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
+}
+static std::atomic<uint64_t> g_graph_replays{0};   // fp_graph_replay_count(): calls served by one hipGraphLaunch
 // fp_set_graph_replay / FP_GRAPH: on unless the environment says 0
 static std::atomic<int> g_graph_replay{[] { const char* e = getenv("FP_GRAPH"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 struct DevBuf {
@@ -67,7 +75,7 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t ensure(size_t need) {
     if (need <= cap) return hipSuccess;
-    g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
+    bump_alloc_gen();
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -92,7 +100,7 @@ struct HostBuf {
   size_t cap = 0;
   hipError_t ensure(size_t need) {
     if (need <= cap) return hipSuccess;
-    g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
+    bump_alloc_gen();
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
@@ -144,6 +152,50 @@ struct Scratch {
     bool valid = false, used_q8 = false, marked = false;
   } graph;
   bool capturing = false;
+  // The learnt capacity and the captured graph belong to a SHAPE {B, Q, n_ivf_probe, n_full_scores, top_k, subset?}.  The fields
+  // above are the state of the shape in use; the states of the other recently used shapes wait here (least recently used one
+  // evicted), so that a caller alternating between a few shapes keeps replaying each of them.
+  struct ShapeState {
+    int64_t key[6] = {-1, -1, -1, -1, -1, -1};
+    int64_t spec_cap = 0, spec_last = 0;
+    GraphCache graph;
+    uint64_t stamp = 0;
+    bool used = false;
+  };
+  static constexpr int kShapes = 8;
+  ShapeState shapes[kShapes];
+  int cur_shape = -1;
+  uint64_t shape_stamp = 0;
+  uint64_t alloc_gen = 0;   // bumped by every (re)allocation of one of this scratch's buffers (t_alloc_gen)
+  void select_shape(const int64_t (&key)[6]) {
+    if (cur_shape >= 0 && std::equal(key, key + 6, shapes[cur_shape].key)) { shapes[cur_shape].stamp = ++shape_stamp; return; }
+    if (cur_shape >= 0) {   // park the live state
+      ShapeState& o = shapes[cur_shape];
+      o.spec_cap = spec_cap; o.spec_last = spec_last; o.graph = graph;
+    }
+    int slot = -1;
+    for (int i = 0; i < kShapes; ++i)
+      if (shapes[i].used && std::equal(key, key + 6, shapes[i].key)) slot = i;
+    if (slot < 0) {
+      for (int i = 0; i < kShapes && slot < 0; ++i)
+        if (!shapes[i].used) slot = i;
+      if (slot < 0) {   // evict the least recently used shape
+        slot = 0;
+        for (int i = 1; i < kShapes; ++i)
+          if (shapes[i].stamp < shapes[slot].stamp) slot = i;
+        if (shapes[slot].graph.exec) (void)hipGraphExecDestroy(shapes[slot].graph.exec);
+      }
+      shapes[slot] = ShapeState{};
+      std::copy(key, key + 6, shapes[slot].key);
+      shapes[slot].used = true;
+    }
+    ShapeState& n = shapes[slot];
+    n.stamp = ++shape_stamp;
+    spec_cap = n.spec_cap; spec_last = n.spec_last; graph = n.graph;
+    n.graph.exec = nullptr;   // (owned by the live fields while the shape is in use)
+    spec_key[0] = key[0]; spec_key[1] = key[1]; spec_key[2] = key[2]; spec_key[3] = key[5];
+    cur_shape = slot;
+  }
   HostBuf h_qin;
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
@@ -158,6 +210,8 @@ struct Scratch {
     h_small.release();
     h_qin.release();
     if (graph.exec) { (void)hipGraphExecDestroy(graph.exec); graph.exec = nullptr; graph.valid = false; }
+    for (auto& sh2 : shapes)
+      if (sh2.graph.exec) { (void)hipGraphExecDestroy(sh2.graph.exec); sh2.graph.exec = nullptr; }
     DevBuf* all[] = {&qin,      &qpad,     &S,        &partial, &cells,   &ucells,     &ncells,  &allow,    &subbm,  &invalid, &sub_ids,
                      &sub_off,  &bitmap,   &blkcnt,   &ncand,   &cand_off, &cand_pid,  &approx,  &hist,     &selstate, &sel_pid, &tie_pid,
                      &sel_approx, &sel_cnt, &exact,   &out_pid, &out_score, &out_cnt,  &tmpf,    &tmpp,     &tok_idx, &recon};
@@ -210,6 +264,7 @@ static Scratch* acquire(fp_index* ix) {
     if (!ix->pool.empty()) {
       Scratch* s = ix->pool.back();
       ix->pool.pop_back();
+      t_alloc_gen = &s->alloc_gen;   // this thread's (re)allocations are this scratch's from here to release()
       return s;
     }
   }
@@ -219,9 +274,11 @@ static Scratch* acquire(fp_index* ix) {
     return nullptr;
   }
   for (auto& e : s->ev) (void)hipEventCreate(&e);
+  t_alloc_gen = &s->alloc_gen;
   return s;
 }
 static void release(fp_index* ix, Scratch* s) {
+  t_alloc_gen = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
   ix->pool.push_back(s);
 }
@@ -993,10 +1050,15 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     hipStream_t st = s->st;
     const int64_t K = p->top_k;
     OutLayout ol(B, K);
+    // the state of this shape (learnt capacity, captured graph) becomes the live one
+    if (!tr) {
+      const int64_t skey[6] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, has_subset ? 1 : 0};
+      s->select_shape(skey);
+    }
     // ---- FP_GRAPH: replay / capture (host-buffer calls of one sub-batch, no subset, no trace)
     const bool graph_ok = graph_env && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3;
     const size_t qbytes = (size_t)B * Q * D.dim * 2;
-    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)g_alloc_gen.load(std::memory_order_relaxed), 1};
+    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)s->alloc_gen, 1};
     bool replayed = false;
     if (graph_ok && s->graph.valid && std::equal(gkey, gkey + 8, s->graph.key)) {
       memcpy(s->h_qin.p, queries, qbytes);
@@ -1008,6 +1070,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         s->fold_stats = true;
         s->ms_marked_now = s->graph.marked;
         replayed = true;
+        g_graph_replays.fetch_add(1, std::memory_order_relaxed);
       } else {   // a runtime that will not launch the graph: plain path from here on
         (void)hipGetLastError();
         s->graph.valid = false;
@@ -1020,7 +1083,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       capture = s->spec_cap > 0 && s->graph.warm >= 1 && std::equal(gkey, gkey + 8, s->graph.last);
       if (capture) {
         HIPCHK(s->h_qin.ensure(qbytes));
-        gkey[6] = (int64_t)g_alloc_gen.load(std::memory_order_relaxed);
+        gkey[6] = (int64_t)s->alloc_gen;
         memcpy(s->h_qin.p, queries, qbytes);
         if (s->graph.exec) { (void)hipGraphExecDestroy(s->graph.exec); s->graph.exec = nullptr; }
         s->graph.valid = false;
@@ -1076,7 +1139,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         const hipError_t ce = hipStreamEndCapture(st, &g);
         s->capturing = false;
         hipGraphExec_t ex = nullptr;
-        const bool usable = ce == hipSuccess && g && P.spec && gkey[6] == (int64_t)g_alloc_gen.load(std::memory_order_relaxed) &&
+        const bool usable = ce == hipSuccess && g && P.spec && gkey[6] == (int64_t)s->alloc_gen &&
                             hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex;
         if (g) (void)hipGraphDestroy(g);
         if (!usable) {
@@ -1088,6 +1151,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
           continue;
         }
         s->graph.exec = ex;
+        s->graph.fails = 0;
         std::copy(gkey, gkey + 8, s->graph.key);
         s->graph.used_q8 = P.used_q8;
         s->graph.marked = s->ms_marked_now;
@@ -1099,6 +1163,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
           b0 -= maxB;
           continue;
         }
+        g_graph_replays.fetch_add(1, std::memory_order_relaxed);   // (the capturing call is itself served by the graph's first launch)
       }
       STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));
@@ -1122,7 +1187,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       else s->graph.warm = P.spec ? 1 : 0;
       std::copy(gkey, gkey + 8, s->graph.last);
       s->graph.last[5] = P.spec ? P.M : 0;
-      s->graph.last[6] = (int64_t)g_alloc_gen.load(std::memory_order_relaxed);
+      s->graph.last[6] = (int64_t)s->alloc_gen;
     }
     if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
     g_last_counts[0] += M_true;
@@ -1260,6 +1325,7 @@ extern "C" int fp_last_search_counts(int64_t* out, int cap) {
 }
 
 extern "C" int fp_set_graph_replay(int enabled) { return g_graph_replay.exchange(enabled ? 1 : 0, std::memory_order_relaxed); }
+extern "C" uint64_t fp_graph_replay_count(void) { return g_graph_replays.load(std::memory_order_relaxed); }
 
 extern "C" int fp_last_search_timings(const char** names, float* ms, int cap) {
   if (!g_have_ms) return 0;

@@ -316,6 +316,11 @@ def set_graph_replay(enabled: bool) -> bool:
     return bool(N.lib().fp_set_graph_replay(1 if enabled else 0))
 
 
+def graph_replay_count() -> int:
+    """fp_graph_replay_count: fp_search calls served by one hipGraphLaunch since the process started."""
+    return int(N.lib().fp_graph_replay_count())
+
+
 def maxsim_columns(index: PyLoadedIndex, query_f16, pids) -> dict:
     """fp_maxsim_columns: the exact stage's MFMA pass on `pids` for one query [q_len, dim], before the exact-order repair."""
     q = np.ascontiguousarray(query_f16, dtype=np.float16)

@@ -141,6 +141,10 @@ int fp_last_search_timings(const char** names, float* ms, int cap);
  * replay off for the calls it measures.  enabled: 0 / 1; returns the previous setting.  Process-wide; default 1 (FP_GRAPH=0 in
  * the environment starts with 0). */
 int fp_set_graph_replay(int enabled);
+/* fp_search calls served by a graph replay since the process started.  The learnt candidate capacity and the captured graph are
+ * kept per shape {n_queries, q_len, n_ivf_probe, n_full_scores, top_k} for the eight most recently used shapes of a scratch, so a
+ * caller that alternates between a few shapes keeps replaying each of them. */
+uint64_t fp_graph_replay_count(void);
 
 /* Work counters of the most recent fp_search on this thread: out[0] = candidate documents
  * summed over queries (S3 output), out[1] = candidates that reached the exact approximate-score

@@ -41,6 +41,7 @@ def lib():
         L.pl_search_trace.argtypes = [vp, vp, i32, i64, i64, i64, vp, i64, i32] + [vp] * 9
         L.pl_exact_scores.argtypes = [vp, vp, i32, vp, i64, vp]
         L.pl_token_scores.argtypes = [vp, vp, i32, i64, vp]
+        L.pl_column_maxima.argtypes = [vp, vp, i32, vp, i64, vp]
         L.pl_num_procs.restype = i32
         _lib = L
     return _lib
@@ -139,6 +140,18 @@ class OracleIndex:
         out = np.zeros(p.shape[0], np.float32)
         lib().pl_exact_scores(self._h, _p(q), q.shape[0], _p(p), p.shape[0], _p(out))
         return out
+
+
+def _column_maxima(self, query, pids):
+    """[n, Q] fp16: per document the column maxima of its token-score matrix (what exact_scores sums)."""
+    q = np.ascontiguousarray(query, np.float16)
+    p = np.ascontiguousarray(pids, np.int64)
+    out = np.zeros((p.shape[0], q.shape[0]), np.float16)
+    lib().pl_column_maxima(self._h, _p(q), q.shape[0], _p(p), p.shape[0], _p(out))
+    return out
+
+
+OracleIndex.column_maxima = _column_maxima
 
 
 def _token_scores(self, query, pid):

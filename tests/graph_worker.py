@@ -33,7 +33,23 @@ def main():
             assert counts[b] == len(t["pids"]), (b, counts[b], len(t["pids"]))
             assert np.array_equal(pids[b, : counts[b]], t["pids"])
             assert np.array_equal(scores[b, : counts[b]], t["scores"])
-    print("GRAPH_OK")
+    # a caller alternating between three batch sizes: the capacity and the graph are kept per shape (eight most recent shapes of
+    # a scratch), so after each shape's two warm-up forms (waited-for, speculative) every call is one graph launch: 24 of these 30
+    before = R.graph_replay_count()
+    alt = []
+    for i in range(30):
+        nb = (6, 3, 1)[i % 3]
+        params = R.SearchParameters(2000, 512, 50, 4)
+        q = fp.synth.make_queries(spec, host["centroids"], nb, 32, seed=900 + i % 3)   # (the same batch per shape: a larger candidate total would raise the learnt capacity, a new key)
+        pids, scores, counts = R.search_arrays(dev, q, params)
+        alt.append((params, q, pids.copy(), scores.copy(), counts.copy()))
+    replays = R.graph_replay_count() - before
+    assert replays >= 24, replays   # 30 calls - 3 shapes x 2 warm-up forms
+    for params, q, pids, scores, counts in alt:
+        for b in range(q.shape[0]):
+            t = R.search_trace(dev, q[b], params)
+            assert counts[b] == len(t["pids"]) and np.array_equal(pids[b, : counts[b]], t["pids"]) and np.array_equal(scores[b, : counts[b]], t["scores"])
+    print("GRAPH_OK replays", replays)
 
 
 if __name__ == "__main__":

@@ -1180,6 +1180,43 @@ def test_full_size_cfg2_id_lists_vs_oracle(fp):
     assert identical >= 14, f"only {identical} of {nq} top-{top_k} id lists are identical to the oracle's"
 
 
+def test_full_size_cfg2_column_certification(fp):
+    """The certification window of the MFMA MaxSim kernel (eps = 2^-19 |q|, an empirical margin ~16 sigma of the accumulation-order
+    noise, below the worst-case bound D * 2^-24 * sum |e^_k q_k|) checked where it matters: BASELINE cfg2 at full size, the
+    rerank lists of 64 queries = 65 536 documents = 2.1 M columns.  Every column the kernel does NOT flag must equal the C
+    oracle's column maximum bit for bit; flagged columns differ by at most one fp16 ulp."""
+    R = fp.fast_plaid_rust
+    c = FULL_SIZE["cfg2"]
+    spec, cent, dev = _full_size_index(fp, c["n_docs"], c["doc_len"], c["n_centroids"])
+    Q, n_full, n_probe = c["Q"], c["n_full"], c["n_probe"]
+    nq = 64
+    q = fp.synth.make_queries(spec, cent, nq, Q, seed=777)
+    Rr = n_full // 4
+    params = R.SearchParameters(2000, n_full, Rr, n_probe)   # top_k = R: the whole rerank list comes back
+    pids, scores, counts = R.search_arrays(dev, q, params)
+    bw = fp.synth.bucket_weights(spec)
+    arr = R.export_index_arrays(dev, centroids=cent, bucket_weights=bw)
+    orc = OC.OracleIndex(nbits=spec.nbits, centroids=cent, bucket_weights=bw, ivf=arr["ivf"], ivf_lengths=arr["ivf_lengths"],
+                         doc_codes=arr["doc_codes"], doc_residuals=arr["doc_residuals"], doc_lengths=arr["doc_lengths"])
+    ncol = nflag = ndiff_flagged = 0
+    for b in range(nq):
+        docs = np.sort(pids[b, : counts[b]])
+        got = R.maxsim_columns(dev, q[b], docs)
+        want = orc.column_maxima(q[b], docs)                      # [n, Q] fp16
+        g = got["col_max"]
+        fl = ((got["flags"][:, (np.arange(Q) // 32)] >> (np.arange(Q) % 32).astype(np.uint32)) & 1).astype(bool)
+        diff = g.view(np.uint16) != want.view(np.uint16)
+        bad = diff & ~fl
+        assert not bad.any(), f"query {b}: {int(bad.sum())} unflagged columns differ from the reference, first at {np.argwhere(bad)[:3].tolist()}"
+        assert np.all(parity_ulp(g[diff], want[diff]) <= 1)
+        ncol += g.size
+        nflag += int(fl.sum())
+        ndiff_flagged += int(diff.sum())
+    assert ncol >= 2_000_000, ncol
+    assert nflag <= 0.05 * ncol, (nflag, ncol)
+    print(f"columns {ncol}, flagged {nflag}, flagged-and-different {ndiff_flagged}")
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_and_replicated_multiprocess(fp, world):
     """real processes (one per rank, all on cuda:0), gloo transport: document-sharded search with the HIP stage
