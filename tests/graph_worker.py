@@ -44,7 +44,8 @@ def main():
         pids, scores, counts = R.search_arrays(dev, q, params)
         alt.append((params, q, pids.copy(), scores.copy(), counts.copy()))
     replays = R.graph_replay_count() - before
-    assert replays >= 24, replays   # 30 calls - 3 shapes x 2 warm-up forms
+    if not os.environ.get("FP_SPEC_CAP_PCT"):   # (the forced-overflow run never keeps a capacity: nothing to replay)
+        assert replays >= 24, replays   # 30 calls - 3 shapes x 2 warm-up forms
     for params, q, pids, scores, counts in alt:
         for b in range(q.shape[0]):
             t = R.search_trace(dev, q[b], params)
