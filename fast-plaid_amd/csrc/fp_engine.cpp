@@ -199,6 +199,7 @@ struct Scratch {
   HostBuf h_qin;
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
+  int l0_poor = 0;              // consecutive batches in which level 0 let more than a quarter of the candidates through
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
   void destroy() {
     out_all.release();
@@ -668,8 +669,7 @@ static int validate_search(const fp_index* ix, int32_t nq, int32_t q_len, int32_
   if (dim != ix->d.dim) return fail(FP_EINVAL, "query dim does not match the index dim");
   if (p->top_k < 0 || p->n_full_scores < 0 || p->n_ivf_probe < 0) return fail(FP_EINVAL, "negative search parameter");
   if ((int64_t)q_len * std::max<int64_t>(p->n_ivf_probe, 1) > (1ll << 28)) return fail(FP_EUNSUPPORTED, "q_len * n_ivf_probe > 2^28");
-  const int64_t R = std::max<int64_t>(p->n_full_scores / 4, 1);
-  if (R > FP_MAX_SORT) return fail(FP_EUNSUPPORTED, "n_full_scores > 65536 is not supported by the LDS sort");
+  if (p->n_full_scores / 4 > (1ll << 24)) return fail(FP_EUNSUPPORTED, "n_full_scores > 2^26");
   return FP_OK;
 }
 
@@ -721,7 +721,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // FP_APPROX_IMPL=l0): S1 then emits level 0's excess table from its epilogue -- floors from a pre-pass over a centroid
   // sample -- and the 8-bit table (C x Qp bytes per query, written and read back twice) is never materialised.  Whether S4
   // then prunes with it or scores everything exactly (few candidates) is still decided from the candidate count.
-  P.l0_ready = want_s8 && q8_env != 1 && fpk_l0_fits(D) && (q8_env == 2 || D.U <= 64 * D.N);
+  P.l0_ready = want_s8 && q8_env != 1 && fpk_l0_fits(D) && (q8_env == 2 || (D.U <= 64 * D.N && s->l0_poor < 2));
   const int nch128 = (int)((D.C + 127) / 128);
   HIPCHK(s->cmax128.ensure((size_t)B * sh.Qp * nch128 * 2));
   if (P.l0_ready) {
@@ -934,7 +934,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st,
              /*short_lists: one workgroup per query; pays off when there are too few queries to fill the chip anyway (measured: B = 8
-               46 vs 53 us, B = 64 90 vs 71 us)*/ B <= 16 && (P.approx_impl != 0 || M <= 16384ll * B));
+               46 vs 53 us, B = 64 90 vs 71 us)*/ B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B));
   STAGE_DONE(ST_MAXSIM);
   return FP_OK;
 }
@@ -1056,7 +1056,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       s->select_shape(skey);
     }
     // ---- FP_GRAPH: replay / capture (host-buffer calls of one sub-batch, no subset, no trace)
-    const bool graph_ok = graph_env && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3;
+    const bool graph_ok = graph_env && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3 &&
+                          P.sh.R <= FP_MAX_SORT;   // (beyond it the final ranking allocates and synchronises: not capturable)
     const size_t qbytes = (size_t)B * Q * D.dim * 2;
     int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)s->alloc_gen, 1};
     bool replayed = false;
@@ -1194,6 +1195,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
       const int64_t* stv = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
+      // Level 0 is worth its scan only while it prunes: a corpus whose documents' code sets overlap every query (survivors above a
+      // quarter of the candidates in two batches running) is switched to the 8-bit bound stage for this scratch, for good (the
+      // selection is the same in every form of S4, only the time differs)
+      if (P.approx_impl == 2 && M_true > 0) {
+        if (stv[0] * 4 > M_true) s->l0_poor = std::min(s->l0_poor + 1, 4);
+        else s->l0_poor = 0;
+      }
       g_last_counts[1] += P.used_q8 ? stv[0] : M_true;
       for (int i = 0; i < B; ++i) g_last_counts[2] += stv[1 + i];
     } else

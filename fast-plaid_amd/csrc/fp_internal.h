@@ -288,6 +288,9 @@ int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n
 // The unique codes in [code_lo, code_hi) of every document packed into 128-byte lines (S4 level 0).  Allocates *lines and *poff [N][2].
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
                      int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl = 8 /*16-byte pieces (6 codes each) per line: 8 or 4*/);
+// final ranking of rerank lists beyond the LDS sort of k_final_topk (segmented device radix sort; synchronises); 0 or a hipError / -1
+int fps_final_topk_big(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride, int B,
+                       int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt, hipStream_t st);
 // Builds the IVF (per-cell ascending unique local doc ids) from the per-document unique codes.
 // Allocates *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
 int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t U, int64_t P, int32_t** ivf_pids,

@@ -2986,6 +2986,11 @@ __global__ __launch_bounds__(1024) void k_sel_front(const float* __restrict__ ap
   if (tid == 0) { s[2] = kstar; s[3] = s_rem; s[5] = s_gt; s[6] = s_eq; s[7] = s_ovf; }
 }
 
+// marks every query for the ordered collection (k_sel_collect): rerank lists too long for the LDS sort of k_sel_finish
+__global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) st[(int64_t)b * 8 + 7] = 1u;
+}
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
                 uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
                 bool short_lists) {
@@ -3001,6 +3006,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx);
     return;
   }
+  const bool big = sh.R > FP_MAX_SORT;   // beyond k_sel_finish's LDS sort: the ordered single-workgroup collection does the whole job
   (void)hipMemsetAsync(hist, 0, (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t), st);
   hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, cand_off, B, sh.n_full, sh.R, selstate, sel_cnt);
   dim3 gh(64, (unsigned)B);
@@ -3010,9 +3016,13 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   hipLaunchKernelGGL(k_sel_scan<1>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
   hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
   hipLaunchKernelGGL(k_sel_scan<2>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
-  hipLaunchKernelGGL(k_sel_gather, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
-                     tie_pid);
-  {
+  if (big) {
+    hipLaunchKernelGGL(k_sel_force_collect, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, selstate, B);
+  } else {
+    hipLaunchKernelGGL(k_sel_gather, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
+                       tie_pid);
+  }
+  if (!big) {
     static std::atomic<uint64_t> lds_ok{0};
     fp_allow_big_lds((const void*)k_sel_finish, lds_ok, 144 * 1024);
     int kp2 = 2;
@@ -3098,11 +3108,20 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
   if (threadIdx.x == 0) out_cnt[b] = m;
 }
 
+__global__ void k_final_stats(const int64_t* __restrict__ stat_total, const int32_t* __restrict__ stat_per_query, int B, int64_t* __restrict__ stat_out) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) stat_out[1 + b] = stat_per_query ? (int64_t)stat_per_query[b] : 0;
+  if (threadIdx.x == 0) stat_out[0] = stat_total ? *stat_total : 0;
+}
 void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
                     int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
                     hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out) {
   int np2 = next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
+  if (stride > FP_MAX_SORT) {   // beyond the LDS sort: segmented device radix sort (rare: n_full_scores > 65536)
+    if (stat_out) hipLaunchKernelGGL(k_final_stats, dim3(1), dim3(256), 0, st, stat_total, stat_per_query, B, stat_out);
+    (void)fps_final_topk_big(score, pid_local, pid_global, cnt, stride, B, top_k, pid_offset, out_pid, out_score, out_cnt, st);
+    return;
+  }
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_topk, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,

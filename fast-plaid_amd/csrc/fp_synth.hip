@@ -480,3 +480,81 @@ fail:
   if (tmp) (void)hipFree(tmp);
   return rc;
 }
+
+
+// ---- final ranking of rerank lists beyond the LDS sort (R > 16384, i.e. n_full_scores > 65536) --------------------------
+// Same keys and order as k_final_topk (score descending, id ascending; padding entries of a sharded buffer skipped), sorted by a
+// segmented device radix sort (one segment per query).  The temporaries are allocated and freed inside the call: a rare path
+// (the reference accepts any n_full_scores, rust/search/search.rs:605-619), kept simple rather than fast.
+static __device__ __forceinline__ uint32_t srt_mono32(float f) {
+  uint32_t b = __float_as_uint(f + 0.0f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ void k_final_keys(const float* __restrict__ score, const int32_t* __restrict__ pid_local, const int64_t* __restrict__ pid_global,
+                             const int32_t* __restrict__ cnt, int64_t stride, int B, int64_t pid_offset, unsigned long long* __restrict__ keys,
+                             int64_t* __restrict__ seg) {
+  const int64_t total = (int64_t)B * stride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / stride);
+    const int64_t r = i - (int64_t)b * stride;
+    unsigned long long key = 0ull;
+    if (r < (cnt ? (int64_t)cnt[b] : stride)) {
+      const int64_t id = pid_local ? (int64_t)pid_local[i] + pid_offset : pid_global[i];
+      if (id >= 0) key = ((unsigned long long)srt_mono32(score[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
+    }
+    keys[i] = key;
+    if (r == 0) seg[b] = i;
+    if (i == total - 1) seg[B] = total;
+  }
+}
+__global__ void k_final_emit(const unsigned long long* __restrict__ keys, int64_t stride, int B, int64_t top_k, int64_t* __restrict__ out_pid,
+                             float* __restrict__ out_score, int32_t* __restrict__ out_cnt) {
+  const int b = blockIdx.x;
+  const unsigned long long* v = keys + (int64_t)b * stride;
+  __shared__ int s_m;
+  if (threadIdx.x == 0) {   // valid keys are > 0 and sorted to the front: first zero by bisection
+    int64_t lo = 0, hi = stride;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (v[mid] != 0ull) lo = mid + 1; else hi = mid; }
+    s_m = (int)(lo < top_k ? lo : top_k);
+    out_cnt[b] = s_m;
+  }
+  __syncthreads();
+  const int m = s_m;
+  for (int64_t i = threadIdx.x; i < top_k; i += blockDim.x) {
+    if (i < m) {
+      const unsigned long long key = v[i];
+      const uint32_t kb = (uint32_t)(key >> 32);
+      out_pid[(int64_t)b * top_k + i] = (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+      out_score[(int64_t)b * top_k + i] = __uint_as_float((kb & 0x80000000u) ? (kb & 0x7FFFFFFFu) : ~kb);
+    } else {
+      out_pid[(int64_t)b * top_k + i] = -1;
+      out_score[(int64_t)b * top_k + i] = 0.f;
+    }
+  }
+}
+int fps_final_topk_big(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride, int B,
+                       int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt, hipStream_t st) {
+  int rc = 0;
+  const int64_t total = (int64_t)B * stride;
+  unsigned long long *ka = nullptr, *kb = nullptr;
+  int64_t* seg = nullptr;
+  void* tmp = nullptr;
+  size_t tb = 0;
+  if (total >= 0x7FFFFFFFll) return -1;
+  HCHK(hipMalloc((void**)&ka, (size_t)total * 8));
+  HCHK(hipMalloc((void**)&kb, (size_t)total * 8));
+  HCHK(hipMalloc((void**)&seg, (size_t)(B + 1) * 8));
+  hipLaunchKernelGGL(k_final_keys, dim3(fp_grid_cap((total + 255) / 256, 256)), dim3(256), 0, st, score, pid_local, pid_global, cnt, stride, B,
+                     pid_offset, ka, seg);
+  HCHK(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(nullptr, tb, ka, kb, (int)total, B, seg, seg + 1, 0, 64, st));
+  HCHK(hipMalloc(&tmp, tb ? tb : 16));
+  HCHK(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(tmp, tb, ka, kb, (int)total, B, seg, seg + 1, 0, 64, st));
+  hipLaunchKernelGGL(k_final_emit, dim3((unsigned)B), dim3(256), 0, st, kb, stride, B, top_k, out_pid, out_score, out_cnt);
+  HCHK(hipStreamSynchronize(st));
+fail:
+  if (ka) (void)hipFree(ka);
+  if (kb) (void)hipFree(kb);
+  if (seg) (void)hipFree(seg);
+  if (tmp) (void)hipFree(tmp);
+  return rc;
+}

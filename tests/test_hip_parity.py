@@ -1245,20 +1245,30 @@ def test_full_size_cleanup(fp):
 
 
 def test_n_full_scores_sweep_vs_oracle(fp):
-    """n_full_scores 16384 and 65536 (R = 4096 / 16384, the largest the LDS sorts take) on a corpus
-    the oracle still walks in seconds: whole-pipeline traces."""
+    """n_full_scores 16384 and 65536 (R = 4096 / 16384, the largest the LDS sorts take) and 100000 / 131072 (R = 25000 / 32768:
+    the ordered collection and the segmented device sort take over; the reference accepts any value, search.rs:605-619) on a
+    corpus the oracle still walks in seconds: whole-pipeline traces, and the batched call against the oracle's lists."""
     R = fp.fast_plaid_rust
     spec = _synth(fp, n_docs=40000, doc_len=32, n_centroids=1024, variable_len=True, seed=3)
     arr = fp.synth.host_index_arrays(spec)
     q = fp.synth.make_queries(spec, arr["centroids"], 3, 32)
     hip = _hip_index(fp, arr)
     orc = _oracle(arr)
-    for n_full in (16384, 65536):
+    for n_full in (16384, 65536, 100000, 131072):
         params = R.SearchParameters(2000, n_full, 50, 16)
         for b in range(q.shape[0]):
             h = R.search_trace(hip, q[b], params)
             o = orc.search_trace(q[b], 50, n_full, 16)
             assert len(o["rerank"]) == min(n_full // 4, len(o["cand"]))
             check_trace(h, o, 32, 16, n_full, 50)
-    with pytest.raises(ValueError):
-        R.search_arrays(hip, q, R.SearchParameters(2000, 65536 * 2, 50, 16))
+    # the batched entry point with a top_k beyond the LDS sort as well
+    params = R.SearchParameters(2000, 100000, 20000, 16)
+    pids, scores, counts = R.search_arrays(hip, q, params)
+    ref = orc.search(q, 20000, 100000, 16, nthreads=3)
+    for b in range(q.shape[0]):
+        n = int(counts[b])
+        assert n == len(ref[b][0]) and n > 16384
+        rmap = dict(zip(np.asarray(ref[b][0]).tolist(), np.asarray(ref[b][1]).tolist()))
+        assert set(pids[b, :n].tolist()) == set(rmap)
+        assert max(abs(rmap[p] - sc) for p, sc in zip(pids[b, :n].tolist(), scores[b, :n].tolist())) <= SCORE_TOL
+        assert np.all(np.diff(scores[b, :n]) <= 0)
