@@ -94,17 +94,25 @@ def _pmc_traffic(kernel_prefix, applicable):
     (profiles/*_pmc_traffic.json, written by tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE in its own
     pass, doubled per MI355X_MICROARCH.md's gfx950 correction).  PMC counters cannot be collected from
     inside this process, so the number is the one measured on the default workload; any other workload
-    reports null."""
+    reports null -- and so does a summary that was measured on a DIFFERENT build of the library than the one
+    loaded now (the summary carries the sha256 of the .so it profiled)."""
     import glob
+    import hashlib
     if not applicable:
         return None, None
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))   # (tags sort by round: r02_f < r03_a)
     if not files:
         return None, None
     try:
-        ks = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        ks = doc["kernels"]
+        lib = os.path.join(here, "fast-plaid_amd", "libfastplaid_hip.so")
+        sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     except Exception:
         return None, None
+    if doc.get("library_sha16") != sha:
+        return None, "profiles/" + os.path.basename(files[-1]) + " is from another build of the library (ignored)"
     for name, e in ks.items():
         if name.startswith(kernel_prefix) and "hbm_read_bytes_corrected" in e:
             return int(e["hbm_read_bytes_corrected"]), "profiles/" + os.path.basename(files[-1])
@@ -365,10 +373,10 @@ def main():
                                                    "offsets + 2 B bound" % (lines_per_doc, ucodes_per_doc),
                          "survey_8d_accounting": {"bytes_per_launch": b_ap, "equivalent_GBps": ach_ap, "equivalent_frac": ach_ap / HBM_PEAK_GBS,
                                                   "note": "4 B (int32 code) per candidate document token, the reference algorithm's traffic"}})
-        traffic, traffic_src = _pmc_traffic("k_maxsim5", default_cfg)
+        traffic, traffic_src = _pmc_traffic("k_maxsim", default_cfg)
         t_ms = stages.get("S6+S7 maxsim", 0.0)   # the MaxSim kernel alone; the exact-order repair behind it is its own stage
         ach = bytes_maxsim / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
-        r_ms = {"kernel": "k_maxsim5 (S6+S7: fused decompress + exact MaxSim; the north star's roofline target)", "bound": "hbm",
+        r_ms = {"kernel": "k_maxsim6 (S6+S7: fused decompress + exact MaxSim; the north star's roofline target)", "bound": "hbm",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_maxsim, "avg_launch_ms": t_ms,
                 "share_of_step": t_ms / ms_per_step if ms_per_step > 0 else 0.0,

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/${TAG}_gpu_tests.log
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 20 --warmup 5 --cpu-queries 0"
@@ -47,8 +47,10 @@ for k, cs in acc.items():
     if "TCC_HIT_sum" in d:
         e["l2_hit_rate"] = round(d["TCC_HIT_sum"] / max(d["TCC_HIT_sum"] + d.get("TCC_MISS_sum", 0.0), 1.0), 4)
     out[k] = e
+import hashlib
+lib_sha = hashlib.sha256(open("$R/fast-plaid_amd/libfastplaid_hip.so", "rb").read()).hexdigest()[:16]
 json.dump({"command": "$CMD3", "note": "per-launch averages; FETCH_SIZE doubled per the guide's gfx950 correction; WRITE_SIZE uncalibrated",
-           "kernels": out}, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+           "library_sha16": lib_sha, "kernels": out}, open("$OUT/${TAG}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
 for k in sorted(out): print(k, out[k])
 PY
 cat $OUT/${TAG}_gpu_tests.log; cat $OUT/${TAG}_bench.json

@@ -11,7 +11,7 @@ def short(name):
     if "trampoline_kernel" in name and m:
         return "rocprim::" + m.group(1)
     name = re.sub(r"\(.*", "", name)
-    return name.replace("void ", "")[:80]
+    return name.replace("void ", "").replace(", ", " ").replace(",", " ")[:80]   # (no commas inside a csv field: template arguments)
 
 
 def main(src, dst, title):
