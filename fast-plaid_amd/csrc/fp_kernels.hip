@@ -1,13 +1,18 @@
 // HIP kernels of the PLAID search hot path for gfx950 (MI355X, CDNA4).  wave = 64.
 //
 // Stage map (reference rust/search/search.rs):
-//   S1 k_centroid_scores   :491        fp16 MFMA GEMM  S[b][c][q] = h(sum_k cent[c,k]*Q[b,q,k])
+//   S1 k_centroid_scores*  :491        fp16 MFMA GEMM  S[b][c][q] = h(sum_k cent[c,k]*Q[b,q,k]); the epilogue also emits the column
+//                                      maxima per 128 centroids (S2) and either level 0's excess byte per centroid or the 8-bit bins
 //   S2 k_probe_*           :518-532    per query token top-n_probe centroids -> sorted unique cells
 //   S3 k_ivf_mark/k_cand_* :535-547    IVF gather + sort + unique  == per-query doc bitmap + ordered compaction
-//   S4 k_approx_q8/k_approx:553-600    sum_q max_t S[code_t, q]   (fp16 max, fp32 sum): 8-bit bounds for every candidate,
-//                                      exact fp16 for the ones that can reach the top-R cut (or exact for all)
+//   S4                     :553-600    sum_q max_t S[code_t, q]   (fp16 max, fp32 sum), three forms with identical selections:
+//        level 0  k_l0_scan (an upper bound of every candidate from its packed code list and a per-centroid byte table in LDS)
+//                 -> k_l0_topcut / k_l0_pilot / k_l0_thr / k_l0_count / k_l0_compact -> k_approx on ~1.5 % of the candidates;
+//        k_approx_q8 (8-bit bounds of every candidate; documents with many distinct codes) -> k_approx on the survivors;
+//        k_approx (exact fp16 for every candidate: small candidate sets, traces)
 //   S5 k_sel_*             :602-623    top-R by approx (radix select, ties -> lower doc id)
-//   S6+S7 k_maxsim         :626-656    decompress (search.rs:53-107) fused with the exact MaxSim
+//   S6+S7 (fp_maxsim.hip)  :626-656    decompress (search.rs:53-107) fused with the exact MaxSim: k_maxsim6 / k_maxsim5 / k_maxsim_generic,
+//                                      k_final_mark + k_maxsim_repair (exact-order repair of near-tied scores)
 //   S8 k_final_topk        :658-692    sort by (score desc, doc id asc), truncate to top_k
 // Beside the search path: k_token_scores (search.rs:668-686), k_reconstruct (embeddings.rs), k_assign_* / k_quantize_pack
 // (index/create.rs:148-184, :404-428), shard helpers, the exhaustive arithmetic self-test.
@@ -3131,8 +3136,9 @@ void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t*
 // ============================================================================================
 // sharded-search helpers.  Both exchanges move ONE fixed-size record buffer per rank (include/fastplaid.h):
 //   rec1 {i64 pid; f32 approx; i32 pad}                       local top-R candidates by approximate score
-//   rec2 {i64 pid; f32 score; f32 exact; f32 unc; i32 pad}    exact scores of the local survivors of the global cut: the MFMA score,
-//                                                             its uncertainty budget, and the fully repaired (reference) score
+//   rec2 {i64 pid; f32 score; f32 unc_down; f32 unc; i32 pad} scores of the local survivors of the global cut: the MFMA score, its
+//                                                             uncertainty budget (unc) and the part of it by which the reference's
+//                                                             score may be LOWER (unc_down); record 0's pad carries the rank's status
 // all_rec* = [G][B][R] as an all-gather lays them out.  The last stage marks the near-tied flagged documents on the UNION exactly
 // as the unsharded search does on its rerank list and takes `exact` for them, `score` for the others: same result bit for bit.
 // ============================================================================================

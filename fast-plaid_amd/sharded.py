@@ -9,7 +9,7 @@ and a contiguous, token-balanced range of documents.  Per batch of queries:
   all-gather        [B,R] records {i64 id, f32 approx} (16 B)                                  (R = max(n_full/4, 1))
   stage2  (local)   global top-R cut == search.rs:605-619 applied to the union, exact
                     MaxSim of the survivors that live here
-  all-gather        [B,R] records {i64 id, f32 score, f32 -, f32 budget} (24 B)
+  all-gather        [B,R] records {i64 id, f32 score, f32 budget_down, f32 budget} (24 B)
   stage3  (local)   union in id order, near-tie marking as in the unsharded search (identical on every rank); exact-order
                     repair of the marked documents that live here
   all-gather        [B,R] f32: the repaired scores, by union position
@@ -71,7 +71,7 @@ def shard_arrays(arrays: dict, begin: int, end: int) -> dict:
 
 
 REC1_BYTES = 16   # fp_shard_rec1 {i64 pid; f32 approx; i32 pad}
-REC2_BYTES = 24   # fp_shard_rec2 {i64 pid; f32 score; f32 exact; f32 unc; i32 pad}
+REC2_BYTES = 24   # fp_shard_rec2 {i64 pid; f32 score; f32 unc_down; f32 unc; i32 pad}
 REC1_DTYPE = np.dtype([("pid", "<i8"), ("approx", "<f4"), ("pad", "<i4")])
 REC2_DTYPE = np.dtype([("pid", "<i8"), ("score", "<f4"), ("unc_down", "<f4"), ("unc", "<f4"), ("pad", "<i4")])
 

@@ -41,8 +41,8 @@ typedef struct fp_shard_ctx fp_shard_ctx; /* one in-flight sharded search (multi
  * Trailing padding rows on doc_codes/doc_residuals (python load.py:298-320) are ignored:
  * only the first sum(doc_lengths) rows are read. */
 typedef struct fp_index_desc {
-  int32_t nbits;                  /* 2 or 4 (8 % nbits == 0; dim*nbits % 8 == 0)          */
-  int32_t dim;                    /* embedding dimension (64 or 128)                      */
+  int32_t nbits;                  /* 1, 2, 4 or 8 (8 % nbits == 0)                        */
+  int32_t dim;                    /* embedding dimension: any multiple of 8 up to 1024    */
   int64_t n_centroids;            /* rows of `centroids`                                  */
   const uint16_t* centroids;      /* [n_centroids, dim] f16                               */
   const uint16_t* avg_residual;   /* [dim] f16 -- accepted, unused by search (may be NULL) */
@@ -116,8 +116,8 @@ int fp_dev_upload(int device_id, void* dev_dst, const void* host_src, size_t byt
 int fp_dev_download(int device_id, void* host_dst, const void* dev_src, size_t bytes);
 
 /* fp_search with the queries already in HBM and the results left in HBM: every pointer except `params` is a DEVICE
- * pointer on the index's GPU (no subsets).  Results are complete when the call returns.  This is what `bench.py` times
- * for `value` (inputs resident in HBM); fp_search adds the host <-> device copies of queries and results. */
+ * pointer on the index's GPU (no subsets).  Results are complete when the call returns.  bench.py times fp_search (the host
+ * boundary) for `value` and this entry point for `value_device_io`; the difference is the PCIe copy of queries and results. */
 int fp_search_device(const fp_index* index, const uint16_t* dev_queries, int32_t n_queries, int32_t q_len, int32_t dim,
                      const fp_search_params* params, int64_t* dev_out_pids, float* dev_out_scores, int32_t* dev_out_counts);
 
