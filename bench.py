@@ -206,6 +206,7 @@ def main():
         for i in range(a.warmup):
             step(i)
         stage_acc: dict[str, float] = {}
+        s4_form = None
         lat = []
         cand_total = 0
         exact_total = 0
@@ -228,6 +229,7 @@ def main():
                 for k, v in R.last_search_timings().items():
                     stage_acc[k] = stage_acc.get(k, 0.0) + v
                 cnts = R.last_search_counts()
+                s4_form = cnts.get("s4_form")
                 cand_total += cnts["candidates"]
                 exact_total += cnts["approx_exact"]
                 repaired_total += cnts.get("repaired", 0)
@@ -252,7 +254,7 @@ def main():
             dev_elapsed = time.perf_counter() - t1
             del dq, dp, dsc, dc
         return dict(index=index, elapsed=elapsed, lat=lat, stage_acc=stage_acc, cand_total=cand_total, exact_total=exact_total,
-                    repaired_total=repaired_total,
+                    repaired_total=repaired_total, s4_form=s4_form,
                     t_build=t_build, dev_elapsed=dev_elapsed)
 
     if use_dist:
@@ -345,7 +347,7 @@ def main():
         t_ap = stages.get("S4 approx", 0.0)
         b_ap = cand_per_step * a.doc_len * 4
         used_bounds = exact_total < cand_total
-        l0 = stages.get("S4 prepare", 0.0) > 0.0
+        l0 = res.get("s4_form") == "l0"   # (the library reports which form of S4 the stage passes ran)
         ap_name = "k_l0_scan" if l0 else ("k_approx_q8" if used_bounds else "k_approx")
         ap_what = {"k_l0_scan": " (S4 level 0: upper bound of every candidate from its code list and a per-centroid byte table in LDS)",
                    "k_approx_q8": " (S4: 8-bit bounds of every candidate)", "k_approx": " (S4: exact approximate score of every candidate)"}[ap_name]

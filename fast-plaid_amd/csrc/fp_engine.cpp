@@ -238,7 +238,7 @@ struct fp_index {
 
 static thread_local float g_last_ms[ST_N];
 static thread_local bool g_have_ms = false;
-static thread_local int64_t g_last_counts[4];  // candidates, exact-scored docs, exact-scored tokens, sub-batches
+static thread_local int64_t g_last_counts[5];  // candidates, exact-scored docs, repaired docs, sub-batches, form of S4 (0 exact / 1 8-bit bounds / 2 level 0; -1: replayed graph)
 
 // results of one (sub-)batch in one device block: ids | scores | counts
 struct OutLayout {
@@ -1191,6 +1191,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       s->graph.last[6] = (int64_t)s->alloc_gen;
     }
     if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
+    g_last_counts[4] = replayed ? -1 : P.approx_impl;
     g_last_counts[0] += M_true;
     g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
@@ -1327,7 +1328,7 @@ extern "C" int fp_search_trace(const fp_index* index, const uint16_t* query, int
 }
 
 extern "C" int fp_last_search_counts(int64_t* out, int cap) {
-  int n = std::min(cap, 4);
+  int n = std::min(cap, 5);
   for (int i = 0; i < n; ++i) out[i] = g_last_counts[i];
   return n;
 }

@@ -335,9 +335,10 @@ def maxsim_columns(index: PyLoadedIndex, query_f16, pids) -> dict:
 
 
 def last_search_counts() -> dict:
-    out = (C.c_int64 * 4)()
-    N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 4)
-    return dict(candidates=int(out[0]), approx_exact=int(out[1]), repaired=int(out[2]), sub_batches=int(out[3]))
+    out = (C.c_int64 * 5)()
+    N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 5)
+    return dict(candidates=int(out[0]), approx_exact=int(out[1]), repaired=int(out[2]), sub_batches=int(out[3]),
+                s4_form={0: "exact", 1: "q8", 2: "l0", -1: "replayed graph"}.get(int(out[4]), "?"))
 
 
 def export_index_arrays(index: PyLoadedIndex, centroids=None, bucket_weights=None) -> dict:

@@ -13,4 +13,4 @@ run cfg4 --docs 100000 --doc-len 1024 --batch 32 --topk 100
 run cfg5 --docs 5000000 --centroids 65536 --batch 128
 run cfg5_nfull16k --docs 5000000 --centroids 65536 --batch 128 --nfull 16384
 run cfg5_nfull64k --docs 5000000 --centroids 65536 --batch 128 --nfull 65536
-run cfg3_1gpu --docs 10000000 --batch 256
+run cfg3_1gpu --config cfg3
