@@ -1407,7 +1407,7 @@ void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* qpad, const FpSearc
                        int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st) {
   if (!fpk_maxsim_fast_shape(ix.dim, ix.nbits) || !aux.unc) return;   // the generic kernel never flags
   // one wave per document; workgroups beyond a query's marked count exit at once
-  const dim3 grid((unsigned)std::min<int64_t>(marks ? 512 : 4096, Rcap), (unsigned)sh.B);
+  const dim3 grid((unsigned)std::min<int64_t>(marks ? 192 : 4096, Rcap), (unsigned)sh.B);   // (workgroups walk the marked list with this stride: ~140 marked documents per query at cfg2)
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
     hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \
