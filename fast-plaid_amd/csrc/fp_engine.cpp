@@ -132,7 +132,7 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -199,13 +199,15 @@ struct Scratch {
   HostBuf h_qin;
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
+  bool pref_ready = false;      // ms_pref holds the prefix of sel_cnt (left by S5's last kernel)
+  bool probe_fb = false;        // a batch overflowed the threshold probe's tie room once: the fallback kernels are enqueued from then on
   int l0_poor = 0;              // consecutive batches in which level 0 let more than a quarter of the candidates through
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
   void destroy() {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets})
       b->release();
     h_out.release();
     h_small.release();
@@ -687,6 +689,8 @@ struct Pipe {
   bool l0_ready = false;  // S1 produced level 0's floors and excess table (instead of the 8-bit table)
   bool allow_spec = false;   // fp_search / fp_search_device: M may be the learnt capacity instead of this batch's total (no mid-pipeline sync)
   bool spec = false;         // ... and it was
+  bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
+  bool probe_prezeroed = false, selhist_prezeroed = false, l0hist_prezeroed = false;   // cleared by the batch's first kernel
 };
 
 // after a batch: the candidate capacity the next batch of this shape runs on (see run_front)
@@ -706,7 +710,28 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   hipStream_t st = s->st;
   const int B = sh.B;
   HIPCHK(s->qpad.ensure((size_t)B * sh.Qp * D.dim * 2));
-  fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st);
+  // The counters, flags and histograms the later stages expect zeroed are cleared by the batch's first kernel (every
+  // hipMemsetAsync is a launch of its own: five of them were ~20 us of a 400 us one-query search).
+  FpZeroList zl{};
+  P.nchunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, D.C / 2048));
+  HIPCHK(s->partial.ensure(fpk_probe_scratch_bytes(D, sh, P.nchunk)));
+  HIPCHK(s->invalid.ensure((size_t)B * 4));
+  HIPCHK(s->tickets.ensure((size_t)(2 * B + 4) * 4));   // [B + 1] candidate lists, [B + 1] survivor lists
+  HIPCHK(s->hist.ensure(fpk_sel_hist_bytes(B)));
+  {
+    void* zp = nullptr;
+    size_t zb = 0;
+    P.probe_prezeroed = sh.n_probe >= 1 && fpk_probe_zero_region(D, sh, P.nchunk, s->partial.as<unsigned long long>(), &zp, &zb) && zl.add(zp, zb);
+    (void)zl.add(s->invalid.p, (size_t)B * 4);
+    (void)zl.add(s->tickets.p, (size_t)(2 * B + 4) * 4);
+    P.selhist_prezeroed = zl.add(s->hist.p, fpk_sel_hist_bytes(B));
+    P.l0hist_prezeroed = false;
+    if (fpk_l0_fits(D)) {
+      HIPCHK(s->l0_hist.ensure(fpk_l0_hist_bytes(B)));
+      P.l0hist_prezeroed = zl.add(s->l0_hist.p, fpk_l0_hist_bytes(B));
+    }
+  }
+  fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st, &zl);
   STAGE_DONE(ST_CENTROID);
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
@@ -753,8 +778,6 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   P.W = ((D.N + 31) / 32 + 63) & ~63ll;
   if (P.W < 64) P.W = 64;
   P.Cw = (D.C + 31) / 32;
-  HIPCHK(s->invalid.ensure((size_t)B * 4));
-  HIPCHK(hipMemsetAsync(s->invalid.p, 0, (size_t)B * 4, st));
   if (has_subset) {
     const int64_t ns = h_sub_off[B];
     HIPCHK(s->sub_ids.ensure((size_t)std::max<int64_t>(ns, 1) * 8));
@@ -772,15 +795,14 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   const int np = (int)std::max<int64_t>(sh.n_probe, 1);
   int NP = 1;
   while (NP < np) NP <<= 1;
-  P.nchunk = (int)std::min<int64_t>(16, std::max<int64_t>(1, D.C / 2048));
   (void)NP;
-  HIPCHK(s->partial.ensure(fpk_probe_scratch_bytes(D, sh, P.nchunk)));
   HIPCHK(s->cells.ensure((size_t)B * sh.Q * np * 4));
   HIPCHK(s->ucells.ensure((size_t)B * sh.Q * np * 4));
   HIPCHK(s->ncells.ensure((size_t)B * 4));
   if (sh.n_probe >= 1) {
     if (fpk_probe(D, s->S.as<uint16_t>(), sh, has_subset ? s->allow.as<uint32_t>() : nullptr, s->partial.as<unsigned long long>(),
-                  P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), s->cmax128.as<uint16_t>(), st))
+                  P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), s->cmax128.as<uint16_t>(), st,
+                  P.probe_prezeroed, !P.probe_no_fb))
       return fail(FP_EUNSUPPORTED, "n_ivf_probe");
   } else {
     HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result
@@ -805,13 +827,17 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     for (int i = 0; i < 4; ++i) s->spec_key[i] = key[i];
   }
   P.spec = P.allow_spec && spec_env && s->spec_cap > 0;
-  HIPCHK(s->spec_total.ensure(16));   // {candidate total, fp_shard_search's overflow mark}
+  HIPCHK(s->spec_total.ensure(32));   // {candidate total, fp_shard_search's overflow mark (int32 at byte 8), the probe's overflow flag (int32 at byte 16)}
   int64_t* d_total = s->spec_total.as<int64_t>();
   fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                  s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st, P.spec ? s->spec_cap : 0,
-                 s->invalid.as<int32_t>(), d_total);
+                 s->invalid.as<int32_t>(), d_total, s->tickets.as<uint32_t>(),
+                 sh.n_probe >= 1 ? fpk_probe_flag(D, sh, P.nchunk, s->partial.as<unsigned long long>()) : nullptr);
   HIPCHK(s->h_small.ensure(4096));
-  HIPCHK(hipMemcpyAsync(s->h_small.p, d_total, 8, hipMemcpyDeviceToHost, st));
+  // total (8 bytes) and, at byte 16, the probe flag: one copy.  (Bytes 8..15 of the pinned block are rewritten by the survivor
+  // total's copy further down when there is one.)
+  if (sh.n_probe < 1) HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(d_total) + 16, 0, 4, st));
+  HIPCHK(hipMemcpyAsync(s->h_small.p, d_total, 24, hipMemcpyDeviceToHost, st));
   STAGE_DONE(ST_COMPACT);
   int64_t M;
   if (P.spec) {
@@ -865,7 +891,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
       HIPCHK(s->l0_ub.ensure(((size_t)M + 8 * (size_t)B + 16) * 2));   // rows start on 16-byte boundaries (l0_row)
       const int64_t pcap = fpk_l0_pilot_cap();
-      HIPCHK(s->l0_hist.ensure((size_t)B * 4096 * 4));
+      HIPCHK(s->l0_hist.ensure(fpk_l0_hist_bytes(B)));
       HIPCHK(s->l0_npilot.ensure((size_t)B * 4));
       HIPCHK(s->l0_pilot_pid.ensure((size_t)B * pcap * 4));
       HIPCHK(s->l0_pilot_approx.ensure((size_t)B * pcap * 4));
@@ -880,8 +906,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                     s->l0_ub.as<uint16_t>(), s->l0_hist.as<uint32_t>(), s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), s->l0_blkx.as<int32_t>(), nblk2,
                     s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>(),
                     s->l0_pilot_idx.as<int32_t>(), s->l0_capprox.as<float>(), s->l0_thr.as<int32_t>(), s->l0_nextra.as<int32_t>(),
-                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>()};
-      fpk_l0_prepare(D, nullptr, sh, w, st);   // floors and table came with S1
+                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>(), s->tickets.as<uint32_t>() + (B + 1)};
+      fpk_l0_prepare(D, nullptr, sh, w, st, P.l0hist_prezeroed);   // floors and table came with S1
       STAGE_DONE(ST_APPROX);
       // (grid: from the previous batch's total when M is the learnt capacity -- every extra workgroup copies the table into LDS;
       // the kernel strides if this batch has more)
@@ -930,11 +956,14 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->sel_approx.ensure((size_t)B * sh.R * 4));
   HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
   HIPCHK(s->tie_pid.ensure((size_t)B * sh.R * 4));
+  HIPCHK(s->ms_pref.ensure((size_t)(B + 1) * 8));
   fpk_select(sh, sel_off, sel_src, s->approx.as<float>(), s->hist.as<uint32_t>(),
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st,
              /*short_lists: one workgroup per query; pays off when there are too few queries to fill the chip anyway (measured: B = 8
-               46 vs 53 us, B = 64 90 vs 71 us)*/ B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B));
+               46 vs 53 us, B = 64 90 vs 71 us)*/ B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B),
+             P.selhist_prezeroed, s->ms_pref.as<int64_t>());
+  s->pref_ready = true;   // (whoever edits sel_cnt before S6 -- the sharded search's cut -- clears it)
   STAGE_DONE(ST_MAXSIM);
   return FP_OK;
 }
@@ -943,7 +972,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
 // near-tied in the final ranking are re-evaluated with the reference's ascending-k chain.  The sharded search splits this:
 // mode 0 = MFMA pass only (scores + budgets stay in the scratch), mode 2 = repair every flagged document of the previous
 // mode-0 pass (the final ranking is only known after the exchange).
-static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, int mode, bool stage_event = false) {
+static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t R, int64_t top_k, int mode, bool stage_event = false,
+                      bool pref_ready = false /*S5 of THIS batch left the count prefix in ms_pref and sel_cnt is untouched since*/) {
   const FpIndexDev& D = ix->d;
   hipStream_t st = s->st;
   const int B = sh.B;
@@ -964,8 +994,9 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
   }
   if (mode != 2) {
     if (fpk_maxsim(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R, s->exact.as<float>(),
-                   s->ms_pref.as<int64_t>(), aux, st))
+                   s->ms_pref.as<int64_t>(), aux, st, pref_ready && s->pref_ready))
       return fail(FP_EUNSUPPORTED, "dim/nbits");
+    s->pref_ready = false;
     LAUNCHCHK("MaxSim");
   }
   if (stage_event) STAGE_DONE(ST_REPAIR);   // "S6+S7 maxsim" is the MaxSim kernel alone (+ the 4 us prefix kernel in front of it)
@@ -1059,7 +1090,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     const bool graph_ok = graph_env && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3 &&
                           P.sh.R <= FP_MAX_SORT;   // (beyond it the final ranking allocates and synchronises: not capturable)
     const size_t qbytes = (size_t)B * Q * D.dim * 2;
-    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)s->alloc_gen, 1};
+    P.probe_no_fb = !tr && !s->probe_fb;
+    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)s->alloc_gen, s->probe_fb ? 2 : 1};
     bool replayed = false;
     if (graph_ok && s->graph.valid && std::equal(gkey, gkey + 8, s->graph.key)) {
       memcpy(s->h_qin.p, queries, qbytes);
@@ -1114,7 +1146,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
     // S6+S7
     const int64_t R = P.sh.R;
-    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true)) return rc;
+    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true, true)) return rc;
     STAGE_DONE(ST_TOPK);
     // S8
     HIPCHK(s->out_all.ensure(ol.total));
@@ -1173,6 +1205,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     if (!dev_io) ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
     const int64_t M_true = *reinterpret_cast<const int64_t*>(s->h_small.p);
+    if (P.probe_no_fb && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 16) != 0) {
+      // some column had more ties at its probe threshold than the candidate lists hold: the device probed nothing (k_probe_merge);
+      // run the batch again with the register top-k fallback, and keep it enqueued for this scratch from now on
+      s->probe_fb = true;
+      b0 -= maxB;
+      continue;
+    }
     if (P.spec && M_true > P.M) {
       // more candidates than the capacity learnt from earlier batches: the device emptied the batch (k_cand_offsets); run it again,
       // this time waiting for the total
@@ -1922,7 +1961,7 @@ static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* 
       need(s->sel_approx.ensure((size_t)B * R * 4));
       need(s->exact.ensure((size_t)B * R * 4));
       need(s->h_small.ensure(4096));
-      need(s->spec_total.ensure(16));
+      need(s->spec_total.ensure(32));
       need(s->tmpp.ensure((size_t)B * R * 8));
       need(s->tmpf.ensure((size_t)4 * B * R * 4));
       need(s->u_cnt.ensure((size_t)B * 4));

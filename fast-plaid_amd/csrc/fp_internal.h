@@ -107,8 +107,23 @@ struct FpSearchShape {
   int64_t n_full;
 };
 
+// regions (16-byte aligned, sizes in 16-byte units) that the first kernel of a batch clears on its way: the counters, flags and
+// histograms later stages expect zeroed
+#define FP_ZERO_REGIONS 6
+struct FpZeroList {
+  void* p[FP_ZERO_REGIONS];
+  uint32_t n16[FP_ZERO_REGIONS];
+  int n;
+  bool add(void* ptr, size_t bytes) {
+    if (n >= FP_ZERO_REGIONS || bytes > ((size_t)1 << 30)) return false;
+    p[n] = ptr;
+    n16[n] = (uint32_t)((bytes + 15) / 16);
+    ++n;
+    return true;
+  }
+};
 void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B*Qp,D]*/, int B, int Q, int Qp, int D,
-                      hipStream_t st);
+                      hipStream_t st, const FpZeroList* zero = nullptr);
 // S8 (nullable; written only when Qp == 32): 8-bit bins [B][C][32]; cmax (nullable): [B*Qp][ceil(C/128)] f16 column maxima per 128-centroid tile
 // S1's optional by-product for S4's level 0: the excess table e8[b][Cpad] (one byte per query and centroid) computed in the
 // epilogue from the column floors of a sampled pre-pass
@@ -124,8 +139,14 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
                         hipStream_t st, int64_t n_rows = 0, int64_t row_stride = 1, const FpS1Excess* exc = nullptr);
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow /*[B][Cw] or null*/,
               unsigned long long* partial, int nchunk, int32_t* cells /*[B][Q][n_probe]*/, int32_t* ucells /*[B][Q*n_probe]*/,
-              int32_t* ncells /*[B]*/, const uint16_t* cmax128 /*nullable: S1's [B*Qp][ceil(C/128)] column maxima*/, hipStream_t st);
+              int32_t* ncells /*[B]*/, const uint16_t* cmax128 /*nullable: S1's [B*Qp][ceil(C/128)] column maxima*/, hipStream_t st,
+              bool prezeroed = false /*the region of fpk_probe_zero_region was cleared earlier in the stream*/,
+              bool with_fallback = true /*false: a column with too many ties at its threshold leaves *fpk_probe_flag != 0 and NO cells;
+                                          the caller reads the flag back and runs the batch again with the fallback*/);
 size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);
+// the counters + overflow flag the threshold probe expects zeroed (inside `partial`); false = this shape takes the other path
+bool fpk_probe_zero_region(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial, void** p, size_t* bytes);
+const int32_t* fpk_probe_flag(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, const unsigned long long* partial);
 void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off /*[B+1] dev*/, int B,
                         uint32_t* subbm /*[B][W]*/, int64_t W, uint32_t* allow /*[B][Cw]*/, int64_t Cw,
                         int32_t* invalid /*[B]*/, hipStream_t st);
@@ -134,7 +155,9 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
 // candidate compaction: count -> scan -> offsets -> compact (ascending doc ids)
 void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                     int32_t* blkcnt, int nblk, int32_t* ncand, int64_t* cand_off /*[B+1]*/, hipStream_t st,
-                    int64_t cap /*0: none*/, int32_t* invalid_rw, int64_t* total_out);
+                    int64_t cap /*0: none*/, int32_t* invalid_rw, int64_t* total_out /*{total, -, int32 probe flag at byte 16}*/,
+                    uint32_t* tickets = nullptr /*[B + 1] zeroed counters -> one launch instead of three*/,
+                    const int32_t* probe_flag = nullptr);
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkcnt /*exclusive-scanned*/, int nblk, const int64_t* cand_off, int32_t* cand_pid,
                       hipStream_t st);
@@ -171,10 +194,13 @@ struct FpL0Scratch {
   int32_t* nextra;      // [B] survivors outside the pilot group
   int32_t* xpid;        // [M] rows at surv_off[b]: their document ids ...
   int32_t* xdst;        // [M] ... and positions in the survivor list
+  uint32_t* tickets;    // nullable: [B + 1] zeroed counters -> count + scans + offsets of the survivor lists in ONE launch
 };
 bool fpk_l0_fits(const FpIndexDev& ix);
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8 /*nullptr: floors and table came with S1*/, const FpSearchShape& sh, FpL0Scratch& w,
-                    hipStream_t st);
+                    hipStream_t st, bool hist_prezeroed = false);
+size_t fpk_l0_hist_bytes(int B);
+size_t fpk_sel_hist_bytes(int B);
 void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride);
 void fpk_l0_floors(const uint8_t* S8_sample, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc,
                    uint16_t* gfl /*[B][Qp] fp16 floors for S1's epilogue*/, hipStream_t st);
@@ -187,7 +213,9 @@ void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const in
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st,
-                bool short_lists = false /*lists of a few thousand entries: one workgroup per query does the whole radix select*/);
+                bool short_lists = false /*lists of a few thousand entries: one workgroup per query does the whole radix select*/,
+                bool hist_prezeroed = false,
+                int64_t* pref = nullptr /*the last kernel also writes the [B + 1] prefix of sel_cnt here*/);
 // ---- fp_maxsim.hip ---------------------------------------------------------------------------
 // per-token norms of a freshly laid-out index (centroids / lut / codes / residuals set in `ix`)
 void fpk_token_norms(const FpIndexDev& ix, uint16_t* norms, hipStream_t st);
@@ -207,7 +235,8 @@ void fpk_resid_native(const FpIndexDev& ix, int64_t t0, int64_t n, uint8_t* tmp,
 void fpk_token_rinv(const FpIndexDev& ix, uint32_t* rinv, unsigned long long* n_hard_dev, hipStream_t st);
 // exact scores of the rerank lists; pref = [B+1] int64 scratch
 int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
-               int64_t Rcap, float* exact /*[B][Rcap]*/, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st);
+               int64_t Rcap, float* exact /*[B][Rcap]*/, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st,
+               bool pref_ready = false /*the selection already left the prefix of sel_cnt in pref (fpk_select's pref argument)*/);
 // flagged documents that are near-tied in the final ranking -> marks [B][stride], nmark [B]; -1 when stride is too large for LDS
 int fpk_final_mark(const float* score, const float* unc, const float* uncm /*nullable: symmetric*/, const int32_t* cnt, int64_t stride, int B,
                    int64_t top_k, int32_t* marks, int32_t* nmark,

@@ -34,8 +34,13 @@
 // ============================================================================================
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
 // ============================================================================================
-__global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Q, int Qp, int D) {
+__global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Q, int Qp, int D, FpZeroList z) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
+  // the batch's small fills ride along (each hipMemsetAsync is a graph node of its own, ~4.5 us of launch tail)
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int r = 0; r < FP_ZERO_REGIONS; ++r)
+    for (int64_t j = i; j < (int64_t)z.n16[r]; j += nthreads) reinterpret_cast<uint4*>(z.p[r])[j] = make_uint4(0, 0, 0, 0);
   int64_t per_row = D / 8;
   int64_t total = (int64_t)B * Qp * per_row;
   if (i >= total) return;
@@ -47,9 +52,11 @@ __global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __rest
   *reinterpret_cast<uint4*>(out + row * D + c8 * 8) = v;
 }
 
-void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st) {
+void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st, const FpZeroList* zero) {
   int64_t total = (int64_t)B * Qp * (D / 8);
-  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D);
+  FpZeroList z{};
+  if (zero) z = *zero;
+  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D, z);
 }
 
 // ============================================================================================
@@ -557,13 +564,23 @@ __global__ __launch_bounds__(256) void k_probe_partial(const uint16_t* __restric
 }
 
 // one wave per (b, q) column: n_probe rounds of "largest key below the previous pick"
-__global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __restrict__ partial, int Q, int Qp, int entries,
+__global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __restrict__ partial, int Q, int Qp, int entries_stride,
                                                     int n_probe, int32_t* __restrict__ cells, const int32_t* __restrict__ flag,
-                                                    int run_if) {
-  if (flag && ((*flag != 0) != (run_if != 0))) return;
+                                                    int run_if, const uint32_t* __restrict__ cnt /*nullable: valid entries per column*/) {
+  int entries = entries_stride;
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
-  const unsigned long long* src = partial + ((int64_t)b * Qp + q) * entries;
+  if (flag && ((*flag != 0) != (run_if != 0))) {
+    // the threshold path gave up (a column overflowed its list): no cells, unless the fallback that follows writes them
+    if (run_if == 0)
+      for (int r = lane; r < n_probe; r += 64) cells[((int64_t)b * Q + q) * n_probe + r] = -1;
+    return;
+  }
+  if (cnt) {
+    const int have = (int)cnt[(int64_t)b * Qp + q];
+    entries = have < entries ? have : entries;
+  }
+  const unsigned long long* src = partial + ((int64_t)b * Qp + q) * entries_stride;
   unsigned long long bound = ~0ull;
   for (int r = 0; r < n_probe; ++r) {
     unsigned long long m = 0ull;
@@ -932,31 +949,64 @@ size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, in
   return cols * PROBE_CAP * 8 + cols * nchunk * 8 * NP * 8 + ((cols * nch2 * 2 + 15) & ~(size_t)15) + cols * 4 + cols * 4 + 64 + bitmap;
 }
 
+namespace {
+struct ProbeLayout {
+  int NP, nch2;
+  bool big_probe, threshold_ok;
+  size_t cols;
+  unsigned long long *cand, *fb_partial;
+  uint16_t* cmax;
+  uint32_t *tau, *cnt;
+  int32_t* flag;
+};
+ProbeLayout probe_layout(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial) {
+  ProbeLayout L;
+  L.NP = 1;
+  while (L.NP < sh.n_probe && L.NP < 32) L.NP <<= 1;   // register top-k fallback: n_probe <= 32 (beyond: k_probe_select)
+  L.big_probe = sh.n_probe > 32;
+  L.cols = (size_t)sh.B * sh.Qp;
+  L.nch2 = (int)((ix.C + PROBE_CHUNK - 1) / PROBE_CHUNK);
+  unsigned char* base = reinterpret_cast<unsigned char*>(partial);
+  L.cand = reinterpret_cast<unsigned long long*>(base);
+  L.fb_partial = reinterpret_cast<unsigned long long*>(base + L.cols * PROBE_CAP * 8);
+  unsigned char* p2 = base + L.cols * PROBE_CAP * 8 + L.cols * nchunk * 8 * L.NP * 8;
+  L.cmax = reinterpret_cast<uint16_t*>(p2);
+  p2 += (L.cols * L.nch2 * 2 + 15) & ~(size_t)15;
+  L.tau = reinterpret_cast<uint32_t*>(p2);
+  L.cnt = L.tau + L.cols;
+  L.flag = reinterpret_cast<int32_t*>(L.cnt + L.cols);
+  static const int force_fb = getenv("FP_PROBE_FALLBACK") ? 1 : 0;
+  // the chunk index must fit the 12 low bits of the tau keys; room for ties at the cut in the candidate list
+  L.threshold_ok = L.nch2 <= 4096 && sh.n_probe <= PROBE_CAP / 2 && !force_fb;
+  return L;
+}
+}  // namespace
+
+bool fpk_probe_zero_region(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial, void** p, size_t* bytes) {
+  const ProbeLayout L = probe_layout(ix, sh, nchunk, partial);
+  *p = L.cnt;                     // (16-byte aligned: cols is a multiple of 32)
+  *bytes = L.cols * 4 + 4;        // counters + flag; rounded up to 16 it ends where the cell bitmap begins
+  return L.threshold_ok;
+}
+const int32_t* fpk_probe_flag(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, const unsigned long long* partial) {
+  return probe_layout(ix, sh, nchunk, const_cast<unsigned long long*>(partial)).flag;
+}
+
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
               unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells,
-              const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st) {
+              const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st, bool prezeroed, bool with_fallback) {
   const int64_t Cw = (ix.C + 31) / 32;
-  int NP = 1;
-  while (NP < sh.n_probe && NP < 32) NP <<= 1;   // register top-k fallback: n_probe <= 32 (beyond: k_probe_select)
-  const bool big_probe = sh.n_probe > 32;
-  const size_t cols = (size_t)sh.B * sh.Qp;
-  const int nch2 = (int)((ix.C + PROBE_CHUNK - 1) / PROBE_CHUNK);
-  unsigned char* base = reinterpret_cast<unsigned char*>(partial);
-  unsigned long long* cand = reinterpret_cast<unsigned long long*>(base);
-  unsigned long long* fb_partial = reinterpret_cast<unsigned long long*>(base + cols * PROBE_CAP * 8);
-  unsigned char* p2 = base + cols * PROBE_CAP * 8 + cols * nchunk * 8 * NP * 8;
-  uint16_t* cmax = reinterpret_cast<uint16_t*>(p2);
-  p2 += (cols * nch2 * 2 + 15) & ~(size_t)15;
-  uint32_t* tau = reinterpret_cast<uint32_t*>(p2);
-  uint32_t* cnt = tau + cols;
-  int32_t* flag = reinterpret_cast<int32_t*>(cnt + cols);
-  // the chunk index must fit the 12 low bits of the tau keys
-  static int force_fb = -1;
-  if (force_fb < 0) force_fb = getenv("FP_PROBE_FALLBACK") ? 1 : 0;
-  const bool threshold_ok = nch2 <= 4096 && sh.n_probe <= PROBE_CAP / 2 && !force_fb;   // room for ties at the cut in the candidate list
+  const ProbeLayout L = probe_layout(ix, sh, nchunk, partial);
+  const int NP = L.NP, nch2 = L.nch2;
+  const bool big_probe = L.big_probe;
+  unsigned long long *cand = L.cand, *fb_partial = L.fb_partial;
+  uint16_t* cmax = L.cmax;
+  uint32_t *tau = L.tau, *cnt = L.cnt;
+  int32_t* flag = L.flag;
+  const bool threshold_ok = L.threshold_ok;
   if (threshold_ok) {
-    // candidate lists, counters and the flag in one fill (the chunk maxima and thresholds between them are rewritten below)
-    (void)hipMemsetAsync(cand, 0, (size_t)(reinterpret_cast<unsigned char*>(flag) + 4 - reinterpret_cast<unsigned char*>(cand)), st);
+    // counters and the flag (the merge reads cnt[col] entries of a column's candidate list, nothing behind them)
+    if (!prezeroed) (void)hipMemsetAsync(cnt, 0, L.cols * 4 + 4, st);
     dim3 grid((unsigned)nch2, (unsigned)(sh.B * (sh.Qp / 32)));
     // S1's 128-centroid column maxima serve as the chunk maxima when no subset masks centroids and their index fits 12 bits:
     // tau is tighter, and the collect pass skips the 128-row sub-chunks that hold nothing >= tau in any of their 32 columns
@@ -972,12 +1022,14 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
                          (const uint16_t*)nullptr, 0);
     }
     hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
-                       flag, 0);
+                       flag, 0, cnt);
   } else {
     (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
   }
-  // fallback (runs only when the flag is set)
-  if (big_probe) {
+  // fallback (its kernels exit at once unless the flag is set).  Without it a flagged batch has no cells at all (k_probe_merge
+  // blanks them) and the caller, who sees the flag after its final sync, runs the batch again with the fallback.
+  if (threshold_ok && !with_fallback) {
+  } else if (big_probe) {
     hipLaunchKernelGGL(k_probe_select, dim3((unsigned)(sh.B * (sh.Qp / 32))), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, sh.n_probe, allow, Cw,
                        cells, flag);
   } else {
@@ -990,7 +1042,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     default: launch_probe_partial<32>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
   }
   hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, fb_partial, sh.Q, sh.Qp, nchunk * 8 * NP, sh.n_probe,
-                     cells, flag, 1);
+                     cells, flag, 1, (const uint32_t*)nullptr);
   }
   const int64_t n64 = (int64_t)sh.Q * sh.n_probe;
   if (n64 > 0x7FFFFFFFll / 4) return -1;
@@ -1158,9 +1210,90 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
 // ---- ordered compaction of the bitmaps ------------------------------------------------------
 #define CAND_WPT 4                           // words per thread
 #define CAND_WPB (256 * CAND_WPT)            // words per block
+// ---- "last workgroup finishes the job": the count -> scan -> offsets chains below were three or four launches of which only the
+// first has real work; each extra launch is ~4.5 us of dispatch tail (40 % of a one-query search was such tails).  Every
+// workgroup publishes its count, then takes a ticket; the one that draws the last ticket of its query scans the query's
+// counts, and the one that finishes the last query writes the offsets.  Tickets are zeroed by the batch's first kernel.
+//   No fences: an agent-scope release (__threadfence) writes back the XCD's whole L2 -- with 10^4 workgroups doing it
+//   k_l0_count took 2.1 ms instead of 20 us.  Counts are PUBLISHED with device-scope atomic exchanges (performed at the
+//   coherence point; thread 0 waits for their return before it draws the ticket) and READ with device-scope atomic loads
+//   after the ticket said "last": per-location coherence of atomics is all this needs.  What the last workgroup writes
+//   is read by the NEXT kernel only.
+__device__ __forceinline__ void fp_publish(int32_t* slot, int32_t v) {   // thread 0 only
+  const int32_t old = atomicExch(slot, v);
+  asm volatile("" ::"v"(old));   // keep the returning form
+}
+__device__ __forceinline__ int32_t fp_read_published(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool fp_ticket_last(uint32_t* ctr, uint32_t expect) {
+  __shared__ uint32_t s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // thread 0's fp_publish calls have been performed
+    s_last = atomicAdd(ctr, 1u) == expect - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  return s_last != 0u;
+}
+// exclusive scan of the published v[0..nblk) in place by a 256-thread workgroup; returns the total
+__device__ __forceinline__ int fp_scan_counts_256(int32_t* v, int nblk, int* s /*[256] LDS*/) {
+  int base = 0;
+  for (int start = 0; start < nblk; start += 256) {
+    const int i = start + (int)threadIdx.x;
+    const int x = (i < nblk) ? fp_read_published(v + i) : 0;
+    __syncthreads();
+    s[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblk) v[i] = base + s[threadIdx.x] - x;
+    base += s[255];
+  }
+  return base;
+}
+// cand_off[0..B] from the per-query totals; cap / invalid / total_out as k_cand_offsets below; a 256-thread workgroup
+__device__ __forceinline__ void fp_offsets_256(int32_t* ncand, int B, int64_t* cand_off, int64_t cap, int32_t* invalid, int64_t* total_out,
+                                               const int32_t* probe_flag) {
+  __shared__ long long so[256];
+  long long base = 0;
+  for (int start = 0; start < B; start += 256) {
+    const int i = start + (int)threadIdx.x;
+    const long long x = (i < B) ? (long long)fp_read_published(ncand + i) : 0ll;
+    __syncthreads();
+    so[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const long long t = ((int)threadIdx.x >= off) ? so[threadIdx.x - off] : 0ll;
+      __syncthreads();
+      so[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < B) cand_off[i] = base + so[threadIdx.x] - x;
+    base += so[255];
+  }
+  const bool over = cap > 0 && base > cap;
+  if (over)
+    for (int i = threadIdx.x; i < B; i += 256) { cand_off[i] = 0; invalid[i] = 1; }
+  if (threadIdx.x == 0) {
+    cand_off[B] = over ? 0 : base;
+    if (total_out) {
+      *total_out = base;
+      if (probe_flag) reinterpret_cast<int32_t*>(total_out)[4] = *probe_flag;   // travels to the host with the total
+    }
+  }
+}
+
+// ctr != nullptr: fused form -- also leaves blkcnt scanned (exclusive, per query), ncand, cand_off and *total_out
 __global__ __launch_bounds__(256) void k_cand_count(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
-                                                    const int32_t* __restrict__ invalid, int64_t W, int32_t* __restrict__ blkcnt,
-                                                    int nblk) {
+                                                    const int32_t* invalid, int64_t W, int32_t* blkcnt, int nblk,
+                                                    uint32_t* ctr = nullptr, int32_t* ncand = nullptr, int B = 0, int64_t* cand_off = nullptr,
+                                                    int64_t cap = 0, int32_t* invalid_rw = nullptr, int64_t* total_out = nullptr,
+                                                    const int32_t* probe_flag = nullptr) {
   const int b = blockIdx.y;
   int cnt = 0;
   if (!(invalid && invalid[b])) {
@@ -1182,56 +1315,69 @@ __global__ __launch_bounds__(256) void k_cand_count(const uint32_t* __restrict__
     if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+  if (!ctr) {
+    if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+    return;
+  }
+  if (threadIdx.x == 0) fp_publish(blkcnt + (int64_t)b * nblk + blockIdx.x, s[0]);
+  if (!fp_ticket_last(ctr + b, (uint32_t)nblk)) return;
+  const int total = fp_scan_counts_256(blkcnt + (int64_t)b * nblk, nblk, s);
+  if (threadIdx.x == 0) fp_publish(ncand + b, total);
+  if (!fp_ticket_last(ctr + B, (uint32_t)B)) return;
+  fp_offsets_256(ncand, B, cand_off, cap, invalid_rw, total_out, probe_flag);
 }
 
-// exclusive scan of blkcnt per query (in place) + per-query totals; one block per query
-__global__ __launch_bounds__(256) void k_cand_scan(int32_t* __restrict__ blkcnt, int nblk, int32_t* __restrict__ ncand) {
+// exclusive scan of blkcnt per query (in place) + per-query totals; one block per query.  Optionally a second array of counts
+// (blkcnt2 -> ncand2) and, with a zeroed ticket, the offsets of the FIRST array's lists by the workgroup that finishes last.
+__global__ __launch_bounds__(256) void k_cand_scan(int32_t* blkcnt, int nblk, int32_t* ncand, int32_t* blkcnt2 = nullptr, int32_t* ncand2 = nullptr,
+                                                   uint32_t* ticket = nullptr, int B = 0, int64_t* cand_off = nullptr, int64_t cap = 0,
+                                                   int32_t* invalid = nullptr, int64_t* total_out = nullptr, const int32_t* probe_flag = nullptr) {
   const int b = blockIdx.x;
   __shared__ int s[256];
-  int32_t* v = blkcnt + (int64_t)b * nblk;
-  int base = 0;
-  for (int start = 0; start < nblk; start += 256) {
-    int i = start + threadIdx.x;
-    int x = (i < nblk) ? v[i] : 0;
-    s[threadIdx.x] = x;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nblk) v[i] = base + s[threadIdx.x] - x;
-    int tot = s[255];
-    __syncthreads();
-    base += tot;
+  const int total = fp_scan_counts_256(blkcnt + (int64_t)b * nblk, nblk, s);
+  if (blkcnt2) {
+    const int total2 = fp_scan_counts_256(blkcnt2 + (int64_t)b * nblk, nblk, s);
+    if (threadIdx.x == 0) ncand2[b] = total2;
   }
-  if (threadIdx.x == 0) ncand[b] = base;
+  if (!ticket) {
+    if (threadIdx.x == 0) ncand[b] = total;
+    return;
+  }
+  if (threadIdx.x == 0) fp_publish(ncand + b, total);
+  if (!fp_ticket_last(ticket, (uint32_t)B)) return;
+  fp_offsets_256(ncand, B, cand_off, cap, invalid, total_out, probe_flag);
 }
 
 // cap > 0 (the host sized the candidate buffers from earlier batches instead of waiting for this total): a total above the
 // capacity empties every list and marks every query invalid, so that nothing downstream writes; the host sees the true total
 // in *total_out after the call's final sync and runs the batch again with buffers of the right size.
-__global__ void k_cand_offsets(const int32_t* __restrict__ ncand, int B, int64_t* __restrict__ cand_off, int64_t cap = 0,
-                               int32_t* __restrict__ invalid = nullptr, int64_t* __restrict__ total_out = nullptr) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    int64_t a = 0;
-    for (int b = 0; b < B; ++b) { cand_off[b] = a; a += ncand[b]; }
-    cand_off[B] = a;
-    if (total_out) *total_out = a;
-    if (cap > 0 && a > cap) {
-      for (int b = 0; b <= B; ++b) cand_off[b] = 0;
-      for (int b = 0; b < B; ++b) invalid[b] = 1;
-    }
-  }
+__global__ __launch_bounds__(256) void k_cand_offsets(int32_t* ncand, int B, int64_t* cand_off, int64_t cap = 0, int32_t* invalid = nullptr,
+                                                      int64_t* total_out = nullptr, const int32_t* probe_flag = nullptr) {
+  fp_offsets_256(ncand, B, cand_off, cap, invalid, total_out, probe_flag);
 }
 
+// ctr (nullable): [B + 1] zeroed tickets.  Few workgroups (a one-query search: 31): ONE launch.  Many: the tickets themselves
+// would cost more than the launches they save (device-scope atomics on one address retire at ~10 ns each: 10^4 workgroups ->
+// 0.3 ms), so only the B scanning workgroups take tickets -- two launches.
+#define FP_TICKET_MAX_WGS 384
 void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W, int32_t* blkcnt,
-                    int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st, int64_t cap, int32_t* invalid_rw, int64_t* total_out) {
-  hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk);
-  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, ncand, B, cand_off, cap, invalid_rw, total_out);
+                    int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st, int64_t cap, int32_t* invalid_rw, int64_t* total_out,
+                    uint32_t* ctr, const int32_t* probe_flag) {
+  if (ctr && (int64_t)nblk * B <= FP_TICKET_MAX_WGS) {
+    hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, ctr, ncand, B,
+                       cand_off, cap, invalid_rw, total_out, probe_flag);
+    return;
+  }
+  hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, (uint32_t*)nullptr,
+                     (int32_t*)nullptr, 0, (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
+  if (ctr) {
+    hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand, (int32_t*)nullptr, (int32_t*)nullptr, ctr + B, B,
+                       cand_off, cap, invalid_rw, total_out, probe_flag);
+    return;
+  }
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                     0, (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(256), 0, st, ncand, B, cand_off, cap, invalid_rw, total_out, probe_flag);
 }
 
 __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
@@ -1818,8 +1964,10 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
   hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), (size_t)bins * 4, st, kq, cand_off, q8hist, bins);
   hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut, bins);
   hipLaunchKernelGGL(k_surv_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cut, blkcnt, nblk);
-  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, nsurv);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr);
+  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, nsurv, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
+                     0, (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(256), 0, st, nsurv, B, surv_off, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr,
+                     (const int32_t*)nullptr);
   hipLaunchKernelGGL(k_surv_compact, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cand_pid, cut, blkcnt, nblk, surv_off,
                      surv_pid);
 }
@@ -2367,8 +2515,9 @@ static_assert(SURV_CHUNK == 256 * 8, "one 16-byte load per thread covers a chunk
 // blkcnt: survivors per chunk; blkcntx: those of them outside the pilot group ("extras": ub < cutp[b], or the group overflowed)
 __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ thr, const int32_t* __restrict__ cutp,
-                                                  const int32_t* __restrict__ npilot, int32_t* __restrict__ blkcnt,
-                                                  int32_t* __restrict__ blkcntx, int nblk) {
+                                                  const int32_t* __restrict__ npilot, int32_t* blkcnt, int32_t* blkcntx, int nblk,
+                                                  uint32_t* ctr /*nullable: [B + 1] zeroed tickets -> also the scans and surv_off*/,
+                                                  int32_t* nsurv, int32_t* nextra, int B, int64_t* surv_off) {
   const int b = blockIdx.y;
   const int64_t n = cand_off[b + 1] - cand_off[b];
   const int64_t i = (int64_t)blockIdx.x * SURV_CHUNK + threadIdx.x * 8;
@@ -2392,10 +2541,23 @@ __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ u
     if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0] & 0xFFFF;
-    blkcntx[(int64_t)b * nblk + blockIdx.x] = s[0] >> 16;
+  if (!ctr) {
+    if (threadIdx.x == 0) {
+      blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0] & 0xFFFF;
+      blkcntx[(int64_t)b * nblk + blockIdx.x] = s[0] >> 16;
+    }
+    return;
   }
+  if (threadIdx.x == 0) {
+    fp_publish(blkcnt + (int64_t)b * nblk + blockIdx.x, s[0] & 0xFFFF);
+    fp_publish(blkcntx + (int64_t)b * nblk + blockIdx.x, s[0] >> 16);
+  }
+  if (!fp_ticket_last(ctr + b, (uint32_t)nblk)) return;
+  const int tot = fp_scan_counts_256(blkcnt + (int64_t)b * nblk, nblk, s);
+  const int totx = fp_scan_counts_256(blkcntx + (int64_t)b * nblk, nblk, s);
+  if (threadIdx.x == 0) { fp_publish(nsurv + b, tot); nextra[b] = totx; }
+  if (!fp_ticket_last(ctr + B, (uint32_t)B)) return;
+  fp_offsets_256(nsurv, B, surv_off, 0, nullptr, nullptr, nullptr);
 }
 
 // A survivor that was in the pilot group (ub >= cutp[b], the group held in full) already has its exact score at
@@ -2489,11 +2651,12 @@ void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, 
 
 // S8 != nullptr: floors and the table from the full 8-bit table (two passes over it);  S8 == nullptr: both were produced
 // around S1 (fpk_l0_floors on a sampled pre-pass, the table in S1's epilogue) and only the histogram is cleared here
-void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st) {
+size_t fpk_l0_hist_bytes(int B) { return (size_t)B * L0_HBINS * 4; }
+void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, FpL0Scratch& w, hipStream_t st, bool hist_prezeroed) {
   const int B = sh.B;
   const int nch = sh.Qp / 32;
   const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
-  (void)hipMemsetAsync(w.hist, 0, (size_t)B * L0_HBINS * 4, st);
+  if (!hist_prezeroed) (void)hipMemsetAsync(w.hist, 0, fpk_l0_hist_bytes(B), st);
   if (!S8) return;
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
@@ -2522,6 +2685,9 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   // the plain grid the workgroups of ~4 queries sweep the corpus together on all XCDs and share the code lines in the
   // memory-side cache.  Experiment only: FP_L0_XCD=1.
   static const int affine_env = [] { const char* e = getenv("FP_L0_XCD"); return e ? atoi(e) : 0; }();
+  // (also tried, round 3: query-fastest dispatch order, so that the 256 resident workgroups belong to all 64 queries and walk the
+  // same stretch of the corpus together -- lines shared in L2 instead of read once per query: 0.98 ms against 0.56 ms, and
+  // fewer, longer workgroups made it worse still; profiles/r03_l0_order_lab.txt)
   const int affine = (affine_env && B % 8 == 0 && bx * (int64_t)B < (1ll << 31)) ? 1 : 0;
   const dim3 grid = affine ? dim3((unsigned)(bx * B)) : dim3((unsigned)bx, (unsigned)B);
 #ifdef FP_ABLATIONS   // timing-only variants of the scan (results are wrong): built only with -DFP_ABLATIONS, never in the shipped library
@@ -2575,11 +2741,18 @@ void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const in
                       int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st) {
   const int B = sh.B;
   hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr);
+  const bool one_launch = w.tickets && (int64_t)w.nblk * B <= FP_TICKET_MAX_WGS;
   hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.thr, w.cut, w.npilot, w.blkcnt,
-                     w.blkcntx, w.nblk);
-  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv);
-  hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcntx, w.nblk, w.nextra);
-  hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(64), 0, st, nsurv, B, surv_off, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr);
+                     w.blkcntx, w.nblk, one_launch ? w.tickets : (uint32_t*)nullptr, nsurv, w.nextra, B, surv_off);
+  if (!one_launch && w.tickets) {   // both scans and the offsets in one more launch
+    hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv, w.blkcntx, w.nextra, w.tickets + B, B, surv_off,
+                       (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
+  } else if (!one_launch) {
+    hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, w.blkcnt, w.nblk, nsurv, w.blkcntx, w.nextra, (uint32_t*)nullptr, 0,
+                       (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
+    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(256), 0, st, nsurv, B, surv_off, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr,
+                       (const int32_t*)nullptr);
+  }
   hipLaunchKernelGGL(k_l0_compact, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.thr, w.cut, w.npilot,
                      w.cand_approx, w.blkcnt, w.blkcntx, w.nblk, surv_off, surv_pid, surv_approx, w.xpid, w.xdst);
 }
@@ -2676,9 +2849,9 @@ __global__ __launch_bounds__(256) void k_sel_scan(const uint32_t* __restrict__ h
 }
 
 // ordered collect: one block per query
-__global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
-                                                      const int64_t* __restrict__ cand_off, const uint32_t* __restrict__ st,
-                                                      int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx) {
+__device__ __forceinline__ void sel_collect_body(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                 const int64_t* __restrict__ cand_off, const uint32_t* __restrict__ st,
+                                                 int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx) {
   const int b = blockIdx.x;
   const uint32_t* s = st + (int64_t)b * 8;
   if (!s[7]) return;  // fallback only: the tie buffer of k_sel_gather overflowed for this query
@@ -2729,6 +2902,35 @@ __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ 
       base_e += te;
     }
     __syncthreads();
+  }
+}
+
+// The selection's last kernel also leaves the prefix of the per-query rerank counts that S6 maps its work items with (workgroup
+// 0 writes pref[0..B]) -- one launch less in front of MaxSim.
+__global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                      const int64_t* __restrict__ cand_off, const uint32_t* __restrict__ st,
+                                                      int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
+                                                      const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref /*nullable*/, int B) {
+  sel_collect_body(approx, cand_pid, cand_off, st, R, sel_pid, sel_approx);
+  if (!pref || blockIdx.x != 0) return;   // (sel_cnt is final before this kernel starts: k_sel_init / k_sel_front wrote it)
+  __syncthreads();
+  __shared__ long long sp[1024];
+  long long base = 0;
+  if (threadIdx.x == 0) pref[0] = 0;
+  for (int start = 0; start < B; start += 1024) {
+    const int i = start + (int)threadIdx.x;
+    const long long x = (i < B) ? (long long)sel_cnt[i] : 0ll;
+    __syncthreads();
+    sp[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const long long t = ((int)threadIdx.x >= off) ? sp[threadIdx.x - off] : 0ll;
+      __syncthreads();
+      sp[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < B) pref[i + 1] = base + sp[threadIdx.x];
+    base += sp[1023];
   }
 }
 
@@ -2996,9 +3198,10 @@ __global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) st[(int64_t)b * 8 + 7] = 1u;
 }
+size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t); }
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
                 uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
-                bool short_lists) {
+                bool short_lists, bool hist_prezeroed, int64_t* pref) {
   const int B = sh.B;
   if (short_lists) {
     hipLaunchKernelGGL(k_sel_front, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, sh.n_full, sh.R, selstate, sel_pid, sel_approx,
@@ -3008,11 +3211,12 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     int kp2 = 2;
     while (kp2 < (int)sh.R) kp2 <<= 1;
     hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8, st, selstate, sh.R, sel_pid, sel_approx, tie_pid);
-    hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx);
+    hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
+                       sel_cnt, pref, B);
     return;
   }
   const bool big = sh.R > FP_MAX_SORT;   // beyond k_sel_finish's LDS sort: the ordered single-workgroup collection does the whole job
-  (void)hipMemsetAsync(hist, 0, (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t), st);
+  if (!hist_prezeroed) (void)hipMemsetAsync(hist, 0, fpk_sel_hist_bytes(B), st);
   hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, cand_off, B, sh.n_full, sh.R, selstate, sel_cnt);
   dim3 gh(64, (unsigned)B);
   hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
@@ -3036,7 +3240,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   }
   // ordered single-block fallback, only for queries whose tie buffer overflowed (e.g. all scores equal)
   hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
-                     sel_approx);
+                     sel_approx, sel_cnt, pref, B);
 }
 
 // S6+S7 (fused decompress + exact MaxSim, per-token norms, exact-order repair): fp_maxsim.hip

@@ -1363,10 +1363,10 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
 // exact scores of the rerank lists.  pref: [B+1] int64 scratch.  aux (all nullable together): per-column maxima, uncertainty
 // budgets and flag masks for the exact-order repair.  Returns 0, or -1 when q_len is too large for the generic kernel.
 int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
-               int64_t Rcap, float* exact, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st) {
+               int64_t Rcap, float* exact, int64_t* pref, const FpMaxsimAux& aux, hipStream_t st, bool pref_ready) {
 #define MS6_CASE(KS4_, NB_) \
   if (ix.dim == KS4_ * 32 && ix.nbits == NB_) { \
-    hipLaunchKernelGGL(k_cnt_prefix, dim3(1), dim3(256), 0, st, sel_cnt, sh.B, pref); \
+    if (!pref_ready) hipLaunchKernelGGL(k_cnt_prefix, dim3(1), dim3(256), 0, st, sel_cnt, sh.B, pref); \
     launch_maxsim6<KS4_, NB_>(ix, qpad, sh, sel_pid, pref, Rcap, exact, aux, st); \
     return 0; \
   }
@@ -1376,7 +1376,7 @@ int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& 
 #undef MS6_CASE
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
-    hipLaunchKernelGGL(k_cnt_prefix, dim3(1), dim3(256), 0, st, sel_cnt, sh.B, pref); \
+    if (!pref_ready) hipLaunchKernelGGL(k_cnt_prefix, dim3(1), dim3(256), 0, st, sel_cnt, sh.B, pref); \
     launch_maxsim5<D_, NB_>(ix, qpad, sh, sel_pid, pref, Rcap, exact, aux, st); \
     return 0; \
   }

@@ -325,6 +325,15 @@ def test_probe_with_massive_ties_takes_device_fallback(fp):
         assert np.array_equal(np.sort(h["cells"]), np.sort(o["cells"])), "tie rule of the probe differs from the oracle"
         assert set(o["cells"].tolist()) >= set(range(100, 108)), "fixture no longer produces the tie it is meant to"
         check_trace(h, o, 32, 8, 256, 20)
+    # the batched search enqueues no fallback kernels: the device blanks the probe, the host reads the flag with the results
+    # and runs the batch again with them (and keeps them for this scratch); twice, the second call being the sticky path
+    ref = orc.search(q, 20, 256, 8)
+    for _ in range(2):
+        pids, scores, counts = R.search_arrays(hip, q, params)
+        for b in range(q.shape[0]):
+            assert counts[b] == len(ref[b][0])
+            assert np.array_equal(pids[b, : counts[b]], ref[b][0]), "batched search after a probe overflow differs from the oracle"
+            assert np.allclose(scores[b, : counts[b]], ref[b][1], atol=1e-3)
 
 
 def test_probe_fallback_path_forced(fp):
