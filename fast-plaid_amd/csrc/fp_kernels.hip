@@ -1454,6 +1454,12 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 //     eight independent row gathers per lane in flight;
 //   * grid = (blocks, queries): the query is blockIdx.y, no per-candidate search.
 // ============================================================================================
+// PPD = lane quads per candidate.  1: a quad walks the document's whole code list, 8 codes a step (many candidates per query:
+// every quad has several documents to pipeline).  4: quad p takes the code groups p, p + 4, ... and the four partial maxima are
+// combined at the end -- a 33-code document is ONE step of row gathers instead of five dependent ones.  For the refine calls
+// of the bound stages (a few thousand documents per query: the chip is short of independent chains, not of lanes; measured at
+// cfg2, S4 refine: 0.457 ms with PPD 1, 0.397 ms with PPD 1 and sixteen times the workgroups, see fpk_approx).
+template <int PPD>
 __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
@@ -1469,14 +1475,18 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
   const int64_t beg = cand_off ? cand_off[b] : (int64_t)b * cap;
   const int64_t n = cnt ? (cnt[b] < cap ? (int64_t)cnt[b] : cap) : cand_off[b + 1] - beg;
   const int64_t sbase = scat ? scat_off[b] : 0;
+  constexpr int CPB = 64 / PPD;               // candidates per block
+  constexpr int TSTEP = 8 * PPD;              // codes between two steps of one quad
   const int sub = threadIdx.x & 3;            // 16-byte piece of the 64-byte row chunk
-  const int grp = threadIdx.x >> 2;           // candidate slot within the block (0..63)
+  const int grp = threadIdx.x >> 2;           // quad within the block (0..63)
+  const int pp = grp % PPD;                   // which quad of the candidate
+  const int t0 = 8 * pp;
   const half_t negm = (half_t)NEG_MASK_F;
   const h2 neg2 = {negm, negm};
   const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
-  const int64_t stride = (int64_t)bx * 64;
+  const int64_t stride = (int64_t)bx * CPB;
   const int nch = Qp / 32;
-  int64_t i = (int64_t)bxi * 64 + grp;
+  int64_t i = (int64_t)bxi * CPB + grp / PPD;
   // Software pipeline over the dependent chain  pid -> offsets -> codes -> rows:
   //   document metadata is fetched one document ahead, the next 8 codes (of this document, or
   //   the first 8 of the next one) are fetched while the current 8 row gathers are in flight,
@@ -1490,9 +1500,9 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     const int32_t pid = cand_pid[beg + i];
     u0 = uoff[pid];
     len = (int)(uoff[pid + 1] - u0);
-    if (len > 0) {
+    if (len > t0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) code[k] = ucodes[u0 + ((k < len) ? k : (len - 1))];
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[u0 + ((t0 + k < len) ? t0 + k : (len - 1))];
     }
   }
   for (; i < n; i += stride) {
@@ -1505,14 +1515,15 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     }
     const int32_t* cp = ucodes + u0;
     float total = 0.f;
+    bool next_loaded = false;
     for (int ch = 0; ch < nch; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
       const uint16_t* Sc = Sb + ch * 32;
-      if (ch > 0 && len > 0) {  // further 32-column chunks restart from the document's first codes
+      if (ch > 0 && len > t0) {  // further 32-column chunks restart from the quad's first codes
 #pragma unroll
-        for (int k = 0; k < 8; ++k) code[k] = cp[(k < len) ? k : (len - 1)];
+        for (int k = 0; k < 8; ++k) code[k] = cp[(t0 + k < len) ? t0 + k : (len - 1)];
       }
-      for (int t = 0; t < len; t += 8) {
+      for (int t = t0; t < len; t += TSTEP) {
         uint4 v[8];
 #if AP_ABL & 1
 #pragma unroll
@@ -1522,17 +1533,18 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
 #endif
         // next codes while the rows are in flight (max is idempotent: the tail re-reads the last code)
-        if (t + 8 < len) {
+        if (t + TSTEP < len) {
 #if AP_ABL & 2
 #pragma unroll
           for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)(code[k] * 2654435761u + k)) % (uint32_t)C);
 #else
 #pragma unroll
-          for (int k = 0; k < 8; ++k) code[k] = cp[(t + 8 + k < len) ? (t + 8 + k) : (len - 1)];
+          for (int k = 0; k < 8; ++k) code[k] = cp[(t + TSTEP + k < len) ? (t + TSTEP + k) : (len - 1)];
 #endif
-        } else if (ch == nch - 1 && nlen > 0) {
+        } else if (ch == nch - 1 && nlen > t0) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+          for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((t0 + k < nlen) ? t0 + k : (nlen - 1))];
+          next_loaded = true;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -1540,6 +1552,15 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
           m1 = pk_max(m1, u32_as_h2(v[k].y));
           m2 = pk_max(m2, u32_as_h2(v[k].z));
           m3 = pk_max(m3, u32_as_h2(v[k].w));
+        }
+      }
+      if constexpr (PPD > 1) {   // the candidate's quads hold maxima over disjoint code groups (a quad without codes: the mask value)
+#pragma unroll
+        for (int x = 4; x < 4 * PPD; x <<= 1) {
+          m0 = pk_max(m0, u32_as_h2((uint32_t)__shfl_xor((int)h2_as_u32(m0), x, 64)));
+          m1 = pk_max(m1, u32_as_h2((uint32_t)__shfl_xor((int)h2_as_u32(m1), x, 64)));
+          m2 = pk_max(m2, u32_as_h2((uint32_t)__shfl_xor((int)h2_as_u32(m2), x, 64)));
+          m3 = pk_max(m3, u32_as_h2((uint32_t)__shfl_xor((int)h2_as_u32(m3), x, 64)));
         }
       }
       const int q0 = ch * 32 + sub * 8;
@@ -1554,15 +1575,15 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
       s += (q0 + 7 < Q) ? (float)m3.y : 0.f;
       total += s;
     }
-    if (len == 0 && nlen > 0) {  // an empty document never reaches the prefetch slot above
+    if (!next_loaded && nlen > t0) {  // a quad without codes in this document never reaches the prefetch slot above
 #pragma unroll
-      for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((k < nlen) ? k : (nlen - 1))];
+      for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((t0 + k < nlen) ? t0 + k : (nlen - 1))];
     }
-    // the 4 lanes of the group hold disjoint column sums (lanes of one group run the same trip
-    // counts, so the shuffles are convergent within the group; other groups may have exited)
+    // the 4 lanes of the quad hold disjoint column sums (the lanes of one candidate run the same outer trip counts, so the
+    // shuffles are convergent within the candidate; other candidates may have exited)
     total += __shfl_xor(total, 1, 64);
     total += __shfl_xor(total, 2, 64);
-    if (sub == 0) {
+    if (sub == 0 && pp == 0) {
       if (approx) approx[beg + i] = total;
       if (scat) scat[sbase + scat_idx[beg + i]] = total;
     }
@@ -1577,15 +1598,24 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   if (M <= 0) return;
   // enough blocks to cover the largest per-query candidate list a few times over
   int64_t per_q = (M + sh.B - 1) / sh.B;
-  int64_t bx = (per_q * 2 + 63) / 64;
-  if (bx > 2048) bx = 2048;
+  // PPD 4 when the lists are short (the refine calls: at most a few x R documents per query)
+  static const int ppd_env = [] { const char* e = getenv("FP_APPROX_PPD"); return e ? atoi(e) : 0; }();   // 1 / 4: force
+  const bool wide = ppd_env ? ppd_env == 4 : per_q <= 16 * sh.R;
+  const int cpb = wide ? 16 : 64;
+  static const int bxmul = [] { const char* e = getenv("FP_APPROX_BXMUL"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();   // block slots per expected candidate
+  int64_t bx = (per_q * bxmul + cpb - 1) / cpb;
+  if (bx > (wide ? 4096 : 2048)) bx = wide ? 4096 : 2048;
   if (bx < 1) bx = 1;
   // walks the per-document UNIQUE code lists (max over a multiset == max over its set).
   // (an XCD-affine query assignment was measured slower when every candidate is scored: 8.3 vs 7.6 ms, round 1; and makes no
   // difference for the refine calls of the bound stages, ~6000 documents per query: 0.445 ms either way, round 3 -- their
   // ~200 k row gathers per query hardly repeat a row, FETCH_SIZE equals the logical bytes)
-  hipLaunchKernelGGL(k_approx, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                     ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off);
+  if (wide)
+    hipLaunchKernelGGL(k_approx<4>, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off);
+  else
+    hipLaunchKernelGGL(k_approx<1>, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off);
 }
 
 // ============================================================================================
