@@ -132,7 +132,7 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -207,7 +207,7 @@ struct Scratch {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all, &tickets})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat})
       b->release();
     h_out.release();
     h_small.release();
@@ -1001,9 +1001,16 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
   }
   if (stage_event) STAGE_DONE(ST_REPAIR);   // "S6+S7 maxsim" is the MaxSim kernel alone (+ the 4 us prefix kernel in front of it)
   if (repair && mode != 0) {
+    // the batch-wide work list needs a zeroed counter: the last word of the ticket block, cleared by the first kernel of a batch
+    // whose front stages ran in this call (pref_ready says so)
+    uint32_t* flat_n = nullptr;
+    if (pref_ready && mode == 1 && s->tickets.p) {
+      HIPCHK(s->ms_flat.ensure((size_t)B * R * 8));
+      flat_n = s->tickets.as<uint32_t>() + (2 * B + 2);
+    }
     const bool marked = mode == 1 && repair_env != 2 &&
                         fpk_final_mark(s->exact.as<float>(), aux.unc, aux.uncm, s->sel_cnt.as<int32_t>(), R, B, top_k, s->ms_marks.as<int32_t>(),
-                                       s->ms_nmark.as<int32_t>(), st) == 0;
+                                       s->ms_nmark.as<int32_t>(), st, flat_n, flat_n ? s->ms_flat.p : nullptr) == 0;
     s->ms_have_marks = false;
     s->ms_marked_now = marked;
     if (marked && !s->fold_stats && (size_t)B * 4 + 64 <= 4096) {   // marked documents per query -> pinned memory, summed for fp_last_search_counts after the final sync
@@ -1012,7 +1019,8 @@ static int run_maxsim(fp_index* ix, Scratch* s, const FpSearchShape& sh, int64_t
       s->ms_have_marks = true;
     }
     fpk_maxsim_repair(D, s->qpad.as<uint16_t>(), sh, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), R,
-                      marked ? s->ms_marks.as<int32_t>() : nullptr, marked ? s->ms_nmark.as<int32_t>() : nullptr, s->exact.as<float>(), aux, st);
+                      marked ? s->ms_marks.as<int32_t>() : nullptr, marked ? s->ms_nmark.as<int32_t>() : nullptr, s->exact.as<float>(), aux, st,
+                      marked ? flat_n : nullptr, marked && flat_n ? s->ms_flat.p : nullptr);
     LAUNCHCHK("MaxSim repair");
   }
   return FP_OK;

@@ -240,10 +240,11 @@ int fpk_maxsim(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape&
 // flagged documents that are near-tied in the final ranking -> marks [B][stride], nmark [B]; -1 when stride is too large for LDS
 int fpk_final_mark(const float* score, const float* unc, const float* uncm /*nullable: symmetric*/, const int32_t* cnt, int64_t stride, int B,
                    int64_t top_k, int32_t* marks, int32_t* nmark,
-                   hipStream_t st);
+                   hipStream_t st, uint32_t* flat_n = nullptr /*a zeroed counter ...*/, void* flat = nullptr /*... and the batch-wide {query, slot} list [B * stride] it counts*/);
 // exact (ascending-k) re-evaluation of the flagged columns of the marked documents (marks == nullptr: of every flagged document)
 void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
-                       int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st);
+                       int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st,
+                       const uint32_t* flat_n = nullptr, const void* flat = nullptr /*fpk_final_mark's batch-wide list: one wave per entry*/);
 // final ranking: sort (score desc, id asc), emit top_k with pid_offset applied
 void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local /*[B][stride] or null*/,
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,

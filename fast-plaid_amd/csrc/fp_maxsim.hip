@@ -1049,7 +1049,8 @@ __global__ __launch_bounds__(64) void k_maxsim_generic(const uint16_t* __restric
 __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ score, const float* __restrict__ unc,
                                                      const float* __restrict__ uncm /*nullable: symmetric intervals*/, const int32_t* __restrict__ cnt,
                                                      int64_t stride, int npow2, int64_t top_k, int32_t* __restrict__ marks,
-                                                     int32_t* __restrict__ nmark) {
+                                                     int32_t* __restrict__ nmark, uint32_t* __restrict__ flat_n /*nullable: zeroed counter*/,
+                                                     uint2* __restrict__ flat /*... and the batch-wide work list {query, slot} it indexes*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);          // [npow2] keys
   float* lo = reinterpret_cast<float*>(smem + (size_t)npow2 * 8);              // [npow2] s - u, then its exclusive prefix-min
@@ -1142,6 +1143,18 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
   }
   __syncthreads();
   if (threadIdx.x == 0) nmark[b] = s_n;
+  if (flat_n) {
+    // The marked documents of ALL queries on one list (any order: documents are repaired independently), so that the repair
+    // kernel's waves share them evenly whatever their spread over the queries (135 per query on average at cfg2).
+    // (The repair itself is bound by re-reading the marked documents' tokens -- 41 KB of centroid rows and residuals per
+    // 128-token document, 5-6.6 TB/s measured with 8.7 k and 32 k documents per batch -- not by the 1.4 flagged columns per
+    // document it re-evaluates: tools/flag_stats.py.)
+    __shared__ uint32_t s_base;
+    const int cntm = s_n;
+    if (threadIdx.x == 0) s_base = cntm > 0 ? atomicAdd(flat_n, (uint32_t)cntm) : 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < cntm; i += blockDim.x) flat[s_base + i] = make_uint2((uint32_t)b, (uint32_t)marks[(int64_t)b * stride + i]);
+  }
 }
 
 // k_maxsim_repair: ONE WAVE (= one 64-thread workgroup) per marked (query, slot) -- or, with marks == nullptr, per slot whose
@@ -1156,20 +1169,29 @@ __global__ __launch_bounds__(64) void k_maxsim_repair(const uint16_t* __restrict
                                                       const uint16_t* __restrict__ qpad, int Q, int Qp, const int32_t* __restrict__ sel_pid,
                                                       const int32_t* __restrict__ sel_cnt, int64_t Rcap, const int32_t* __restrict__ marks,
                                                       const int32_t* __restrict__ nmark, float* __restrict__ exact, float* __restrict__ unc,
-                                                      uint16_t* __restrict__ cm16, uint32_t* __restrict__ flags) {
+                                                      uint16_t* __restrict__ cm16, uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ flat_n, const uint2* __restrict__ flat) {
   using Cf = MsCfg<D, NBITS>;
   constexpr int native = ms6_shape(D, NBITS) ? 1 : 0;   // the stored unit order of this shape's residual rows
   constexpr int NE = Cf::NE, RW = Cf::RW, PB = Cf::PB;
   __shared__ uint16_t slut[256 * PB];
-  const int b = blockIdx.y;
-  const int nwork = marks ? nmark[b] : sel_cnt[b];
+  // work items: the batch-wide list (1-D grid), or per query (blockIdx.y) the marked slots / every slot
+  int b = flat ? 0 : (int)blockIdx.y;
+  const int nwork = flat ? (int)*flat_n : (marks ? nmark[b] : sel_cnt[b]);
   if ((int)blockIdx.x >= nwork) return;
   const int lane = threadIdx.x;
   for (int i = lane; i < 256 * PB; i += 64) slut[i] = lut_g[i];
   __syncthreads();
   const int nflag = Qp / 32;
   for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-    const int r = marks ? marks[(int64_t)b * Rcap + wi] : wi;
+    int r;
+    if (flat) {
+      const uint2 it = flat[wi];
+      b = (int)it.x;
+      r = (int)it.y;
+    } else {
+      r = marks ? marks[(int64_t)b * Rcap + wi] : wi;
+    }
     const int64_t slot = (int64_t)b * Rcap + r;
     if (!(unc[slot] > 0.f)) continue;
     const int32_t pid = sel_pid[slot];
@@ -1392,26 +1414,31 @@ int fpk_maxsim(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& 
 // marks the flagged documents that are near-tied in the final ranking (marks / nmark), or nothing when npow2 keys do not fit LDS
 int fpk_final_mark(const float* score, const float* unc, const float* uncm, const int32_t* cnt, int64_t stride, int B, int64_t top_k, int32_t* marks,
                    int32_t* nmark,
-                   hipStream_t st) {
+                   hipStream_t st, uint32_t* flat_n, void* flat) {
   int np2 = fp_next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
   if (np2 > 8192) return -1;   // 16 B of LDS per entry, 16 scan elements per thread
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_mark, lds_ok, 136 * 1024);
-  hipLaunchKernelGGL(k_final_mark, dim3((unsigned)B), dim3(1024), (size_t)np2 * 16, st, score, unc, uncm, cnt, stride, np2, top_k, marks, nmark);
+  hipLaunchKernelGGL(k_final_mark, dim3((unsigned)B), dim3(1024), (size_t)np2 * 16, st, score, unc, uncm, cnt, stride, np2, top_k, marks, nmark,
+                     flat_n, static_cast<uint2*>(flat));
   return 0;
 }
 
 // marks == nullptr: every slot with a budget > 0 is repaired
 void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* qpad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
-                       int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st) {
+                       int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st,
+                       const uint32_t* flat_n, const void* flat) {
   if (!fpk_maxsim_fast_shape(ix.dim, ix.nbits) || !aux.unc) return;   // the generic kernel never flags
-  // one wave per document; workgroups beyond a query's marked count exit at once
-  const dim3 grid((unsigned)std::min<int64_t>(marks ? 192 : 4096, Rcap), (unsigned)sh.B);   // (workgroups walk the marked list with this stride: ~140 marked documents per query at cfg2)
+  // one wave per document; workgroups beyond the work list exit at once.  Batch-wide list: 2 x the average marked count of the
+  // benchmark (~140 per query) in waves, the kernel strides if a batch has more.
+  const dim3 grid = flat ? dim3((unsigned)std::min<int64_t>(320 * (int64_t)sh.B, std::min<int64_t>(Rcap * sh.B, 1 << 20)))
+                         : dim3((unsigned)std::min<int64_t>(marks ? 192 : 4096, Rcap), (unsigned)sh.B);
 #define MS_CASE(D_, NB_) \
   if (ix.dim == D_ && ix.nbits == NB_) { \
     hipLaunchKernelGGL((k_maxsim_repair<D_, NB_>), grid, dim3(64), 0, st, ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, \
-                       ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags); \
+                       ix.doc_off, qpad, sh.Q, sh.Qp, sel_pid, sel_cnt, Rcap, marks, nmark, exact, aux.unc, aux.cm16, aux.flags, flat_n, \
+                       static_cast<const uint2*>(flat)); \
     return; \
   }
   MS_CASE(128, 4) MS_CASE(128, 2) MS_CASE(128, 8) MS_CASE(128, 1) MS_CASE(96, 4) MS_CASE(96, 2) MS_CASE(64, 4) MS_CASE(64, 2) MS_CASE(48, 4) MS_CASE(48, 2)
