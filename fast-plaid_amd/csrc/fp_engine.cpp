@@ -950,7 +950,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   }
   STAGE_DONE(ST_SELECT);
   // S5
-  HIPCHK(s->hist.ensure((size_t)3 * B * FP_SEL_BINS * 4));
+  HIPCHK(s->hist.ensure(fpk_sel_hist_bytes(B)));
   HIPCHK(s->selstate.ensure((size_t)B * 8 * 4));
   HIPCHK(s->sel_pid.ensure((size_t)B * sh.R * 4));
   HIPCHK(s->sel_approx.ensure((size_t)B * sh.R * 4));

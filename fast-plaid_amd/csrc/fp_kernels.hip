@@ -2794,67 +2794,32 @@ void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const in
 // the monotone key, then one ordered collect pass per query.
 // selstate[b] = {need_select, keep, prefix, k_rem, n, -, -, -}
 // ============================================================================================
-__global__ void k_sel_init(const int64_t* __restrict__ cand_off, int B, int64_t n_full, int64_t R, uint32_t* __restrict__ st,
-                           int32_t* __restrict__ sel_cnt) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  int64_t n = cand_off[b + 1] - cand_off[b];
-  int64_t keep = n;
+// The radix select used to be init + 3 x (histogram, scan) + gather: eleven launches with the fill.  The one-workgroup-per-query
+// steps now ride in the kernel that needs their result: every workgroup of histogram pass p+1 (and of the gather) repeats the
+// scan of pass p's 2048 bins for itself (2 us of a 256-thread workgroup) and workgroup 0 records it for the launches after.
+// State between launches: st[b] = {need_select, keep, prefix0 = 0, k_rem0 = keep, n, gt, eq, overflow}, ext[b] = {prefix, k_rem}
+// after pass 0 and after pass 1 (two pairs: a launch never reads a word that one of its own workgroups writes).
+__device__ __forceinline__ void sel_init_values(int64_t n, int64_t n_full, int64_t R, int64_t& keep) {
+  keep = n;
   if (n_full < keep) keep = n_full;   // search.rs:605-611
   if (R < keep) keep = R;             // :614-619 (R = max(n_full/4, 1))
   if (keep < 0) keep = 0;
-  uint32_t* s = st + (int64_t)b * 8;
-  s[0] = (keep < n) ? 1u : 0u;
-  s[1] = (uint32_t)keep;
-  s[2] = 0u;
-  s[3] = (uint32_t)keep;
-  s[4] = (uint32_t)n;
-  s[5] = 0u;  // elements strictly above the threshold gathered so far
-  s[6] = 0u;  // elements equal to the threshold seen
-  s[7] = 0u;  // tie buffer overflow -> ordered fallback
-  sel_cnt[b] = (int32_t)keep;
 }
-
+// scan of one pass's histogram `g` from the top by a 256-thread workgroup: (prefix, k_rem) -> those after the pass, in all threads
 template <int PASS>
-__global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ approx, const int64_t* __restrict__ cand_off,
-                                                  const uint32_t* __restrict__ st, uint32_t* __restrict__ hist) {
-  constexpr int SHIFT = (PASS == 0) ? 21 : (PASS == 1) ? 10 : 0;
-  constexpr int WIDTH = (PASS == 2) ? 10 : 11;
-  const int b = blockIdx.y;
-  const uint32_t* s = st + (int64_t)b * 8;
-  if (!s[0]) return;
-  __shared__ uint32_t h[FP_SEL_BINS];
-  for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256) h[i] = 0;
-  __syncthreads();
-  const uint32_t prefix = s[2];
-  const int64_t beg = cand_off[b], end = cand_off[b + 1];
-  for (int64_t i = beg + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256) {
-    uint32_t k = mono32(approx[i]);
-    bool match = (PASS == 0) ? true : ((k >> (SHIFT + WIDTH)) == prefix);
-    if (match) atomicAdd(&h[(k >> SHIFT) & ((1u << WIDTH) - 1)], 1u);
-  }
-  __syncthreads();
-  uint32_t* g = hist + ((int64_t)PASS * gridDim.y + b) * FP_SEL_BINS;
-  for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256)
-    if (h[i]) atomicAdd(&g[i], h[i]);
-}
-
-template <int PASS>
-__global__ __launch_bounds__(256) void k_sel_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ st, int B) {
+__device__ __forceinline__ void sel_scan_local(const uint32_t* __restrict__ g, uint32_t& prefix, uint32_t& k_rem) {
   constexpr int WIDTH = (PASS == 2) ? 10 : 11;
   constexpr int NB = 1 << WIDTH;
   constexpr int PER = NB / 256;  // bins per thread (8 or 4)
-  const int b = blockIdx.x;
-  uint32_t* s = st + (int64_t)b * 8;
-  if (!s[0]) return;
-  const uint32_t* g = hist + ((int64_t)PASS * B + b) * FP_SEL_BINS;
   // thread t owns bins [NB-1 - t*PER - (PER-1), NB-1 - t*PER] walking from the top
   uint32_t loc[PER];
   uint32_t sum = 0;
 #pragma unroll
   for (int j = 0; j < PER; ++j) { loc[j] = g[NB - 1 - (threadIdx.x * PER + j)]; sum += loc[j]; }
   __shared__ uint32_t sc[256];
+  __shared__ uint32_t s_out[2];
   sc[threadIdx.x] = sum;
+  if (threadIdx.x == 0) { s_out[0] = prefix << WIDTH; s_out[1] = k_rem; }
   __syncthreads();
   for (int off = 1; off < 256; off <<= 1) {
     uint32_t t = ((int)threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
@@ -2862,22 +2827,82 @@ __global__ __launch_bounds__(256) void k_sel_scan(const uint32_t* __restrict__ h
     sc[threadIdx.x] += t;
     __syncthreads();
   }
-  const uint32_t k_rem = s[3];
   const uint32_t incl = sc[threadIdx.x], excl = incl - sum;
-  __syncthreads();
   if (excl < k_rem && incl >= k_rem) {  // exactly one thread
     uint32_t cum = excl;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       if (cum + loc[j] >= k_rem) {
-        uint32_t bin = NB - 1 - (threadIdx.x * PER + j);
-        s[2] = (s[2] << WIDTH) | bin;
-        s[3] = k_rem - cum;  // still needed from inside this bin
+        const uint32_t bin = NB - 1 - (threadIdx.x * PER + j);
+        s_out[0] = (prefix << WIDTH) | bin;
+        s_out[1] = k_rem - cum;  // still needed from inside this bin
         break;
       }
       cum += loc[j];
     }
   }
+  __syncthreads();
+  prefix = s_out[0];
+  k_rem = s_out[1];
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ approx, const int64_t* __restrict__ cand_off,
+                                                  uint32_t* __restrict__ st, uint32_t* __restrict__ hist, uint32_t* __restrict__ ext,
+                                                  int64_t n_full, int64_t R, int32_t* __restrict__ sel_cnt) {
+  constexpr int SHIFT = (PASS == 0) ? 21 : (PASS == 1) ? 10 : 0;
+  constexpr int WIDTH = (PASS == 2) ? 10 : 11;
+  const int b = blockIdx.y, B = gridDim.y;
+  uint32_t* s = st + (int64_t)b * 8;
+  uint32_t* e = ext + (int64_t)b * 4;
+  const int64_t beg = cand_off[b], end = cand_off[b + 1];
+  uint32_t prefix = 0;
+  if (PASS == 0) {
+    const int64_t n = end - beg;
+    int64_t keep;
+    sel_init_values(n, n_full, R, keep);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      s[0] = (keep < n) ? 1u : 0u;
+      s[1] = (uint32_t)keep;
+      s[2] = 0u;
+      s[3] = (uint32_t)keep;
+      s[4] = (uint32_t)n;
+      s[5] = 0u;  // elements strictly above the threshold gathered so far
+      s[6] = 0u;  // elements equal to the threshold seen
+      s[7] = 0u;  // tie buffer overflow -> ordered fallback
+      sel_cnt[b] = (int32_t)keep;
+    }
+    if (!(keep < n)) return;
+  } else {
+    if (!s[0]) return;
+    uint32_t k_rem;
+    if (PASS == 1) { prefix = s[2]; k_rem = s[3]; } else { prefix = e[0]; k_rem = e[1]; }
+    sel_scan_local<PASS - 1 < 0 ? 0 : PASS - 1>(hist + ((int64_t)(PASS - 1) * B + b) * FP_SEL_BINS, prefix, k_rem);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { e[2 * (PASS - 1)] = prefix; e[2 * (PASS - 1) + 1] = k_rem; }
+  }
+  __shared__ uint32_t h[FP_SEL_BINS];
+  for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  for (int64_t i = beg + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256) {
+    uint32_t k = mono32(approx[i]);
+    bool match = (PASS == 0) ? true : ((k >> (SHIFT + WIDTH)) == prefix);
+    if (match) atomicAdd(&h[(k >> SHIFT) & ((1u << WIDTH) - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t* g = hist + ((int64_t)PASS * B + b) * FP_SEL_BINS;
+  for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256)
+    if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// the last scan on its own (rerank lists beyond the LDS sort: no gather kernel follows the third histogram)
+__global__ __launch_bounds__(256) void k_sel_scan_final(const uint32_t* __restrict__ hist, uint32_t* __restrict__ st,
+                                                        const uint32_t* __restrict__ ext, int B) {
+  const int b = blockIdx.x;
+  uint32_t* s = st + (int64_t)b * 8;
+  if (!s[0]) return;
+  uint32_t prefix = ext[(int64_t)b * 4 + 2], k_rem = ext[(int64_t)b * 4 + 3];
+  sel_scan_local<2>(hist + ((int64_t)2 * B + b) * FP_SEL_BINS, prefix, k_rem);
+  if (threadIdx.x == 0) { s[2] = prefix; s[3] = k_rem; }
 }
 
 // ordered collect: one block per query
@@ -2944,7 +2969,7 @@ __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ 
                                                       int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
                                                       const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref /*nullable*/, int B) {
   sel_collect_body(approx, cand_pid, cand_off, st, R, sel_pid, sel_approx);
-  if (!pref || blockIdx.x != 0) return;   // (sel_cnt is final before this kernel starts: k_sel_init / k_sel_front wrote it)
+  if (!pref || blockIdx.x != 0) return;   // (sel_cnt is final before this kernel starts: k_sel_hist<0> / k_sel_front wrote it)
   __syncthreads();
   __shared__ long long sp[1024];
   long long base = 0;
@@ -2972,11 +2997,18 @@ __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_sel_gather(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
                                                     const int64_t* __restrict__ cand_off, uint32_t* __restrict__ st, int64_t R,
                                                     int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
-                                                    int32_t* __restrict__ tie_pid) {
+                                                    int32_t* __restrict__ tie_pid, const uint32_t* __restrict__ hist,
+                                                    const uint32_t* __restrict__ ext) {
   const int b = blockIdx.y;
   uint32_t* s = st + (int64_t)b * 8;
   const bool need = s[0] != 0;
-  const uint32_t kstar = s[2];
+  uint32_t kstar = 0;
+  if (need) {   // the third pass's scan, by every workgroup for itself; workgroup 0 records {threshold key, ties still needed}
+    uint32_t k_rem = ext[(int64_t)b * 4 + 3];
+    kstar = ext[(int64_t)b * 4 + 2];
+    sel_scan_local<2>(hist + ((int64_t)2 * gridDim.y + b) * FP_SEL_BINS, kstar, k_rem);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { s[2] = kstar; s[3] = k_rem; }
+  }
   const uint32_t keep = s[1];
   const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
   int32_t* op = sel_pid + (int64_t)b * R;
@@ -3230,7 +3262,7 @@ __global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) st[(int64_t)b * 8 + 7] = 1u;
 }
-size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t); }
+size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t) + (size_t)B * 16; }   // three histograms per query + {prefix, k_rem} x 2
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
                 uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
                 bool short_lists, bool hist_prezeroed, int64_t* pref) {
@@ -3249,19 +3281,17 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   }
   const bool big = sh.R > FP_MAX_SORT;   // beyond k_sel_finish's LDS sort: the ordered single-workgroup collection does the whole job
   if (!hist_prezeroed) (void)hipMemsetAsync(hist, 0, fpk_sel_hist_bytes(B), st);
-  hipLaunchKernelGGL(k_sel_init, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, cand_off, B, sh.n_full, sh.R, selstate, sel_cnt);
+  uint32_t* ext = hist + (size_t)3 * B * FP_SEL_BINS;   // [B][4], behind the histograms (fpk_sel_hist_bytes)
   dim3 gh(64, (unsigned)B);
-  hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
-  hipLaunchKernelGGL(k_sel_scan<0>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
-  hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
-  hipLaunchKernelGGL(k_sel_scan<1>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
-  hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist);
-  hipLaunchKernelGGL(k_sel_scan<2>, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, B);
+  hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
+  hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
+  hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
   if (big) {
+    hipLaunchKernelGGL(k_sel_scan_final, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, ext, B);
     hipLaunchKernelGGL(k_sel_force_collect, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, selstate, B);
   } else {
     hipLaunchKernelGGL(k_sel_gather, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
-                       tie_pid);
+                       tie_pid, hist, ext);
   }
   if (!big) {
     static std::atomic<uint64_t> lds_ok{0};
