@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
       const int32_t cell = ucells[(int64_t)b * ucstride + cb + j];
       if (cell >= 0 && cell < P) {
         long long beg = ivf_off[cell], end = ivf_off[cell + 1];
-        if (search) {
+        if (search) {   // (both bounds in one four-way search, six independent loads per round trip: S3 0.107 -> 0.134 ms, round 3 -- not the bottleneck)
           long long l = beg, h = end;
           while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < tile_lo) l = m + 1; else h = m; }
           beg = l;
