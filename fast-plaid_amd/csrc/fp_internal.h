@@ -43,9 +43,10 @@ struct FpIndexDev {
   const int64_t* uoff;     // [N+1]
   int64_t U;
   int max_doc_len;
-  const uint4* pcodes;     // [NL] x 128 B: the unique codes again, packed into whole lines per document (fp_synth.hip, "packed unique
-                           //       codes"); nullptr when C > 2^17
-  const int32_t* poff;     // [N][2] {first line, line count} of each document in pcodes
+  const uint4* pcodes;     // [NL] lines of 128 B (64 B: l0_ppl 4): the unique codes again, packed into whole lines per document (fp_synth.hip,
+                           //       "packed unique codes").  Line d < N is document d's first line (addressed by the id, no lookup); the extra
+                           //       lines of documents with more codes than a line holds follow behind.  nullptr: no level 0 for this index
+  const int32_t* poff;     // [N][2] {first extra line, extra line count} of each document in pcodes (read for flagged first lines only)
   // centroid ranges of 2^17 (FP_L0_RANGE) for tables beyond 2^17 centroids: range r has its own lines / offsets with codes
   // relative to r * 2^17; [0] aliases pcodes / poff
   int n_ranges;
@@ -315,7 +316,7 @@ int fps_sort_docs(int32_t* codes, uint8_t* residuals, const int64_t* doc_off_dev
 // Per-document sorted unique codes (allocates *ucodes, fills uoff_dev [N+1]).
 int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n_docs, int max_len, int32_t** ucodes, int64_t* U,
                      int64_t* uoff_dev, hipStream_t st);
-// The unique codes in [code_lo, code_hi) of every document packed into 128-byte lines (S4 level 0).  Allocates *lines and *poff [N][2].
+// The unique codes in [code_lo, code_hi) of every document packed into lines (S4 level 0): N first lines + the extra lines.  Allocates *lines and *poff [N][2].
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
                      int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl = 8 /*16-byte pieces (6 codes each) per line: 8 or 4*/);
 // final ranking of rerank lists beyond the LDS sort of k_final_topk (segmented device radix sort; synchronises); 0 or a hipError / -1

@@ -2139,10 +2139,12 @@ __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8
 }
 
 // ub[cand] = min(F + sum e(c), 0xFFFE), or 0xFFFF when some code has an infinite excess.
-// The candidates' codes come from the packed lines (fp_synth.hip "packed unique codes"): one aligned 128-byte line per document
-// (more for documents with > 48 distinct codes), 8 lanes per line, one 16-byte piece = 6 codes per lane, nothing shared
-// between lanes but the final sum.  A lane group takes FOUR consecutive candidates per iteration; the line loads of the next
-// iteration, the line offsets of the one after and the ids of the one after that are in flight while it computes.  Escape
+// The candidates' codes come from the packed lines (fp_synth.hip "packed unique codes"): one aligned 128-byte line per document,
+// line <document id> (documents with > 48 distinct codes: extra lines behind the first lines, found through a side table on
+// the rare path), 8 lanes per line, one 16-byte piece = 6 codes per lane, nothing shared between lanes but the final sum.
+// A lane group takes FOUR consecutive candidates per iteration; the line loads of the next iteration and the ids of the two
+// after that are in flight while it computes.  (Until round 3 a {first line, line count} lookup sat between the id and the
+// line: 8 B more per candidate and one more dependent load in the chain.)  Escape
 // slots / infinite entries take a rare second pass over the candidate.  The histogram of (ub - F) >> 2 that the pilot cut
 // needs is built here in LDS.
 #define L0_HBINS 4096
@@ -2205,17 +2207,16 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   if ((int64_t)bxi * CPI >= n) return;
   const uint32_t F = Fsum[b];
   const int sub = tid & (LPC - 1);
-  const int kq = sub & 3;                      // the candidate of the group's four whose id / line offsets this lane fetches
+  const int kq = sub & 3;                      // the candidate of the group's four whose id this lane fetches
   const int64_t stride = (int64_t)bxn * CPI;
   const int32_t* cpids = cand_pid + beg;
   const uint2* pmeta = reinterpret_cast<const uint2*>(poff);
   uint16_t* ubrow = ub + l0_row(cand_off, b);
   int64_t i = (int64_t)bxi * CPI + (tid / LPC) * L0_UNROLL;
-  // Software pipeline over the dependent chain  id -> {first line, line count} -> code line(s):  while iteration t is
-  // computed, the code lines of t+1, the offsets of t+2 and the ids of t+3 are in flight (one workgroup per CU -- the table
-  // takes the LDS -- leaves only 4 waves per SIMD to hide latency otherwise).  Ids and offsets are fetched cooperatively: each
-  // lane of a quad loads ONE of the group's four candidates and the values are exchanged by quad broadcasts -- 2 load
-  // instructions per iteration instead of 12 through the CU's one address unit.
+  // Software pipeline over the dependent chain  id -> code line:  while iteration t is computed, the code lines of t+1 and the
+  // ids of t+2 / t+3 are in flight (one workgroup per CU -- the table takes the LDS -- leaves only 4 waves per SIMD to hide
+  // latency otherwise).  Ids are fetched cooperatively: each lane of a quad loads ONE of the group's four candidates and the
+  // values are exchanged by quad broadcasts -- 1 load instruction per iteration instead of 4 through the CU's one address unit.
   auto qb = [](uint32_t v, int k) -> uint32_t {   // value of lane k of this lane's quad
     switch (k) {
       case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, true);
@@ -2225,7 +2226,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     }
   };
   // The loads are unconditional: positions past the end of the list are clamped to its last entry (their results are never
-  // stored), and a document without codes (line count 0) reads line 0 and has its sum masked -- the guards cost a branch, an
+  // stored); a document without codes owns an empty line (all counts 0: it sums to nothing) -- guards cost a branch, an
   // exec-mask save and four zeroing moves per load otherwise.
   const int64_t nlast = n - 1;
   auto pos = [&](int64_t at) -> int64_t { return at + kq < nlast ? at + kq : nlast; };
@@ -2233,13 +2234,13 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     if (ABL & 2) return make_uint4(line * 2654435761u & 0x1FFFFu, line * 40503u & 0x1FFFFu, line * 7919u & 0x1FFFFu, 0x06000000u | (line & 0xFFFFu));
     return pcodes[(int64_t)line * LPC + sub];
   };
-  uint2 m0 = pmeta[cpids[pos(i)]];                     // iteration t
-  uint2 m1 = pmeta[cpids[pos(i + stride)]];            // t+1
-  uint2 m2 = pmeta[cpids[pos(i + 2 * stride)]];        // t+2
-  int32_t pid3 = cpids[pos(i + 3 * stride)];
+  // (a document's first line is line <document id>: no lookup between the id and the line)
+  int32_t p0 = cpids[pos(i)];                          // iteration t
+  int32_t p1 = cpids[pos(i + stride)];                 // t+1
+  int32_t p2 = cpids[pos(i + 2 * stride)];             // t+2
   uint4 pcA[L0_UNROLL], pcB[L0_UNROLL];                // first code lines of t / t+1, roles swapped every iteration
 #pragma unroll
-  for (int k = 0; k < L0_UNROLL; ++k) pcA[k] = load_line(qb(m0.x, k));
+  for (int k = 0; k < L0_UNROLL; ++k) pcA[k] = load_line(qb((uint32_t)p0, k));
   // the query's table -> LDS, behind the pipeline's first loads (nothing above touches LDS): the copy's latency overlaps theirs
   {
     const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad + tab_off);
@@ -2264,7 +2265,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     c[5] = (pc.w >> 4) & 0xFFFFFu;
   };
   auto piece = [&](const uint4& pc) -> uint32_t {
-    const uint32_t cnt = pc.w >> 24;
+    const uint32_t cnt = (pc.w >> 24) & 0x7Fu;   // (bit 31 of the word: "the document has extra lines", first line's last piece only)
     uint32_t c[6], v[6];
     codes6(pc, c);
 #pragma unroll
@@ -2277,14 +2278,13 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       m6 = max(m6, v[j]);
     }
     s6 -= (6u - cnt) * last;
-    return s6 + ((cnt && m6 >= L0_ESC_BASE) ? (1u << 24) : 0u);
+    return s6 + ((cnt && m6 >= L0_ESC_BASE) ? (1u << 24) : 0u) + ((pc.w >> 31) << 30);   // bit 30: "extra lines" (set in one piece of a first line at most)
   };
   auto body = [&](uint4 (&pc)[L0_UNROLL], uint4 (&pcn)[L0_UNROLL]) {
-    // issue: lines of t+1, offsets of t+2, ids of t+3
+    // issue: lines of t+1, ids of t+3
 #pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(qb(m1.x, k));
-    const uint2 m3 = pmeta[pid3];
-    const int32_t pid4 = cpids[pos(i + 4 * stride)];
+    for (int k = 0; k < L0_UNROLL; ++k) pcn[k] = load_line(qb((uint32_t)p1, k));
+    const int32_t p3 = cpids[pos(i + 3 * stride)];
     uint32_t outv[L0_UNROLL], sums[L0_UNROLL];
     uint16_t prev[L0_UNROLL] = {0, 0, 0, 0};   // the bounds so far (later ranges of a table beyond 2^17 centroids)
     if (!first) {
@@ -2300,23 +2300,28 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       for (int k = 0; k < L0_UNROLL; ++k) sums[k] = piece(pc[k]);   // straight-line: all 24 table reads of the lane in flight together
     }
 #pragma unroll
-    for (int k = 0; k < L0_UNROLL; ++k) sums[k] = qb(m0.y, k) ? sums[k] : 0u;   // a document without codes read line 0
-#pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
-      const uint32_t l0k = qb(m0.x, k), nlk = qb(m0.y, k);
-      uint32_t sum = sums[k];
-      for (uint32_t t = 1; t < nlk; ++t) {   // documents with more than 48 distinct codes
-        const uint4 more = pcodes[((int64_t)l0k + t) * LPC + sub];
-        sum += piece(more);
+      // bits 24.. of the sum count the pieces that hold an escaped / infinite code (at most 8 in a first line); bit 30 says that
+      // the document has extra lines (more than one line's worth of distinct codes in this range): rare, {first, count} then
+      // come from the side table.  The group branches as one (the reduced values are the same in all its lanes).
+      uint32_t sum = l0_red<LPC>(sums[k]);
+      uint32_t xl0 = 0, nx = 0;
+      if (sum & (1u << 30)) {
+        sum -= 1u << 30;
+        const uint2 mx = pmeta[qb((uint32_t)p0, k)];
+        xl0 = mx.x;
+        nx = mx.y;
+        uint32_t sx = 0;
+        for (uint32_t t = 0; t < nx; ++t) sx += piece(pcodes[((int64_t)xl0 + t) * LPC + sub]);
+        sum += l0_red<LPC>(sx);
       }
-      sum = l0_red<LPC>(sum);   // bits 24.. count the pieces that hold an escaped / infinite code (at most 8 x lines, far below 2^8)
       if (sum >> 24) {
         // some code of this candidate has an escaped (e >= 800) or infinite excess: a second pass that takes the escape values
-        // from LDS.  The group branches as one (the sum is the same in its 8 lanes); the first line is still in registers.
+        // from LDS; the first line is still in registers.
         uint32_t s2 = 0, inf = 0;
-        for (uint32_t t = 0; t < nlk; ++t) {
-          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)l0k + t) * LPC + sub];
-          const uint32_t cnt = q.w >> 24;
+        for (uint32_t t = 0; t <= nx; ++t) {
+          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)xl0 + t - 1) * LPC + sub];
+          const uint32_t cnt = (q.w >> 24) & 0x7Fu;
           uint32_t c[6];
           codes6(q, c);
           uint32_t s6 = 0, i6 = 0, last = 0;
@@ -2351,8 +2356,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
           if (i + k < n) ubrow[i + k] = (uint16_t)outv[k];
       }
     }
-    m0 = m1; m1 = m2; m2 = m3;
-    pid3 = pid4;
+    p0 = p1; p1 = p2; p2 = p3;
   };
   while (i < n) {
     body(pcA, pcB);

@@ -1331,7 +1331,8 @@ static void launch_maxsim6(const FpIndexDev& ix, const uint16_t* qpad, const FpS
     if ((int64_t)g * waves > tot_max) g = (int)std::max<int64_t>(1, (tot_max + waves - 1) / waves);
     return g;
   };
-  static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  static const float eps_env = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  const float eps_rel = eps_env * (ix.dim > 128 ? (float)ix.dim / 128.f : 1.f);   // (the window was measured at dim 128; the reorder noise grows with the number of terms)
   static const int xcd = [] { const char* e = getenv("FP_MS_XCD"); return e ? atoi(e) : 0; }();
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
            Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, ix.rinv, xcd};
@@ -1361,7 +1362,8 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
   const int64_t tot_max = (int64_t)sh.B * Rcap;
   int grid = ms_num_cus();
   if ((int64_t)grid * MS_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS_WAVES - 1) / MS_WAVES);
-  static const float eps_rel = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  static const float eps_env = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  const float eps_rel = eps_env * (ix.dim > 128 ? (float)ix.dim / 128.f : 1.f);   // (the window was measured at dim 128; the reorder noise grows with the number of terms)
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
            Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, nullptr, 0};
   static std::atomic<uint64_t> ok1{0}, ok2{0};

@@ -322,35 +322,47 @@ __global__ void k_pcode_range(const int32_t* __restrict__ ucodes, const int64_t*
     re[d] = z0;
   }
 }
-__global__ void k_pcode_lines(const int64_t* __restrict__ rs, const int64_t* __restrict__ re, int64_t n_docs, int64_t* __restrict__ nlines, int cpl /*codes per line*/) {
-  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= n_docs; d += (int64_t)gridDim.x * blockDim.x)
-    nlines[d] = d < n_docs ? (re[d] - rs[d] + cpl - 1) / cpl : 0;
+// lines beyond a document's first ("extra" lines: documents with more codes in the range than one line holds)
+__global__ void k_pcode_lines(const int64_t* __restrict__ rs, const int64_t* __restrict__ re, int64_t n_docs, int64_t* __restrict__ nextra, int cpl /*codes per line*/) {
+  for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= n_docs; d += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nl = d < n_docs ? (re[d] - rs[d] + cpl - 1) / cpl : 0;
+    nextra[d] = nl > 1 ? nl - 1 : 0;
+  }
 }
+// Layout: line d (d < n_docs) is document d's FIRST line -- the scan addresses it by the document id, no lookup -- and the extra
+// lines of the documents that need them follow behind, contiguous per document; poff[d] = {n_docs + first extra line, count}.
+// A document with extra lines carries bit 7 in the count byte of its first line's last piece.
 __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ ucodes, const int64_t* __restrict__ rs,
                                                     const int64_t* __restrict__ re, int64_t n_docs, int32_t code_base,
-                                                    const int64_t* __restrict__ loff, int32_t* __restrict__ poff, uint4* __restrict__ lines,
+                                                    const int64_t* __restrict__ xoff /*[n_docs + 1] exclusive scan of the extra-line counts*/,
+                                                    int32_t* __restrict__ poff, uint4* __restrict__ lines,
                                                     int ppl /*pieces per line: 8 or 4*/) {
   // one thread per piece
-  const int64_t nl = loff[n_docs];
+  const int64_t nl = n_docs + xoff[n_docs];
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nl * ppl + n_docs + 1; g += (int64_t)gridDim.x * blockDim.x) {
-    if (g >= nl * ppl) {   // per document {first line, line count}
+    if (g >= nl * ppl) {   // per document {first extra line, extra line count}
       const int64_t d = g - nl * ppl;
       if (d < n_docs) {
-        poff[2 * d] = (int32_t)loff[d];
-        poff[2 * d + 1] = (int32_t)(loff[d + 1] - loff[d]);
+        poff[2 * d] = (int32_t)(n_docs + xoff[d]);
+        poff[2 * d + 1] = (int32_t)(xoff[d + 1] - xoff[d]);
       }
       continue;
     }
     const int64_t line = g / ppl;
     const int piece = (int)(g % ppl);
-    // document of `line`: last d with loff[d] <= line
-    int64_t lo = 0, hi = n_docs;
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (loff[mid] <= line) lo = mid; else hi = mid;
+    int64_t doc = line, lineno = 0;
+    if (line >= n_docs) {   // an extra line: its document is the last d with xoff[d] <= x
+      const int64_t x = line - n_docs;
+      int64_t lo = 0, hi = n_docs;
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (xoff[mid] <= x) lo = mid; else hi = mid;
+      }
+      doc = lo;
+      lineno = 1 + (x - xoff[lo]);
     }
-    const int64_t u0 = rs[lo], n = re[lo] - u0;
-    const int64_t first = (line - loff[lo]) * (PCODES_PER_PIECE * ppl) + (int64_t)piece * PCODES_PER_PIECE;
+    const int64_t u0 = rs[doc], n = re[doc] - u0;
+    const int64_t first = lineno * (PCODES_PER_PIECE * ppl) + (int64_t)piece * PCODES_PER_PIECE;
     // piece = 6 codes of 20 bits (bits 0..119) + the count in bits 120..127.  Slots past the piece's last code repeat that code
     // (an empty piece holds code 0 six times): the scan sums all six table entries and takes (6 - count) x the last one off
     // again, instead of predicating every lookup
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
       }
       bits |= (unsigned __int128)(c & 0xFFFFFu) << (20 * j);
     }
+    if (lineno == 0 && piece == ppl - 1 && xoff[doc + 1] > xoff[doc]) cnt |= 0x80u;   // "this document has extra lines"
     bits |= (unsigned __int128)cnt << 120;
     uint32_t w[4];
     for (int k = 0; k < 4; ++k) w[k] = (uint32_t)(bits >> (32 * k));
@@ -372,8 +385,9 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
   }
 }
 
-// The unique codes in [code_lo, code_hi) (at most 2^17 values) of every document, packed into 128-byte lines.  Allocates
-// *lines ([NL] x 128 B) and *poff ([N] x {first line, line count} i32 pairs); returns 0 or a hipError
+// The unique codes in [code_lo, code_hi) (at most 2^17 values) of every document, packed into 128-byte (ppl 8) or 64-byte (ppl 4)
+// lines.  Allocates *lines ([n_docs first lines + the extra lines]) and *poff ([N] x {first extra line, extra line count} i32
+// pairs); *n_lines = lines in all; returns 0 or a hipError
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
                      int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl) {
   int rc = 0;
@@ -400,7 +414,9 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   HCHK(hipMemcpyAsync(n_lines, loff + n_docs, 8, hipMemcpyDeviceToHost, st));
   HCHK(hipStreamSynchronize(st));
   if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
-  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 16 * ppl + 256));   // a document without codes at the very end reads "its" line: one line of slack
+  *n_lines += n_docs;   // the first lines
+  if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
+  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 16 * ppl + 256));
   {
     const int64_t work = *n_lines * ppl + n_docs + 1;
     hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, rs, re, n_docs, (int32_t)code_lo, loff,
