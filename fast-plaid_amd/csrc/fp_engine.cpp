@@ -903,7 +903,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       HIPCHK(s->l0_xdst.ensure((size_t)M * 4));
       HIPCHK(s->l0_blkx.ensure((size_t)B * nblk2 * 4));
       FpL0Scratch w{s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(),
-                    s->l0_ub.as<uint16_t>(), s->l0_hist.as<uint32_t>(), s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), s->l0_blkx.as<int32_t>(), nblk2,
+                    s->l0_ub.as<uint16_t>(), s->l0_hist.as<uint32_t>(), s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), s->l0_blkx.as<int32_t>(),
+                    (int)((max_n + FP_L0_CHUNK - 1) / FP_L0_CHUNK),
                     s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>(),
                     s->l0_pilot_idx.as<int32_t>(), s->l0_capprox.as<float>(), s->l0_thr.as<int32_t>(), s->l0_nextra.as<int32_t>(),
                     s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>(), s->tickets.as<uint32_t>() + (B + 1)};

@@ -170,6 +170,7 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
+#define FP_L0_CHUNK 8192   // candidates per workgroup of level 0's survivor count / compaction
 void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid,
                           int64_t M, uint32_t* kq, hipStream_t st);
 void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, uint32_t* q8hist, uint32_t* kq,
@@ -185,7 +186,7 @@ struct FpL0Scratch {
   int32_t* cut;         // [B]
   int32_t* blkcnt;      // [B][nblk] survivors per chunk
   int32_t* blkcntx;     // [B][nblk] survivors outside the pilot group per chunk
-  int nblk;             // ceil(max candidates per query / FP_SURV_CHUNK)
+  int nblk;             // ceil(max candidates per query / FP_L0_CHUNK)
   int32_t* npilot;      // [B] (may exceed the capacity: then nothing is pruned)
   int32_t* pilot_pid;   // [B][fpk_l0_pilot_cap()]
   float* pilot_approx;  // [B][fpk_l0_pilot_cap()]

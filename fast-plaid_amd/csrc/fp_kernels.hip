@@ -1939,9 +1939,13 @@ __global__ __launch_bounds__(256) void k_surv_compact(const uint32_t* __restrict
     __syncthreads();
   }
   int64_t pos = surv_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x] + (s[threadIdx.x] - cnt);
+  if (!cnt) return;
+  int32_t pid[PER];   // the gathers first, then the stores (interleaved, every survivor costs a round trip of its own: k_l0_compact)
+#pragma unroll
+  for (int k = 0; k < PER; ++k) pid[k] = keep[k] ? cand_pid[beg + c0 + threadIdx.x * PER + k] : 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    if (keep[k]) surv_pid[pos++] = cand_pid[beg + c0 + threadIdx.x * PER + k];
+    if (keep[k]) surv_pid[pos++] = pid[k];
   }
 }
 
@@ -2451,10 +2455,22 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
   const int64_t hi = lo + per < n ? lo + per : n;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  for (int64_t i0 = lo; i0 < hi; i0 += 2048) {
+  for (int64_t i00 = lo; i00 < hi; i00 += 4 * 2048) {
+  // four steps' bounds are fetched together (one load per thread and step left the kernel at 1.7 TB/s)
+  uint4 vv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = i00 + j * 2048 + threadIdx.x * 8;
+    vv[j] = make_uint4(0, 0, 0, 0);
+    if (i < hi) vv[j] = *reinterpret_cast<const uint4*>(row + i);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i0 = i00 + j * 2048;
+    if (i0 >= hi) break;   // (uniform)
     const int64_t i = i0 + threadIdx.x * 8;
     if (i < hi) {
-      const uint4 v = *reinterpret_cast<const uint4*>(row + i);
+      const uint4 v = vv[j];
       uint32_t m = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) m |= (i + k < hi && l0_u16(v, k) >= ct) ? (1u << k) : 0u;
@@ -2483,6 +2499,7 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
       if (threadIdx.x == 0) s_cnt = 0;
       __syncthreads();
     }
+  }
   }
 }
 
@@ -2546,8 +2563,12 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
   }
 }
 
-// ordered compaction of { ub >= thr[b] } (same scheme as k_surv_count / k_surv_compact; 8 bounds per thread in one 16-byte load)
-static_assert(SURV_CHUNK == 256 * 8, "one 16-byte load per thread covers a chunk");
+// ordered compaction of { ub >= thr[b] } (same scheme as k_surv_count / k_surv_compact).  A workgroup takes a chunk of
+// FP_L0_CHUNK = 8192 bounds: four 16-byte loads per thread, all in flight together (with one load per thread and 2048-bound
+// chunks the two kernels were 10^4 workgroups of three dependent round trips each: 22 + 44 us for 42 MB).  Candidate order
+// inside a chunk: (vector v, thread t, element k) -> position c0 + 2048 v + 8 t + k.
+#define L0_VPT 4
+static_assert(FP_L0_CHUNK == 256 * 8 * L0_VPT, "L0_VPT 16-byte loads per thread cover a chunk");
 // blkcnt: survivors per chunk; blkcntx: those of them outside the pilot group ("extras": ub < cutp[b], or the group overflowed)
 __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ thr, const int32_t* __restrict__ cutp,
@@ -2556,22 +2577,33 @@ __global__ __launch_bounds__(256) void k_l0_count(const uint16_t* __restrict__ u
                                                   int32_t* nsurv, int32_t* nextra, int B, int64_t* surv_off) {
   const int b = blockIdx.y;
   const int64_t n = cand_off[b + 1] - cand_off[b];
-  const int64_t i = (int64_t)blockIdx.x * SURV_CHUNK + threadIdx.x * 8;
+  const int64_t c0 = (int64_t)blockIdx.x * FP_L0_CHUNK;
   int cnt = 0, cx = 0;
-  if (i < n) {
+  if (c0 < n) {
     const uint32_t ct = (uint32_t)thr[b];
     const uint32_t cp = npilot[b] <= L0_PILOT_MAX ? (uint32_t)cutp[b] : 0x10000u;
-    const uint4 v = *reinterpret_cast<const uint4*>(ub + l0_row(cand_off, b) + i);
+    const uint16_t* row = ub + l0_row(cand_off, b);
+    uint4 v[L0_VPT];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t u = l0_u16(v, k);
-      const bool keep = i + k < n && u >= ct;
-      cnt += keep ? 1 : 0;
-      cx += (keep && u < cp) ? 1 : 0;
+    for (int j = 0; j < L0_VPT; ++j) {
+      const int64_t i = c0 + j * 2048 + threadIdx.x * 8;
+      v[j] = make_uint4(0, 0, 0, 0);
+      if (i < n) v[j] = *reinterpret_cast<const uint4*>(row + i);
+    }
+#pragma unroll
+    for (int j = 0; j < L0_VPT; ++j) {
+      const int64_t i = c0 + j * 2048 + threadIdx.x * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t u = l0_u16(v[j], k);
+        const bool keep = i + k < n && u >= ct;
+        cnt += keep ? 1 : 0;
+        cx += (keep && u < cp) ? 1 : 0;
+      }
     }
   }
   __shared__ int s[256];
-  s[threadIdx.x] = cnt | (cx << 16);   // both fit 16 bits (<= 2048 per chunk)
+  s[threadIdx.x] = cnt | (cx << 16);   // both fit 16 bits (<= 8192 per chunk)
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
@@ -2609,52 +2641,102 @@ __global__ __launch_bounds__(256) void k_l0_compact(const uint16_t* __restrict__
   const int b = blockIdx.y;
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
-  const int64_t c0 = (int64_t)blockIdx.x * SURV_CHUNK;
+  const int64_t c0 = (int64_t)blockIdx.x * FP_L0_CHUNK;
   if (c0 >= n) return;
   const uint32_t ct = (uint32_t)thr[b];
   const uint32_t cp = npilot[b] <= L0_PILOT_MAX ? (uint32_t)cutp[b] : 0x10000u;
-  const int64_t i = c0 + threadIdx.x * 8;
-  uint32_t keep = 0, inp = 0;
-  if (i < n) {
-    const uint4 v = *reinterpret_cast<const uint4*>(ub + l0_row(cand_off, b) + i);
+  const uint16_t* row = ub + l0_row(cand_off, b);
+  uint4 v[L0_VPT];
+#pragma unroll
+  for (int j = 0; j < L0_VPT; ++j) {
+    const int64_t i = c0 + j * 2048 + threadIdx.x * 8;
+    v[j] = make_uint4(0, 0, 0, 0);
+    if (i < n) v[j] = *reinterpret_cast<const uint4*>(row + i);
+  }
+  uint32_t keep[L0_VPT], inp[L0_VPT];
+  int packed[L0_VPT];   // survivors | extras << 16 of this thread's eight bounds of vector j
+#pragma unroll
+  for (int j = 0; j < L0_VPT; ++j) {
+    const int64_t i = c0 + j * 2048 + threadIdx.x * 8;
+    keep[j] = 0;
+    inp[j] = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const uint32_t u = l0_u16(v, k);
+      const uint32_t u = l0_u16(v[j], k);
       if (i + k < n && u >= ct) {
-        keep |= 1u << k;
-        if (u >= cp) inp |= 1u << k;
+        keep[j] |= 1u << k;
+        if (u >= cp) inp[j] |= 1u << k;
       }
     }
+    packed[j] = __popc(keep[j]) | (__popc(keep[j] & ~inp[j]) << 16);
   }
-  const int cnt = __popc(keep), cx = __popc(keep & ~inp);
-  __shared__ int s[256];
-  s[threadIdx.x] = cnt | (cx << 16);
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-    __syncthreads();
-    s[threadIdx.x] += t;
-    __syncthreads();
-  }
-  if (!keep) return;
-  const int64_t sb = surv_off[b];
-  const int incl = s[threadIdx.x];
-  int64_t pos = sb + blkoff[(int64_t)b * nblk + blockIdx.x] + ((incl & 0xFFFF) - cnt);
-  int64_t xp = sb + blkoffx[(int64_t)b * nblk + blockIdx.x] + ((incl >> 16) - cx);
+  // The gathers of everything this thread keeps, issued before the prefix is even known (they do not depend on it): by the time
+  // the scans are through, the values are there.  (Interleaved with the stores -- a load, its store, the next load -- every
+  // survivor of a wave cost a round trip of its own, up to 32 in a row per workgroup.)
+  int32_t pid[L0_VPT][8];
+  float ap[L0_VPT][8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    if (keep & (1u << k)) {
-      const int32_t pid = cand_pid[beg + i + k];
-      surv_pid[pos] = pid;
-      if (inp & (1u << k)) {
-        surv_approx[pos] = cand_approx[beg + i + k];
-      } else {
-        xpid[xp] = pid;
-        xdst[xp] = (int32_t)(pos - sb);
-        ++xp;
-      }
-      ++pos;
+  for (int j = 0; j < L0_VPT; ++j) {
+    const int64_t i = c0 + j * 2048 + threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      pid[j][k] = (keep[j] & (1u << k)) ? cand_pid[beg + i + k] : 0;
+      ap[j][k] = (inp[j] & (1u << k)) ? cand_approx[beg + i + k] : 0.f;
     }
+  }
+  // inclusive scans of the four vectors: inside a wave by shuffles, across the four waves through 16 words of LDS (one barrier
+  // instead of the sixteen of a shared-memory scan)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl[L0_VPT];
+#pragma unroll
+  for (int j = 0; j < L0_VPT; ++j) {
+    int x = packed[j];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    incl[j] = x;
+  }
+  __shared__ int wtot[L0_VPT][4];
+  if (lane == 63) {
+#pragma unroll
+    for (int j = 0; j < L0_VPT; ++j) wtot[j][wave] = incl[j];
+  }
+  __syncthreads();
+  const int64_t sb = surv_off[b];
+  int64_t pos0 = sb + blkoff[(int64_t)b * nblk + blockIdx.x];
+  int64_t xp0 = sb + blkoffx[(int64_t)b * nblk + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < L0_VPT; ++j) {
+    int before = 0, tot = 0;   // survivors | extras of the earlier waves / of the whole vector
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int t = wtot[j][w];
+      before += w < wave ? t : 0;
+      tot += t;
+    }
+    if (keep[j]) {
+      const int excl = before + incl[j] - packed[j];
+      int64_t pos = pos0 + (excl & 0xFFFF);
+      int64_t xp = xp0 + (excl >> 16);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (keep[j] & (1u << k)) {
+          surv_pid[pos] = pid[j][k];
+          if (inp[j] & (1u << k)) {
+            surv_approx[pos] = ap[j][k];
+          } else {
+            xpid[xp] = pid[j][k];
+            xdst[xp] = (int32_t)(pos - sb);
+            ++xp;
+          }
+          ++pos;
+        }
+      }
+    }
+    pos0 += tot & 0xFFFF;
+    xp0 += tot >> 16;
   }
 }
 
@@ -2762,7 +2844,11 @@ void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_
   static const int mult = [] { const char* e = getenv("FP_L0_PILOT"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
   hipLaunchKernelGGL(k_l0_topcut, dim3((unsigned)B), dim3(1024), 0, st, w.hist, cand_off, sh.n_full, sh.R, mult, w.Fsum, w.cut, w.npilot);
   const int64_t per_q = (M + B - 1) / B;
-  int64_t bx = (per_q + 8191) / 8192;
+  // candidates per workgroup: every workgroup ends with one atomic on its query's counter, and the B counters share a cache
+  // line -- device-scope atomics on one line retire at ~6 ns each, whatever the address (8192 / 16384 / 32768 / 65536 per
+  // workgroup at cfg2: 28.3 / 19.8 / 25.7 / 42.3 us; k_l0_count reads the same 42 MB without the atomics in 12.7 us)
+  static const int cpb = [] { const char* e = getenv("FP_L0_PILOT_CPB"); const int v = e ? atoi(e) : 16384; return v >= 2048 ? v : 16384; }();
+  int64_t bx = (per_q + cpb - 1) / cpb;
   if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(k_l0_pilot, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, cand_pid, w.cut, w.npilot, w.pilot_pid,
