@@ -204,6 +204,7 @@ struct FpL0Scratch {
 struct FpL0Multi {         // the per-range arrays of a multi-range table, by value to the scan kernel
   int nr;
   int seq_r;               // one launch per range: the range of this launch
+  int pair;                // 64-byte lines read as 128-byte pairs of ranges by 8 lanes (half of them count)
   int64_t ub_stride;       // entries between the ranges' partial-bound arrays
   const uint4* x[8];       // extra lines of range r
   const int32_t* po[8];    // {first extra line, count} of range r

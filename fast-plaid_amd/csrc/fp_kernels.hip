@@ -2209,6 +2209,11 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   if (inter) poff = mr.po[rng];
   const uint4* __restrict__ xcodes = inter ? mr.x[rng] : pcodes;   // extra lines: the range's own array, or behind the first lines
   const int pstr = inter ? mr.nr : 1;
+  // pair mode (LPC == 8 over the 64-byte lines of a multi-range table): the 8 lanes of a candidate load the 128-byte PAIR of
+  // lines of ranges (2p, 2p + 1) in one request; only the half that belongs to this workgroup's range counts.  The partner
+  // range's workgroup issues the same request moments later and finds the line in L2.
+  const bool pair = multi && mr.pair != 0 && LPC == 8;
+  const int xlp = pair ? 4 : LPC;            // pieces per extra line
   uint8_t* tab = l0s;                                                  // [tab_bytes + 16]
   uint32_t* es = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [64]
   uint32_t* hl = es + 64;                                              // [L0_HBINS]
@@ -2239,6 +2244,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   if ((int64_t)bxi * CPI >= n) return;
   const uint32_t F = multi ? 0u : Fsum[b];
   const int sub = tid & (LPC - 1);
+  const bool active = !pair || (sub >> 2) == (rng & 1);   // pair mode: this lane holds a piece of the workgroup's own range
   const int kq = sub & 3;                      // the candidate of the group's four whose id this lane fetches
   const int64_t stride = (int64_t)bxn * CPI;
   const int32_t* cpids = cand_pid + beg;
@@ -2264,6 +2270,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   auto pos = [&](int64_t at) -> int64_t { return at + kq < nlast ? at + kq : nlast; };
   auto load_line = [&](uint32_t line) -> uint4 {
     if (ABL & 2) return make_uint4(line * 2654435761u & 0x1FFFFu, line * 40503u & 0x1FFFFu, line * 7919u & 0x1FFFFu, 0x06000000u | (line & 0xFFFFu));
+    if (pair) return pcodes[((int64_t)line * pstr + (rng & ~1)) * 4 + sub];
     return pcodes[((int64_t)line * pstr + rng) * LPC + sub];
   };
   // (a document's first line is line <document id>: no lookup between the id and the line)
@@ -2330,6 +2337,10 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     } else {
 #pragma unroll
       for (int k = 0; k < L0_UNROLL; ++k) sums[k] = piece(pc[k]);   // straight-line: all 24 table reads of the lane in flight together
+      if (pair) {
+#pragma unroll
+        for (int k = 0; k < L0_UNROLL; ++k) sums[k] = active ? sums[k] : 0u;
+      }
     }
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
@@ -2344,7 +2355,10 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         xl0 = mx.x;
         nx = mx.y;
         uint32_t sx = 0;
-        for (uint32_t t = 0; t < nx; ++t) sx += piece(xcodes[((int64_t)xl0 + t) * LPC + sub]);
+        for (uint32_t t = 0; t < nx; ++t) {
+          const uint32_t px = piece(xcodes[((int64_t)xl0 + t) * xlp + (sub & (xlp - 1))]);
+          sx += active ? px : 0u;
+        }
         sum += l0_red<LPC>(sx);
       }
       if (sum >> 24) {
@@ -2352,7 +2366,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         // from LDS; the first line is still in registers.
         uint32_t s2 = 0, inf = 0;
         for (uint32_t t = 0; t <= nx; ++t) {
-          const uint4 q = t == 0 ? pc[k] : xcodes[((int64_t)xl0 + t - 1) * LPC + sub];
+          const uint4 q = t == 0 ? pc[k] : xcodes[((int64_t)xl0 + t - 1) * xlp + (sub & (xlp - 1))];
           const uint32_t cnt = (q.w >> 24) & 0x7Fu;
           uint32_t c[6];
           codes6(q, c);
@@ -2365,8 +2379,8 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
             last = v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
             s6 += last;
           }
-          s2 += s6 - (6u - cnt) * last;
-          inf |= cnt ? i6 : 0u;
+          s2 += active ? s6 - (6u - cnt) * last : 0u;
+          inf |= (cnt && active) ? i6 : 0u;
         }
         sum = l0_red<LPC>(s2);
         sum = l0_maxg<LPC>(inf) ? 0xFFFFFFu : sum;
@@ -2898,7 +2912,9 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   static const int multi_env = [] { const char* e = getenv("FP_L0_MULTI"); return e ? atoi(e) : 1; }();
   if (ix.n_ranges > 1 && multi_env && w.ub_parts && ((bx + 7) & ~7ll) * ix.n_ranges * (int64_t)B < 0x7FFFFFFFll) {
     const dim3 g1((unsigned)(((bx + 7) & ~7ll) * ix.n_ranges * B));
-    if (ix.l0_ppl == 4)
+    static const int pair_env = [] { const char* e = getenv("FP_L0_PAIR"); return e ? atoi(e) : 1; }();
+    mr.pair = (pair_env && ix.l0_ppl == 4 && ix.n_ranges % 2 == 0) ? 1 : 0;
+    if (ix.l0_ppl == 4 && !mr.pair)
       hipLaunchKernelGGL((k_l0_scan<0, 4>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
                          (const int32_t*)nullptr, ix.pcodes, w.ub_parts, w.hist, 1, 0, (int)bx, 2, mr);
     else
