@@ -452,7 +452,7 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     for (int r = 0; r < nr; ++r) {
       void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
       const int64_t lo = (int64_t)r << 17, hi = std::min<int64_t>(D.C, lo + (1ll << 17));
-      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st, D.l0_ppl, shared, nr, r);
+      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st, D.l0_ppl, D.C, shared, nr, r);
       if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 16 * D.l0_ppl; D.n_lines += nl; }
       if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
       if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");

@@ -330,7 +330,8 @@ int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n
                      int64_t* uoff_dev, hipStream_t st);
 // The unique codes in [code_lo, code_hi) of every document packed into lines (S4 level 0): N first lines + the extra lines.  Allocates *lines and *poff [N][2].
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
-                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl = 8 /*16-byte pieces (6 codes each) per line: 8 or 4*/,
+                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl /*16-byte pieces (6 codes each) per line: 8 or 4*/,
+                     int64_t n_centroids /*of the whole table: fixes the pad slot of this range*/,
                      void* shared_first = nullptr /*multi-range tables: the interleaved first lines [n_docs * nr] -> *lines holds the extra lines only*/,
                      int nr = 1, int r = 0);
 // final ranking of rerank lists beyond the LDS sort of k_final_topk (segmented device radix sort; synchronises); 0 or a hipError / -1

@@ -2304,20 +2304,19 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     c[5] = (pc.w >> 4) & 0xFFFFFu;
   };
   auto piece = [&](const uint4& pc) -> uint32_t {
-    const uint32_t cnt = (pc.w >> 24) & 0x7Fu;   // (bit 31 of the word: "the document has extra lines", first line's last piece only)
+    // (slots past the piece's count point at a zero byte behind the table slice: all six are summed as they are; bit 31 of the
+    // word: "the document has extra lines", first line's last piece only)
     uint32_t c[6], v[6];
     codes6(pc, c);
 #pragma unroll
     for (int j = 0; j < 6; ++j) v[j] = *reinterpret_cast<l0_lds_u8*>((uintptr_t)c[j]);
-    uint32_t s6 = 0, m6 = 0, last = 0;
+    uint32_t s6 = 0, m6 = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      last = (uint32_t)max((int)v[j], 8 * (int)v[j] - 8 * L0_LIN + L0_LIN);
-      s6 += last;
+      s6 += (uint32_t)max((int)v[j], 8 * (int)v[j] - 8 * L0_LIN + L0_LIN);
       m6 = max(m6, v[j]);
     }
-    s6 -= (6u - cnt) * last;
-    return s6 + ((cnt && m6 >= L0_ESC_BASE) ? (1u << 24) : 0u) + ((pc.w >> 31) << 30);   // bit 30: "extra lines" (set in one piece of a first line at most)
+    return s6 + (m6 >= L0_ESC_BASE ? (1u << 24) : 0u) + ((pc.w >> 31) << 30);   // bit 30: "extra lines" (set in one piece of a first line at most)
   };
   auto body = [&](uint4 (&pc)[L0_UNROLL], uint4 (&pcn)[L0_UNROLL]) {
     // issue: lines of t+1, ids of t+3
@@ -2367,20 +2366,18 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         uint32_t s2 = 0, inf = 0;
         for (uint32_t t = 0; t <= nx; ++t) {
           const uint4 q = t == 0 ? pc[k] : xcodes[((int64_t)xl0 + t - 1) * xlp + (sub & (xlp - 1))];
-          const uint32_t cnt = (q.w >> 24) & 0x7Fu;
           uint32_t c[6];
           codes6(q, c);
-          uint32_t s6 = 0, i6 = 0, last = 0;
+          uint32_t s6 = 0, i6 = 0;
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
             const uint32_t v = tab[c[j]];
             const uint32_t ev = es[(max(v, (uint32_t)L0_ESC_BASE) - L0_ESC_BASE) & 63];
             i6 |= (v == 255u) ? 1u : 0u;
-            last = v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
-            s6 += last;
+            s6 += v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
           }
-          s2 += active ? s6 - (6u - cnt) * last : 0u;
-          inf |= (cnt && active) ? i6 : 0u;
+          s2 += active ? s6 : 0u;
+          inf |= active ? i6 : 0u;
         }
         sum = l0_red<LPC>(s2);
         sum = l0_maxg<LPC>(inf) ? 0xFFFFFFu : sum;
@@ -2912,7 +2909,7 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   static const int multi_env = [] { const char* e = getenv("FP_L0_MULTI"); return e ? atoi(e) : 1; }();
   if (ix.n_ranges > 1 && multi_env && w.ub_parts && ((bx + 7) & ~7ll) * ix.n_ranges * (int64_t)B < 0x7FFFFFFFll) {
     const dim3 g1((unsigned)(((bx + 7) & ~7ll) * ix.n_ranges * B));
-    static const int pair_env = [] { const char* e = getenv("FP_L0_PAIR"); return e ? atoi(e) : 1; }();
+    static const int pair_env = [] { const char* e = getenv("FP_L0_PAIR"); return e ? atoi(e) : 0; }();   // (measured slower at cfg3: 61.0 vs 46.9 ms -- experiment only)
     mr.pair = (pair_env && ix.l0_ppl == 4 && ix.n_ranges % 2 == 0) ? 1 : 0;
     if (ix.l0_ppl == 4 && !mr.pair)
       hipLaunchKernelGGL((k_l0_scan<0, 4>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
