@@ -2341,12 +2341,33 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         for (int k = 0; k < L0_UNROLL; ++k) sums[k] = active ? sums[k] : 0u;
       }
     }
+    uint32_t red[L0_UNROLL];
+#pragma unroll
+    for (int k = 0; k < L0_UNROLL; ++k) red[k] = l0_red<LPC>(sums[k]);
+    // The common case -- none of the group's four candidates has an escaped code or extra lines (bits 24.. clear) -- is finished
+    // "transposed": lane j of the group completes candidate j & 3 alone (floor sum, saturation, histogram bin) and the four
+    // results return to lane 0 by quad broadcasts.  Every lane finishing all four candidates was 4 x ~20 vector instructions per
+    // iteration beside the 4 x 32 of the lookups themselves.
+    const bool plain4 = ((red[0] | red[1] | red[2] | red[3]) >> 24) == 0u;
+    if (plain4) {
+      const int kk = sub & 3;
+      const uint32_t mys = kk == 0 ? red[0] : (kk == 1 ? red[1] : (kk == 2 ? red[2] : red[3]));
+      const uint32_t myp = kk == 0 ? (uint32_t)prev[0] : (kk == 1 ? (uint32_t)prev[1] : (kk == 2 ? (uint32_t)prev[2] : (uint32_t)prev[3]));
+      uint32_t v = (first ? F : myp) + mys;
+      v = (!first && myp == L0_INF) ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
+      if (last && sub < 4 && i + kk < n) {
+        const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
+        atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
+      }
+#pragma unroll
+      for (int k = 0; k < L0_UNROLL; ++k) outv[k] = qb(v, k);
+    } else {
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
       // bits 24.. of the sum count the pieces that hold an escaped / infinite code (at most 8 in a first line); bit 30 says that
       // the document has extra lines (more than one line's worth of distinct codes in this range): rare, {first, count} then
       // come from the side table.  The group branches as one (the reduced values are the same in all its lanes).
-      uint32_t sum = l0_red<LPC>(sums[k]);
+      uint32_t sum = red[k];
       uint32_t xl0 = 0, nx = 0;
       if (sum & (1u << 30)) {
         sum -= 1u << 30;
@@ -2389,6 +2410,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
         atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
       }
+    }
     }
     if (sub == 0) {   // the group's four bounds leave as one 8-byte store when they can (2-byte stores are one fabric write each)
       if (i + L0_UNROLL <= n) {
