@@ -132,7 +132,7 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -207,7 +207,7 @@ struct Scratch {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp})
       b->release();
     h_out.release();
     h_small.release();
@@ -439,17 +439,27 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     static const int ppl_env = [] { const char* e2 = getenv("FP_L0_PPL"); return e2 ? atoi(e2) : 0; }();
     if (ppl_env == 4 || ppl_env == 8) D.l0_ppl = ppl_env;
     else if (nr > 1 && D.N > 0 && (double)D.U / ((double)D.N * nr) <= 14.0) D.l0_ppl = 4;
+    // several ranges: ONE array of first lines, a document's ranges side by side (the scan then runs all ranges in one launch
+    // and the lines of a document's ranges share fabric requests); the per-range arrays hold the extra lines only
+    void* shared = nullptr;
+    if (nr > 1) {
+      const size_t sb = (size_t)D.N * nr * 16 * D.l0_ppl + 256;
+      if (hipMalloc(&shared, sb) != hipSuccess) return fail(FP_EHIP, "packed-code build failed (out of memory)");
+      ix->owned.push_back(shared);
+      ix->bytes += (int64_t)sb;
+      D.n_lines += D.N * nr;
+    }
     for (int r = 0; r < nr; ++r) {
       void* lines = nullptr; int32_t* poff = nullptr; int64_t nl = 0;
       const int64_t lo = (int64_t)r << 17, hi = std::min<int64_t>(D.C, lo + (1ll << 17));
-      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st, D.l0_ppl);
+      const int prc = fps_build_pcodes(D.ucodes, D.uoff, D.N, lo, hi, &lines, &poff, &nl, st, D.l0_ppl, D.C, shared, nr, r);
       if (lines) { ix->owned.push_back(lines); ix->bytes += nl * 16 * D.l0_ppl; D.n_lines += nl; }
       if (poff) { ix->owned.push_back(poff); ix->bytes += (D.N + 1) * 8; }
       if (prc != 0) return fail(FP_EHIP, "packed-code build failed (hip error " + std::to_string(prc) + ")");
       D.pcodes_r[r] = static_cast<const uint4*>(lines); D.poff_r[r] = poff;
     }
     D.n_ranges = nr;
-    D.pcodes = D.pcodes_r[0]; D.poff = D.poff_r[0];
+    D.pcodes = nr > 1 ? static_cast<const uint4*>(shared) : D.pcodes_r[0]; D.poff = D.poff_r[0];
   }
   return FP_OK;
 }
@@ -890,6 +900,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       HIPCHK(s->l0_e8.ensure((size_t)B * Cpad));
       HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
       HIPCHK(s->l0_ub.ensure(((size_t)M + 8 * (size_t)B + 16) * 2));   // rows start on 16-byte boundaries (l0_row)
+      const int64_t ub_stride = ((int64_t)M + 8 * (int64_t)B + 16 + 7) & ~7ll;
+      if (D.n_ranges > 1) HIPCHK(s->l0_ubp.ensure((size_t)ub_stride * D.n_ranges * 2 + 64));
       const int64_t pcap = fpk_l0_pilot_cap();
       HIPCHK(s->l0_hist.ensure(fpk_l0_hist_bytes(B)));
       HIPCHK(s->l0_npilot.ensure((size_t)B * 4));
@@ -907,7 +919,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                     (int)((max_n + FP_L0_CHUNK - 1) / FP_L0_CHUNK),
                     s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>(),
                     s->l0_pilot_idx.as<int32_t>(), s->l0_capprox.as<float>(), s->l0_thr.as<int32_t>(), s->l0_nextra.as<int32_t>(),
-                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>(), s->tickets.as<uint32_t>() + (B + 1)};
+                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>(), s->tickets.as<uint32_t>() + (B + 1),
+                    D.n_ranges > 1 ? s->l0_ubp.as<uint16_t>() : nullptr, ub_stride};
       fpk_l0_prepare(D, nullptr, sh, w, st, P.l0hist_prezeroed);   // floors and table came with S1
       STAGE_DONE(ST_APPROX);
       // (grid: from the previous batch's total when M is the learnt capacity -- every extra workgroup copies the table into LDS;

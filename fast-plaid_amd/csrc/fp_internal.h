@@ -49,7 +49,8 @@ struct FpIndexDev {
   const int32_t* poff;     // [N][2] {first extra line, extra line count} of each document in pcodes (read for flagged first lines only)
   // centroid ranges of 2^17 (FP_L0_RANGE) for tables beyond 2^17 centroids: range r has its own lines / offsets with codes
   // relative to r * 2^17; [0] aliases pcodes / poff
-  int n_ranges;
+  int n_ranges;            // > 1: pcodes holds the ranges' first lines INTERLEAVED (line d * n_ranges + r = document d, range r: the lines of a
+                           // document's ranges share 128-byte fabric requests) and pcodes_r[r] only range r's extra lines
   int l0_ppl;              // 16-byte pieces per code line: 8 (128-byte lines) or 4 (64-byte lines; tables of several ranges)
   int64_t n_lines;         // code lines over all ranges
   const uint4* pcodes_r[8];
@@ -197,6 +198,16 @@ struct FpL0Scratch {
   int32_t* xpid;        // [M] rows at surv_off[b]: their document ids ...
   int32_t* xdst;        // [M] ... and positions in the survivor list
   uint32_t* tickets;    // nullable: [B + 1] zeroed counters -> count + scans + offsets of the survivor lists in ONE launch
+  uint16_t* ub_parts;   // nullable: [n_ranges][ub_stride] partial bounds of a multi-range table (all ranges in one launch)
+  int64_t ub_stride;
+};
+struct FpL0Multi {         // the per-range arrays of a multi-range table, by value to the scan kernel
+  int nr;
+  int seq_r;               // one launch per range: the range of this launch
+  int pair;                // 64-byte lines read as 128-byte pairs of ranges by 8 lanes (half of them count)
+  int64_t ub_stride;       // entries between the ranges' partial-bound arrays
+  const uint4* x[8];       // extra lines of range r
+  const int32_t* po[8];    // {first extra line, count} of range r
 };
 bool fpk_l0_fits(const FpIndexDev& ix);
 void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8 /*nullptr: floors and table came with S1*/, const FpSearchShape& sh, FpL0Scratch& w,
@@ -319,7 +330,10 @@ int fps_build_ucodes(const int32_t* codes, const int64_t* doc_off_dev, int64_t n
                      int64_t* uoff_dev, hipStream_t st);
 // The unique codes in [code_lo, code_hi) of every document packed into lines (S4 level 0): N first lines + the extra lines.  Allocates *lines and *poff [N][2].
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
-                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl = 8 /*16-byte pieces (6 codes each) per line: 8 or 4*/);
+                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl /*16-byte pieces (6 codes each) per line: 8 or 4*/,
+                     int64_t n_centroids /*of the whole table: fixes the pad slot of this range*/,
+                     void* shared_first = nullptr /*multi-range tables: the interleaved first lines [n_docs * nr] -> *lines holds the extra lines only*/,
+                     int nr = 1, int r = 0);
 // final ranking of rerank lists beyond the LDS sort of k_final_topk (segmented device radix sort; synchronises); 0 or a hipError / -1
 int fps_final_topk_big(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride, int B,
                        int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt, hipStream_t st);

@@ -2175,6 +2175,11 @@ __device__ __forceinline__ uint32_t l0_maxg(uint32_t v) {
 // index's per-range code lines): the first launch writes F + its sum, the later ones add theirs (saturating, infinite stays
 // infinite), the last one builds the histogram from the final values.
 typedef __attribute__((address_space(3))) const uint8_t l0_lds_u8;
+__device__ __forceinline__ uint32_t l0_u16(const uint4& v, int k) {
+  const uint32_t w = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
+  return (k & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+#define FP_L0_RANGE_C (1ll << 17)   // == FP_L0_RANGE (defined with the launchers below)
 // LPC = lanes per candidate = 16-byte pieces per code line: 8 (128-byte lines, 48 codes: one line per document for tables of one
 // range) or 4 (64-byte lines, 24 codes: tables of several ranges, where a document has ~8 codes per range and 8 lanes per
 // candidate would spend three quarters of their lookups on empty pieces).
@@ -2184,9 +2189,31 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ poff,
                                                   const uint4* __restrict__ pcodes, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist,
-                                                  int first, int last, int bxn, int xcd_affine) {
+                                                  int first, int last, int bxn, int xcd_affine, FpL0Multi mr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)l0s != 0u) __builtin_trap();   // the table must sit at LDS address 0
+  // xcd_affine == 2: ALL RANGES OF A MULTI-RANGE TABLE IN ONE LAUNCH (see fpk_l0_scan): workgroup = (query, chunk, range r); it
+  // takes range r's slice of the table, reads line <document id> * nr + r of the interleaved first lines and writes its
+  // partial sums (no floor sum, no histogram) to part r of `ub`; k_l0_combine adds the parts up.
+  const bool multi = xcd_affine == 2;
+  const bool inter = mr.nr > 1;          // interleaved first lines (tables of several ranges)
+  int rng = inter ? mr.seq_r : 0;        // (one launch per range, FP_L0_MULTI=0: the host names the range)
+  if (multi) {
+    const int W = ((bxn + 7) & ~7) * mr.nr;           // workgroups per query
+    const int l = (int)(blockIdx.x % (unsigned)W);
+    rng = (l % (8 * mr.nr)) / 8;
+    tab_off = (int64_t)rng * FP_L0_RANGE_C;
+    tab_bytes = (int)(Cpad - tab_off < FP_L0_RANGE_C ? Cpad - tab_off : FP_L0_RANGE_C);
+    ub += (int64_t)rng * mr.ub_stride;
+  }
+  if (inter) poff = mr.po[rng];
+  const uint4* __restrict__ xcodes = inter ? mr.x[rng] : pcodes;   // extra lines: the range's own array, or behind the first lines
+  const int pstr = inter ? mr.nr : 1;
+  // pair mode (LPC == 8 over the 64-byte lines of a multi-range table): the 8 lanes of a candidate load the 128-byte PAIR of
+  // lines of ranges (2p, 2p + 1) in one request; only the half that belongs to this workgroup's range counts.  The partner
+  // range's workgroup issues the same request moments later and finds the line in L2.
+  const bool pair = multi && mr.pair != 0 && LPC == 8;
+  const int xlp = pair ? 4 : LPC;            // pieces per extra line
   uint8_t* tab = l0s;                                                  // [tab_bytes + 16]
   uint32_t* es = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [64]
   uint32_t* hl = es + 64;                                              // [L0_HBINS]
@@ -2196,7 +2223,13 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   // XCD b % 8 only.  bxn = chunks per query; needs B % 8 == 0.
   const int tid = threadIdx.x;
   int b, bxi;
-  if (xcd_affine) {
+  if (multi) {
+    const int W = ((bxn + 7) & ~7) * mr.nr;
+    const int l = (int)(blockIdx.x % (unsigned)W);
+    b = (int)(blockIdx.x / (unsigned)W);
+    bxi = (l / (8 * mr.nr)) * 8 + (l & 7);
+    if (bxi >= bxn) return;
+  } else if (xcd_affine) {
     const int lin = blockIdx.x;                 // 1-D launch of bxn * B workgroups
     const int xcd = lin & 7, slot = lin >> 3;   // slot-th workgroup of this XCD
     b = (slot / bxn) * 8 + xcd;
@@ -2209,8 +2242,9 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   const int64_t n = cand_off[b + 1] - beg;
   constexpr int CPI = (1024 / LPC) * L0_UNROLL;   // candidates per workgroup iteration
   if ((int64_t)bxi * CPI >= n) return;
-  const uint32_t F = Fsum[b];
+  const uint32_t F = multi ? 0u : Fsum[b];
   const int sub = tid & (LPC - 1);
+  const bool active = !pair || (sub >> 2) == (rng & 1);   // pair mode: this lane holds a piece of the workgroup's own range
   const int kq = sub & 3;                      // the candidate of the group's four whose id this lane fetches
   const int64_t stride = (int64_t)bxn * CPI;
   const int32_t* cpids = cand_pid + beg;
@@ -2236,7 +2270,8 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   auto pos = [&](int64_t at) -> int64_t { return at + kq < nlast ? at + kq : nlast; };
   auto load_line = [&](uint32_t line) -> uint4 {
     if (ABL & 2) return make_uint4(line * 2654435761u & 0x1FFFFu, line * 40503u & 0x1FFFFu, line * 7919u & 0x1FFFFu, 0x06000000u | (line & 0xFFFFu));
-    return pcodes[(int64_t)line * LPC + sub];
+    if (pair) return pcodes[((int64_t)line * pstr + (rng & ~1)) * 4 + sub];
+    return pcodes[((int64_t)line * pstr + rng) * LPC + sub];
   };
   // (a document's first line is line <document id>: no lookup between the id and the line)
   int32_t p0 = cpids[pos(i)];                          // iteration t
@@ -2269,20 +2304,19 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     c[5] = (pc.w >> 4) & 0xFFFFFu;
   };
   auto piece = [&](const uint4& pc) -> uint32_t {
-    const uint32_t cnt = (pc.w >> 24) & 0x7Fu;   // (bit 31 of the word: "the document has extra lines", first line's last piece only)
+    // (slots past the piece's count point at a zero byte behind the table slice: all six are summed as they are; bit 31 of the
+    // word: "the document has extra lines", first line's last piece only)
     uint32_t c[6], v[6];
     codes6(pc, c);
 #pragma unroll
     for (int j = 0; j < 6; ++j) v[j] = *reinterpret_cast<l0_lds_u8*>((uintptr_t)c[j]);
-    uint32_t s6 = 0, m6 = 0, last = 0;
+    uint32_t s6 = 0, m6 = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      last = (uint32_t)max((int)v[j], 8 * (int)v[j] - 8 * L0_LIN + L0_LIN);
-      s6 += last;
+      s6 += (uint32_t)max((int)v[j], 8 * (int)v[j] - 8 * L0_LIN + L0_LIN);
       m6 = max(m6, v[j]);
     }
-    s6 -= (6u - cnt) * last;
-    return s6 + ((cnt && m6 >= L0_ESC_BASE) ? (1u << 24) : 0u) + ((pc.w >> 31) << 30);   // bit 30: "extra lines" (set in one piece of a first line at most)
+    return s6 + (m6 >= L0_ESC_BASE ? (1u << 24) : 0u) + ((pc.w >> 31) << 30);   // bit 30: "extra lines" (set in one piece of a first line at most)
   };
   auto body = [&](uint4 (&pc)[L0_UNROLL], uint4 (&pcn)[L0_UNROLL]) {
     // issue: lines of t+1, ids of t+3
@@ -2302,13 +2336,38 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     } else {
 #pragma unroll
       for (int k = 0; k < L0_UNROLL; ++k) sums[k] = piece(pc[k]);   // straight-line: all 24 table reads of the lane in flight together
+      if (pair) {
+#pragma unroll
+        for (int k = 0; k < L0_UNROLL; ++k) sums[k] = active ? sums[k] : 0u;
+      }
     }
+    uint32_t red[L0_UNROLL];
+#pragma unroll
+    for (int k = 0; k < L0_UNROLL; ++k) red[k] = l0_red<LPC>(sums[k]);
+    // The common case -- none of the group's four candidates has an escaped code or extra lines (bits 24.. clear) -- is finished
+    // "transposed": lane j of the group completes candidate j & 3 alone (floor sum, saturation, histogram bin) and the four
+    // results return to lane 0 by quad broadcasts.  Every lane finishing all four candidates was 4 x ~20 vector instructions per
+    // iteration beside the 4 x 32 of the lookups themselves.
+    const bool plain4 = ((red[0] | red[1] | red[2] | red[3]) >> 24) == 0u;
+    if (plain4) {
+      const int kk = sub & 3;
+      const uint32_t mys = kk == 0 ? red[0] : (kk == 1 ? red[1] : (kk == 2 ? red[2] : red[3]));
+      const uint32_t myp = kk == 0 ? (uint32_t)prev[0] : (kk == 1 ? (uint32_t)prev[1] : (kk == 2 ? (uint32_t)prev[2] : (uint32_t)prev[3]));
+      uint32_t v = (first ? F : myp) + mys;
+      v = (!first && myp == L0_INF) ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
+      if (last && sub < 4 && i + kk < n) {
+        const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
+        atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
+      }
+#pragma unroll
+      for (int k = 0; k < L0_UNROLL; ++k) outv[k] = qb(v, k);
+    } else {
 #pragma unroll
     for (int k = 0; k < L0_UNROLL; ++k) {
       // bits 24.. of the sum count the pieces that hold an escaped / infinite code (at most 8 in a first line); bit 30 says that
       // the document has extra lines (more than one line's worth of distinct codes in this range): rare, {first, count} then
       // come from the side table.  The group branches as one (the reduced values are the same in all its lanes).
-      uint32_t sum = l0_red<LPC>(sums[k]);
+      uint32_t sum = red[k];
       uint32_t xl0 = 0, nx = 0;
       if (sum & (1u << 30)) {
         sum -= 1u << 30;
@@ -2316,7 +2375,10 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         xl0 = mx.x;
         nx = mx.y;
         uint32_t sx = 0;
-        for (uint32_t t = 0; t < nx; ++t) sx += piece(pcodes[((int64_t)xl0 + t) * LPC + sub]);
+        for (uint32_t t = 0; t < nx; ++t) {
+          const uint32_t px = piece(xcodes[((int64_t)xl0 + t) * xlp + (sub & (xlp - 1))]);
+          sx += active ? px : 0u;
+        }
         sum += l0_red<LPC>(sx);
       }
       if (sum >> 24) {
@@ -2324,21 +2386,19 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         // from LDS; the first line is still in registers.
         uint32_t s2 = 0, inf = 0;
         for (uint32_t t = 0; t <= nx; ++t) {
-          const uint4 q = t == 0 ? pc[k] : pcodes[((int64_t)xl0 + t - 1) * LPC + sub];
-          const uint32_t cnt = (q.w >> 24) & 0x7Fu;
+          const uint4 q = t == 0 ? pc[k] : xcodes[((int64_t)xl0 + t - 1) * xlp + (sub & (xlp - 1))];
           uint32_t c[6];
           codes6(q, c);
-          uint32_t s6 = 0, i6 = 0, last = 0;
+          uint32_t s6 = 0, i6 = 0;
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
             const uint32_t v = tab[c[j]];
             const uint32_t ev = es[(max(v, (uint32_t)L0_ESC_BASE) - L0_ESC_BASE) & 63];
             i6 |= (v == 255u) ? 1u : 0u;
-            last = v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
-            s6 += last;
+            s6 += v >= L0_ESC_BASE ? ev : (uint32_t)max((int)v, 8 * (int)v - 8 * L0_LIN + L0_LIN);
           }
-          s2 += s6 - (6u - cnt) * last;
-          inf |= cnt ? i6 : 0u;
+          s2 += active ? s6 : 0u;
+          inf |= active ? i6 : 0u;
         }
         sum = l0_red<LPC>(s2);
         sum = l0_maxg<LPC>(inf) ? 0xFFFFFFu : sum;
@@ -2350,6 +2410,7 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
         const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
         atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
       }
+    }
     }
     if (sub == 0) {   // the group's four bounds leave as one 8-byte store when they can (2-byte stores are one fabric write each)
       if (i + L0_UNROLL <= n) {
@@ -2369,9 +2430,52 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
     body(pcB, pcA);
     i += stride;
   }
+  if (!last) return;   // (uniform)
   __syncthreads();
   uint32_t* hg = hist + (int64_t)b * L0_HBINS;
   for (int i2 = tid; i2 < L0_HBINS; i2 += 1024) {
+    const uint32_t v = hl[i2];
+    if (v) atomicAdd(&hg[i2], v);
+  }
+}
+
+// ub[b][i] = min(F + sum over the ranges of part_r[b][i], 0xFFFE), 0xFFFF if any part is infinite; + the histogram of (ub - F) >> 2
+__global__ __launch_bounds__(256) void k_l0_combine(const uint16_t* __restrict__ parts, int nr, int64_t pstride, const uint32_t* __restrict__ Fsum,
+                                                    const int64_t* __restrict__ cand_off, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t hl[L0_HBINS];
+  const int b = blockIdx.y;
+  const int64_t n = cand_off[b + 1] - cand_off[b];
+  const int64_t row = l0_row(cand_off, b);
+  const uint32_t F = Fsum[b];
+  for (int i = threadIdx.x; i < L0_HBINS; i += 256) hl[i] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 2048 + threadIdx.x * 8; i < n; i += (int64_t)gridDim.x * 2048) {
+    uint32_t sum[8], inf = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum[k] = F;
+    for (int r = 0; r < nr; ++r) {
+      const uint4 v = *reinterpret_cast<const uint4*>(parts + (int64_t)r * pstride + row + i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t u = l0_u16(v, k);
+        sum[k] += u;
+        inf |= (u == L0_INF) ? (1u << k) : 0u;
+      }
+    }
+    uint32_t o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = (inf & (1u << k)) ? L0_INF : (sum[k] > 0xFFFEu ? 0xFFFEu : sum[k]);
+      if (i + k < n) {
+        const uint32_t hb = (o[k] >= F ? o[k] - F : 0u) >> 2;
+        atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
+      }
+    }
+    *reinterpret_cast<uint4*>(ub + row + i) = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+  }
+  __syncthreads();
+  uint32_t* hg = hist + (int64_t)b * L0_HBINS;
+  for (int i2 = threadIdx.x; i2 < L0_HBINS; i2 += 256) {
     const uint32_t v = hl[i2];
     if (v) atomicAdd(&hg[i2], v);
   }
@@ -2434,10 +2538,6 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
 // atomic per step (a per-wave atomic on the query's counter cost 1.1 ms at cfg2: ~3000 same-address atomics per query
 // serialise at the memory side).  pilot_pid / pilot_idx [b][0..min(npilot[b], L0_PILOT_MAX)); npilot may exceed the
 // capacity (then nothing is pruned).
-__device__ __forceinline__ uint32_t l0_u16(const uint4& v, int k) {
-  const uint32_t w = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
-  return (k & 1) ? (w >> 16) : (w & 0xFFFFu);
-}
 __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ ub, const int64_t* __restrict__ cand_off,
                                                   const int32_t* __restrict__ cand_pid, const int32_t* __restrict__ cut,
                                                   int32_t* __restrict__ npilot, int32_t* __restrict__ pilot_pid,
@@ -2817,12 +2917,42 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
     fp_allow_big_lds((const void*)k_l0_scan<3, 8>, ok2c, 160 * 1024);
   }
 #endif
+  FpL0Multi mr{};
+  mr.nr = ix.n_ranges;
+  mr.ub_stride = w.ub_stride;
+  mr.seq_r = 0;
+  for (int r = 0; r < ix.n_ranges && r < 8; ++r) { mr.x[r] = ix.pcodes_r[r]; mr.po[r] = ix.poff_r[r]; }
+  // Tables of several ranges: ALL ranges in one launch.  A document's first lines of the nr ranges lie side by side (64-byte
+  // lines: two ranges per 128-byte fabric request -- the fabric moves ~47 G requests/s whatever their size, and one launch per
+  // range over the range's own lines made every 64-byte line a request of its own: 2.6 G requests = the 52 ms of cfg3's
+  // scan).  The nr workgroups of a chunk are dealt to the SAME XCD (ids 8 apart) back to back, so they run together and the
+  // second range's line is an L2 hit.  Each writes its partial sums to its own array; k_l0_combine adds F and the parts and
+  // builds the histogram.  FP_L0_MULTI=0: one launch per range, accumulating in place (the form before round 3's end).
+  static const int multi_env = [] { const char* e = getenv("FP_L0_MULTI"); return e ? atoi(e) : 1; }();
+  if (ix.n_ranges > 1 && multi_env && w.ub_parts && ((bx + 7) & ~7ll) * ix.n_ranges * (int64_t)B < 0x7FFFFFFFll) {
+    const dim3 g1((unsigned)(((bx + 7) & ~7ll) * ix.n_ranges * B));
+    static const int pair_env = [] { const char* e = getenv("FP_L0_PAIR"); return e ? atoi(e) : 0; }();   // (measured slower at cfg3: 61.0 vs 46.9 ms -- experiment only)
+    mr.pair = (pair_env && ix.l0_ppl == 4 && ix.n_ranges % 2 == 0) ? 1 : 0;
+    if (ix.l0_ppl == 4 && !mr.pair)
+      hipLaunchKernelGGL((k_l0_scan<0, 4>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
+                         (const int32_t*)nullptr, ix.pcodes, w.ub_parts, w.hist, 1, 0, (int)bx, 2, mr);
+    else
+      hipLaunchKernelGGL((k_l0_scan<0, 8>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
+                         (const int32_t*)nullptr, ix.pcodes, w.ub_parts, w.hist, 1, 0, (int)bx, 2, mr);
+    int64_t cb = (per_q + 16383) / 16384;
+    if (cb > 256) cb = 256;
+    if (cb < 1) cb = 1;
+    hipLaunchKernelGGL(k_l0_combine, dim3((unsigned)cb, (unsigned)B), dim3(256), 0, st, w.ub_parts, ix.n_ranges, w.ub_stride, w.Fsum, cand_off, w.ub,
+                       w.hist);
+    return;
+  }
   for (int r = 0; r < ix.n_ranges; ++r) {
     const int64_t off = (int64_t)r * FP_L0_RANGE;
     const int tb = (int)std::min<int64_t>(FP_L0_RANGE, Cpad - off);
+    mr.seq_r = r;
 #define L0_LAUNCH(A_, L_) \
     hipLaunchKernelGGL((k_l0_scan<A_, L_>), grid, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
-                       cand_pid, ix.poff_r[r], ix.pcodes_r[r], w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, (int)bx, affine)
+                       cand_pid, ix.poff_r[r], ix.pcodes, w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, (int)bx, affine, mr)
 #ifdef FP_ABLATIONS
     if (ix.l0_ppl == 8 && (abl & 3)) {
       switch (abl & 3) {

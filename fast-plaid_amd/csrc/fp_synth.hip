@@ -336,14 +336,16 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
                                                     const int64_t* __restrict__ re, int64_t n_docs, int32_t code_base,
                                                     const int64_t* __restrict__ xoff /*[n_docs + 1] exclusive scan of the extra-line counts*/,
                                                     int32_t* __restrict__ poff, uint4* __restrict__ lines,
-                                                    int ppl /*pieces per line: 8 or 4*/) {
-  // one thread per piece
+                                                    int ppl /*pieces per line: 8 or 4*/, uint32_t pad_code, uint4* __restrict__ shared_first, int nr, int r) {
+  // one thread per piece.  shared_first != nullptr (tables of several ranges): the first lines go to shared_first, line
+  // d * nr + r, `lines` holds the extra lines only and poff's first index counts from 0
   const int64_t nl = n_docs + xoff[n_docs];
+  const int64_t xbase = shared_first ? 0 : n_docs;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nl * ppl + n_docs + 1; g += (int64_t)gridDim.x * blockDim.x) {
     if (g >= nl * ppl) {   // per document {first extra line, extra line count}
       const int64_t d = g - nl * ppl;
       if (d < n_docs) {
-        poff[2 * d] = (int32_t)(n_docs + xoff[d]);
+        poff[2 * d] = (int32_t)(xbase + xoff[d]);
         poff[2 * d + 1] = (int32_t)(xoff[d + 1] - xoff[d]);
       }
       continue;
@@ -363,16 +365,15 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
     }
     const int64_t u0 = rs[doc], n = re[doc] - u0;
     const int64_t first = lineno * (PCODES_PER_PIECE * ppl) + (int64_t)piece * PCODES_PER_PIECE;
-    // piece = 6 codes of 20 bits (bits 0..119) + the count in bits 120..127.  Slots past the piece's last code repeat that code
-    // (an empty piece holds code 0 six times): the scan sums all six table entries and takes (6 - count) x the last one off
-    // again, instead of predicating every lookup
+    // piece = 6 codes of 20 bits (bits 0..119) + the count in bits 120..127.  Slots past the piece's last code hold pad_code:
+    // the index of a byte behind the range's table slice that the scan keeps zero, so that all six lookups can be summed
+    // without a predicate or a correction
     unsigned __int128 bits = 0;
-    uint32_t cnt = 0, last = 0;
+    uint32_t cnt = 0;
     for (int j = 0; j < PCODES_PER_PIECE; ++j) {
-      uint32_t c = last;
+      uint32_t c = pad_code;
       if (first + j < n) {
         c = (uint32_t)(ucodes[u0 + first + j] - code_base);
-        last = c;
         ++cnt;
       }
       bits |= (unsigned __int128)(c & 0xFFFFFu) << (20 * j);
@@ -381,7 +382,10 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
     bits |= (unsigned __int128)cnt << 120;
     uint32_t w[4];
     for (int k = 0; k < 4; ++k) w[k] = (uint32_t)(bits >> (32 * k));
-    lines[g] = make_uint4(w[0], w[1], w[2], w[3]);
+    const uint4 out = make_uint4(w[0], w[1], w[2], w[3]);
+    if (!shared_first) lines[g] = out;
+    else if (line < n_docs) shared_first[(line * nr + r) * ppl + piece] = out;
+    else lines[(line - n_docs) * ppl + piece] = out;
   }
 }
 
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256) void k_pcode_pack(const int32_t* __restrict__ 
 // lines.  Allocates *lines ([n_docs first lines + the extra lines]) and *poff ([N] x {first extra line, extra line count} i32
 // pairs); *n_lines = lines in all; returns 0 or a hipError
 int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t code_lo, int64_t code_hi, void** lines,
-                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl) {
+                     int32_t** poff, int64_t* n_lines, hipStream_t st, int ppl, int64_t n_centroids, void* shared_first, int nr, int r) {
   int rc = 0;
   int64_t* nlines = nullptr;
   int64_t* loff = nullptr;
@@ -400,6 +404,9 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   *lines = nullptr;
   *poff = nullptr;
   *n_lines = 0;
+  // the scan keeps 16 zero bytes behind its table slice [code_lo, min(code_lo + 2^17, Cpad)): the pad slots point there
+  const int64_t Cpad = (n_centroids + 15) & ~(int64_t)15;
+  const uint32_t pad_code = (uint32_t)std::min<int64_t>((int64_t)1 << 17, Cpad - code_lo);
   HCHK(hipMalloc((void**)poff, (size_t)(n_docs + 1) * 8 + 64));
   HCHK(hipMalloc((void**)&nlines, (size_t)(n_docs + 1) * 8));
   HCHK(hipMalloc((void**)&loff, (size_t)(n_docs + 1) * 8));
@@ -414,13 +421,15 @@ int fps_build_pcodes(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_d
   HCHK(hipMemcpyAsync(n_lines, loff + n_docs, 8, hipMemcpyDeviceToHost, st));
   HCHK(hipStreamSynchronize(st));
   if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
-  *n_lines += n_docs;   // the first lines
-  if (*n_lines >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
-  HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 16 * ppl + 256));
   {
-    const int64_t work = *n_lines * ppl + n_docs + 1;
+    const int64_t n_extra = *n_lines;
+    const int64_t all = n_extra + n_docs;   // with the first lines
+    if (all >= 0x7FFFFFFFll || n_docs * (int64_t)nr >= 0x7FFFFFFFll) { rc = (int)hipErrorInvalidValue; goto fail; }
+    *n_lines = shared_first ? n_extra : all;   // lines in *lines
+    HCHK(hipMalloc(lines, (size_t)(*n_lines > 0 ? *n_lines : 1) * 16 * ppl + 256));
+    const int64_t work = all * ppl + n_docs + 1;
     hipLaunchKernelGGL(k_pcode_pack, dim3(fp_grid_cap((work + 255) / 256, 256)), dim3(256), 0, st, ucodes, rs, re, n_docs, (int32_t)code_lo, loff,
-                       *poff, static_cast<uint4*>(*lines), ppl);
+                       *poff, static_cast<uint4*>(*lines), ppl, pad_code, static_cast<uint4*>(shared_first), nr, r);
   }
   HCHK(hipStreamSynchronize(st));
 fail:
