@@ -84,6 +84,7 @@ SYMBOLS = {
     "fp_index_read_ivf": (_i64, [_vp, _i64, _vp, _i64]),
     "fp_selftest_arith": (C.c_int, [C.c_int, _vp]),
     "fp_last_search_counts": (C.c_int, [_vp, C.c_int]),
+    "fp_last_s1_counts": (C.c_int, [_vp, C.c_int]),
     "fp_index_ivf_total": (_i64, [_vp]),
     "fp_index_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
 }

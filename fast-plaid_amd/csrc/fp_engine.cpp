@@ -132,7 +132,7 @@ struct Scratch {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -207,7 +207,7 @@ struct Scratch {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats})
       b->release();
     h_out.release();
     h_small.release();
@@ -236,10 +236,13 @@ struct fp_index {
   std::vector<Scratch*> pool;
   bool synthetic = false;
   int64_t n_hard_tokens = 0;   // tokens without a one-multiply reciprocal (k_token_rinv)
+  float cent_norm_max = 1.f;   // largest centroid norm (>= 1): scales S1's certification window (FpS1Exact)
 };
 
 static thread_local float g_last_ms[ST_N];
 static thread_local bool g_have_ms = false;
+static thread_local uint64_t g_last_s1[4];   // FP_S1_STATS: S1's certification counters of the last call (flagged, changed, slow path, mode-2 unflagged differences)
+static bool s1_stats_enabled() { static const bool on = getenv("FP_S1_STATS") != nullptr; return on; }
 static thread_local int64_t g_last_counts[5];  // candidates, exact-scored docs, repaired docs, sub-batches, form of S4 (0 exact / 1 8-bit bounds / 2 level 0; -1: replayed graph)
 
 // results of one (sub-)batch in one device block: ids | scores | counts
@@ -308,6 +311,21 @@ static void build_lut_host(int nbits, const uint16_t* weights, std::vector<uint1
     int j = 0;
     for (int k = per - 1; k >= 0; --k) lut[(size_t)v * per + j++] = weights[(out >> (k * nbits)) & mask];
   }
+}
+
+// largest row norm of an fp16 matrix (never below 1): the rounding noise of a score's fp32 chain scales with |c| |q|
+static float max_row_norm_f16(const uint16_t* m, int64_t rows, int dim) {
+  double best = 1.0;
+  for (int64_t r = 0; r < rows; ++r) {
+    double ss = 0.0;
+    const uint16_t* row = m + r * dim;
+    for (int k = 0; k < dim; ++k) {
+      const double x = (double)(float)__builtin_bit_cast(_Float16, row[k]);
+      ss += x * x;
+    }
+    if (ss > best * best) best = std::sqrt(ss);
+  }
+  return (float)best;
 }
 
 template <typename T>
@@ -501,6 +519,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   ICHK(hipStreamCreate(&st));
   ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
   ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
+  ix->cent_norm_max = max_row_norm_f16(d->centroids, D.C, D.dim);
   std::vector<uint16_t> hlut;
   build_lut_host(D.nbits, d->bucket_weights, hlut);
   ICHK(dev_alloc(ix, &lut, hlut.size()));
@@ -596,6 +615,7 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   ICHK(hipStreamCreate(&st));
   ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
   ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
+  ix->cent_norm_max = max_row_norm_f16(d->centroids, D.C, D.dim);
   std::vector<uint16_t> hlut;
   build_lut_host(D.nbits, d->bucket_weights, hlut);
   ICHK(dev_alloc(ix, &lut, hlut.size()));
@@ -701,6 +721,7 @@ struct Pipe {
   bool spec = false;         // ... and it was
   bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
   bool probe_prezeroed = false, selhist_prezeroed = false, l0hist_prezeroed = false;   // cleared by the batch's first kernel
+  int s1_mode = 0;           // FpS1Exact::mode of this batch's S1
 };
 
 // after a batch: the candidate capacity the next batch of this shape runs on (see run_front)
@@ -741,7 +762,27 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       P.l0hist_prezeroed = zl.add(s->l0_hist.p, fpk_l0_hist_bytes(B));
     }
   }
-  fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st, &zl);
+  // S1 exact mode (FpS1Exact): certification window w0 |q_n| + kappa |x| around the MFMA result; FP_S1_EXACT=0 switches the
+  // certification off (S then differs from the reference's matmul by one fp16 ulp in ~0.05 % of its entries), 2 re-evaluates
+  // every entry (tests); FP_S1_W0_LOG2 / FP_S1_KAPPA_LOG2 move the window (defaults 2^-21 and 2^-19.5, x dim / 128 above 128)
+  static const int s1x_env = [] { const char* e = getenv("FP_S1_EXACT"); return e ? atoi(e) : 1; }();
+  static const float s1x_w0 = [] { const char* e = getenv("FP_S1_W0_LOG2"); return std::exp2(e ? (float)atof(e) : -21.0f); }();
+  static const float s1x_kappa = [] { const char* e = getenv("FP_S1_KAPPA_LOG2"); return std::exp2(e ? (float)atof(e) : -19.5f); }();
+  const bool s1x_stats = s1_stats_enabled() && !s->capturing;
+  P.s1_mode = s1x_env < 0 ? 0 : (s1x_env > 2 ? 2 : s1x_env);
+  const float dim_scale = D.dim > 128 ? (float)D.dim / 128.0f : 1.0f;
+  FpS1Exact xe{P.s1_mode, nullptr, s1x_kappa * dim_scale, nullptr};
+  if (P.s1_mode) {
+    HIPCHK(s->wcol.ensure((size_t)B * sh.Qp * 4 + 16));
+    xe.wcol = s->wcol.as<float>();
+    if (s1x_stats) {
+      HIPCHK(s->s1stats.ensure(32));
+      HIPCHK(hipMemsetAsync(s->s1stats.p, 0, 32, st));
+      xe.stats = s->s1stats.as<unsigned long long>();
+    }
+  }
+  fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st, &zl, P.s1_mode ? s->wcol.as<float>() : nullptr,
+                   s1x_w0 * dim_scale * ix->cent_norm_max);
   STAGE_DONE(ST_CENTROID);
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
@@ -775,12 +816,12 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     fpk_l0_floors(s->S8.as<uint8_t>(), ns, sh, s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_esc.as<uint32_t>(), s->l0_gfl.as<uint16_t>(), st);
     if (Cpad > D.C) HIPCHK(hipMemsetAsync(s->l0_e8.p, 0, (size_t)B * Cpad, st));   // pad entries behind the table stay 0
     FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_gfl.as<uint16_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q};
-    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex))
+    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex, &xe))
       return fail(FP_EUNSUPPORTED, "dim");
   } else {
     if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
     if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
-                            s->cmax128.as<uint16_t>(), st))
+                            s->cmax128.as<uint16_t>(), st, 0, 1, nullptr, &xe))
       return fail(FP_EUNSUPPORTED, "dim");
   }
   STAGE_DONE(ST_PROBE);
@@ -812,7 +853,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   if (sh.n_probe >= 1) {
     if (fpk_probe(D, s->S.as<uint16_t>(), sh, has_subset ? s->allow.as<uint32_t>() : nullptr, s->partial.as<unsigned long long>(),
                   P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), s->cmax128.as<uint16_t>(), st,
-                  P.probe_prezeroed, !P.probe_no_fb))
+                  P.probe_prezeroed, !P.probe_no_fb, P.s1_mode != 0))
       return fail(FP_EUNSUPPORTED, "n_ivf_probe");
   } else {
     HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result
@@ -1109,7 +1150,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       s->select_shape(skey);
     }
     // ---- FP_GRAPH: replay / capture (host-buffer calls of one sub-batch, no subset, no trace)
-    const bool graph_ok = graph_env && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3 &&
+    const bool graph_ok = graph_env && !s1_stats_enabled() && !dev_io && !tr && !has_subset && nq <= maxB && s->graph.fails < 3 &&
                           P.sh.R <= FP_MAX_SORT;   // (beyond it the final ranking allocates and synchronises: not capturable)
     const size_t qbytes = (size_t)B * Q * D.dim * 2;
     P.probe_no_fb = !tr && !s->probe_fb;
@@ -1225,6 +1266,11 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     }
     }   // !replayed
     if (!dev_io) ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
+    if (s1_stats_enabled() && !replayed && !capture && s->s1stats.p) {   // diagnostics: blocking copy after the call's sync
+      uint64_t h4[4] = {0, 0, 0, 0};
+      HIPCHK(hipMemcpy(h4, s->s1stats.p, 32, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 4; ++i) g_last_s1[i] = (b0 == 0 ? 0 : g_last_s1[i]) + h4[i];
+    }
     // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
     const int64_t M_true = *reinterpret_cast<const int64_t*>(s->h_small.p);
     if (P.probe_no_fb && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 16) != 0) {
@@ -1391,6 +1437,12 @@ extern "C" int fp_search_trace(const fp_index* index, const uint16_t* query, int
 extern "C" int fp_last_search_counts(int64_t* out, int cap) {
   int n = std::min(cap, 5);
   for (int i = 0; i < n; ++i) out[i] = g_last_counts[i];
+  return n;
+}
+
+extern "C" int fp_last_s1_counts(uint64_t* out, int cap) {
+  const int n = std::min(cap, 4);
+  for (int i = 0; i < n; ++i) out[i] = g_last_s1[i];
   return n;
 }
 

@@ -125,7 +125,9 @@ struct FpZeroList {
   }
 };
 void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B*Qp,D]*/, int B, int Q, int Qp, int D,
-                      hipStream_t st, const FpZeroList* zero = nullptr);
+                      hipStream_t st, const FpZeroList* zero = nullptr,
+                      float* wcol = nullptr /*[B*Qp]: w0 * |q_n| per packed row (0 for the zero rows), the absolute part of S1's certification window*/,
+                      float w0 = 0.f);
 // S8 (nullable; written only when Qp == 32): 8-bit bins [B][C][32]; cmax (nullable): [B*Qp][ceil(C/128)] f16 column maxima per 128-centroid tile
 // S1's optional by-product for S4's level 0: the excess table e8[b][Cpad] (one byte per query and centroid) computed in the
 // epilogue from the column floors of a sampled pre-pass
@@ -137,14 +139,30 @@ struct FpS1Excess {
   int64_t Cpad;
   int Q;                   // real query columns
 };
+// Exact centroid scores (round 4).  The MFMA sums the 128 products in another order than the reference's ascending fp32 chain
+// (search.rs:491 = ATen's half matmul), so ~0.05 % of the fp16 results differed by one ulp.  S1 now certifies every entry: the fp32
+// accumulator x is flagged when a rounding boundary of fp16 lies within +-(wcol[n] + kappa |x|) of it -- only then can another
+// summation order round differently -- and every flagged entry is re-evaluated with the ascending chain acc = fma(c_k, q_k, acc)
+// inside the kernel (centroid rows from the LDS tile, query rows from the MFMA A fragments), before the tile and its by-products
+// (excess bytes, 8-bit bins) leave.  S is then bit-identical to the reference's matmul.
+struct FpS1Exact {
+  int mode;                    // 0 off, 1 certify + repair, 2 (tests) re-evaluate EVERY entry and count the unflagged differences
+  const float* wcol;           // [B*Qp] absolute window per query column: w0 |q_n| (0 for zero rows: their scores are exact zeros)
+  float kappa;                 // relative part of the window
+  unsigned long long* stats;   // nullable [4]: flagged entries, repaired values that differ from the MFMA's, entries beyond the
+                               // LDS list (slow path), mode 2: unflagged differences
+};
+// the column maxima S1 emits (cmax) are taken over the UPPER candidates h(x + w): >= the exact maximum, at most one fp16 step above
 int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
-                        hipStream_t st, int64_t n_rows = 0, int64_t row_stride = 1, const FpS1Excess* exc = nullptr);
+                        hipStream_t st, int64_t n_rows = 0, int64_t row_stride = 1, const FpS1Excess* exc = nullptr,
+                        const FpS1Exact* exact = nullptr);
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow /*[B][Cw] or null*/,
               unsigned long long* partial, int nchunk, int32_t* cells /*[B][Q][n_probe]*/, int32_t* ucells /*[B][Q*n_probe]*/,
               int32_t* ncells /*[B]*/, const uint16_t* cmax128 /*nullable: S1's [B*Qp][ceil(C/128)] column maxima*/, hipStream_t st,
               bool prezeroed = false /*the region of fpk_probe_zero_region was cleared earlier in the stream*/,
               bool with_fallback = true /*false: a column with too many ties at its threshold leaves *fpk_probe_flag != 0 and NO cells;
-                                          the caller reads the flag back and runs the batch again with the fallback*/);
+                                          the caller reads the flag back and runs the batch again with the fallback*/,
+              bool cmax_upper = false /*cmax128 came from S1's exact mode: upper bounds, at most one fp16 step above an element*/);
 size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);
 // the counters + overflow flag the threshold probe expects zeroed (inside `partial`); false = this shape takes the other path
 bool fpk_probe_zero_region(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial, void** p, size_t* bytes);

@@ -34,13 +34,33 @@
 // ============================================================================================
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
 // ============================================================================================
-__global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Q, int Qp, int D, FpZeroList z) {
+__global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Q, int Qp, int D, FpZeroList z,
+                               float* __restrict__ wcol, float w0) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
   // the batch's small fills ride along (each hipMemsetAsync is a graph node of its own, ~4.5 us of launch tail)
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
 #pragma unroll
   for (int r = 0; r < FP_ZERO_REGIONS; ++r)
     for (int64_t j = i; j < (int64_t)z.n16[r]; j += nthreads) reinterpret_cast<uint4*>(z.p[r])[j] = make_uint4(0, 0, 0, 0);
+  // S1's certification window per packed row: w0 |q_n| (thread n < B * Qp walks row n; 0 for the zero rows appended to a query)
+  if (wcol && i < (int64_t)B * Qp) {
+    const int b = (int)(i / Qp), q = (int)(i % Qp);
+    float ss = 0.f;
+    if (q < Q) {
+      const uint16_t* row = in + ((int64_t)b * Q + q) * D;
+      for (int k = 0; k < D; k += 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + k);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const h2 pr = u32_as_h2(w[t]);
+          ss = __builtin_fmaf((float)pr.x, (float)pr.x, ss);
+          ss = __builtin_fmaf((float)pr.y, (float)pr.y, ss);
+        }
+      }
+    }
+    wcol[i] = w0 * __builtin_sqrtf(ss);
+  }
   int64_t per_row = D / 8;
   int64_t total = (int64_t)B * Qp * per_row;
   if (i >= total) return;
@@ -52,11 +72,11 @@ __global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __rest
   *reinterpret_cast<uint4*>(out + row * D + c8 * 8) = v;
 }
 
-void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st, const FpZeroList* zero) {
+void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st, const FpZeroList* zero, float* wcol, float w0) {
   int64_t total = (int64_t)B * Qp * (D / 8);
   FpZeroList z{};
   if (zero) z = *zero;
-  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D, z);
+  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D, z, wcol, w0);
 }
 
 // ============================================================================================
@@ -108,16 +128,85 @@ __device__ __forceinline__ S1Groups s1_groups(int64_t n0, int Qp) {
   }
   return G;
 }
-template <int NWC /*wave columns: 2 (256 threads, 64 x 64 per wave) or 4 (512 threads, 64 x 32 per wave)*/, bool DMA_WAIT = false,
-          int NWR = 2 /*wave rows: 2, or 4 (32 query columns per wave)*/>
-__device__ __forceinline__ void s1_epilogue(f16v (&acc)[4 / NWR][4 / NWC], unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
-                                            const int tile_idx, uint16_t* __restrict__ S, const int64_t C, const int64_t Ntot, const int Qp,
-                                            uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, const int nch, const FpS1Excess& ex, const S1Groups& G) {
+// ---- exact centroid scores: certification of the MFMA result and ascending-chain re-evaluation of the flagged entries ----------
+// (FpS1Exact, fp_internal.h.)  A lane's 32 accumulators are 16 PAIRS of adjacent query columns; pair pj = (a * NB + b) * 8 + j holds
+// acc[a][b][2 j], acc[a][b][2 j + 1].  Flag word: bit pj = the pair's even element, bit 16 + pj = its odd element.
+#define S1X_CAP 384          // listed entries per wave and tile (18 % of its 2048 outputs; ~6.6 % are flagged on unit vectors)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t s1_cvt_pk(float a, float b) {
+  uint32_t r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// hw = the UPPER candidates h(x + u) of every entry (== h(x) wherever the entry is not flagged); returns the flag word.
+// mode 2: *all_mask = every entry of a non-zero query column (tests: everything is re-evaluated)
+template <int NA, int NB, typename WF>
+__device__ __forceinline__ uint32_t s1_certify(const f16v (&acc)[NA][NB], uint32_t (&hw)[NA][NB][8], const int mode, const float kappa, WF wpair,
+                                               uint32_t* all_mask) {
+  static_assert(NA * NB * 8 <= 16, "one 32-bit flag word per lane");
+  if (!mode) {   // (wave-uniform) plain rounding
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hw[a][b][j] = s1_cvt_pk(acc[a][b][2 * j], acc[a][b][2 * j + 1]);
+    *all_mask = 0u;
+    return 0u;
+  }
+  uint32_t A = 0u, M = 0u;
+  const f2v kap = f2v{kappa, kappa};
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0 += 4) {   // four window pairs at a time (all sixteen up front cost registers the kernel does not have)
+      f2v w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = wpair(a, j0 + j);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = j0 + jj;
+        const uint32_t nz = (w[jj].x > 0.f ? 1u : 0u) | (w[jj].y > 0.f ? 0x10000u : 0u);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int pj = (a * NB + b) * 8 + j;
+          const f2v x = f2v{acc[a][b][2 * j], acc[a][b][2 * j + 1]};
+          const f2v u = __builtin_elementwise_abs(x) * kap + w[jj];
+          const f2v up = x + u, lo = x - u;
+          const uint32_t hu = s1_cvt_pk(up.x, up.y), hl = s1_cvt_pk(lo.x, lo.y);
+          hw[a][b][j] = hu;
+          uint32_t t;
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(hu ^ hl), "v"(0x00010001u));   // {even differs, odd differs} in bits 0 and 16
+          A |= t << pj;
+          M |= nz << pj;
+        }
+      }
+    }
+  *all_mask = M;
+  return A;
+}
+// accumulator index -> query column inside the wave's 32-column group (the 32x32 MFMA's D layout), element rr of lane half hi
+__device__ __forceinline__ int s1_col_of(int rr, int hi) { return (rr & 3) + 8 * (rr >> 2) + 4 * hi; }
+// eight steps of the reference's chain acc = fma(c_k, q_k, acc), k ascending, on packed fp16 pairs (k_maxsim_repair's spelling:
+// v_fma_mix_f32 takes the halves in place; left to the compiler the pair becomes v_dot2, which rounds differently)
+__device__ __forceinline__ void s1_chain8(float& acc, const uint4 c, const uint4 q) {
+  const uint32_t cw[4] = {c.x, c.y, c.z, c.w}, qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\ts_nop 0\n\t"
+                 "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\ts_nop 0"
+                 : "+v"(acc)
+                 : "v"(cw[t]), "v"(qw[t]));
+}
+
+// ---- epilogue of one 128 x 128 output tile, part 1: the fp16 tile (upper candidates) staged in LDS + the column maxima ----------
+template <int NWC /*wave columns: 2 (256 threads, 64 x 64 per wave) or 4 (512 threads, 64 x 32 per wave)*/, int NWR = 2 /*wave rows: 2, or 4 (32 query columns per wave)*/>
+__device__ __forceinline__ void s1_stage(const uint32_t (&hw)[4 / NWR][4 / NWC][8], unsigned char* smem, const int tid, const int64_t c0, const int64_t C,
+                                         const bool want_cmax) {
   const int wave = tid >> 6, lane = tid & 63;
   constexpr int NB = 4 / NWC;          // 32-centroid MFMA tiles per wave
   constexpr int NA = 4 / NWR;          // 32-column query groups per wave
-  constexpr int NT = 64 * NWR * NWC;   // threads
-  constexpr int NIT = 2048 / NT;       // 16-byte pieces of the output tile per thread
   const int wr = wave / NWC, wc = wave % NWC;
   const int l31 = lane & 31, hi = lane >> 5;
   __syncthreads();  // operand tiles are dead: the same LDS now stages the output
@@ -141,25 +230,15 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[4 / NWR][4 / NWC], unsig
       const int f = (cl >> 2) & 3;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {             // q = 8*q4 + 4*hi + 0..3  -> chunk q4, half hi
-        h2 lo, hi2;
-        lo.x = (half_t)acc[a][b][4 * q4 + 0];
-        lo.y = (half_t)acc[a][b][4 * q4 + 1];
-        hi2.x = (half_t)acc[a][b][4 * q4 + 2];
-        hi2.y = (half_t)acc[a][b][4 * q4 + 3];
-#if S1_ABL == 2   // timing only: 8-byte pieces straight from the accumulators into a row-contiguous (column-permuted) layout
-        if (cok && n0 + g * 32 < Ntot)
-          *reinterpret_cast<uint2*>(S + (((n0 + g * 32) / Qp) * C + c0 + cl) * Qp + ((n0 + g * 32) % Qp) + hi * 16 + q4 * 4) =
-              make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
-#else
-        *reinterpret_cast<uint2*>(orow + ((q4 ^ f) * 16) + hi * 8) = make_uint2(h2_as_u32(lo), h2_as_u32(hi2));
-#endif
+        const uint32_t lo = hw[a][b][2 * q4], hi2 = hw[a][b][2 * q4 + 1];
+        *reinterpret_cast<uint2*>(orow + ((q4 ^ f) * 16) + hi * 8) = make_uint2(lo, hi2);
         if (cok) {
-          cm[2 * q4] = pk_max_raw(cm[2 * q4], h2_as_u32(lo));
-          cm[2 * q4 + 1] = pk_max_raw(cm[2 * q4 + 1], h2_as_u32(hi2));
+          cm[2 * q4] = pk_max_raw(cm[2 * q4], lo);
+          cm[2 * q4 + 1] = pk_max_raw(cm[2 * q4 + 1], hi2);
         }
       }
     }
-    if (cmax) {  // max over this wave's 64 centroids: DPP inside the 16-lane rows, one cross-row exchange
+    if (want_cmax) {  // max over this wave's 64 centroids: DPP inside the 16-lane rows, one cross-row exchange
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         uint32_t v = cm[r];
@@ -179,6 +258,21 @@ __device__ __forceinline__ void s1_epilogue(f16v (&acc)[4 / NWR][4 / NWC], unsig
       }
     }
   }
+}
+// LDS address of the staged fp16 value of (32-column group g, centroid cl of the tile, accumulator element rr of lane half hi)
+__device__ __forceinline__ uint16_t* s1_staged_slot(unsigned char* Os, int g, int cl, int rr, int hi) {
+  return reinterpret_cast<uint16_t*>(Os + ((size_t)(g * 128 + cl)) * 64 + (((rr >> 2) ^ ((cl >> 2) & 3)) * 16) + hi * 8 + (rr & 3) * 2);
+}
+
+// ---- part 2: write-out of the staged tile (16 B per lane) with the by-products (8-bit bins or the level-0 excess byte) ----------
+template <int NWC, bool DMA_WAIT = false, int NWR = 2>
+__device__ __forceinline__ void s1_writeout(unsigned char* smem, const int tid, const int64_t n0, const int64_t c0,
+                                            const int tile_idx, uint16_t* __restrict__ S, const int64_t C, const int64_t Ntot, const int Qp,
+                                            uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, const int nch, const FpS1Excess& ex, const S1Groups& G) {
+  constexpr int NT = 64 * NWR * NWC;   // threads
+  constexpr int NIT = 2048 / NT;       // 16-byte pieces of the output tile per thread
+  unsigned char* Os = smem;                                           // 32 KiB
+  uint16_t* red = reinterpret_cast<uint16_t*>(smem + 4 * 128 * 64);   // [NWC][128 n] column maxima of each wave's centroids
   __syncthreads();
   // k_centroid_scores_stream: the next tile's operand loads (straight into the other LDS buffer) were issued before this
   // tile's MFMAs; waiting for them here, in front of this tile's stores, keeps the wait from covering the stores' latency too
@@ -289,7 +383,7 @@ template <int KS, int NWC>
 __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad,
                                                          uint16_t* __restrict__ S, int64_t C, int64_t Ntot, int Qp,
                                                          uint8_t* __restrict__ S8 /*nullable*/, uint16_t* __restrict__ cmax /*nullable*/,
-                                                         int nch, int D, int64_t crow_stride, FpS1Excess ex, int nrt_xcd) {
+                                                         int nch, int D, int64_t crow_stride, FpS1Excess ex, int nrt_xcd, FpS1Exact xe) {
   // K is consumed in slices of KS dims: the operand tiles take 2 x 128 x KS x 2 B of LDS (32 KiB at KS = 64) instead of
   // 64 KiB for the whole K = 128, which lifts the kernel from 2 to 3 workgroups per CU (VGPR limit) so that one
   // workgroup's store phase overlaps another's MFMA phase.  Any dim that is a multiple of 8 (one 16-byte piece): KS = 64 /
@@ -358,7 +452,57 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   }
-  s1_epilogue<NWC>(acc, smem, tid, n0, c0, tile_c, S, C, Ntot, Qp, S8, cmax, nch, ex, s1_groups(n0, Qp));
+  // certification of the accumulators (upper candidates staged), then the flagged entries through the ascending chain.  This
+  // kernel holds only the last K slice in LDS, so both operand rows come from global memory (L2): every lane walks its OWN
+  // flagged entries.  The fast path for the big tables is k_centroid_scores_stream.
+  uint32_t hw[2][NB][8];
+  uint32_t A = 0u, Aall = 0u;
+  const int xmode = (NB == 1) ? xe.mode : 0;   // (the 64 x 64-per-wave layout has 64 accumulators per lane: exact mode runs the 4-column form)
+  if constexpr (NB == 1) {
+    A = s1_certify<2, NB>(acc, hw, xmode, xe.kappa, [&](int a, int j) -> f2v {
+      const int64_t n = n0 + (wr * 2 + a) * 32 + s1_col_of(2 * j, hi);
+      f2v w = f2v{0.f, 0.f};
+      if (n + 1 < Ntot) { const float2 t = *reinterpret_cast<const float2*>(xe.wcol + n); w = f2v{t.x, t.y}; }
+      else if (n < Ntot) w.x = xe.wcol[n];
+      return w;
+    }, &Aall);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hw[a][b][j] = s1_cvt_pk(acc[a][b][2 * j], acc[a][b][2 * j + 1]);
+  }
+  s1_stage<NWC>(hw, smem, tid, c0, C, cmax != nullptr);
+  if (xmode) {
+    const uint32_t Aw = A;
+    if (xmode == 2) A = Aall;
+    if (c0 + wc * (32 * NB) + l31 >= C) A = 0u;   // rows beyond the table are never written
+    uint32_t nflag = (uint32_t)__popc(A), nchg = 0u, nunf = 0u;
+    uint32_t rem = A;
+    while (rem) {
+      const int p = __builtin_ctz(rem);
+      rem &= rem - 1u;
+      const int pj = p & 15, a = pj >> 3, rr = 2 * (pj & 7) + (p >> 4);
+      const int cl = wc * (32 * NB) + l31;
+      const int64_t n = n0 + (wr * 2 + a) * 32 + s1_col_of(rr, hi);
+      const uint16_t* crow = cent + (c0 + cl) * crow_stride * D;
+      const uint16_t* qrow = qpad + n * D;
+      float ch = 0.f;
+      for (int k = 0; k < D; k += 8) s1_chain8(ch, *reinterpret_cast<const uint4*>(crow + k), *reinterpret_cast<const uint4*>(qrow + k));
+      const uint16_t val = __builtin_bit_cast(uint16_t, (half_t)ch);
+      uint16_t* slot = s1_staged_slot(smem, wr * 2 + a, cl, rr, hi);
+      if (*slot != val) { ++nchg; if (!((Aw >> p) & 1u)) ++nunf; }
+      *slot = val;
+    }
+    if (xe.stats) {
+      if (nflag) atomicAdd(&xe.stats[0], (unsigned long long)nflag);
+      if (nchg) atomicAdd(&xe.stats[1], (unsigned long long)nchg);
+      if (nunf) atomicAdd(&xe.stats[3], (unsigned long long)nunf);
+    }
+  }
+  s1_writeout<NWC>(smem, tid, n0, c0, tile_c, S, C, Ntot, Qp, S8, cmax, nch, ex, s1_groups(n0, Qp));
 }
 
 // The streaming form of the same GEMM (dim 128 / 64, main pass): a workgroup of 8 waves (4 x 2: 32 query columns x 64 centroids
@@ -378,7 +522,7 @@ template <int DK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, uint16_t* __restrict__ S, int64_t C,
                               int64_t Ntot, int Qp, uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, int nch, int nct, int nrt,
-                              FpS1Excess ex) {
+                              FpS1Excess ex, FpS1Exact xe) {
   constexpr int CH = DK / 8;             // 16-byte chunks per row
   constexpr int ROWB = DK * 2;           // bytes per row
   constexpr int KSTEPS = DK / 16;
@@ -397,9 +541,13 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
   const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
   // piece i of this lane: centroid row i * (512 / CH) + rbase of the tile, 16-byte chunk j16 / 16 of it (the swizzle does not
   // depend on i: the row advances by a multiple of CH)
-  const uint32_t rbase = (uint32_t)(tid / CH);
-  const uint32_t j16 = (uint32_t)(((tid % CH) ^ ((tid / CH) & (CH - 1))) * 16);
   auto prefetch = [&](int tile, uint32_t buf_off) {
+    int tidp = tid;
+#if S1_LAUNDER
+    asm volatile("" : "+v"(tidp));   // (per-piece offsets recomputed per tile instead of living in registers -- or scratch -- across the loop)
+#endif
+    const uint32_t rbase = (uint32_t)(tidp / CH);
+    const uint32_t j16 = (uint32_t)(((tidp % CH) ^ ((tidp / CH) & (CH - 1))) * 16);
     const int64_t c0 = (int64_t)tile * 128;
     const uint16_t* tile_base = cent + c0 * DK;                        // (scalar)
     const uint32_t rows_valid = (uint32_t)(C - c0 < 128 ? C - c0 : 128);   // rows past the end read row 0 of the tile (never stored)
@@ -425,12 +573,29 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     af[ks] = __builtin_bit_cast(h8, v);
   }
   const S1Groups G0 = s1_groups((int64_t)tile_n * 128, Qp);
+  // exact mode: the certification windows of the workgroup's 128 query columns (0 beyond the batch: those accumulators are exact
+  // zeros) and a list of S1X_CAP flagged entries per wave, both behind the two tile buffers
+  float* wtab = reinterpret_cast<float*>(smem + 2 * S1_BUF);
+  if (xe.mode && tid < 128) {
+    const int64_t n = (int64_t)tile_n * 128 + tid;
+    wtab[tid] = n < Ntot ? xe.wcol[n] : 0.f;
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first tile and the A fragments (a builtin: the compiler's wait insertion then knows that nothing is pending at the loop head)
   for (int t = t_first; t < t_end; ++t) {
     const uint32_t cur_off = (uint32_t)((t - t_first) & 1) * (uint32_t)S1_BUF;
     unsigned char* cur = smem + cur_off;
     __syncthreads();   // every wave's pieces of tile t have landed; nobody still reads the other buffer (tile t-1's staging)
     if (t + 1 < t_end) prefetch(t + 1, (uint32_t)S1_BUF - cur_off);
+    // (the lane id is laundered per tile: every per-lane LDS address below -- the sixteen swizzled operand chunks, the staging
+    // rows, the write-out offsets -- is then recomputed from it inside the iteration instead of being hoisted out of the loop,
+    // where the exact mode's chains leave no registers for them and they would be spilled: a scratch reload waits with vmcnt(0),
+    // i.e. for the prefetch just issued)
+    int tidv = tid;
+#if S1_LAUNDER
+    asm volatile("" : "+v"(tidv));
+#endif
+    const int lane = tidv & 63, l31 = lane & 31, hi = lane >> 5;
+    uint16_t* lst = reinterpret_cast<uint16_t*>(smem + 2 * S1_BUF + 512) + __builtin_amdgcn_readfirstlane(tidv >> 6) * S1X_CAP;
     f16v acc[1][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -460,18 +625,140 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
       asm volatile("" : "+s"(G.q0[g]));
     }
 #endif
-    s1_epilogue<2, true, 4>(acc, cur, tid, (int64_t)tn * 128, (int64_t)t * 128, t, S, C, Ntot, Qp, S8, cmax, nch, ex, G);
+    // ---- certification + exact re-evaluation of the flagged entries (FpS1Exact).  The centroid tile is still in LDS and the
+    // query rows are in the A fragments: lane (n, hi) holds the chunks 2 ks + hi of column n, so a lane that re-evaluates column
+    // n' fetches them with ds_bpermute from lanes n' and n' + 32.  The wave first lists its flagged entries (round-robin over the
+    // lanes' flag words), then lane i re-evaluates list entry 64 p + i: ~6.6 % of the 2048 outputs, two to three passes.
+    uint32_t hw[1][2][8];
+    uint32_t Aall = 0u;
+    uint32_t A = s1_certify<1, 2>(acc, hw, xe.mode, xe.kappa, [&](int, int j) -> f2v {
+      const float2 t2 = *reinterpret_cast<const float2*>(wtab + wr * 32 + s1_col_of(2 * j, hi));
+      return f2v{t2.x, t2.y};
+    }, &Aall);
+    const uint32_t Aw = A;
+    if (xe.mode == 2) A = Aall;
+    uint32_t listed = 0u;
+    if (xe.mode) {
+      uint32_t rem = A, off = 0u;
+      while (true) {
+        const bool act = rem != 0u;
+        const unsigned long long bal = __ballot(act);
+        if (!bal) break;
+        const uint32_t slot = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (act) {
+          const uint32_t p = (uint32_t)__builtin_ctz(rem);
+          rem &= rem - 1u;
+          if (slot < S1X_CAP) lst[slot] = (uint16_t)(((uint32_t)lane << 5) | p);
+        }
+        off += (uint32_t)__popcll(bal);
+      }
+      listed = off < S1X_CAP ? off : S1X_CAP;   // (wave-uniform)
+      for (uint32_t p0 = 0; p0 < listed; p0 += 64) {
+        const uint32_t idx = p0 + (uint32_t)lane;
+        const bool valid = idx < listed;
+        const uint32_t e = valid ? (uint32_t)lst[idx] : 0u;
+        const int ls = (int)(e >> 5), p = (int)(e & 31u), pj = p & 15, rr = 2 * (pj & 7) + (p >> 4);
+        const int cl = wc * 64 + (pj >> 3) * 32 + (ls & 31);
+        const int ncol = s1_col_of(rr, ls >> 5);
+        const unsigned char* crow = cur + cl * ROWB;
+        const int swz = cl & (CH - 1);
+        // (operands of chunk jj + 1 are fetched while chunk jj is chained; the empty asm keeps the compiler from hoisting the
+        // fetches of all sixteen chunks to the top, which spills)
+        float chn = 0.f;
+        auto fetch_q = [&](int jj) -> uint4 {
+          const uint4 av = __builtin_bit_cast(uint4, af[jj >> 1]);
+          const int src = (ncol + 32 * (jj & 1)) * 4;
+          uint4 qv;
+          qv.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.x);
+          qv.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.y);
+          qv.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.z);
+          qv.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.w);
+          return qv;
+        };
+        uint4 cv = *reinterpret_cast<const uint4*>(crow + ((0 ^ swz) * 16)), qv = fetch_q(0);
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+          uint4 cvn = cv, qvn = qv;
+          if (jj + 1 < CH) {
+            cvn = *reinterpret_cast<const uint4*>(crow + (((jj + 1) ^ swz) * 16));
+            qvn = fetch_q(jj + 1);
+          }
+          asm volatile("" ::: "memory");
+          s1_chain8(chn, cv, qv);
+          cv = cvn;
+          qv = qvn;
+        }
+        if (valid) lst[idx] = __builtin_bit_cast(uint16_t, (half_t)chn);
+      }
+    }
+    s1_stage<2, 4>(hw, cur, tidv, (int64_t)t * 128, C, cmax != nullptr);
+    if (xe.mode) {
+      // every lane writes the re-evaluated values of ITS entries over the staged upper candidates (same wave, LDS is in order);
+      // the slot numbers are those of the listing loop above.  Entries beyond the list (never seen on unit vectors) are
+      // re-evaluated here with the centroid row from global memory -- the tile's LDS copy is gone.
+      uint32_t rem = A, off = 0u, nchg = 0u, nunf = 0u, nslow = 0u;
+      while (true) {
+        const bool act = rem != 0u;
+        const unsigned long long bal = __ballot(act);
+        if (!bal) break;
+        const uint32_t slot = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        int p = 0;
+        if (act) { p = __builtin_ctz(rem); rem &= rem - 1u; }
+        const int pj = p & 15, rr = 2 * (pj & 7) + (p >> 4);
+        const int cl = wc * 64 + (pj >> 3) * 32 + l31;
+        uint16_t val = 0;
+        const bool slow = act && slot >= S1X_CAP;
+        if (__any(slow)) {
+          const int ncol = s1_col_of(rr, hi);
+          const int64_t crow_i = (int64_t)t * 128 + cl;
+          const uint16_t* crow = cent + (crow_i < C ? crow_i : 0) * DK;
+          float chn = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < CH; ++jj) {
+            const uint4 cv = *reinterpret_cast<const uint4*>(crow + jj * 8);
+            const uint4 av = __builtin_bit_cast(uint4, af[jj >> 1]);
+            const int src = (ncol + 32 * (jj & 1)) * 4;
+            uint4 qv;
+            qv.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.x);
+            qv.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.y);
+            qv.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.z);
+            qv.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.w);
+            asm volatile("" ::: "memory");   // (rare path: one chunk at a time)
+            s1_chain8(chn, cv, qv);
+          }
+          val = __builtin_bit_cast(uint16_t, (half_t)chn);
+          if (slow) ++nslow;
+        }
+        if (act) {
+          if (slot < S1X_CAP) val = lst[slot];
+          uint16_t* sp = s1_staged_slot(cur, wr, cl, rr, hi);
+          if (*sp != val) { ++nchg; if (!((Aw >> p) & 1u)) ++nunf; }
+          *sp = val;
+        }
+        off += (uint32_t)__popcll(bal);
+      }
+      if (xe.stats) {
+        const uint32_t nflag = (uint32_t)__popc(A);
+        if (nflag) atomicAdd(&xe.stats[0], (unsigned long long)nflag);
+        if (nchg) atomicAdd(&xe.stats[1], (unsigned long long)nchg);
+        if (nslow) atomicAdd(&xe.stats[2], (unsigned long long)nslow);
+        if (nunf) atomicAdd(&xe.stats[3], (unsigned long long)nunf);
+      }
+    }
+    s1_writeout<2, true, 4>(cur, tidv, (int64_t)tn * 128, (int64_t)t * 128, t, S, C, Ntot, Qp, S8, cmax, nch, ex, G);
   }
 }
 
 int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
-                        hipStream_t st, int64_t n_rows, int64_t row_stride, const FpS1Excess* exc) {
+                        hipStream_t st, int64_t n_rows, int64_t row_stride, const FpS1Excess* exc, const FpS1Exact* exact) {
   // n_rows / row_stride: score only the centroids 0, row_stride, 2 row_stride, ... (n_rows of them; S / S8 are then n_rows tall)
   const int64_t Ntot = (int64_t)B * Qp;
   const int64_t C = n_rows > 0 ? n_rows : ix.C;
   const int64_t rs = n_rows > 0 ? row_stride : 1;
   FpS1Excess ex{};
   if (exc) ex = *exc;
+  FpS1Exact xe{};
+  if (exact && exact->wcol) xe = *exact;
   const int nch = (int)((C + S1_TILE - 1) / S1_TILE);
   dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
   if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
@@ -480,21 +767,23 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   if (D % 8 != 0 || D < 8) return -1;
   // streaming form: main pass only (the sampled pre-pass has too few tiles to walk), dim 128 / 64
   static const int stream_env = [] { const char* e = getenv("FP_S1_STREAM"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup; n > 1: tiles per workgroup
-  if ((D == 128 || D == 64) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= 2048) {
+  static const int64_t stream_min = [] { const char* e = getenv("FP_S1_STREAM_MIN"); return e ? atoll(e) : 2048ll; }();   // tests: 1 = the streaming kernel for every size
+  if ((D == 128 || D == 64) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= stream_min) {
     const int nrt = (int)grid.y;
     const int nct = stream_env > 1 ? stream_env : 8;
     const unsigned nwg = (unsigned)((nch + nct - 1) / nct) * (unsigned)nrt;
-    const size_t lds = 2 * (size_t)S1_BUF;   // 66 KiB: above the 64 KiB that need no opt-in
+    const size_t lds = 2 * (size_t)S1_BUF + 512 + 8 * S1X_CAP * 2;   // 72.5 KiB (tile buffers + windows + the waves' lists): above the 64 KiB that need no opt-in
     static std::atomic<uint64_t> ok128{0}, ok64{0};
     if (D == 128) fp_allow_big_lds((const void*)k_centroid_scores_stream<128>, ok128, 80 * 1024);
     else fp_allow_big_lds((const void*)k_centroid_scores_stream<64>, ok64, 80 * 1024);
     if (D == 128)
-      hipLaunchKernelGGL(k_centroid_scores_stream<128>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex);
+      hipLaunchKernelGGL(k_centroid_scores_stream<128>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex, xe);
     else
-      hipLaunchKernelGGL(k_centroid_scores_stream<64>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex);
+      hipLaunchKernelGGL(k_centroid_scores_stream<64>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex, xe);
     return 0;
   }
-  static const int nwc = [] { const char* e = getenv("FP_S1_WAVES"); return (e && atoi(e) == 4) ? 2 : 4; }();   // FP_S1_WAVES=4: 2 x 2 waves (round 1)
+  static const int nwc_env = [] { const char* e = getenv("FP_S1_WAVES"); return (e && atoi(e) == 4) ? 2 : 4; }();   // FP_S1_WAVES=4: 2 x 2 waves (round 1)
+  const int nwc = xe.mode ? 4 : nwc_env;   // (the exact mode's flag word covers 32 accumulators per lane)
   static const int xcd_env = [] { const char* e = getenv("FP_S1_XCD"); return e ? atoi(e) : 0; }();   // 1: XCD-aware tile order (measured 315 vs 297 us: the memory-side cache already serves the re-reads)
   int nrt = 0;
   if (xcd_env && grid.y > 1 && (int64_t)((nch + 7) / 8) * 8 * grid.y < (1ll << 31)) {
@@ -503,16 +792,16 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   }
   if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
-    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<64, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
-    else hipLaunchKernelGGL((k_centroid_scores<64, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<64, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
+    else hipLaunchKernelGGL((k_centroid_scores<64, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
   } else if (D % 32 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 32 * 2, out_lds);
-    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<32, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
-    else hipLaunchKernelGGL((k_centroid_scores<32, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<32, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
+    else hipLaunchKernelGGL((k_centroid_scores<32, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
   } else {
     const size_t lds = std::max<size_t>(2 * 128 * 16 * 2, out_lds);
-    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<16, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
-    else hipLaunchKernelGGL((k_centroid_scores<16, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt);
+    if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<16, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
+    else hipLaunchKernelGGL((k_centroid_scores<16, 2>), grid, dim3(256), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
   }
   return 0;
 }
@@ -840,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_probe_chunkmax(const uint16_t* __restri
 // on registers (re-reading global memory every round cost 24 us at cfg2).
 template <int KPL>
 __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ cmax, int Q, int Qp, int nchunk, int n_probe,
-                                                  uint32_t* __restrict__ tau /*[B*Qp]*/) {
+                                                  uint32_t* __restrict__ tau /*[B*Qp]*/, int upper /*the maxima are upper bounds, at most one fp16 step above an element*/) {
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
   const uint16_t* src = cmax + ((int64_t)b * Qp + q) * nchunk;
@@ -866,14 +1155,20 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     }
     bound = m;
   }
-  if (lane == 0) tau[(int64_t)b * Qp + q] = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
+  if (lane == 0) {
+    uint32_t t = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
+    // S1's exact mode takes the maxima over the upper candidates of the flagged entries: every chunk then holds an element of
+    // at least the fp16 value one step BELOW its maximum, so that is what n_probe elements are guaranteed to reach
+    if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (key 0x7FFF is -0, which mono16 folds into +0)
+    tau[(int64_t)b * Qp + q] = t;
+  }
 }
 
-static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st) {
+static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st, int upper = 0) {
   const dim3 grid((unsigned)(sh.B * sh.Q));
-  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau);
-  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau);
-  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau);   // nchunk <= 4096
+  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper);
+  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper);
+  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper);   // nchunk <= 4096
 }
 
 __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
@@ -994,7 +1289,8 @@ const int32_t* fpk_probe_flag(const FpIndexDev& ix, const FpSearchShape& sh, int
 
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
               unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells,
-              const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st, bool prezeroed, bool with_fallback) {
+              const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st, bool prezeroed, bool with_fallback,
+              bool cmax_upper) {
   const int64_t Cw = (ix.C + 31) / 32;
   const ProbeLayout L = probe_layout(ix, sh, nchunk, partial);
   const int NP = L.NP, nch2 = L.nch2;
@@ -1013,7 +1309,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     const int nch128 = (int)((ix.C + 127) / 128);
     const bool fused = cmax128 != nullptr && allow == nullptr && nch128 <= 4096;
     if (fused) {
-      launch_probe_tau(cmax128, sh, nch128, tau, st);
+      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper ? 1 : 0);
       hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag, cmax128, nch128);
     } else {
       hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);

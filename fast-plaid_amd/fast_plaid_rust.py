@@ -341,6 +341,13 @@ def last_search_counts() -> dict:
                 s4_form={0: "exact", 1: "q8", 2: "l0", -1: "replayed graph"}.get(int(out[4]), "?"))
 
 
+def last_s1_counts() -> dict:
+    """fp_last_s1_counts (FP_S1_STATS in the environment): the certification counters of S1."""
+    out = (C.c_uint64 * 4)()
+    N.lib().fp_last_s1_counts(C.cast(out, C.c_void_p), 4)
+    return dict(flagged=int(out[0]), changed=int(out[1]), slow_path=int(out[2]), unflagged_differences=int(out[3]))
+
+
 def export_index_arrays(index: PyLoadedIndex, centroids=None, bucket_weights=None) -> dict:
     """construct_index argument set copied back from the device (fp_index_export)."""
     T, Nd, Cn = index.n_tokens, index.n_docs, index.n_centroids

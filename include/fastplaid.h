@@ -153,6 +153,15 @@ uint64_t fp_graph_replay_count(void);
  * (0 every candidate scored exactly, 1 8-bit bound stage, 2 level 0; -1 when the call was a graph replay).  Returns entries written. */
 int fp_last_search_counts(int64_t* out, int cap);
 
+/* Centroid scores (S1, search.rs:491) are exact: every fp32 MFMA result that lies within a certification window of an fp16
+ * rounding boundary -- the only place where the reference's ascending fp32 chain can round differently -- is re-evaluated with
+ * that chain inside the kernel, so S, and with it every later stage, equals the reference's bit for bit.  With FP_S1_STATS set in
+ * the environment (diagnostics: it also switches the graph replay off) the counters of the most recent fp_search on this thread
+ * are kept: out[0] = flagged entries, out[1] = re-evaluated entries whose value is not the upper candidate that was staged,
+ * out[2] = entries that overflowed a wave's list (re-evaluated on the slow path), out[3] = FP_S1_EXACT=2 only (every entry is
+ * re-evaluated): entries the window did NOT flag whose chain value differs from the MFMA's -- must be 0.  Returns entries written. */
+int fp_last_s1_counts(uint64_t* out, int cap);
+
 /* Diagnostic / test entry point: the MFMA pass of the exact stage (S6+S7) on the given documents for ONE query, before the
  * exact-order repair.  scores [n]; col_max [n, q_len] f16 bits = per query column the maximum over the document's tokens as the
  * kernel rounds it; unc [n] = uncertainty budget (sum of the fp16 ulps of the flagged columns); flags [n, ceil(q_len/32)] = bit
