@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfastplaid_hip.so")
+LIB_PATH = os.environ.get("FP_LIB_PATH") or os.path.join(_HERE, "libfastplaid_hip.so")   # (FP_LIB_PATH: A/B runs of library variants, tools/)
 
 
 class FpIndexDesc(C.Structure):

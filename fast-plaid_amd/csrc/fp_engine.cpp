@@ -57,25 +57,27 @@ extern "C" int fp_device_count(void) {
 // ------------------------------------------------------------------------------------------
 // grow-only device buffer
 // ------------------------------------------------------------------------------------------
-// bumped by every (re)allocation of a scratch buffer: a captured graph (FP_GRAPH) holds raw pointers and is only replayed while
-// the count it was captured under still stands
-static std::atomic<uint64_t> g_alloc_gen{0};
-// ... counted per scratch: the thread that holds a scratch points this at the scratch's own counter (search_impl), so that a
-// (re)allocation in another thread / index / scratch does not invalidate this scratch's graphs
-static thread_local uint64_t* t_alloc_gen = nullptr;
-static inline void bump_alloc_gen() {
-  if (t_alloc_gen) ++*t_alloc_gen;
-  else g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
-}
+// A captured graph (FP_GRAPH) holds raw pointers and is only replayed while nothing it points to has moved: every (re)allocation
+// of a buffer bumps the allocation generation of the scratch that OWNS the buffer, and the generation is part of the graph's key.
+// The owner is fixed when the buffer is constructed (a buffer that is a member of a Scratch picks up that scratch's counter
+// through t_ctor_gen, see ScratchGen), not looked up through the calling thread: the staged shard API holds a scratch across
+// calls, possibly on several threads and interleaved with other searches.
+static std::atomic<uint64_t> g_alloc_gen{0};   // buffers outside any scratch
+static thread_local uint64_t* t_ctor_gen = nullptr;
 static std::atomic<uint64_t> g_graph_replays{0};   // fp_graph_replay_count(): calls served by one hipGraphLaunch
 // fp_set_graph_replay / FP_GRAPH: on unless the environment says 0
 static std::atomic<int> g_graph_replay{[] { const char* e = getenv("FP_GRAPH"); return (e && atoi(e) == 0) ? 0 : 1; }()};
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  uint64_t* gen = t_ctor_gen;   // the owning scratch's allocation generation (nullptr: the process-wide one)
+  void bump() {
+    if (gen) ++*gen;
+    else g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
+  }
   hipError_t ensure(size_t need) {
     if (need <= cap) return hipSuccess;
-    bump_alloc_gen();
+    bump();
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -98,9 +100,11 @@ struct DevBuf {
 struct HostBuf {
   void* p = nullptr;
   size_t cap = 0;
+  uint64_t* gen = t_ctor_gen;
   hipError_t ensure(size_t need) {
     if (need <= cap) return hipSuccess;
-    bump_alloc_gen();
+    if (gen) ++*gen;
+    else g_alloc_gen.fetch_add(1, std::memory_order_relaxed);
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
@@ -126,7 +130,13 @@ static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 p
 // profiler's per-kernel time; "S4 prepare" = level 0's floors + excess table (zero otherwise); "S4 refine" = the cut, the
 // survivor compaction and their exact rescoring (zero when every candidate is scored exactly).
 
-struct Scratch {
+// base of Scratch: constructed before the buffer members, so that each of them records &alloc_gen as its owner
+struct ScratchGen {
+  uint64_t alloc_gen = 0;   // bumped by every (re)allocation of one of this scratch's buffers
+  ScratchGen() { t_ctor_gen = &alloc_gen; }
+};
+struct Scratch : ScratchGen {
+  Scratch() { t_ctor_gen = nullptr; }   // (runs after the members' initialisers)
   hipStream_t st = nullptr;
   hipEvent_t ev[ST_N + 1] = {};
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
@@ -166,7 +176,6 @@ struct Scratch {
   ShapeState shapes[kShapes];
   int cur_shape = -1;
   uint64_t shape_stamp = 0;
-  uint64_t alloc_gen = 0;   // bumped by every (re)allocation of one of this scratch's buffers (t_alloc_gen)
   void select_shape(const int64_t (&key)[6]) {
     if (cur_shape >= 0 && std::equal(key, key + 6, shapes[cur_shape].key)) { shapes[cur_shape].stamp = ++shape_stamp; return; }
     if (cur_shape >= 0) {   // park the live state
@@ -270,7 +279,6 @@ static Scratch* acquire(fp_index* ix) {
     if (!ix->pool.empty()) {
       Scratch* s = ix->pool.back();
       ix->pool.pop_back();
-      t_alloc_gen = &s->alloc_gen;   // this thread's (re)allocations are this scratch's from here to release()
       return s;
     }
   }
@@ -280,11 +288,9 @@ static Scratch* acquire(fp_index* ix) {
     return nullptr;
   }
   for (auto& e : s->ev) (void)hipEventCreate(&e);
-  t_alloc_gen = &s->alloc_gen;
   return s;
 }
 static void release(fp_index* ix, Scratch* s) {
-  t_alloc_gen = nullptr;
   std::lock_guard<std::mutex> g(ix->mu);
   ix->pool.push_back(s);
 }
@@ -752,7 +758,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   {
     void* zp = nullptr;
     size_t zb = 0;
-    P.probe_prezeroed = sh.n_probe >= 1 && fpk_probe_zero_region(D, sh, P.nchunk, s->partial.as<unsigned long long>(), &zp, &zb) && zl.add(zp, zb);
+    // (a shape the threshold probe does not serve -- n_ivf_probe > 32, FP_PROBE_FALLBACK -- always runs the other kernels: their
+    // raised flag is no overflow and must not send the batch round again)
+    const bool thr_ok = sh.n_probe >= 1 && fpk_probe_zero_region(D, sh, P.nchunk, s->partial.as<unsigned long long>(), &zp, &zb);
+    if (!thr_ok) P.probe_no_fb = false;
+    P.probe_prezeroed = thr_ok && zl.add(zp, zb);
     (void)zl.add(s->invalid.p, (size_t)B * 4);
     (void)zl.add(s->tickets.p, (size_t)(2 * B + 4) * 4);
     P.selhist_prezeroed = zl.add(s->hist.p, fpk_sel_hist_bytes(B));
@@ -764,10 +774,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   }
   // S1 exact mode (FpS1Exact): certification window w0 |q_n| + kappa |x| around the MFMA result; FP_S1_EXACT=0 switches the
   // certification off (S then differs from the reference's matmul by one fp16 ulp in ~0.05 % of its entries), 2 re-evaluates
-  // every entry (tests); FP_S1_W0_LOG2 / FP_S1_KAPPA_LOG2 move the window (defaults 2^-21 and 2^-19.5, x dim / 128 above 128)
+  // every entry (tests); FP_S1_W0_LOG2 / FP_S1_KAPPA_LOG2 move the window (defaults 2^-21.5 and 2^-20, x dim / 128 above 128)
   static const int s1x_env = [] { const char* e = getenv("FP_S1_EXACT"); return e ? atoi(e) : 1; }();
-  static const float s1x_w0 = [] { const char* e = getenv("FP_S1_W0_LOG2"); return std::exp2(e ? (float)atof(e) : -21.0f); }();
-  static const float s1x_kappa = [] { const char* e = getenv("FP_S1_KAPPA_LOG2"); return std::exp2(e ? (float)atof(e) : -19.5f); }();
+  static const float s1x_w0 = [] { const char* e = getenv("FP_S1_W0_LOG2"); return std::exp2(e ? (float)atof(e) : -21.5f); }();
+  static const float s1x_kappa = [] { const char* e = getenv("FP_S1_KAPPA_LOG2"); return std::exp2(e ? (float)atof(e) : -20.0f); }();
   const bool s1x_stats = s1_stats_enabled() && !s->capturing;
   P.s1_mode = s1x_env < 0 ? 0 : (s1x_env > 2 ? 2 : s1x_env);
   const float dim_scale = D.dim > 128 ? (float)D.dim / 128.0f : 1.0f;
@@ -2019,6 +2029,13 @@ static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* 
     // THIS call; the communicator is aborted so that peers already waiting for this rank get an error instead of a hang) ----
     int status = 0;
     std::string first_err;
+    // a failure that makes THIS rank leave the protocol (a collective that could not be enqueued, a device error behind the last
+    // exchange): the communicator is aborted, so that the peers -- inside this batch's collectives or about to enter the next
+    // sub-batch's -- get an error from RCCL instead of waiting for a rank that has returned
+    auto leave = [&](int rc) {
+      if (api->CommAbort && comm->comm) { (void)api->CommAbort(comm->comm); comm->comm = nullptr; }
+      return rc;
+    };
     auto note = [&](int rc) {   // a local failure: remember the first message, keep going with an empty contribution
       if (rc != FP_OK && !(status & SH_FAILED)) { status |= SH_FAILED; first_err = g_err; }
     };
@@ -2068,7 +2085,7 @@ static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* 
     // exchange 1: local top-R by approximate score
     fpk_shard_pack1(s->sel_approx.as<float>(), s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R, D.pid_offset, s->sh_rec.p, st,
                     (have_front && P.spec) ? s->spec_total.as<int64_t>() : nullptr, (have_front && P.spec) ? P.M : 0, status);
-    if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+    if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 16, /*ncclInt8*/ 0, comm->comm, st)) return leave(rccl_fail("ncclAllGather", rc));
     fpk_shard_status(s->sh_all.p, G, (int64_t)B * R * 16, 12, d_flags, st);
     // global cut on the union (sort in LDS, or select + ordered compaction when n_ranks * R is beyond it)
     if (fpk_shard_global_cut(s->sh_all.p, G, B, R, D.pid_offset, D.pid_offset + D.N, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), st)) {
@@ -2087,7 +2104,7 @@ static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* 
     fpk_shard_pack2(s->exact.as<float>(), (have_scores && s->ms_repairable) ? s->ms_unc.as<float>() : nullptr,
                     (have_scores && s->ms_repairable) ? s->ms_uncm.as<float>() : nullptr, s->sel_pid.as<int32_t>(), s->sel_cnt.as<int32_t>(), B, R,
                     D.pid_offset, s->sh_rec.p, st, status);
-    if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+    if (int rc = api->AllGather(s->sh_rec.p, s->sh_all.p, (size_t)B * R * 24, 0, comm->comm, st)) return leave(rccl_fail("ncclAllGather", rc));
     fpk_shard_status(s->sh_all.p, G, (int64_t)B * R * 24, 20, d_flags, st);
     // exchange 3: the union and its near-tie marking are identical on every rank; each rank repairs the marked documents it holds
     // and ships their scores ([B][R] floats by union position)
@@ -2096,25 +2113,34 @@ static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* 
     note(shard_mark_and_repair(ix, s, P.sh, s->sh_all.p, G, comm->rank, !have_scores, K, s->sh_x.as<float>(), st));
     if (shard_marks_mode(R) != 0) {   // (the same on every rank whatever happened locally: a function of the environment and R)
       (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->sh_x.as<int32_t>() + (int64_t)B * R), status, 1, st);
-      if (int rc = api->AllGather(s->sh_x.p, s->sh_xall.p, (size_t)xstride * 4, 0, comm->comm, st)) return rccl_fail("ncclAllGather", rc);
+      if (int rc = api->AllGather(s->sh_x.p, s->sh_xall.p, (size_t)xstride * 4, 0, comm->comm, st)) return leave(rccl_fail("ncclAllGather", rc));
       fpk_shard_status(s->sh_xall.p, G, xstride * 4, (int64_t)B * R * 4, d_flags, st);
     }
     // ---- past the last collective: the merge, the download, and the verdict of all ranks ----
     (void)hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, d_flags, 4, hipMemcpyDeviceToHost, st);
     const int mrc = (status & SH_FAILED) ? FP_OK : shard_apply_and_rank(s, P.sh, s->sh_xall.as<float>(), K, out_pids, out_scores, out_counts, st, xstride);
-    HIPCHK(hipStreamSynchronize(st));
-    if (hipError_t le = hipGetLastError(); le != hipSuccess) note(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(le) + " (sharded search)"));
+    if (hipError_t se = hipStreamSynchronize(st); se != hipSuccess)
+      return leave(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(se) + " (sharded search; the communicator was aborted)"));
+    const bool late_err = [&] {   // an error that surfaced behind the last exchange: the peers have not heard of it
+      if (hipError_t le = hipGetLastError(); le != hipSuccess) { (void)fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(le) + " (sharded search)"); return true; }
+      return false;
+    }();
     const int flags = *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 40);
     if (status & SH_FAILED) return fail(FP_EHIP, "fp_shard_search failed on this rank (every rank reports the batch as failed): " + first_err);
     if (flags & SH_FAILED) {
       for (int i = 0; i < B; ++i) out_counts[i] = 0;
       return fail(FP_EHIP, "fp_shard_search: another rank failed during this batch (its error is reported there); no rank returns results");
     }
-    if (mrc) return mrc;
+    // every rank saw the same status words: an overflow anywhere -> EVERY rank goes round again, whatever its own merge did with
+    // the discarded attempt (a rank that returned here instead would leave the others alone in attempt 1's collectives)
     if (attempt == 0 && (flags & SH_OVERFLOW)) {
       s->spec_cap = 0;   // (the rank that overflowed; harmless on the others: the second attempt waits everywhere)
       continue;
     }
+    // a failure of this rank's own merge / ranking behind the last exchange is not in any status word: the other ranks return
+    // results and move on to the next sub-batch's collectives, so this rank aborts the communicator on its way out
+    if (mrc) return leave(mrc);
+    if (late_err) return leave(FP_EHIP);
     if (have_front) learn_capacity(s, *reinterpret_cast<const int64_t*>(s->h_small.p));
     return FP_OK;
   }

@@ -131,7 +131,7 @@ __device__ __forceinline__ S1Groups s1_groups(int64_t n0, int Qp) {
 // ---- exact centroid scores: certification of the MFMA result and ascending-chain re-evaluation of the flagged entries ----------
 // (FpS1Exact, fp_internal.h.)  A lane's 32 accumulators are 16 PAIRS of adjacent query columns; pair pj = (a * NB + b) * 8 + j holds
 // acc[a][b][2 j], acc[a][b][2 j + 1].  Flag word: bit pj = the pair's even element, bit 16 + pj = its odd element.
-#define S1X_CAP 384          // listed entries per wave and tile (18 % of its 2048 outputs; ~6.6 % are flagged on unit vectors)
+#define S1X_CAP 256          // listed entries per wave and tile (12.5 % of its 2048 outputs; ~5 % are flagged on unit vectors)
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t s1_cvt_pk(float a, float b) {
   uint32_t r;
@@ -595,7 +595,9 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     asm volatile("" : "+v"(tidv));
 #endif
     const int lane = tidv & 63, l31 = lane & 31, hi = lane >> 5;
-    uint16_t* lst = reinterpret_cast<uint16_t*>(smem + 2 * S1_BUF + 512) + __builtin_amdgcn_readfirstlane(tidv >> 6) * S1X_CAP;
+    const int wave = __builtin_amdgcn_readfirstlane(tidv >> 6), wr = wave >> 1, wc = wave & 1;   // (scalar registers)
+    uint16_t* lst = reinterpret_cast<uint16_t*>(smem + 2 * S1_BUF + 512) + wave * (2 * S1X_CAP);   // entries
+    uint16_t* res = lst + S1X_CAP;                                                                                                       // ... and their values
     f16v acc[1][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -637,7 +639,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     }, &Aall);
     const uint32_t Aw = A;
     if (xe.mode == 2) A = Aall;
-    uint32_t listed = 0u;
+    uint32_t listed = 0u, flagged_total = 0u;
     if (xe.mode) {
       uint32_t rem = A, off = 0u;
       while (true) {
@@ -652,6 +654,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
         }
         off += (uint32_t)__popcll(bal);
       }
+      flagged_total = off;
       listed = off < S1X_CAP ? off : S1X_CAP;   // (wave-uniform)
       for (uint32_t p0 = 0; p0 < listed; p0 += 64) {
         const uint32_t idx = p0 + (uint32_t)lane;
@@ -688,14 +691,25 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
           cv = cvn;
           qv = qvn;
         }
-        if (valid) lst[idx] = __builtin_bit_cast(uint16_t, (half_t)chn);
+        if (valid) res[idx] = __builtin_bit_cast(uint16_t, (half_t)chn);
       }
     }
     s1_stage<2, 4>(hw, cur, tidv, (int64_t)t * 128, C, cmax != nullptr);
-    if (xe.mode) {
-      // every lane writes the re-evaluated values of ITS entries over the staged upper candidates (same wave, LDS is in order);
-      // the slot numbers are those of the listing loop above.  Entries beyond the list (never seen on unit vectors) are
-      // re-evaluated here with the centroid row from global memory -- the tile's LDS copy is gone.
+    if (xe.mode && flagged_total <= S1X_CAP && !xe.stats) {
+      // the re-evaluated values go over the staged upper candidates: the lane that ran an entry's chain writes it (the staging
+      // stores of the whole wave are older in its LDS queue)
+      for (uint32_t p0 = 0; p0 < listed; p0 += 64) {
+        const uint32_t idx = p0 + (uint32_t)lane;
+        if (idx < listed) {
+          const uint32_t e = (uint32_t)lst[idx];
+          const int ls = (int)(e >> 5), p = (int)(e & 31u), pj = p & 15, rr = 2 * (pj & 7) + (p >> 4);
+          *s1_staged_slot(cur, wr, wc * 64 + (pj >> 3) * 32 + (ls & 31), rr, ls >> 5) = res[idx];
+        }
+      }
+    } else if (xe.mode) {
+      // the general form (a wave with more flagged entries than its list holds -- never seen on unit vectors --, or the counters
+      // are wanted): every lane walks ITS entries in the order of the listing loop; entries beyond the list are re-evaluated
+      // here with the centroid row from global memory -- the tile's LDS copy is gone.
       uint32_t rem = A, off = 0u, nchg = 0u, nunf = 0u, nslow = 0u;
       while (true) {
         const bool act = rem != 0u;
@@ -730,7 +744,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
           if (slow) ++nslow;
         }
         if (act) {
-          if (slot < S1X_CAP) val = lst[slot];
+          if (slot < S1X_CAP) val = res[slot];
           uint16_t* sp = s1_staged_slot(cur, wr, cl, rr, hi);
           if (*sp != val) { ++nchg; if (!((Aw >> p) & 1u)) ++nunf; }
           *sp = val;
@@ -772,7 +786,7 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
     const int nrt = (int)grid.y;
     const int nct = stream_env > 1 ? stream_env : 8;
     const unsigned nwg = (unsigned)((nch + nct - 1) / nct) * (unsigned)nrt;
-    const size_t lds = 2 * (size_t)S1_BUF + 512 + 8 * S1X_CAP * 2;   // 72.5 KiB (tile buffers + windows + the waves' lists): above the 64 KiB that need no opt-in
+    const size_t lds = 2 * (size_t)S1_BUF + 512 + 8 * 2 * S1X_CAP * 2;   // 74.5 KiB (tile buffers + windows + the waves' entry / value lists): above the 64 KiB that need no opt-in
     static std::atomic<uint64_t> ok128{0}, ok64{0};
     if (D == 128) fp_allow_big_lds((const void*)k_centroid_scores_stream<128>, ok128, 80 * 1024);
     else fp_allow_big_lds((const void*)k_centroid_scores_stream<64>, ok64, 80 * 1024);
@@ -1859,26 +1873,32 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
           m3 = pk_max(m3, u32_as_h2((uint32_t)__shfl_xor((int)h2_as_u32(m3), x, 64)));
         }
       }
+      // fp32 sum over the columns in ASCENDING order, like the oracle's (sum(dtype=Float), search.rs:401): the running total
+      // walks the quad's four lanes, eight columns each (every lane adds its columns to the incoming total, lane l's result is
+      // the one passed on).  A blocked order differs in the last bit whenever a column maximum is tiny against the total.
       const int q0 = ch * 32 + sub * 8;
-      float s = 0.f;
-      s += (q0 + 0 < Q) ? (float)m0.x : 0.f;
-      s += (q0 + 1 < Q) ? (float)m0.y : 0.f;
-      s += (q0 + 2 < Q) ? (float)m1.x : 0.f;
-      s += (q0 + 3 < Q) ? (float)m1.y : 0.f;
-      s += (q0 + 4 < Q) ? (float)m2.x : 0.f;
-      s += (q0 + 5 < Q) ? (float)m2.y : 0.f;
-      s += (q0 + 6 < Q) ? (float)m3.x : 0.f;
-      s += (q0 + 7 < Q) ? (float)m3.y : 0.f;
-      total += s;
+      const float c0 = (q0 + 0 < Q) ? (float)m0.x : 0.f, c1 = (q0 + 1 < Q) ? (float)m0.y : 0.f;
+      const float c2 = (q0 + 2 < Q) ? (float)m1.x : 0.f, c3 = (q0 + 3 < Q) ? (float)m1.y : 0.f;
+      const float c4 = (q0 + 4 < Q) ? (float)m2.x : 0.f, c5 = (q0 + 5 < Q) ? (float)m2.y : 0.f;
+      const float c6 = (q0 + 6 < Q) ? (float)m3.x : 0.f, c7 = (q0 + 7 < Q) ? (float)m3.y : 0.f;
+#define AP_LANE_STEP(CTRL)                                                                                     \
+      {                                                                                                            \
+        float r = total;                                                                                           \
+        r += c0; r += c1; r += c2; r += c3; r += c4; r += c5; r += c6; r += c7;                                    \
+        total = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(r), CTRL, 0xF, 0xF, false));               \
+      }
+      AP_LANE_STEP(0x00)   // quad_perm [0,0,0,0]: lane 0's sum of the columns 0..7 ...
+      AP_LANE_STEP(0x55)   // ... then lane 1's on top of it, ...
+      AP_LANE_STEP(0xAA)
+      AP_LANE_STEP(0xFF)
+#undef AP_LANE_STEP
     }
     if (!next_loaded && nlen > t0) {  // a quad without codes in this document never reaches the prefetch slot above
 #pragma unroll
       for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((t0 + k < nlen) ? t0 + k : (nlen - 1))];
     }
-    // the 4 lanes of the quad hold disjoint column sums (the lanes of one candidate run the same outer trip counts, so the
-    // shuffles are convergent within the candidate; other candidates may have exited)
-    total += __shfl_xor(total, 1, 64);
-    total += __shfl_xor(total, 2, 64);
+    // (the lanes of one candidate run the same outer trip counts, so the quad exchanges above are convergent within the
+    // candidate; other candidates may have exited)
     if (sub == 0 && pp == 0) {
       if (approx) approx[beg + i] = total;
       if (scat) scat[sbase + scat_idx[beg + i]] = total;

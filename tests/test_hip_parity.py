@@ -73,12 +73,13 @@ def test_golden_stagewise(fp, name):
         h = R.search_trace(hip, q[b], params, sub)
         o = orc.search_trace(q[b], top_k, n_full, n_probe, sub)
         check_trace(h, o, q.shape[1], n_probe, n_full, top_k)
-        # golden (ATen) final results: ids identical modulo near-ties, scores within 1e-3
-        check_final(h["pids"], h["scores"], z[f"pids_{b}"], z[f"scores_{b}"], top_k,
-                    excused=set(h["rerank"].tolist()) ^ set(z[f"rerank_{b}"].tolist()))
+        # golden (ATen) results: the stages bit for bit, the final ids identical, scores within 1e-3
+        assert np.array_equal(h["S"].view(np.uint16), z[f"S_{b}"].view(np.uint16)) if f"S_{b}" in z else True
+        assert np.array_equal(h["rerank"], z[f"rerank_{b}"]), "rerank list differs from the ATen-produced golden"
+        check_final(h["pids"], h["scores"], z[f"pids_{b}"], z[f"scores_{b}"], top_k)
         n_exact_id_match += int(np.array_equal(h["pids"], z[f"pids_{b}"]))
-    # fixtures were chosen free of exact ties: the id lists should agree outright almost always
-    assert n_exact_id_match >= q.shape[0] - 1, f"only {n_exact_id_match}/{q.shape[0]} id lists identical to the goldens"
+    # fixtures were chosen free of exact ties: every id list agrees outright
+    assert n_exact_id_match == q.shape[0], f"only {n_exact_id_match}/{q.shape[0]} id lists identical to the goldens"
 
 
 @pytest.mark.parametrize("name", ["base_d128_nb4", "subset", "d64_nb2", "topk_gt_ndocs", "empty_doc"])
@@ -205,7 +206,7 @@ def test_degenerate_parameters_match_the_oracle(fp):
         ref = orc.search(queries, top_k, n_full, n_probe, subset=subs)
         for b in range(queries.shape[0]):
             assert c[b] == len(ref[b][0]), (params_tuple, b, c[b], len(ref[b][0]))
-            check_final(p[b, : c[b]], s[b, : c[b]], ref[b][0], ref[b][1], max(top_k, 1), excused=set(range(200)))
+            check_final(p[b, : c[b]], s[b, : c[b]], ref[b][0], ref[b][1], max(top_k, 1))
         return c
 
     assert np.all(same((2000, 4096, 0, 4), q) == 0)                  # top_k = 0
@@ -297,8 +298,9 @@ def test_synthetic_vs_oracle(fp, cfg):
         o = orc.search_trace(q[b], cfg["top_k"], cfg["n_full"], cfg["n_probe"])
         check_trace(h, o, cfg["Q"], cfg["n_probe"], cfg["n_full"], cfg["top_k"])
         assert np.array_equal(pids[b, : counts[b]], h["pids"])
+        check_final(pids[b, : counts[b]], scores[b, : counts[b]], ref[b][0], ref[b][1], cfg["top_k"])   # the oracle's ids, in its order
         identical += int(np.array_equal(pids[b, : counts[b]], ref[b][0]))
-    assert identical >= cfg["B"] // 2, f"only {identical}/{cfg['B']} queries returned id lists identical to the oracle"
+    print(f"{identical}/{cfg['B']} id lists identical outright (the others: exact ties of the reference's scores)")
 
 
 def test_probe_with_massive_ties_takes_device_fallback(fp):
@@ -1144,13 +1146,9 @@ def _same_order_modulo_ref_ties(ids_hip, ids_ref, score_ref):
 
 def test_full_size_cfg2_id_lists_vs_oracle(fp):
     """BASELINE cfg2 AT FULL SIZE (1 M documents, top_k = 1000) against the C oracle run on the exported index, 16 queries
-    (north star: identical top-k doc ids).  Per query:
-      * the id SETS are identical except for documents excused by an S1 rounding near-tie: a document that only one side
-        exact-scored because its approximate score sits at the R-cut (or whose probed cell sits at the probe cut);
-      * on the documents both lists hold, the ORDER is the oracle's wherever the oracle's scores are distinct -- this is what
-        the exact-order repair of near-tied final scores (k_final_mark / k_maxsim_repair) is for;
-      * scores within 1e-3.
-    At least 14 of the 16 lists must be identical outright."""
+    (north star: identical top-k doc ids).  Every id list must be the oracle's, in the oracle's order (documents whose
+    reference scores are EXACTLY equal may be permuted: the reference's tie order is implementation-defined), scores within
+    1e-3 -- S1 is exact since round 4, so nothing upstream of the final ranking can differ."""
     R = fp.fast_plaid_rust
     c = FULL_SIZE["cfg2"]
     spec, cent, dev = _full_size_index(fp, c["n_docs"], c["doc_len"], c["n_centroids"])
@@ -1169,24 +1167,16 @@ def test_full_size_cfg2_id_lists_vs_oracle(fp):
         gp, gs = pids[b, : counts[b]], scores[b, : counts[b]]
         rp, rs = ref[b]
         assert len(gp) == len(rp) == top_k
-        rmap = dict(zip(rp.tolist(), rs.tolist()))
-        gmap = dict(zip(gp.tolist(), gs.tolist()))
-        common = set(rmap) & set(gmap)
-        assert max(abs(rmap[p] - gmap[p]) for p in common) <= SCORE_TOL
-        if np.array_equal(gp, rp):
-            identical += 1
-            continue
-        only = set(rmap) ^ set(gmap)
-        if only:   # must be explained by the stage traces: cells / rerank sets differ at a near-tie of S
+        try:
+            identical += int(check_final(gp, gs, rp, rs, top_k))
+        except AssertionError:
+            # say which stage moved before failing
             ht = R.search_trace(dev, q[b], params)
             rt = orc.search_trace(q[b], top_k, n_full, n_probe)
-            check_trace(ht, rt, Q, n_probe, n_full, top_k)   # asserts every stage difference is a bounded near-tie
-            excused = set(ht["rerank"].tolist()) ^ set(rt["rerank"].tolist())
-            assert excused, f"query {b}: id sets differ ({sorted(only)}) although both sides exact-scored the same documents"
-            # a document outside both lists' intersection is either excused itself or was displaced by an excused one
-            assert len(only) <= 2 * len(excused), (b, sorted(only), sorted(excused))
-        _same_order_modulo_ref_ties([p for p in gp.tolist() if p in common], [p for p in rp.tolist() if p in common], rmap)
-    assert identical >= 14, f"only {identical} of {nq} top-{top_k} id lists are identical to the oracle's"
+            check_trace(ht, rt, Q, n_probe, n_full, top_k)
+            raise
+    print(f"{identical} of {nq} id lists identical outright")
+    assert identical >= nq - 1, f"only {identical} of {nq} top-{top_k} id lists are identical to the oracle's (exact ties of reference scores are rare)"
 
 
 def test_full_size_cfg2_column_certification(fp):
