@@ -66,7 +66,9 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
     ap.add_argument("--workload", type=str, default="", help="label override")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
-    ap.add_argument("--dist-mode", choices=["auto", "replica", "split", "shard"], default="auto",
+    ap.add_argument("--doc-shards", type=int, default=0, help="grid mode: document shards per query group (0 = 2; the other factor of "
+                    "--gpus is the number of query groups)")
+    ap.add_argument("--dist-mode", choices=["auto", "replica", "split", "shard", "grid"], default="auto",
                     help="N>1: replica = full index per GPU, every rank searches its OWN batch of --batch queries per step, no "
                          "data-path collective (weak scaling: the reference's replicas, one client stream per GPU); split = "
                          "full index per GPU, ONE batch split across the ranks + a result all-gather (strong); shard = document "
@@ -171,8 +173,18 @@ def main():
     def run_mode(mode):
         """builds the index for `mode`, W warm-up steps, then EXACTLY K timed steps bracketed by
         barrier + synchronize; returns the max-over-ranks elapsed time and per-step records."""
+        shard_group, gsz = None, 1
         if mode == "shard":
             lo, hi = sharded.plan_shards(a.docs, world)[rank]
+        elif mode == "grid":
+            # 2-D layout: `gsz` consecutive ranks hold the corpus as gsz document shards and search one slice of the batch
+            gsz = a.doc_shards if a.doc_shards > 0 else 2
+            if world % gsz:
+                gsz = 1
+            d_idx, g_idx = sharded.plan_grid(world, gsz)[rank]
+            lo, hi = sharded.plan_shards(a.docs, gsz)[d_idx]
+            groups = [dist.new_group([g * gsz + d for d in range(gsz)]) for g in range(world // gsz)]   # (every rank creates every group)
+            shard_group = groups[g_idx]
         else:
             lo, hi = 0, a.docs
         t0 = time.time()
@@ -180,9 +192,9 @@ def main():
         t_build = time.time() - t0
         native_comm = None
         engine = None
-        if mode == "shard":
+        if mode in ("shard", "grid"):
             if a.dist_impl == "native" and a.dist_backend == "nccl":
-                native_comm = sharded.NativeComm.from_torch_dist(index.device_id, dist)
+                native_comm = sharded.NativeComm.from_torch_dist(index.device_id, dist, group=shard_group)
             else:
                 engine = sharded.HipShardEngine(index, dev)
 
@@ -196,6 +208,13 @@ def main():
                 if native_comm is not None:
                     return sharded.native_sharded_search(index, native_comm, q, params)
                 return sharded.sharded_search(engine, q, params, dist=dist, force_collectives=True)
+            if mode == "grid":
+                if native_comm is not None:
+                    in_group = lambda qs: sharded.native_sharded_search(index, native_comm, qs, params)   # noqa: E731
+                else:
+                    in_group = lambda qs: sharded.sharded_search(engine, qs, params, dist=dist, group=shard_group, force_collectives=True)   # noqa: E731
+                return sharded.replicated_search(in_group, q, a.topk, dist=dist, device=("cpu" if a.dist_backend == "gloo" else dev),
+                                                 force_collectives=True, group_size=gsz)
             if mode == "split":
                 return sharded.replicated_search(lambda qs: R.search_arrays(index, qs, params), q, a.topk, dist=dist,
                                                  device=("cpu" if a.dist_backend == "gloo" else dev), force_collectives=True)
@@ -263,7 +282,10 @@ def main():
         fits = est_bytes * 2.2 + a.batch * C * 64 < 0.8 * hbm   # index + build scratch + S
         # auto: BASELINE configs[2] is the SHARDED index (documents split over the ranks, RCCL all-gathers in the data path, strong
         # scaling against `--gpus 1 --config cfg3`); replicas only for an explicitly requested single-GPU-sized workload
-        primary = a.dist_mode if a.dist_mode != "auto" else ("shard" if (a.cfg == "cfg3" or not fits) else "replica")
+        # (round 4: the sharded default is the 2-D layout -- 2 document shards x N/2 query groups -- because a pure document split
+        # repeats S1, the centroid GEMM of the WHOLE batch, on every rank: 6 of 68 ms at cfg3, the term that capped 8 ranks at
+        # 5.6 x.  With two ranks it is the pure document split.)
+        primary = a.dist_mode if a.dist_mode != "auto" else (("grid" if world % 2 == 0 else "shard") if (a.cfg == "cfg3" or not fits) else "replica")
         other = "shard" if primary in ("replica", "split") else "split"
         run_other = a.alt_mode and (not a.no_alt_mode) and (other == "shard" or fits)
     else:
@@ -289,13 +311,17 @@ def main():
                       "fp_search; no data-path collective (barrier + max-over-ranks timing only)" % (world, a.batch),
            "split": "full index replica per GPU, batch split %d-way, result all-gather over %s" % (
                world, "RCCL" if a.dist_backend == "nccl" else "gloo (test mode: ranks share the visible GPUs)"),
+           "grid": "%d document shards x %d query groups: fp_shard_search (3 RCCL all-gathers/batch) inside a group of %d neighbouring "
+                   "ranks on its slice of the batch, one result all-gather over all ranks" % (
+                       (a.doc_shards or 2) if world % (a.doc_shards or 2) == 0 else 1, world // ((a.doc_shards or 2) if world % (a.doc_shards or 2) == 0 else 1),
+                       (a.doc_shards or 2) if world % (a.doc_shards or 2) == 0 else 1),
            "shard": "document-sharded x%d, 3 RCCL all-gathers/batch (%s)" % (
                world, "issued by the library on the search stream" if (a.dist_impl == "native" and a.dist_backend == "nccl") else "torch.distributed between four stage calls")}[primary]
 
     out = {
         "metric": "queries/sec @ top_k=%d (batch=%d, dim=%d); p50 search latency" % (a.topk, a.batch, a.dim),
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": ("strong" if primary in ("shard", "split") else "weak"),
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": ("strong" if primary in ("shard", "split", "grid") else "weak"),
         "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {
@@ -307,7 +333,7 @@ def main():
         },
         "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
     }
-    if primary in ("shard", "split") or (a.cfg == "cfg3" and world == 1):
+    if primary in ("shard", "split", "grid") or (a.cfg == "cfg3" and world == 1):
         # the one-GPU anchor of the strong-scaling series: `python bench.py --gpus 1 --config cfg3` (the newest committed measurement of it)
         import glob
         anchors = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cfg3_1gpu.json")))

@@ -167,7 +167,11 @@ __device__ __forceinline__ uint32_t s1_certify(const f16v (&acc)[NA][NB], uint32
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int j = j0 + jj;
-        const uint32_t nz = (w[jj].x > 0.f ? 1u : 0u) | (w[jj].y > 0.f ? 0x10000u : 0u);
+        if (mode == 2) {   // (wave-uniform; tests only)
+          const uint32_t nz = (w[jj].x > 0.f ? 1u : 0u) | (w[jj].y > 0.f ? 0x10000u : 0u);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) M |= nz << ((a * NB + b) * 8 + j);
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const int pj = (a * NB + b) * 8 + j;
@@ -179,7 +183,6 @@ __device__ __forceinline__ uint32_t s1_certify(const f16v (&acc)[NA][NB], uint32
           uint32_t t;
           asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(hu ^ hl), "v"(0x00010001u));   // {even differs, odd differs} in bits 0 and 16
           A |= t << pj;
-          M |= nz << pj;
         }
       }
     }
@@ -192,12 +195,22 @@ __device__ __forceinline__ int s1_col_of(int rr, int hi) { return (rr & 3) + 8 *
 // v_fma_mix_f32 takes the halves in place; left to the compiler the pair becomes v_dot2, which rounds differently)
 __device__ __forceinline__ void s1_chain8(float& acc, const uint4 c, const uint4 q) {
   const uint32_t cw[4] = {c.x, c.y, c.z, c.w}, qw[4] = {q.x, q.y, q.z, q.w};
+#ifndef S1X_NOP
+#define S1X_NOP 1   // 0 (experiments): no wait state between the dependent v_fma_mix instructions
+#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t)
+#if S1X_NOP
     asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\ts_nop 0\n\t"
                  "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\ts_nop 0"
                  : "+v"(acc)
                  : "v"(cw[t]), "v"(qw[t]));
+#else
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\t"
+                 "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]"
+                 : "+v"(acc)
+                 : "v"(cw[t]), "v"(qw[t]));
+#endif
 }
 
 // ---- epilogue of one 128 x 128 output tile, part 1: the fp16 tile (upper candidates) staged in LDS + the column maxima ----------
@@ -530,7 +543,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;  // 4 x 2 waves, 32 (n) x 64 (c) each
+  const int wr = wave >> 1;  // 4 x 2 waves, 32 (n) x 64 (c) each (the tile loop derives its own copies from the laundered lane id)
   const int l31 = lane & 31, hi = lane >> 5;
   // (the divide runs on the vector unit: readfirstlane puts the wave-uniform results back into scalar registers)
   const int tile_n = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nrt));
@@ -656,35 +669,70 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
       }
       flagged_total = off;
       listed = off < S1X_CAP ? off : S1X_CAP;   // (wave-uniform)
-      for (uint32_t p0 = 0; p0 < listed; p0 += 64) {
-        const uint32_t idx = p0 + (uint32_t)lane;
-        const bool valid = idx < listed;
-        const uint32_t e = valid ? (uint32_t)lst[idx] : 0u;
+      // One pass = 64 list entries, one per lane; while more than 64 remain a pass takes 128, TWO per lane, whose chains are
+      // interleaved (the wait state a dependent v_fma_mix needs is then filled by the other chain instead of an s_nop, and the
+      // loop's bookkeeping is shared): ~5 % flagged = ~107 entries per wave and tile = one double pass.
+      struct Ent { const unsigned char* crow; int swz, ncol; };
+      auto decode = [&](uint32_t e) -> Ent {
         const int ls = (int)(e >> 5), p = (int)(e & 31u), pj = p & 15, rr = 2 * (pj & 7) + (p >> 4);
         const int cl = wc * 64 + (pj >> 3) * 32 + (ls & 31);
-        const int ncol = s1_col_of(rr, ls >> 5);
-        const unsigned char* crow = cur + cl * ROWB;
-        const int swz = cl & (CH - 1);
+        return Ent{cur + cl * ROWB, cl & (CH - 1), s1_col_of(rr, ls >> 5)};
+      };
+      auto fetch_q = [&](const Ent& en, int jj) -> uint4 {
+        const uint4 av = __builtin_bit_cast(uint4, af[jj >> 1]);
+        const int src = (en.ncol + 32 * (jj & 1)) * 4;
+        uint4 qv;
+        qv.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.x);
+        qv.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.y);
+        qv.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.z);
+        qv.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.w);
+        return qv;
+      };
+      auto fetch_c = [&](const Ent& en, int jj) -> uint4 { return *reinterpret_cast<const uint4*>(en.crow + ((jj ^ en.swz) * 16)); };
+      uint32_t p0 = 0;
+      for (; p0 + 64 < listed; p0 += 128) {   // double passes
+        const uint32_t i0 = p0 + (uint32_t)lane, i1 = i0 + 64u;
+        const bool v1 = i1 < listed;
+        const Ent e0 = decode((uint32_t)lst[i0]), e1 = decode(v1 ? (uint32_t)lst[i1] : 0u);
+        float ch0 = 0.f, ch1 = 0.f;
         // (operands of chunk jj + 1 are fetched while chunk jj is chained; the empty asm keeps the compiler from hoisting the
         // fetches of all sixteen chunks to the top, which spills)
+        uint4 c0v = fetch_c(e0, 0), q0v = fetch_q(e0, 0), c1v = fetch_c(e1, 0), q1v = fetch_q(e1, 0);
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+          uint4 c0n = c0v, q0n = q0v, c1n = c1v, q1n = q1v;
+          if (jj + 1 < CH) {
+            c0n = fetch_c(e0, jj + 1); q0n = fetch_q(e0, jj + 1);
+            c1n = fetch_c(e1, jj + 1); q1n = fetch_q(e1, jj + 1);
+          }
+          asm volatile("" ::: "memory");
+          const uint32_t a0[4] = {c0v.x, c0v.y, c0v.z, c0v.w}, b0[4] = {q0v.x, q0v.y, q0v.z, q0v.w};
+          const uint32_t a1[4] = {c1v.x, c1v.y, c1v.z, c1v.w}, b1[4] = {q1v.x, q1v.y, q1v.z, q1v.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            asm volatile("v_fma_mix_f32 %0, %2, %3, %0 op_sel_hi:[1,1,0]\n\t"
+                         "v_fma_mix_f32 %1, %4, %5, %1 op_sel_hi:[1,1,0]\n\t"
+                         "v_fma_mix_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\t"
+                         "v_fma_mix_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,1,0]"
+                         : "+v"(ch0), "+v"(ch1)
+                         : "v"(a0[u]), "v"(b0[u]), "v"(a1[u]), "v"(b1[u]));
+          c0v = c0n; q0v = q0n; c1v = c1n; q1v = q1n;
+        }
+        res[i0] = __builtin_bit_cast(uint16_t, (half_t)ch0);
+        if (v1) res[i1] = __builtin_bit_cast(uint16_t, (half_t)ch1);
+      }
+      for (; p0 < listed; p0 += 64) {   // the last (or only) 64
+        const uint32_t idx = p0 + (uint32_t)lane;
+        const bool valid = idx < listed;
+        const Ent en = decode(valid ? (uint32_t)lst[idx] : 0u);
         float chn = 0.f;
-        auto fetch_q = [&](int jj) -> uint4 {
-          const uint4 av = __builtin_bit_cast(uint4, af[jj >> 1]);
-          const int src = (ncol + 32 * (jj & 1)) * 4;
-          uint4 qv;
-          qv.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.x);
-          qv.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.y);
-          qv.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.z);
-          qv.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)av.w);
-          return qv;
-        };
-        uint4 cv = *reinterpret_cast<const uint4*>(crow + ((0 ^ swz) * 16)), qv = fetch_q(0);
+        uint4 cv = fetch_c(en, 0), qv = fetch_q(en, 0);
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
           uint4 cvn = cv, qvn = qv;
           if (jj + 1 < CH) {
-            cvn = *reinterpret_cast<const uint4*>(crow + (((jj + 1) ^ swz) * 16));
-            qvn = fetch_q(jj + 1);
+            cvn = fetch_c(en, jj + 1);
+            qvn = fetch_q(en, jj + 1);
           }
           asm volatile("" ::: "memory");
           s1_chain8(chn, cv, qv);

@@ -240,16 +240,35 @@ def split_batch(n_queries: int, world_size: int) -> list[tuple[int, int]]:
     return out
 
 
-def replicated_search(search_local, queries_f16, top_k: int, dist=None, group=None, device="cpu", force_collectives=False):
+def plan_grid(world_size: int, doc_shards: int) -> list[tuple[int, int]]:
+    """2-D layout of `world_size` ranks: (document shard d, query group g) of every rank, rank = g * doc_shards + d.  The
+    ranks of one query group are consecutive (on one node: neighbouring GPUs, whose xGMI links carry the group's exchanges)."""
+    if doc_shards < 1 or world_size % doc_shards:
+        raise ValueError(f"{world_size} ranks do not divide into groups of {doc_shards} document shards")
+    return [(r % doc_shards, r // doc_shards) for r in range(world_size)]
+
+
+def replicated_search(search_local, queries_f16, top_k: int, dist=None, group=None, device="cpu", force_collectives=False,
+                      group_size: int = 1):
     """`search_local(q [b,Q,D]) -> (pids [b,top_k] i64, scores [b,top_k] f32, counts [b] i32)` on this
-    rank's full replica.  Returns the whole batch's (pids, scores, counts), identical on every rank."""
+    rank's full replica.  Returns the whole batch's (pids, scores, counts), identical on every rank.
+
+    group_size > 1 = the 2-D layout (plan_grid): `group_size` consecutive ranks form a query group that holds the corpus
+    split into `group_size` document shards; the batch is cut into one slice per GROUP and `search_local` is the group's
+    document-sharded search of its slice (a collective over the group: fp_shard_search on the group's communicator), whose
+    result is the same on the group's ranks.  S1 -- the stage a document-sharded search replicates on every rank -- then
+    runs on 1/n_groups of the batch per rank."""
     import torch
     q = np.ascontiguousarray(queries_f16)
     B = q.shape[0]
     live = dist is not None and dist.is_initialized()
     world = dist.get_world_size(group) if live else 1
     rank = dist.get_rank(group) if live else 0
-    ranges = split_batch(B, world)
+    if group_size < 1 or world % group_size:
+        raise ValueError(f"{world} ranks do not divide into groups of {group_size}")
+    gsz = group_size
+    ranges_g = split_batch(B, world // gsz)
+    ranges = [ranges_g[r // gsz] for r in range(world)]   # (per rank; the ranks of a group share a slice)
     lo, hi = ranges[rank]
     mb = max(h - l for l, h in ranges)
     pids = np.full((mb, top_k), -1, np.int64)
@@ -258,7 +277,7 @@ def replicated_search(search_local, queries_f16, top_k: int, dist=None, group=No
     if hi > lo:
         p, s, c = search_local(q[lo:hi])
         pids[: hi - lo], scores[: hi - lo], counts[: hi - lo] = p, s, c
-    if not live or (world == 1 and not force_collectives):
+    if not live or (world == gsz and not force_collectives):   # one group: its result is the batch's
         return pids[:B], scores[:B], counts[:B]
     # ONE exchange per batch: ids | scores | counts packed row-wise into a byte tensor (three separate small all-gathers cost
     # three collective latencies, which is what a rank's 8-query slice of a 64-query batch is measured in)
@@ -271,8 +290,9 @@ def replicated_search(search_local, queries_f16, top_k: int, dist=None, group=No
     g = torch.empty((world * mb, row), dtype=torch.uint8, device=t.device)
     dist.all_gather_into_tensor(g, t, group=group)
     allp = g.cpu().numpy().reshape(world, mb, row)
-    P = np.concatenate([np.ascontiguousarray(allp[r, : h - l, : top_k * 8]).view(np.int64).reshape(h - l, top_k) for r, (l, h) in enumerate(ranges)], axis=0)
+    lead = [(r, lh) for r, lh in enumerate(ranges) if r % gsz == 0]   # one contribution per group: its first rank's
+    P = np.concatenate([np.ascontiguousarray(allp[r, : h - l, : top_k * 8]).view(np.int64).reshape(h - l, top_k) for r, (l, h) in lead], axis=0)
     S = np.concatenate([np.ascontiguousarray(allp[r, : h - l, top_k * 8: top_k * 12]).view(np.float32).reshape(h - l, top_k)
-                        for r, (l, h) in enumerate(ranges)], axis=0)
-    Cn = np.concatenate([np.ascontiguousarray(allp[r, : h - l, top_k * 12:]).view(np.int32).reshape(h - l) for r, (l, h) in enumerate(ranges)], axis=0)
+                        for r, (l, h) in lead], axis=0)
+    Cn = np.concatenate([np.ascontiguousarray(allp[r, : h - l, top_k * 12:]).view(np.int32).reshape(h - l) for r, (l, h) in lead], axis=0)
     return P, S, Cn

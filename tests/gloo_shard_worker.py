@@ -123,6 +123,26 @@ def main():
     # more ranks than queries: some ranks hold an empty slice
     rp1, rs1, rc1 = sharded.replicated_search(search_local, q[:1], 20, dist=dist)
     assert rp1.shape == (1, 20) and np.array_equal(rp1[0, : rc1[0]], ref[0][0])
+    # 2-D layout (world 4: 2 document shards x 2 query groups): the group's document-sharded search over its own process
+    # group, the batch cut into one slice per group, one result all-gather over the world
+    if world % 2 == 0 and world >= 4:
+        D = 2
+        grid = sharded.plan_grid(world, D)
+        d, g = grid[rank]
+        groups = [dist.new_group([gg * D + dd for dd in range(D)]) for gg in range(world // D)]   # (every rank creates every group)
+        gb, ge = sharded.plan_shards(arr["doc_lengths"], D)[d]
+        geng = OracleShardEngine(arr, gb, ge)
+        gp, gs, gc = sharded.replicated_search(lambda qs: sharded.sharded_search(geng, qs, params, dist=dist, group=groups[g]), q, 20,
+                                               dist=dist, group_size=D)
+        assert gp.shape == (5, 20)
+        for i in range(5):
+            assert gc[i] == len(ref[i][0])
+            assert np.array_equal(gp[i, : gc[i]], ref[i][0]) and np.array_equal(gs[i, : gc[i]], ref[i][1]), (rank, i)
+        # one query over two groups: the second group's slice is empty
+        gp1, gs1, gc1 = sharded.replicated_search(lambda qs: sharded.sharded_search(geng, qs, params, dist=dist, group=groups[g]), q[:1], 20,
+                                                  dist=dist, group_size=D)
+        assert gp1.shape == (1, 20) and np.array_equal(gp1[0, : gc1[0]], ref[0][0])
+        print("GRID_OK rank", rank, "shard", d, "group", g)
     dist.barrier()
     print("SHARDED_OK rank", rank)
     dist.destroy_process_group()

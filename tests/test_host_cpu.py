@@ -126,10 +126,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_protocol_gloo(world):
-    """world_size-2/3 gloo runs of fast_plaid_amd.sharded.sharded_search (document shards) and
-    replicated_search (batch split) with an oracle-backed engine standing in for the HIP stages
+    """world_size-2/3/4 gloo runs of fast_plaid_amd.sharded.sharded_search (document shards),
+    replicated_search (batch split) and, with four ranks, the 2-D layout (2 document shards x 2 query groups: the sharded
+    search over a sub-group, the batch split over the groups) with an oracle-backed engine standing in for the HIP stages
     (test infrastructure): the protocols (fixed-size all-gathers, global cut, merge, result
     gather) must reproduce the unsharded oracle exactly."""
     port = _free_port()
@@ -143,6 +144,7 @@ def test_sharded_protocol_gloo(world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert "SHARDED_OK" in o, o
+        assert world < 4 or "GRID_OK" in o, o
 
 
 def test_index_directory_matches_the_reference_loader():
