@@ -793,7 +793,13 @@ __global__ __launch_bounds__(ms6_waves(KS4, NCH, NBITS) * 64) __attribute__((amd
       if constexpr (LB % 16 == 0) {
 #pragma unroll
         for (int i = 0; i < LB / 16; ++i) {
+#ifdef FP_MS6_NT   // experiment: the residual stream with the non-temporal hint (read once: keep it out of the L2's way)
+          typedef uint32_t ms_u4v __attribute__((ext_vector_type(4)));
+          const ms_u4v t = __builtin_nontemporal_load(reinterpret_cast<const ms_u4v*>(rp + 16 * i));
+          const uint4 v = make_uint4(t.x, t.y, t.z, t.w);
+#else
           const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
+#endif
           bf.rw[4 * i] = v.x; bf.rw[4 * i + 1] = v.y; bf.rw[4 * i + 2] = v.z; bf.rw[4 * i + 3] = v.w;
         }
       } else if constexpr (LB % 8 == 0) {

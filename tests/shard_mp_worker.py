@@ -37,6 +37,17 @@ def main():
     assert all(np.array_equal(x, y) for x, y in zip(got, want)), f"rank {rank}: sharded != unsharded"
     rep = sharded.replicated_search(lambda qs: R.search_arrays(whole, qs, params), q, params.top_k, dist=dist, device="cpu")
     assert all(np.array_equal(x, y) for x, y in zip(rep, want)), f"rank {rank}: replicated != unsharded"
+    if world == 4:
+        # 2-D layout: 2 document shards x 2 query groups; the group's sharded search runs over its own process group
+        D = 2
+        d, g = sharded.plan_grid(world, D)[rank]
+        groups = [dist.new_group([gg * D + dd for dd in range(D)]) for gg in range(world // D)]
+        gb, ge = sharded.plan_shards(arr["doc_lengths"], D)[d]
+        geng = sharded.HipShardEngine(mk(sharded.shard_arrays(arr, gb, ge), pid_offset=gb), "cuda:0")
+        grid = sharded.replicated_search(lambda qs: sharded.sharded_search(geng, qs, params, dist=dist, group=groups[g]), q, params.top_k,
+                                         dist=dist, device="cpu", group_size=D)
+        assert all(np.array_equal(x, y) for x, y in zip(grid, want)), f"rank {rank}: 2 x 2 grid != unsharded"
+        print("GRID_MP_OK rank", rank)
     dist.barrier()
     print("SHARD_MP_OK rank", rank)
     dist.destroy_process_group()

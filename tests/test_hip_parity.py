@@ -1216,10 +1216,11 @@ def test_full_size_cfg2_column_certification(fp):
     print(f"columns {ncol}, flagged {nflag}, flagged-and-different {ndiff_flagged}")
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_and_replicated_multiprocess(fp, world):
     """real processes (one per rank, all on cuda:0), gloo transport: document-sharded search with the HIP stage
-    engine and the replicated batch split both return exactly the unsharded result on every rank."""
+    engine and the replicated batch split both return exactly the unsharded result on every rank; with four ranks also the
+    2-D layout (2 document shards x 2 query groups, the default of `bench.py --gpus N`)."""
     import socket
     import subprocess
     import sys
@@ -1234,6 +1235,7 @@ def test_sharded_and_replicated_multiprocess(fp, world):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "SHARD_MP_OK" in o, f"rank {r}:\n{o}"
+        assert world != 4 or "GRID_MP_OK" in o, f"rank {r}:\n{o}"
 
 
 def test_full_size_cleanup(fp):
