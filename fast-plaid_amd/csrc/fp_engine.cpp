@@ -754,6 +754,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->partial.ensure(fpk_probe_scratch_bytes(D, sh, P.nchunk)));
   HIPCHK(s->invalid.ensure((size_t)B * 4));
   HIPCHK(s->tickets.ensure((size_t)(2 * B + 4) * 4));   // [B + 1] candidate lists, [B + 1] survivor lists
+  // "The last workgroup finishes the job" (fp_kernels.hip, fp_publish / fp_read_published) publishes counts with device-scope
+  // atomic exchanges and reads them back with device-scope atomic loads -- no fence, which is what makes it cheap, and which
+  // relies on gfx950 keeping device-scope atomics coherent at L2 (checked by the tests on this part, outside the letter of the
+  // HIP memory model).  FP_TICKETS=0 takes the plain count -> scan -> offsets launches instead.
+  static const bool tickets_on = [] { const char* e = getenv("FP_TICKETS"); return !(e && atoi(e) == 0); }();
   HIPCHK(s->hist.ensure(fpk_sel_hist_bytes(B)));
   {
     void* zp = nullptr;
@@ -892,7 +897,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   int64_t* d_total = s->spec_total.as<int64_t>();
   fpk_cand_count(s->bitmap.as<uint32_t>(), has_subset ? s->subbm.as<uint32_t>() : nullptr, s->invalid.as<int32_t>(), B, P.W,
                  s->blkcnt.as<int32_t>(), P.nblk, s->ncand.as<int32_t>(), s->cand_off.as<int64_t>(), st, P.spec ? s->spec_cap : 0,
-                 s->invalid.as<int32_t>(), d_total, s->tickets.as<uint32_t>(),
+                 s->invalid.as<int32_t>(), d_total, tickets_on ? s->tickets.as<uint32_t>() : nullptr,
                  sh.n_probe >= 1 ? fpk_probe_flag(D, sh, P.nchunk, s->partial.as<unsigned long long>()) : nullptr);
   HIPCHK(s->h_small.ensure(4096));
   // total (8 bytes) and, at byte 16, the probe flag: one copy.  (Bytes 8..15 of the pinned block are rewritten by the survivor
@@ -970,7 +975,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                     (int)((max_n + FP_L0_CHUNK - 1) / FP_L0_CHUNK),
                     s->l0_npilot.as<int32_t>(), s->l0_pilot_pid.as<int32_t>(), s->l0_pilot_approx.as<float>(),
                     s->l0_pilot_idx.as<int32_t>(), s->l0_capprox.as<float>(), s->l0_thr.as<int32_t>(), s->l0_nextra.as<int32_t>(),
-                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>(), s->tickets.as<uint32_t>() + (B + 1),
+                    s->l0_xpid.as<int32_t>(), s->l0_xdst.as<int32_t>(), tickets_on ? s->tickets.as<uint32_t>() + (B + 1) : nullptr,
                     D.n_ranges > 1 ? s->l0_ubp.as<uint16_t>() : nullptr, ub_stride};
       fpk_l0_prepare(D, nullptr, sh, w, st, P.l0hist_prezeroed);   // floors and table came with S1
       STAGE_DONE(ST_APPROX);
@@ -1225,11 +1230,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     HIPCHK(s->out_all.ensure(ol.total));
     HIPCHK(s->h_out.ensure(ol.total));
     char* od = s->out_all.as<char>();
-    fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
-                   reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st,
-                   (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
-                   (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
-                   s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr);
+    if (const int trc = fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
+                                       reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st,
+                                       (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
+                                       (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
+                                       s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr))
+      return trc < 0 ? fail(FP_EUNSUPPORTED, "n_queries * max(n_full_scores / 4, 1) >= 2^31 in one sub-batch of the final ranking")
+                     : fail(FP_EHIP, "final ranking failed (hip error " + std::to_string(trc) + ")");
     if (dev_io) {
       HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, od, ol.nk * 8, hipMemcpyDeviceToDevice, st));
       HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, od + ol.score_off, ol.nk * 4, hipMemcpyDeviceToDevice, st));
@@ -1893,8 +1900,10 @@ static int shard_apply_and_rank(Scratch* s, const FpSearchShape& sh, const float
   HIPCHK(s->out_all.ensure(ol.total));
   HIPCHK(s->h_out.ensure(ol.total));
   char* od = s->out_all.as<char>();
-  fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->u_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
-                 reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st);
+  if (const int trc = fpk_final_topk(u_score, nullptr, s->tmpp.as<int64_t>(), s->u_cnt.as<int32_t>(), R, B, K, 0, reinterpret_cast<int64_t*>(od),
+                                     reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st))
+    return trc < 0 ? fail(FP_EUNSUPPORTED, "n_queries * n_ranks * max(n_full_scores / 4, 1) >= 2^31 in the final ranking of the union")
+                   : fail(FP_EHIP, "final ranking of the union failed (hip error " + std::to_string(trc) + ")");
   LAUNCHCHK("sharded merge");
   HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

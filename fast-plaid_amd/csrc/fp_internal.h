@@ -276,8 +276,9 @@ int fpk_final_mark(const float* score, const float* unc, const float* uncm /*nul
 void fpk_maxsim_repair(const FpIndexDev& ix, const uint16_t* q_pad, const FpSearchShape& sh, const int32_t* sel_pid, const int32_t* sel_cnt,
                        int64_t Rcap, const int32_t* marks, const int32_t* nmark, float* exact, const FpMaxsimAux& aux, hipStream_t st,
                        const uint32_t* flat_n = nullptr, const void* flat = nullptr /*fpk_final_mark's batch-wide list: one wave per entry*/);
-// final ranking: sort (score desc, id asc), emit top_k with pid_offset applied
-void fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local /*[B][stride] or null*/,
+// final ranking: sort (score desc, id asc), emit top_k with pid_offset applied; 0, or the error of the segmented device sort
+// that takes over beyond FP_MAX_SORT entries per query (a hipError, -1 when B * stride >= 2^31): nothing was written then
+int fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local /*[B][stride] or null*/,
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,
                     int64_t stride, int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid /*[B][top_k]*/,
                     float* out_score, int32_t* out_cnt, hipStream_t st, const int64_t* stat_total = nullptr, const int32_t* stat_per_query = nullptr,

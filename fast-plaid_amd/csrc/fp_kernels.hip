@@ -652,21 +652,20 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     }, &Aall);
     const uint32_t Aw = A;
     if (xe.mode == 2) A = Aall;
-    uint32_t listed = 0u, flagged_total = 0u;
+    uint32_t listed = 0u, flagged_total = 0u, lbase = 0u;
     if (xe.mode) {
-      uint32_t rem = A, off = 0u;
-      while (true) {
-        const bool act = rem != 0u;
-        const unsigned long long bal = __ballot(act);
-        if (!bal) break;
-        const uint32_t slot = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (act) {
-          const uint32_t p = (uint32_t)__builtin_ctz(rem);
-          rem &= rem - 1u;
-          if (slot < S1X_CAP) lst[slot] = (uint16_t)(((uint32_t)lane << 5) | p);
-        }
-        off += (uint32_t)__popcll(bal);
+      // list position of a lane's first entry = exclusive prefix of the lanes' counts (<= 32 each): one ballot per count bit
+      const uint32_t cnt = (uint32_t)__popc(A);
+      uint32_t off = 0u;
+      lbase = 0u;
+#pragma unroll
+      for (int bit = 0; bit < 6; ++bit) {
+        const unsigned long long bal = __ballot(((cnt >> bit) & 1u) != 0u);
+        lbase += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)) << bit;
+        off += (uint32_t)__popcll(bal) << bit;
       }
+      for (uint32_t rem = A, slot = lbase; rem != 0u; rem &= rem - 1u, ++slot)
+        if (slot < S1X_CAP) lst[slot] = (uint16_t)(((uint32_t)lane << 5) | (uint32_t)__builtin_ctz(rem));
       flagged_total = off;
       listed = off < S1X_CAP ? off : S1X_CAP;   // (wave-uniform)
       // One pass = 64 list entries, one per lane; while more than 64 remain a pass takes 128, TWO per lane, whose chains are
@@ -756,14 +755,12 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
       }
     } else if (xe.mode) {
       // the general form (a wave with more flagged entries than its list holds -- never seen on unit vectors --, or the counters
-      // are wanted): every lane walks ITS entries in the order of the listing loop; entries beyond the list are re-evaluated
+      // are wanted): every lane walks ITS entries (list positions lbase, lbase + 1, ...); entries beyond the list are re-evaluated
       // here with the centroid row from global memory -- the tile's LDS copy is gone.
-      uint32_t rem = A, off = 0u, nchg = 0u, nunf = 0u, nslow = 0u;
-      while (true) {
+      uint32_t rem = A, slot = lbase, nchg = 0u, nunf = 0u, nslow = 0u;
+      for (;; ++slot) {
         const bool act = rem != 0u;
-        const unsigned long long bal = __ballot(act);
-        if (!bal) break;
-        const uint32_t slot = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (!__any(act)) break;
         int p = 0;
         if (act) { p = __builtin_ctz(rem); rem &= rem - 1u; }
         const int pj = p & 15, rr = 2 * (pj & 7) + (p >> 4);
@@ -797,7 +794,6 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
           if (*sp != val) { ++nchg; if (!((Aw >> p) & 1u)) ++nunf; }
           *sp = val;
         }
-        off += (uint32_t)__popcll(bal);
       }
       if (xe.stats) {
         const uint32_t nflag = (uint32_t)__popc(A);
@@ -3967,20 +3963,21 @@ __global__ void k_final_stats(const int64_t* __restrict__ stat_total, const int3
   for (int b = threadIdx.x; b < B; b += blockDim.x) stat_out[1 + b] = stat_per_query ? (int64_t)stat_per_query[b] : 0;
   if (threadIdx.x == 0) stat_out[0] = stat_total ? *stat_total : 0;
 }
-void fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
-                    int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
-                    hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out) {
+int fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
+                   int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
+                   hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out) {
   int np2 = next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
   if (stride > FP_MAX_SORT) {   // beyond the LDS sort: segmented device radix sort (rare: n_full_scores > 65536)
     if (stat_out) hipLaunchKernelGGL(k_final_stats, dim3(1), dim3(256), 0, st, stat_total, stat_per_query, B, stat_out);
-    (void)fps_final_topk_big(score, pid_local, pid_global, cnt, stride, B, top_k, pid_offset, out_pid, out_score, out_cnt, st);
-    return;
+    // (allocates 2 * B * stride keys and synchronises; -1: B * stride does not fit its 32-bit segment offsets -- nothing was written)
+    return fps_final_topk_big(score, pid_local, pid_global, cnt, stride, B, top_k, pid_offset, out_pid, out_score, out_cnt, st);
   }
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_topk, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,
                      top_k, pid_offset, out_pid, out_score, out_cnt, stat_total, stat_per_query, stat_out);
+  return 0;
 }
 
 // ============================================================================================

@@ -414,6 +414,38 @@ def test_level0_forced(fp, tail, pilot, ppl):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_without_tickets_and_with_every_score_reevaluated(fp):
+    """two switches that must not change any result: FP_TICKETS=0 (the plain count -> scan -> offsets launches instead of the
+    'last workgroup finishes the job' chains, whose fence-free publish relies on gfx950's coherent device-scope atomics) and
+    FP_S1_EXACT=2 (every centroid score goes through the ascending chain, not only the flagged ones): the forced level-0
+    worker compares fp_search with the traces under both."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"FP_TICKETS": "0"}, {"FP_S1_EXACT": "2", "FP_S1_STREAM_MIN": "1"}):
+        env = dict(os.environ, FP_APPROX_IMPL="l0", **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "Q8_OK" in r.stdout, str(extra) + r.stdout + r.stderr
+
+
+def test_centroid_scores_exact_streaming_kernel(fp):
+    """S1 with the streaming kernel under the traces (FP_S1_STREAM_MIN=1; a trace has one query, which normally takes the
+    one-tile kernel): S bit-identical to the oracle on goldens and on synthetic corpora of dim 128 / 64 with an unnormalised
+    query and a query whose second half is zero rows (tools/s1_exact_lab.py asserts nothing itself: its output is parsed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FP_S1_STREAM_MIN="1", FP_S1_STATS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "s1_exact_lab.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if "S mismatches" in ln]
+    assert len(lines) >= 20, r.stdout
+    for ln in lines:
+        assert "S mismatches 0" in ln and "'unflagged_differences': 0" in ln, ln
+    assert "downstream differs" not in r.stdout, r.stdout
+    assert any("'flagged': 0," not in ln for ln in lines), "the certification flagged nothing: the exact mode did not run"
+
+
 @pytest.mark.parametrize("mode,extra", [("2", {}), ("1", {}), ("2", {"FP_MS_RINV_HARD_EVERY": "5"}), ("2", {"FP_MS_RINV": "0"})])
 def test_maxsim_repair_vs_oracle(fp, mode, extra):
     """exact-order repair of the MFMA MaxSim pass (tests/repair_worker.py): with every flagged document repaired

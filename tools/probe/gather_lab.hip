@@ -24,6 +24,9 @@ struct Args {
   int nd, doclen;
   uint4* out;
   int part;   // M2 only: 1 = centroid rows, 2 = residuals, 3 = both
+  const int32_t* ucodes;   // M7 / M8: per-document ascending unique codes ...
+  const int32_t* uoff;     // ... [NDOCS + 1]
+  const uint8_t* rank;     // ... and every token's position in its document's unique list
 };
 
 __device__ __forceinline__ void xacc(uint4& a, const uint4 v) { a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
@@ -40,7 +43,42 @@ __global__ __launch_bounds__(1024) void k(const Args a, const int nwaves) {
   uint4* wl = reinterpret_cast<uint4*>(smem) + wave * 512;   // 8 KiB per wave (M3 / M4)
   for (int d = d0; d < d1; ++d) {
     const long long off = (long long)a.docs[d] * a.doclen;
-    if constexpr (MODE == 6) {
+    if constexpr (MODE == 7 || MODE == 8) {
+      // round 4: every DISTINCT centroid row of a document (M7) / of a 16-token step (M8) goes to LDS ONCE, whole rows, 16 lanes
+      // per row (global_load_lds_dwordx4: 4 rows per instruction); the tokens then read their row from LDS in the 16x16x32 MFMA
+      // operand order (lane (r, g): chunks 4 s + g of row rank[token r]); residuals: the step's contiguous kilobyte, 16 B per lane.
+      const int r = lane & 15, g = lane >> 4;
+      const int32_t* up = a.ucodes + a.uoff[a.docs[d]];
+      const int nu = a.uoff[a.docs[d] + 1] - a.uoff[a.docs[d]];
+      const uint32_t m0base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wl;
+      auto stage = [&](int u0, int n) {   // rows u0 .. u0 + n - 1 of the unique list -> LDS slots 0 .. n - 1
+        for (int i = 0; i < n; i += 4) {
+          int u = u0 + i + g;
+          u = u < u0 + n ? u : u0 + n - 1;
+          const int code = up[u];
+          const uint4* src = a.tab + (long long)code * 16 + (r ^ ((i + g) & 7));   // piece p of slot row t holds global piece p ^ (t & 7)
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(__builtin_amdgcn_readfirstlane(m0base + (uint32_t)i * 256u)), "v"(src) : "memory");
+        }
+      };
+      if constexpr (MODE == 7) { stage(0, nu < 32 ? nu : 32); }   // (timing lab: documents with more than 32 distinct rows are clamped)
+      for (int t0 = 0; t0 < a.doclen; t0 += 16) {
+        const long long row = off + t0 + r;
+        const int rk = a.rank[row];
+        const uint4 rq = a.resid[(off + t0) * 4 + lane];   // linear: the step's kilobyte, 16 B per lane
+        int slot = rk < 32 ? rk : 31;
+        if constexpr (MODE == 8) {
+          const int rk0 = __builtin_amdgcn_readfirstlane(a.rank[off + t0]);
+          const int rk1 = __builtin_amdgcn_readfirstlane(a.rank[off + (t0 + 15 < a.doclen ? t0 + 15 : a.doclen - 1)]);
+          stage(rk0, rk1 - rk0 + 1);
+          slot = rk - rk0;
+          slot = slot < 0 ? 0 : (slot > 15 ? 15 : slot);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) xacc(acc, wl[slot * 16 + ((4 * s2 + g) ^ (slot & 7))]);
+        xacc(acc, rq);
+      }
+    } else if constexpr (MODE == 6) {
       const int r = lane & 15, g = lane >> 4;
       for (int t0 = 0; t0 < a.doclen; t0 += 16) {
         const long long row = off + t0 + r;
@@ -232,14 +270,45 @@ int main(int argc, char** argv) {
     std::sort(l.begin(), l.end());
     std::copy(l.begin(), l.end(), docs.begin() + q * 1024);
   }
+  std::vector<int32_t> ucodes; std::vector<int32_t> uoff(NDOCS + 1, 0); std::vector<uint8_t> rank((size_t)T);
+  for (int d = 0; d < NDOCS; ++d) {
+    const int32_t* c = &codes[(size_t)d * L];
+    int n = 0;
+    for (int t = 0; t < L; ++t) {
+      if (t == 0 || c[t] != c[t - 1]) { ucodes.push_back(c[t]); ++n; }
+      rank[(size_t)d * L + t] = (uint8_t)(n - 1);
+    }
+    uoff[d + 1] = uoff[d] + n;
+  }
+  printf("distinct codes per document: %.2f\n", (double)ucodes.size() / NDOCS);
   Args a{};
   uint4* tab; int32_t* dcodes; uint4* resid; int32_t* ddocs; uint4* out;
+  int32_t* ducodes; int32_t* duoff; uint8_t* drank;
+  CHK(hipMalloc(&ducodes, ucodes.size() * 4)); CHK(hipMemcpy(ducodes, ucodes.data(), ucodes.size() * 4, hipMemcpyHostToDevice));
+  CHK(hipMalloc(&duoff, uoff.size() * 4)); CHK(hipMemcpy(duoff, uoff.data(), uoff.size() * 4, hipMemcpyHostToDevice));
+  CHK(hipMalloc(&drank, rank.size())); CHK(hipMemcpy(drank, rank.data(), rank.size(), hipMemcpyHostToDevice));
   CHK(hipMalloc(&tab, (size_t)C * 256)); CHK(hipMemset(tab, 1, (size_t)C * 256));
   CHK(hipMalloc(&dcodes, (size_t)T * 4)); CHK(hipMemcpy(dcodes, codes.data(), (size_t)T * 4, hipMemcpyHostToDevice));
   CHK(hipMalloc(&resid, (size_t)T * 64)); CHK(hipMemset(resid, 2, (size_t)T * 64));
   CHK(hipMalloc(&ddocs, ND * 4)); CHK(hipMemcpy(ddocs, docs.data(), ND * 4, hipMemcpyHostToDevice));
   CHK(hipMalloc(&out, (size_t)256 * 1024 * 16));
   a.part = 3; a.tab = tab; a.codes = dcodes; a.resid = resid; a.docs = ddocs; a.nd = ND; a.doclen = L; a.out = out;
+  a.ucodes = ducodes; a.uoff = duoff; a.rank = drank;
+  CHK(hipFuncSetAttribute((const void*)k<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHK(hipFuncSetAttribute((const void*)k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int nwaves : {16, 12, 8})
+    for (int mode : {7, 8})
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        CHK(hipEventRecord(e0));
+        const size_t lds = (size_t)nwaves * 8192;   // 8 KiB per wave: 32 row slots (M7: a document's <= 32 distinct rows; the lab's documents have ~33: clamped)
+        if (mode == 7) hipLaunchKernelGGL(k<7>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves);
+        else hipLaunchKernelGGL(k<8>, dim3(256), dim3(nwaves * 64), lds, 0, a, nwaves);
+        CHK(hipGetLastError());
+        CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("M%d distinct rows -> LDS once per %s, MFMA-order LDS reads, linear residuals, %d waves: %.1f us\n", mode, mode == 7 ? "document" : "16-token step", nwaves, ms * 1e3);
+      }
   const char* names[6] = {"M0 token/lane 64-step", "M1 half row/lane 32-step", "M2 16 lanes/row coalesced", "M3 M2 via LDS DMA + transposed read", "M4 M2 + ds_write/ds_read transpose", "M5 M2 with 2 steps in flight"};
   CHK(hipFuncSetAttribute((const void*)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   CHK(hipFuncSetAttribute((const void*)k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
