@@ -103,7 +103,16 @@ int64_t fp_index_num_hard_tokens(const fp_index* index);
  * out_counts [n_queries] = results per query = min(top_k, max(n_full/4,1), candidates)
  * (search.rs:614, :666); rows are sorted by descending score; the slots [count, top_k) of
  * a row hold id -1 and score 0.  A query whose per-query search fails in the reference
- * (search.rs:268 `.unwrap_or_default()`) gets count 0 (its row is left untouched). */
+ * (search.rs:268 `.unwrap_or_default()`) gets count 0 (its row is left untouched).
+ *
+ * What is exact.  The returned ids are the reference's, in the reference's order (documents whose reference scores are
+ * EXACTLY equal may come in another order: the reference's own tie order is implementation-defined; ours is id ascending).
+ * Every stage up to the rerank list reproduces the reference bit for bit (centroid scores, probed cells, candidates,
+ * approximate scores).  The returned MaxSim SCORES are within 1e-3 of the reference's: the MFMA pass can round one query
+ * column of a document one fp16 step away (<= 4.9e-4); only the documents whose rank could depend on that -- the near-tied
+ * ones -- are re-evaluated in the reference's summation order (their scores are then the reference's bit for bit), the
+ * others keep the MFMA score.  FP_MAXSIM_REPAIR=2 in the environment re-evaluates every flagged document: every returned
+ * score is then the reference's. */
 int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
               const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets,
               int64_t* out_pids, float* out_scores, int32_t* out_counts);
