@@ -142,7 +142,7 @@ struct Scratch : ScratchGen {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats, qpad_s1;
   HostBuf h_out, h_small;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
@@ -216,7 +216,7 @@ struct Scratch : ScratchGen {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats, &qpad_s1})
       b->release();
     h_out.release();
     h_small.release();
@@ -400,6 +400,24 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (token norms)");
     D.norms = norms;
+  }
+  // S1's zero-padded view of the centroid table (FpIndexDev::cent_s1)
+  D.cent_s1 = nullptr;
+  D.dim_s1 = D.dim;
+  static const bool pad_env = [] { const char* e2 = getenv("FP_S1_PAD"); return !(e2 && atoi(e2) == 0); }();
+  if (pad_env && D.dim < 128 && D.dim != 64) {
+    const int dp = D.dim < 64 ? 64 : 128;
+    uint16_t* cp = nullptr;
+    hipError_t e = hipMalloc((void**)&cp, (size_t)D.C * dp * 2 + 64);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (padded centroid table)");
+    ix->owned.push_back(cp);
+    ix->bytes += D.C * dp * 2;
+    e = hipMemsetAsync(cp, 0, (size_t)D.C * dp * 2, st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(cp, (size_t)dp * 2, D.centroids, (size_t)D.dim * 2, (size_t)D.dim * 2, (size_t)D.C, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (padded centroid table)");
+    D.cent_s1 = cp;
+    D.dim_s1 = dp;
   }
   D.resid_native = 0;
   D.rinv = nullptr;
@@ -796,8 +814,17 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       xe.stats = s->s1stats.as<unsigned long long>();
     }
   }
+  // S1 runs on the zero-padded view of the table when the index has one (dims below 128 other than 64)
+  FpIndexDev D1 = D;
+  const uint16_t* q_s1 = s->qpad.as<uint16_t>();
+  if (D.cent_s1) {
+    HIPCHK(s->qpad_s1.ensure((size_t)B * sh.Qp * D.dim_s1 * 2));
+    D1.centroids = D.cent_s1;
+    D1.dim = D.dim_s1;
+    q_s1 = s->qpad_s1.as<uint16_t>();
+  }
   fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st, &zl, P.s1_mode ? s->wcol.as<float>() : nullptr,
-                   s1x_w0 * dim_scale * ix->cent_norm_max);
+                   s1x_w0 * dim_scale * ix->cent_norm_max, D.cent_s1 ? s->qpad_s1.as<uint16_t>() : nullptr, D.dim_s1);
   STAGE_DONE(ST_CENTROID);
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
@@ -807,12 +834,15 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     const char* e = getenv("FP_APPROX_IMPL");
     return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : (e[0] == 'l' ? 2 : 0)));
   }();
-  const bool want_s8 = !P.exact_all && (sh.Qp == 32 || sh.Qp == 64) && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
+  // (bound stages: level 0 for q_len <= 128, the 8-bit stage for q_len <= 64)
+  const bool l0_possible = q8_env != 1 && fpk_l0_fits(D) && (q8_env == 2 || (D.U <= 64 * D.N && s->l0_poor < 2));
+  const bool qp_ok = sh.Qp == 32 || sh.Qp == 64 || (sh.Qp == 128 && l0_possible);
+  const bool want_s8 = !P.exact_all && qp_ok && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
   // Level 0 is decided HERE when the index suits it (the table fits, documents of <= 64 distinct codes on average; forced by
   // FP_APPROX_IMPL=l0): S1 then emits level 0's excess table from its epilogue -- floors from a pre-pass over a centroid
   // sample -- and the 8-bit table (C x Qp bytes per query, written and read back twice) is never materialised.  Whether S4
   // then prunes with it or scores everything exactly (few candidates) is still decided from the candidate count.
-  P.l0_ready = want_s8 && q8_env != 1 && fpk_l0_fits(D) && (q8_env == 2 || (D.U <= 64 * D.N && s->l0_poor < 2));
+  P.l0_ready = want_s8 && l0_possible;
   const int nch128 = (int)((D.C + 127) / 128);
   HIPCHK(s->cmax128.ensure((size_t)B * sh.Qp * nch128 * 2));
   if (P.l0_ready) {
@@ -825,17 +855,17 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     HIPCHK(s->l0_F.ensure((size_t)B * 4));
     HIPCHK(s->l0_e8.ensure((size_t)B * Cpad));
     HIPCHK(s->l0_esc.ensure((size_t)B * 64 * 4));
-    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->Ssample.as<uint16_t>(), B, sh.Qp, s->S8.as<uint8_t>(), nullptr, st, ns, sstride))
+    if (fpk_centroid_scores(D1, q_s1, s->Ssample.as<uint16_t>(), B, sh.Qp, s->S8.as<uint8_t>(), nullptr, st, ns, sstride))
       return fail(FP_EUNSUPPORTED, "dim");
     HIPCHK(s->l0_gfl.ensure((size_t)B * sh.Qp * 2));
     fpk_l0_floors(s->S8.as<uint8_t>(), ns, sh, s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_esc.as<uint32_t>(), s->l0_gfl.as<uint16_t>(), st);
     if (Cpad > D.C) HIPCHK(hipMemsetAsync(s->l0_e8.p, 0, (size_t)B * Cpad, st));   // pad entries behind the table stay 0
     FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_gfl.as<uint16_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q};
-    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex, &xe))
+    if (fpk_centroid_scores(D1, q_s1, s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex, &xe))
       return fail(FP_EUNSUPPORTED, "dim");
   } else {
     if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
-    if (fpk_centroid_scores(D, s->qpad.as<uint16_t>(), s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
+    if (fpk_centroid_scores(D1, q_s1, s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
                             s->cmax128.as<uint16_t>(), st, 0, 1, nullptr, &xe))
       return fail(FP_EUNSUPPORTED, "dim");
   }
@@ -1100,7 +1130,7 @@ static FpSearchShape make_shape(int B, int Q, const fp_search_params* p) {
   FpSearchShape sh{};
   sh.B = B;
   sh.Q = Q;
-  sh.Qp = (Q + 31) & ~31;
+  sh.Qp = fp_padded_qlen(Q);
   sh.n_probe = (int)p->n_ivf_probe;
   sh.n_full = p->n_full_scores;
   sh.R = std::max<int64_t>(p->n_full_scores / 4, 1);
@@ -1140,7 +1170,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     }
   } rel{ix, s};
   const bool graph_env = g_graph_replay.load(std::memory_order_relaxed) != 0;
-  const int Qp = (Q + 31) & ~31;
+  const int Qp = fp_padded_qlen(Q);
   // sub-batch so that the centroid-score table stays within a budget
   static const size_t budget_env = getenv("FP_S_BUDGET_KB") ? (size_t)atoll(getenv("FP_S_BUDGET_KB")) << 10 : 0;   // tests: force sub-batching
   const size_t perq = (size_t)D.C * Qp * 2;
@@ -2174,7 +2204,7 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   // Sub-batches against a FIXED budget of the centroid-score table (every rank must split the batch identically, so the budget
   // may not depend on a rank's free memory as fp_search's does): 16 GiB, FP_SHARD_S_BUDGET_KB for tests
   static const int64_t budget = [] { const char* e = getenv("FP_SHARD_S_BUDGET_KB"); return e ? atoll(e) * 1024 : (16ll << 30); }();
-  const int Qp = (Q + 31) & ~31;
+  const int Qp = fp_padded_qlen(Q);
   const int64_t per_query = (int64_t)ix->d.C * Qp * 2;
   const int maxB = (int)std::max<int64_t>(1, std::min<int64_t>(nq, budget / std::max<int64_t>(per_query, 1)));
   const int64_t K = p->top_k;

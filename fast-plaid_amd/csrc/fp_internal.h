@@ -60,6 +60,13 @@ struct FpIndexDev {
                               //    handed over by the caller and everything exported are in the reference's order
   const uint32_t* rinv;       // [T]   fp32 bits of a reciprocal r with h(fl32(e_k * r)) == h(fl32(e_k / n)) for every dim of the token
                               //         (bit 31 set: no such r within the search range -> the kernel takes the exact path for the step); nullable
+  // S1's view of the centroid table (round 4): dims other than 64 / 128 below 128 are ZERO-PADDED to 64 / 128 in a second copy
+  // [C][dim_s1], so that the centroid scores run through the streaming kernel -- whose exact mode re-evaluates the flagged scores
+  // from LDS and registers; the one-tile kernel fetches both rows of every flagged score from L2 (dim 96: S1 0.94 ms against
+  // 0.29 without the certification).  Zero products change neither the MFMA sum nor the ascending chain.  nullptr: S1 reads
+  // `centroids` (dim 64 / 128, and dims above 128, which stay on the one-tile kernel).
+  const uint16_t* cent_s1;
+  int dim_s1;
 };
 
 // Native unit order of a token's residual bytes (k_maxsim6): a unit = 8 dims = nbits bytes; unit u = 4 s + g (k-step s of 32 dims,
@@ -100,10 +107,14 @@ static inline unsigned fp_grid_cap(int64_t blocks, int block_size) {
 
 // ---- launch wrappers implemented in fp_kernels.hip -----------------------------------------
 // All run on `st`; none synchronises.
+// padded query length: Q rounded up to a multiple of 32 (zero rows appended) -- and to 128 for 64 < Q <= 128, so that a query's
+// column groups fill whole 128-column S1 tiles and level 0's excess byte can be summed inside one tile (round 4: queries of 65 ..
+// 128 tokens take the bound stage too; before, they scored every candidate exactly)
+static inline int fp_padded_qlen(int Q) { return (Q > 64 && Q <= 128) ? 128 : ((Q + 31) & ~31); }
 struct FpSearchShape {
   int B;       // queries in this sub-batch
   int Q;       // real query tokens
-  int Qp;      // Q rounded up to a multiple of 32 (zero rows appended)
+  int Qp;      // fp_padded_qlen(Q)
   int n_probe;
   int64_t R;   // exact-scoring budget per query = max(n_full/4, 1)
   int64_t n_full;
@@ -127,8 +138,9 @@ struct FpZeroList {
 void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B*Qp,D]*/, int B, int Q, int Qp, int D,
                       hipStream_t st, const FpZeroList* zero = nullptr,
                       float* wcol = nullptr /*[B*Qp]: w0 * |q_n| per packed row (0 for the zero rows), the absolute part of S1's certification window*/,
-                      float w0 = 0.f);
-// S8 (nullable; written only when Qp == 32): 8-bit bins [B][C][32]; cmax (nullable): [B*Qp][ceil(C/128)] f16 column maxima per 128-centroid tile
+                      float w0 = 0.f, uint16_t* q_pad2 = nullptr /*[B*Qp, D2]: a second copy with the rows zero-padded to D2 >= D dims (S1's view)*/,
+                      int D2 = 0);
+// S8 (nullable; written only when Qp is 32, 64 or 128): 8-bit bins [B][Qp/32][C][32]; cmax (nullable): [B*Qp][ceil(C/128)] f16 column maxima per 128-centroid tile
 // S1's optional by-product for S4's level 0: the excess table e8[b][Cpad] (one byte per query and centroid) computed in the
 // epilogue from the column floors of a sampled pre-pass
 struct FpS1Excess {

@@ -35,7 +35,7 @@
 // query packing: [B,Q,D] -> [B*Qp, D] with zero rows for q >= Q
 // ============================================================================================
 __global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int Q, int Qp, int D, FpZeroList z,
-                               float* __restrict__ wcol, float w0) {
+                               float* __restrict__ wcol, float w0, uint16_t* __restrict__ out2, int D2) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 halfs
   // the batch's small fills ride along (each hipMemsetAsync is a graph node of its own, ~4.5 us of launch tail)
   const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
@@ -61,22 +61,26 @@ __global__ void k_pack_queries(const uint16_t* __restrict__ in, uint16_t* __rest
     }
     wcol[i] = w0 * __builtin_sqrtf(ss);
   }
-  int64_t per_row = D / 8;
+  // (one thread per 16-byte piece of the WIDER of the two output rows)
+  const int Dw = out2 ? D2 : D;
+  int64_t per_row = Dw / 8;
   int64_t total = (int64_t)B * Qp * per_row;
   if (i >= total) return;
   int64_t row = i / per_row;
   int c8 = (int)(i % per_row);
   int b = (int)(row / Qp), q = (int)(row % Qp);
   uint4 v = make_uint4(0, 0, 0, 0);
-  if (q < Q) v = *reinterpret_cast<const uint4*>(in + ((int64_t)b * Q + q) * D + c8 * 8);
-  *reinterpret_cast<uint4*>(out + row * D + c8 * 8) = v;
+  if (q < Q && c8 * 8 < D) v = *reinterpret_cast<const uint4*>(in + ((int64_t)b * Q + q) * D + c8 * 8);
+  if (c8 * 8 < D) *reinterpret_cast<uint4*>(out + row * D + c8 * 8) = v;
+  if (out2) *reinterpret_cast<uint4*>(out2 + row * D2 + c8 * 8) = v;
 }
 
-void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st, const FpZeroList* zero, float* wcol, float w0) {
-  int64_t total = (int64_t)B * Qp * (D / 8);
+void fpk_pack_queries(const uint16_t* in, uint16_t* out, int B, int Q, int Qp, int D, hipStream_t st, const FpZeroList* zero, float* wcol, float w0,
+                      uint16_t* q_pad2, int D2) {
+  int64_t total = (int64_t)B * Qp * ((q_pad2 ? D2 : D) / 8);
   FpZeroList z{};
   if (zero) z = *zero;
-  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D, z, wcol, w0);
+  hipLaunchKernelGGL(k_pack_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, B, Q, Qp, D, z, wcol, w0, q_pad2, D2);
 }
 
 // ============================================================================================
@@ -375,17 +379,20 @@ __device__ __forceinline__ void s1_writeout(unsigned char* smem, const int tid, 
     }
   }
   if (ex.e8 && (tid & 3) == 0) {
-    // one byte per (query, centroid): with Qp == 64 a query's two 32-column groups (pieces 512 apart) belong together
-    const int per_q = Qp / 32;   // groups per query: 1 or 2
+    // one byte per (query, centroid): with Qp == 64 / 128 a query's two / four 32-column groups (pieces 512 apart) belong
+    // together (Qp divides the tile's 128 columns, so a query's groups never straddle two tiles)
+    const int per_q = Qp / 32;   // groups per query: 1, 2 or 4
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int g = (it * NT) >> 9, cl0 = ((it * NT) >> 2) & 127;
-      if (per_q == 2 && (g & 1)) continue;
+      if (g & (per_q - 1)) continue;
       const int64_t nb = n0 + g * 32;
       const int64_t c = c0 + cl0 + clt;
       if (nb >= Ntot || c >= C) continue;
       uint32_t acc = eacc[it];
-      if (per_q == 2) acc += eacc[(it + 512 / NT) % NIT];   // (index always < NIT here: g is even)
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        if (j < per_q) acc += eacc[(it + j * (512 / NT)) % NIT];   // (index always < NIT here: g is a multiple of per_q)
       const int64_t bq = G.bq[g];
       ex.e8[bq * ex.Cpad + c] = l0_encode(acc & (L0_EINF - 1u), acc >= L0_EINF, ex.esc + bq * 64);
     }
@@ -819,7 +826,7 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   if (exact && exact->wcol) xe = *exact;
   const int nch = (int)((C + S1_TILE - 1) / S1_TILE);
   dim3 grid((unsigned)nch, (unsigned)((Ntot + 127) / 128));
-  if (Qp != 32 && Qp != 64) S8 = nullptr;   // the bound stage handles one or two 32-column chunks
+  if (Qp != 32 && Qp != 64 && Qp != 128) S8 = nullptr;   // the bound stages handle one, two or (level 0 only) four 32-column chunks
   const size_t out_lds = 4 * 128 * 64 + 4 * 128 * 2;
   const int D = ix.dim;
   if (D % 8 != 0 || D < 8) return -1;
@@ -2441,7 +2448,7 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
     }
   }
   __syncthreads();
-  __shared__ uint32_t fl[64];
+  __shared__ uint32_t fl[128];
   if (tid < ncol) {
     uint32_t f = 0;
     if (tid < Q) {   // smallest bin f such that at most tail * ns samples lie above it
@@ -2470,7 +2477,7 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
 __global__ __launch_bounds__(256) void k_l0_table(const uint8_t* __restrict__ S8, int64_t C, int64_t Cpad, int Q, int nch,
                                                   const uint8_t* __restrict__ floors, uint8_t* __restrict__ e8, uint32_t* __restrict__ esc) {
   const int b = blockIdx.y;
-  __shared__ uint8_t fl[64];
+  __shared__ uint8_t fl[128];
   if (threadIdx.x < nch * 32) fl[threadIdx.x] = floors[(int64_t)b * nch * 32 + threadIdx.x];
   __syncthreads();
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -3221,7 +3228,7 @@ void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, 
   const int nch = sh.Qp / 32;
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
-  fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
+  fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
   // n_rows <= L0_SAMPLE * 2: the kernel's own sampling stride over this table is 1 or (for 8192 < n_rows) still covers it
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum, esc,
                      reinterpret_cast<half_t*>(gfl));
@@ -3238,7 +3245,7 @@ void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape
   if (!S8) return;
   static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
-  fp_allow_big_lds((const void*)k_l0_floor, ok1, 72 * 1024);
+  fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum, w.esc,
                      (half_t*)nullptr);
   hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,

@@ -1141,6 +1141,10 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
         const float lmin = i > 0 ? lo[i - 1] : inf;               // higher-ranked documents
         const float hmax = i + 1 < npow2 ? hi[i + 1] : -inf;      // lower-ranked documents (also those below the cut)
         conflict = !(si + up < lmin) || !(si - um > hmax);
+        // ... and an emitted document whose flagged columns could add up to more than the score tolerance (three or more of them
+        // on one side in the top binade: rare at 32 query tokens, less so at 128) is re-evaluated too, so that EVERY returned score
+        // is within 1e-3 of the reference's by construction, not by the odds
+        conflict = conflict || um > 0.00095f || up > 0.00095f;
       } else {
         conflict = !(si + up < lmin_top);                         // outside the emitted range: only a jump into it matters
       }
