@@ -211,6 +211,7 @@ struct Scratch : ScratchGen {
   bool pref_ready = false;      // ms_pref holds the prefix of sel_cnt (left by S5's last kernel)
   bool probe_fb = false;        // a batch overflowed the threshold probe's tie room once: the fallback kernels are enqueued from then on
   int l0_poor = 0;              // consecutive batches in which level 0 let more than a quarter of the candidates through
+  int l0h_poor = 0;             // ... and its hot-code form
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
   void destroy() {
     out_all.release();
@@ -741,6 +742,7 @@ struct Pipe {
   bool used_q8 = false;   // a bound stage pruned the candidates (8-bit bounds or level 0)
   int approx_impl = 0;    // 0 exact for all, 1 8-bit bounds, 2 level 0
   bool l0_ready = false;  // S1 produced level 0's floors and excess table (instead of the 8-bit table)
+  bool l0_hot = false;    // ... for the hot-code scan (k_l0h_scan) instead of the code-line scan
   bool allow_spec = false;   // fp_search / fp_search_device: M may be the learnt capacity instead of this batch's total (no mid-pipeline sync)
   bool spec = false;         // ... and it was
   bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
@@ -830,12 +832,21 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
   // per-128-centroid column maxima for the threshold probe
   // FP_APPROX_IMPL: exact | q8 | l0 force a form of S4 (tests); otherwise chosen below from the table size and the candidate count
-  static const int q8_env = [] {
+  static const int q8_env = [] {   // exact | q8 | l0 (code lines, sum of excesses) | l0h (hot codes, per-column maxima)
     const char* e = getenv("FP_APPROX_IMPL");
-    return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : (e[0] == 'l' ? 2 : 0)));
+    return !e ? 0 : (e[0] == 'q' ? 1 : (e[0] == 'e' ? -1 : (e[0] == 'l' ? ((e[1] == '0' && e[2] == 'h') ? 3 : 2) : 0)));
   }();
-  // (bound stages: level 0 for q_len <= 128, the 8-bit stage for q_len <= 64)
-  const bool l0_possible = q8_env != 1 && fpk_l0_fits(D) && (q8_env == 2 || (D.U <= 64 * D.N && s->l0_poor < 2));
+  // (bound stages: level 0 for q_len <= 128, the 8-bit stage for q_len <= 64.)  Level 0 has two scans over the same excess table:
+  // the sum of excesses along a document's packed code line (documents of <= 64 distinct codes on average: the index carries
+  // the lines) and, for documents with MORE codes, the per-column maxima over the document's hot codes (k_l0h_scan; round 4 --
+  // until then such indexes took the 8-bit stage, which gathers a row of bins for every code).  Either is dropped for the
+  // scratch when it lets more than a quarter of the candidates through two batches running.
+  const bool lines_ok = (q8_env == 0 || q8_env == 2) && fpk_l0_fits(D) && (q8_env == 2 || (D.U <= 64 * D.N && s->l0_poor < 2));
+  // (the hot form pays from ~128 distinct codes per document: at 77 -- the Gaussian-mixture corpus of tools/bench_gmm.py -- floors low
+  // enough for the top documents to rise above them leave a third of the codes hot, and the 8-bit stage is as fast)
+  const bool hot_ok = !lines_ok && (q8_env == 0 || q8_env == 3) && fpk_l0h_fits(D) && (q8_env == 3 || (D.U > 128 * D.N && s->l0h_poor < 2));
+  const bool l0_possible = lines_ok || hot_ok;
+  P.l0_hot = hot_ok;
   const bool qp_ok = sh.Qp == 32 || sh.Qp == 64 || (sh.Qp == 128 && l0_possible);
   const bool want_s8 = !P.exact_all && qp_ok && q8_env >= 0 && (q8_env > 0 || D.C * 64 >= (2ll << 20));
   // Level 0 is decided HERE when the index suits it (the table fits, documents of <= 64 distinct codes on average; forced by
@@ -858,7 +869,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     if (fpk_centroid_scores(D1, q_s1, s->Ssample.as<uint16_t>(), B, sh.Qp, s->S8.as<uint8_t>(), nullptr, st, ns, sstride))
       return fail(FP_EUNSUPPORTED, "dim");
     HIPCHK(s->l0_gfl.ensure((size_t)B * sh.Qp * 2));
-    fpk_l0_floors(s->S8.as<uint8_t>(), ns, sh, s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_esc.as<uint32_t>(), s->l0_gfl.as<uint16_t>(), st);
+    fpk_l0_floors(s->S8.as<uint8_t>(), ns, sh, s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_esc.as<uint32_t>(), s->l0_gfl.as<uint16_t>(), st,
+                  P.l0_hot ? std::min(0.02f, std::max(0.001f, (float)((double)std::max<int64_t>(D.N, 1) / (1.2 * (double)std::max<int64_t>(D.U, 1))))) : 0.f);
     if (Cpad > D.C) HIPCHK(hipMemsetAsync(s->l0_e8.p, 0, (size_t)B * Cpad, st));   // pad entries behind the table stay 0
     FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_gfl.as<uint16_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q};
     if (fpk_centroid_scores(D1, q_s1, s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex, &xe))
@@ -966,7 +978,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   const bool q8_auto = !P.l0_ready && D.C * 64 >= (2ll << 20) && M > 4 * (int64_t)B * sh.R && M / B >= 32768;
   P.approx_impl = 0;
   if (want_s8 && M > 0) {
-    if (q8_env == 2) P.approx_impl = l0_ok ? 2 : 0;
+    if (q8_env == 2 || q8_env == 3) P.approx_impl = l0_ok ? 2 : 0;
     else if (q8_env == 1) P.approx_impl = P.l0_ready ? 0 : 1;
     else P.approx_impl = l0_auto ? 2 : (q8_auto ? 1 : 0);
   }
@@ -1011,6 +1023,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       STAGE_DONE(ST_APPROX);
       // (grid: from the previous batch's total when M is the learnt capacity -- every extra workgroup copies the table into LDS;
       // the kernel strides if this batch has more)
+      if (P.l0_hot) fpk_l0h_scan(D, s->S.as<uint16_t>(), sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), P.spec && s->spec_last > 0 ? std::min(M, s->spec_last) : M, w, st);
+      else
       fpk_l0_scan(D, sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), P.spec && s->spec_last > 0 ? std::min(M, s->spec_last) : M, w, st);
       STAGE_DONE(ST_REFINE);
       fpk_l0_pilot(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, w, st);
@@ -1345,7 +1359,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       s->graph.last[6] = (int64_t)s->alloc_gen;
     }
     if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
-    g_last_counts[4] = replayed ? -1 : P.approx_impl;
+    g_last_counts[4] = replayed ? -1 : (P.approx_impl == 2 && P.l0_hot ? 3 : P.approx_impl);
     g_last_counts[0] += M_true;
     g_last_counts[3] += 1;
     if (s->fold_stats) {   // the statistics came down with the results
@@ -1354,8 +1368,9 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       // quarter of the candidates in two batches running) is switched to the 8-bit bound stage for this scratch, for good (the
       // selection is the same in every form of S4, only the time differs)
       if (P.approx_impl == 2 && M_true > 0) {
-        if (stv[0] * 4 > M_true) s->l0_poor = std::min(s->l0_poor + 1, 4);
-        else s->l0_poor = 0;
+        int& poor = P.l0_hot ? s->l0h_poor : s->l0_poor;
+        if (stv[0] * 4 > M_true) poor = std::min(poor + 1, 4);
+        else poor = 0;
       }
       g_last_counts[1] += P.used_q8 ? stv[0] : M_true;
       for (int i = 0; i < B; ++i) g_last_counts[2] += stv[1 + i];

@@ -246,7 +246,11 @@ size_t fpk_l0_hist_bytes(int B);
 size_t fpk_sel_hist_bytes(int B);
 void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride);
 void fpk_l0_floors(const uint8_t* S8_sample, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc,
-                   uint16_t* gfl /*[B][Qp] fp16 floors for S1's epilogue*/, hipStream_t st);
+                   uint16_t* gfl /*[B][Qp] fp16 floors for S1's epilogue*/, hipStream_t st, float hot_tail = 0.f /*> 0: k_l0h_scan's floors, the (1 - hot_tail) quantile*/);
+// level 0 for documents with many distinct codes: per-column maxima over the HOT codes only (k_l0h_scan); same outputs as fpk_l0_scan
+bool fpk_l0h_fits(const FpIndexDev& ix);
+void fpk_l0h_scan(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M,
+                  FpL0Scratch& w, hipStream_t st);
 void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w,
                  hipStream_t st);
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st);

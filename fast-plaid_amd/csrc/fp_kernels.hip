@@ -2806,6 +2806,141 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   }
 }
 
+// ---- level 0, "hot" form (round 4): documents with MANY distinct codes -----------------------------------------------------
+// The sum of excesses above grows with the number of codes of a document -- at 300 codes (1024-token documents) 61 % of the
+// candidates survived it -- because it adds what the score takes a per-column maximum of.  This form keeps the per-column
+// maximum and still touches S only where it can matter:
+//   a code is HOT for the query when its excess byte is non-zero, i.e. some column's bin lies above that column's floor;
+//   UBh(d) = sum_q max(f_q, max over the HOT codes c of d of bin(S[c][q]))
+// A code that is not hot has bin <= f_q in every column, so leaving it out cannot lower a column's term below the true maximum's
+// bin: UBh(d) >= K(d), the same inequality the pilot / threshold logic of level 0 rests on -- and UBh <= UB0.  With the floors at
+// a quantile matched to the documents' code count (tail = 1 / (1.2 x distinct codes per document), FP_L0H_TAIL overrides: a
+// document reaches about that quantile in a typical column anyway, so the floors cost little and few codes rise above them)
+// ~6 % of a document's codes are hot: the scan walks the document's unique-code list (4 B per code, streamed), looks every code
+// up in the LDS byte table, and gathers the 64-byte row of S for the hot ones only -- where the 8-bit stage gathers a row for
+// EVERY code.  One lane quad per candidate (8 columns of a 32-column chunk per lane, like k_approx), bins from the fp16 maxima
+// at the end (bin is monotone: the maximum's bin is the bins' maximum).  Output: the same ub / histogram as k_l0_scan, so the
+// pilot, threshold and survivor kernels are shared.  Tables up to 2^17 centroids (one LDS slice).
+__global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e8, int64_t Cpad, int tab_bytes, const uint8_t* __restrict__ floors,
+                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
+                                                   const int32_t* __restrict__ cand_pid, const int64_t* __restrict__ uoff,
+                                                   const int32_t* __restrict__ ucodes, const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
+                                                   uint16_t* __restrict__ ub, uint32_t* __restrict__ hist, int bxn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
+  uint8_t* tab = l0s;                                                  // [tab_bytes]
+  uint32_t* hl = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [L0_HBINS]
+  uint8_t* fl = reinterpret_cast<uint8_t*>(hl + L0_HBINS);             // [Qp]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, bxi = blockIdx.x;
+  const int64_t beg = cand_off[b];
+  const int64_t n = cand_off[b + 1] - beg;
+  if ((int64_t)bxi * 256 >= n) return;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad);
+    uint4* dst = reinterpret_cast<uint4*>(tab);
+    for (int j = tid; j < tab_bytes / 16; j += 1024) dst[j] = src[j];
+    for (int j = tid; j < L0_HBINS; j += 1024) hl[j] = 0u;
+    if (tid < Qp) fl[tid] = floors[(int64_t)b * Qp + tid];
+  }
+  __syncthreads();
+  const uint32_t F = Fsum[b];
+  const int sub = tid & 3;
+  const int nch = Qp / 32;
+  const half_t ninf = __builtin_bit_cast(half_t, (uint16_t)0xFC00);
+  const h2 ninf2 = {ninf, ninf};
+  uint16_t* ubrow = ub + l0_row(cand_off, b);
+  const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
+  for (int64_t i = (int64_t)bxi * 256 + (tid >> 2); i < n; i += (int64_t)bxn * 256) {
+    const int32_t pid = cand_pid[beg + i];
+    const int64_t u0 = uoff[pid];
+    const int len = (int)(uoff[pid + 1] - u0);
+    const int32_t* cp = ucodes + u0;
+    // Per 32-column chunk: the code list in steps of 16 codes -- each lane of the quad loads FOUR of them (one 16-byte load,
+    // dword-aligned; the next step's are in flight while this step's rows are), looks its four up in the LDS byte table, and the
+    // quad ORs its hot bits together; the rows of the HOT codes only are then gathered, up to four at a time so that a step's
+    // row loads are in flight together (a load per hot code followed by its maximum is one round trip per code: 17 ms at cfg4;
+    // every lane looking all the codes up itself: 1.75 ms, the 8-bit stage's time).
+    uint32_t sum = 0u, inf = 0u;
+    const int qbase = (tid & 63) & ~3;   // first lane of this quad
+    auto load4 = [&](int t) -> int4 {
+      int4 a;
+      __builtin_memcpy(&a, cp + t + 4 * sub, 16);   // (the list buffer is padded: positions past the document's end are masked below)
+      return a;
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+      h2 m0 = ninf2, m1 = ninf2, m2 = ninf2, m3 = ninf2;
+      const uint16_t* Sc = Sb + ch * 32;
+      int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
+      if (len > 0) cur = load4(0);
+      for (int t = 0; t < len; t += 16) {
+        if (t + 16 < len) nxt = load4(t + 16);
+        const int tb = t + 4 * sub;
+        uint32_t hot = 0u;
+        hot |= (tb + 0 < len && tab[cur.x] != 0) ? 1u : 0u;
+        hot |= (tb + 1 < len && tab[cur.y] != 0) ? 2u : 0u;
+        hot |= (tb + 2 < len && tab[cur.z] != 0) ? 4u : 0u;
+        hot |= (tb + 3 < len && tab[cur.w] != 0) ? 8u : 0u;
+        hot <<= 4 * sub;
+        hot |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hot, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        hot |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hot, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        while (hot) {   // (the same word in the quad's four lanes: they branch together)
+          uint4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u] = make_uint4(0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u);
+            if (hot) {
+              const int k = __builtin_ctz(hot);
+              hot &= hot - 1u;
+              const int kk = k & 3;
+              const int32_t mine = kk == 0 ? cur.x : (kk == 1 ? cur.y : (kk == 2 ? cur.z : cur.w));
+              const int32_t code = __shfl(mine, qbase + (k >> 2), 64);
+              v[u] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code * Qp);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            m0 = pk_max(m0, u32_as_h2(v[u].x));
+            m1 = pk_max(m1, u32_as_h2(v[u].y));
+            m2 = pk_max(m2, u32_as_h2(v[u].z));
+            m3 = pk_max(m3, u32_as_h2(v[u].w));
+          }
+        }
+        cur = nxt;
+      }
+      const h2 mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = ch * 32 + sub * 8 + j;
+        const h2 pr = mm[j >> 1];
+        float x = (float)((j & 1) ? pr.y : pr.x);
+        x = x > -2.f ? x : -2.f;                       // (no hot code in the column: bin 0)
+        int bin = (int)floorf(x * 128.0f) + 100;       // == S1's bins
+        bin = bin < 0 ? 0 : (bin > 255 ? 255 : bin);
+        if (q < Q) {
+          inf |= (bin == 255) ? 1u : 0u;               // clamped: no upper bound on the score behind it
+          const int f = (int)fl[q];
+          sum += bin > f ? (uint32_t)(bin - f) : 0u;
+        }
+      }
+    }
+    sum = l0_red<4>(sum);
+    inf = l0_maxg<4>(inf);
+    uint32_t v = F + sum;
+    v = inf ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
+    if (sub == 0) {
+      ubrow[i] = (uint16_t)v;
+      const uint32_t hb = (v >= F ? v - F : 0u) >> 2;
+      atomicAdd(&hl[hb > L0_HBINS - 1 ? L0_HBINS - 1 : hb], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* hg = hist + (int64_t)b * L0_HBINS;
+  for (int i2 = tid; i2 < L0_HBINS; i2 += 1024) {
+    const uint32_t v = hl[i2];
+    if (v) atomicAdd(&hg[i2], v);
+  }
+}
+
 // ub[b][i] = min(F + sum over the ranges of part_r[b][i], 0xFFFE), 0xFFFF if any part is infinite; + the histogram of (ub - F) >> 2
 __global__ __launch_bounds__(256) void k_l0_combine(const uint16_t* __restrict__ parts, int nr, int64_t pstride, const uint32_t* __restrict__ Fsum,
                                                     const int64_t* __restrict__ cand_off, uint16_t* __restrict__ ub, uint32_t* __restrict__ hist) {
@@ -3213,6 +3348,22 @@ size_t fpk_l0_lds_bytes(const FpIndexDev& ix) {
   return (size_t)std::min<int64_t>(Cpad, FP_L0_RANGE) + 16 + 256 + L0_HBINS * 4;
 }
 bool fpk_l0_fits(const FpIndexDev& ix) { return ix.n_ranges >= 1 && ix.pcodes != nullptr; }
+// the "hot" form of level 0 (k_l0h_scan): any index whose byte table is one LDS slice
+bool fpk_l0h_fits(const FpIndexDev& ix) { return ix.C <= FP_L0_RANGE && ix.ucodes != nullptr; }
+void fpk_l0h_scan(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M,
+                  FpL0Scratch& w, hipStream_t st) {
+  const int B = sh.B;
+  const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
+  static std::atomic<uint64_t> okh{0};
+  fp_allow_big_lds((const void*)k_l0h_scan, okh, 160 * 1024);
+  const int64_t per_q = (M + B - 1) / B;
+  int64_t bx = (per_q + 4095) / 4096;
+  if (bx > 8192) bx = 8192;
+  if (bx < 1) bx = 1;
+  const size_t lds = (size_t)Cpad + 16 + L0_HBINS * 4 + 256;
+  hipLaunchKernelGGL(k_l0h_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), lds, st, w.e8, Cpad, (int)Cpad, w.floors, w.Fsum, cand_off, cand_pid,
+                     ix.uoff, ix.ucodes, S, ix.C, sh.Q, sh.Qp, w.ub, w.hist, (int)bx);
+}
 
 // level 0 in launch groups so that the scan kernel can be timed alone:
 //   prepare: floors + excess table;  scan: UB0 of every candidate (+ its histogram);  pilot: the top mult*keep documents by UB0
@@ -3224,9 +3375,11 @@ void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride) 
   *n_rows = (ix.C + *stride - 1) / *stride;
 }
 void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, uint16_t* gfl,
-                   hipStream_t st) {
+                   hipStream_t st, float hot_tail) {
   const int nch = sh.Qp / 32;
-  static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
+  static const float tail0 = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
+  static const float tailh = [] { const char* e = getenv("FP_L0H_TAIL"); const float v = e ? (float)atof(e) : 0.f; return (v > 0.f && v < 0.5f) ? v : 0.f; }();   // (0: the caller's)
+  const float tail = hot_tail > 0.f ? (tailh > 0.f ? tailh : hot_tail) : tail0;
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
   // n_rows <= L0_SAMPLE * 2: the kernel's own sampling stride over this table is 1 or (for 8192 < n_rows) still covers it

@@ -159,7 +159,7 @@ uint64_t fp_graph_replay_count(void);
  * summed over queries (S3 output), out[1] = candidates that reached the exact approximate-score
  * kernel (== out[0] unless a bound stage pruned), out[2] = documents whose near-tied final score was re-evaluated in the
  * reference's summation order (exact-order repair), out[3] = sub-batches, out[4] = the form of S4 the last sub-batch ran
- * (0 every candidate scored exactly, 1 8-bit bound stage, 2 level 0; -1 when the call was a graph replay).  Returns entries written. */
+ * (0 every candidate scored exactly, 1 8-bit bound stage, 2 level 0, 3 level 0 over the hot codes; -1 when the call was a graph replay).  Returns entries written. */
 int fp_last_search_counts(int64_t* out, int cap);
 
 /* Centroid scores (S1, search.rs:491) are exact: every fp32 MFMA result that lies within a certification window of an fp16

@@ -37,7 +37,7 @@ def same_as_trace(idx, q, params, subs=None):
 
 
 def main():
-    assert os.environ.get("FP_APPROX_IMPL") in ("q8", "l0")
+    assert os.environ.get("FP_APPROX_IMPL") in ("q8", "l0", "l0h")
     # committed fixtures (subset, empty documents, zero-padded query rows, unnormalised documents, ...)
     for name in golden_cases():
         z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))

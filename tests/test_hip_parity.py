@@ -414,6 +414,20 @@ def test_level0_forced(fp, tail, pilot, ppl):
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_level0_hot_form_forced(fp):
+    """level 0's scan for documents with many distinct codes (k_l0h_scan: per-column maxima over a document's HOT codes -- the
+    codes whose excess byte is non-zero -- instead of the sum of excesses along its code line), forced on the worker's corpora
+    (goldens, pruning corpora incl. 65 .. 128-token queries, out-of-range scores, odd shapes, 4000 tied documents): fp_search
+    must equal fp_search_trace bit for bit, for two floor quantiles."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tail in ("0.004", "0.05"):
+        env = dict(os.environ, FP_APPROX_IMPL="l0h", FP_L0H_TAIL=tail)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "Q8_OK" in r.stdout, tail + r.stdout + r.stderr
+
+
 def test_without_tickets_and_with_every_score_reevaluated(fp):
     """two switches that must not change any result: FP_TICKETS=0 (the plain count -> scan -> offsets launches instead of the
     'last workgroup finishes the job' chains, whose fence-free publish relies on gfx950's coherent device-scope atomics) and
