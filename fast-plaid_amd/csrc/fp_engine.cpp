@@ -406,8 +406,8 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   D.cent_s1 = nullptr;
   D.dim_s1 = D.dim;
   static const bool pad_env = [] { const char* e2 = getenv("FP_S1_PAD"); return !(e2 && atoi(e2) == 0); }();
-  if (pad_env && D.dim < 128 && D.dim != 64) {
-    const int dp = D.dim < 64 ? 64 : 128;
+  if (pad_env && D.dim < 256 && D.dim != 64 && D.dim != 128) {
+    const int dp = D.dim < 64 ? 64 : (D.dim < 128 ? 128 : 256);
     uint16_t* cp = nullptr;
     hipError_t e = hipMalloc((void**)&cp, (size_t)D.C * dp * 2 + 64);
     if (e != hipSuccess) return fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e) + " (padded centroid table)");

@@ -60,11 +60,11 @@ struct FpIndexDev {
                               //    handed over by the caller and everything exported are in the reference's order
   const uint32_t* rinv;       // [T]   fp32 bits of a reciprocal r with h(fl32(e_k * r)) == h(fl32(e_k / n)) for every dim of the token
                               //         (bit 31 set: no such r within the search range -> the kernel takes the exact path for the step); nullable
-  // S1's view of the centroid table (round 4): dims other than 64 / 128 below 128 are ZERO-PADDED to 64 / 128 in a second copy
+  // S1's view of the centroid table (round 4): dims below 256 other than 64 / 128 are ZERO-PADDED to 64 / 128 / 256 in a second copy
   // [C][dim_s1], so that the centroid scores run through the streaming kernel -- whose exact mode re-evaluates the flagged scores
   // from LDS and registers; the one-tile kernel fetches both rows of every flagged score from L2 (dim 96: S1 0.94 ms against
   // 0.29 without the certification).  Zero products change neither the MFMA sum nor the ascending chain.  nullptr: S1 reads
-  // `centroids` (dim 64 / 128, and dims above 128, which stay on the one-tile kernel).
+  // `centroids` (dim 64 / 128 / 256, and dims above 256, which stay on the one-tile kernel).
   const uint16_t* cent_s1;
   int dim_s1;
 };

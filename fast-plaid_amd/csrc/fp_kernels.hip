@@ -537,9 +537,11 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
 #ifndef S1_LAUNDER
 #define S1_LAUNDER 1
 #endif
-#define S1_BUF (4 * 128 * 64 + 4 * 128 * 2)   // operand tile / output staging (32 KiB) + the epilogue's column-maximum scratch
+// one of the two LDS buffers: the operand tile (128 rows of DK halves; the staged output tile and, behind it at 32 KiB, the epilogue's
+// column-maximum scratch reuse the space) -- 33 KiB up to dim 128, 65 KiB at dim 256 (one workgroup per CU then)
+static constexpr int s1_buf_bytes(int dk) { return (128 * dk * 2 > 4 * 128 * 64 ? 128 * dk * 2 : 4 * 128 * 64) + 4 * 128 * 2; }
 template <int DK>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DK > 128 ? 2 : 4, DK > 128 ? 2 : 4)))
 void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, uint16_t* __restrict__ S, int64_t C,
                               int64_t Ntot, int Qp, uint8_t* __restrict__ S8, uint16_t* __restrict__ cmax, int nch, int nct, int nrt,
                               FpS1Excess ex, FpS1Exact xe) {
@@ -547,6 +549,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
   constexpr int ROWB = DK * 2;           // bytes per row
   constexpr int KSTEPS = DK / 16;
   constexpr int NLD = 128 * CH / 512;    // 16-byte pieces of a centroid tile per thread
+  constexpr int S1_BUF = s1_buf_bytes(DK);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -559,21 +562,22 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
   if (t_first >= nch) return;   // (uniform)
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
-  // piece i of this lane: centroid row i * (512 / CH) + rbase of the tile, 16-byte chunk j16 / 16 of it (the swizzle does not
-  // depend on i: the row advances by a multiple of CH)
+  // piece i of this lane: centroid row i * (512 / CH) + rbase of the tile, 16-byte chunk jcol of it, stored at the chunk
+  // position jcol ^ (row % CH) of its LDS row (what the MFMA loop's reads undo)
   auto prefetch = [&](int tile, uint32_t buf_off) {
     int tidp = tid;
 #if S1_LAUNDER
     asm volatile("" : "+v"(tidp));   // (per-piece offsets recomputed per tile instead of living in registers -- or scratch -- across the loop)
 #endif
     const uint32_t rbase = (uint32_t)(tidp / CH);
-    const uint32_t j16 = (uint32_t)(((tidp % CH) ^ ((tidp / CH) & (CH - 1))) * 16);
+    const uint32_t jcol = (uint32_t)(tidp % CH);
     const int64_t c0 = (int64_t)tile * 128;
     const uint16_t* tile_base = cent + c0 * DK;                        // (scalar)
     const uint32_t rows_valid = (uint32_t)(C - c0 < 128 ? C - c0 : 128);   // rows past the end read row 0 of the tile (never stored)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const uint32_t row = rbase + (uint32_t)(i * (512 / CH));
+      const uint32_t j16 = (jcol ^ (row & (uint32_t)(CH - 1))) * 16u;   // (at dim <= 128 the row advances by a multiple of CH: the same for every i)
       const uint32_t voff = (row < rows_valid ? row : 0u) * (uint32_t)ROWB + j16;
       // lane l's 16 bytes land at LDS address M0 + 16 l
       const uint32_t m0v = lds0 + buf_off + ((uint32_t)i * 8u + wave_s) * 1024u;
@@ -833,15 +837,18 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   // streaming form: main pass only (the sampled pre-pass has too few tiles to walk), dim 128 / 64
   static const int stream_env = [] { const char* e = getenv("FP_S1_STREAM"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup; n > 1: tiles per workgroup
   static const int64_t stream_min = [] { const char* e = getenv("FP_S1_STREAM_MIN"); return e ? atoll(e) : 2048ll; }();   // tests: 1 = the streaming kernel for every size
-  if ((D == 128 || D == 64) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= stream_min) {
+  if ((D == 128 || D == 64 || D == 256) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= stream_min) {
     const int nrt = (int)grid.y;
     const int nct = stream_env > 1 ? stream_env : 8;
     const unsigned nwg = (unsigned)((nch + nct - 1) / nct) * (unsigned)nrt;
-    const size_t lds = 2 * (size_t)S1_BUF + 512 + 8 * 2 * S1X_CAP * 2;   // 74.5 KiB (tile buffers + windows + the waves' entry / value lists): above the 64 KiB that need no opt-in
-    static std::atomic<uint64_t> ok128{0}, ok64{0};
+    const size_t lds = 2 * (size_t)s1_buf_bytes(D) + 512 + 8 * 2 * S1X_CAP * 2;   // 74.5 KiB (tile buffers + windows + the waves' entry / value lists; 138.5 KiB at dim 256): above the 64 KiB that need no opt-in
+    static std::atomic<uint64_t> ok128{0}, ok64{0}, ok256{0};
     if (D == 128) fp_allow_big_lds((const void*)k_centroid_scores_stream<128>, ok128, 80 * 1024);
+    else if (D == 256) fp_allow_big_lds((const void*)k_centroid_scores_stream<256>, ok256, 144 * 1024);
     else fp_allow_big_lds((const void*)k_centroid_scores_stream<64>, ok64, 80 * 1024);
-    if (D == 128)
+    if (D == 256)
+      hipLaunchKernelGGL(k_centroid_scores_stream<256>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex, xe);
+    else if (D == 128)
       hipLaunchKernelGGL(k_centroid_scores_stream<128>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex, xe);
     else
       hipLaunchKernelGGL(k_centroid_scores_stream<64>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex, xe);

@@ -40,7 +40,7 @@ for name in golden_cases():
 print("goldens total entries", tot, "mismatches", bad, flush=True)
 
 for (dim, C, nd, dl, Q, seed) in [(128, 1 << 13, 4000, 64, 32, 1), (128, 1 << 15, 20000, 48, 32, 2), (64, 1 << 13, 4000, 64, 40, 3), (96, 1 << 12, 3000, 64, 32, 4),
-                                  (256, 1 << 12, 2000, 48, 20, 5), (40, 1 << 11, 2000, 48, 32, 6), (128, 1 << 17, 30000, 32, 32, 7)]:
+                                  (256, 1 << 12, 2000, 48, 20, 5), (40, 1 << 11, 2000, 48, 32, 6), (128, 1 << 17, 30000, 32, 32, 7), (160, 1 << 12, 2000, 48, 32, 8), (72, 1 << 12, 2000, 48, 32, 9)]:
     spec = fp.synth.SynthSpec(n_docs=nd, doc_len=dl, n_centroids=C, dim=dim, variable_len=True, seed=seed)
     arr = fp.synth.host_index_arrays(spec)
     q = fp.synth.make_queries(spec, arr["centroids"], 3, Q, seed=seed + 50)
