@@ -816,7 +816,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       xe.stats = s->s1stats.as<unsigned long long>();
     }
   }
-  // S1 runs on the zero-padded view of the table when the index has one (dims below 128 other than 64)
+  // S1 runs on the zero-padded view of the table when the index has one (dims below 256 other than 64 / 128)
   FpIndexDev D1 = D;
   const uint16_t* q_s1 = s->qpad.as<uint16_t>();
   if (D.cent_s1) {
