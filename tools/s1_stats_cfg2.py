@@ -1,5 +1,5 @@
 """S1 certification counters and stage times on BASELINE cfg2 (GPU).  Usage: [FP_S1_EXACT=0|1|2] [FP_S1_W0_LOG2=-21] FP_S1_STATS=1
-python tools/s1_stats_cfg2.py [batches] [docs]"""
+python tools/s1_stats_cfg2.py [batches] [docs] [dim]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,8 +8,9 @@ import fast_plaid_amd as fp
 R = fp.fast_plaid_rust
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 docs = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 C = fp.synth.default_num_centroids(docs * 128)
-spec = fp.synth.SynthSpec(n_docs=docs, doc_len=128, n_centroids=C, seed=42)
+spec = fp.synth.SynthSpec(n_docs=docs, doc_len=128, n_centroids=C, seed=42, dim=dim)
 cent = fp.synth.centroids(spec)
 index = R.construct_synthetic_index(spec, "cuda:0", centroids=cent, bucket_weights=fp.synth.bucket_weights(spec))
 params = R.SearchParameters(2000, 4096, 1000, 8)
