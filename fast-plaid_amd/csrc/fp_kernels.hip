@@ -834,12 +834,16 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   const size_t out_lds = 4 * 128 * 64 + 4 * 128 * 2;
   const int D = ix.dim;
   if (D % 8 != 0 || D < 8) return -1;
-  // streaming form: main pass only (the sampled pre-pass has too few tiles to walk), dim 128 / 64
+  // streaming form: main pass only (the sampled pre-pass walks a strided table), dim 64 / 128 / 256.  Tiles per workgroup: 8 for
+  // the big batches (cfg2: 16384 tiles), fewer while that would leave CUs without a workgroup -- the kernel is used for small
+  // batches too since round 4, because its exact mode repairs from the LDS tile where the one-tile kernel fetches both rows of
+  // every flagged score from L2 (cfg2's table, S1 stage: B = 1 79 -> 52 us, B = 4 143 -> 71 us, B = 8 120 -> 99 us)
   static const int stream_env = [] { const char* e = getenv("FP_S1_STREAM"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup; n > 1: tiles per workgroup
-  static const int64_t stream_min = [] { const char* e = getenv("FP_S1_STREAM_MIN"); return e ? atoll(e) : 2048ll; }();   // tests: 1 = the streaming kernel for every size
+  static const int64_t stream_min = [] { const char* e = getenv("FP_S1_STREAM_MIN"); return e ? atoll(e) : 1ll; }();   // tiles below which the one-tile kernel runs (experiments)
   if ((D == 128 || D == 64 || D == 256) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= stream_min) {
     const int nrt = (int)grid.y;
-    const int nct = stream_env > 1 ? stream_env : 8;
+    const int64_t tiles = (int64_t)nch * grid.y;
+    const int nct = stream_env > 1 ? stream_env : (int)std::min<int64_t>(8, std::max<int64_t>(1, tiles / 512));
     const unsigned nwg = (unsigned)((nch + nct - 1) / nct) * (unsigned)nrt;
     const size_t lds = 2 * (size_t)s1_buf_bytes(D) + 512 + 8 * 2 * S1X_CAP * 2;   // 74.5 KiB (tile buffers + windows + the waves' entry / value lists; 138.5 KiB at dim 256): above the 64 KiB that need no opt-in
     static std::atomic<uint64_t> ok128{0}, ok64{0}, ok256{0};
@@ -2456,27 +2460,47 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
   }
   __syncthreads();
   __shared__ uint32_t fl[128];
-  if (tid < ncol) {
+  // f = the smallest bin such that at most tail * ns samples lie above it = the largest k >= 1 whose suffix count
+  // #{bin >= k} exceeds lim (0 if none).  One wave per column: lane l holds bins 4 l .. 4 l + 3, the suffix counts over the
+  // lanes come from six shuffles (a thread per column walking down from bin 255 was ~120 dependent LDS reads: 5 of the
+  // kernel's 16 us, at every batch size)
+  const uint32_t lim = (uint32_t)(tail * (float)ns);
+  const int lane = tid & 63;
+  for (int col = tid >> 6; col < ncol; col += 16) {   // (wave-uniform)
     uint32_t f = 0;
-    if (tid < Q) {   // smallest bin f such that at most tail * ns samples lie above it
-      const uint32_t lim = (uint32_t)(tail * (float)ns);
-      uint32_t above = 0;
-      int k = 255;
-      for (; k > 0; --k) {
-        above += l0h[tid * 257 + k];
-        if (above > lim) break;
+    if (col < Q) {
+      const uint32_t* h = &l0h[col * 257 + 4 * lane];
+      const uint32_t b0 = h[0], b1 = h[1], b2 = h[2], b3 = h[3];
+      const uint32_t own = b0 + b1 + b2 + b3;
+      uint32_t suf = own;   // bins >= 4 lane
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_down(suf, d, 64);
+        if (lane + d < 64) suf += o;
       }
-      f = (uint32_t)k;
+      const unsigned long long bal = __ballot(suf > lim);   // (suf falls with the lane: the set bits are lanes 0 .. L)
+      if (bal) {
+        const int L = 63 - __builtin_clzll(bal);
+        uint32_t above = suf - own;   // bins >= 4 (lane + 1)
+        int k = 4 * lane;
+        if (above + b3 > lim) k = 4 * lane + 3;
+        else if (above + b3 + b2 > lim) k = 4 * lane + 2;
+        else if (above + b3 + b2 + b1 > lim) k = 4 * lane + 1;
+        f = (uint32_t)__shfl(k, L, 64);
+      }
     }
-    fl[tid] = f;
-    floors[(int64_t)b * ncol + tid] = (uint8_t)f;
-    if (gfl) gfl[(int64_t)b * ncol + tid] = tid < Q ? (half_t)((float)f - 100.f) : (half_t)2000.f;   // S1's epilogue form of the floors
+    if (lane == 0) {
+      fl[col] = f;
+      floors[(int64_t)b * ncol + col] = (uint8_t)f;
+      if (gfl) gfl[(int64_t)b * ncol + col] = col < Q ? (half_t)((float)f - 100.f) : (half_t)2000.f;   // S1's epilogue form of the floors
+    }
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t s = 0;
-    for (int i = 0; i < ncol; ++i) s += fl[i];
-    Fsum[b] = s;
+  if (tid < 64) {
+    uint32_t s = (tid < ncol ? fl[tid] : 0u) + (tid + 64 < ncol ? fl[tid + 64] : 0u);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (tid == 0) Fsum[b] = s;
   }
 }
 

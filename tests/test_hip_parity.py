@@ -436,20 +436,22 @@ def test_without_tickets_and_with_every_score_reevaluated(fp):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"FP_TICKETS": "0"}, {"FP_S1_EXACT": "2", "FP_S1_STREAM_MIN": "1"}):
+    for extra in ({"FP_TICKETS": "0"}, {"FP_S1_EXACT": "2"}, {"FP_S1_EXACT": "2", "FP_S1_STREAM": "0"}):   # (both S1 kernels)
         env = dict(os.environ, FP_APPROX_IMPL="l0", **extra)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0 and "Q8_OK" in r.stdout, str(extra) + r.stdout + r.stderr
 
 
-def test_centroid_scores_exact_streaming_kernel(fp):
-    """S1 with the streaming kernel under the traces (FP_S1_STREAM_MIN=1; a trace has one query, which normally takes the
-    one-tile kernel): S bit-identical to the oracle on goldens and on synthetic corpora of dim 128 / 64 with an unnormalised
-    query and a query whose second half is zero rows (tools/s1_exact_lab.py asserts nothing itself: its output is parsed)."""
+@pytest.mark.parametrize("kernel", ["stream", "one_tile"])
+def test_centroid_scores_exact_streaming_kernel(fp, kernel):
+    """S1's exact mode under the traces, with the streaming kernel (the default for every table since round 4: 1 .. 8 tiles
+    per workgroup by the number of tiles) and with the one-tile kernel (FP_S1_STREAM=0; it still serves the sampled pre-pass):
+    S bit-identical to the oracle on goldens and on synthetic corpora of dims 40 .. 256 with an unnormalised query and a query
+    whose second half is zero rows (tools/s1_exact_lab.py asserts nothing itself: its output is parsed)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FP_S1_STREAM_MIN="1", FP_S1_STATS="1")
+    env = dict(os.environ, FP_S1_STATS="1", **({"FP_S1_STREAM": "0"} if kernel == "one_tile" else {}))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "s1_exact_lab.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if "S mismatches" in ln]
