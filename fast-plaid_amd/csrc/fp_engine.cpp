@@ -1571,7 +1571,13 @@ extern "C" int fp_maxsim_columns(const fp_index* cix, const uint16_t* query, int
     return fail(FP_EUNSUPPORTED, "dim/nbits");
   HIPCHK(hipMemcpyAsync(scores, s->exact.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   if (unc) HIPCHK(hipMemcpyAsync(unc, s->ms_unc.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  if (flags) HIPCHK(hipMemcpyAsync(flags, s->ms_flags.p, (size_t)n * nflag * 4, hipMemcpyDeviceToHost, st));
+  // the caller's `flags` is [n, ceil(q_len / 32)] (fastplaid.h); the device rows are Qp / 32 words wide, which is MORE for
+  // 64 < q_len <= 96 (padded to 128 columns): repack like col_max below instead of copying Qp / 32 words per row
+  std::vector<uint32_t> fl;
+  if (flags) {
+    fl.resize((size_t)n * nflag);
+    HIPCHK(hipMemcpyAsync(fl.data(), s->ms_flags.p, fl.size() * 4, hipMemcpyDeviceToHost, st));
+  }
   std::vector<uint16_t> cm;
   if (col_max) {
     cm.resize((size_t)n * sh.Qp);
@@ -1581,6 +1587,11 @@ extern "C" int fp_maxsim_columns(const fp_index* cix, const uint16_t* query, int
   if (col_max)
     for (int64_t i = 0; i < n; ++i)
       for (int q = 0; q < Q; ++q) col_max[i * Q + q] = cm[(size_t)i * sh.Qp + q];
+  if (flags) {
+    const int nw = (Q + 31) / 32;
+    for (int64_t i = 0; i < n; ++i)
+      for (int w = 0; w < nw; ++w) flags[i * nw + w] = fl[(size_t)i * nflag + w];
+  }
   return FP_OK;
 }
 

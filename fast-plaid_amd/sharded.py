@@ -130,6 +130,19 @@ class HipShardEngine:
         N.lib().fp_shard_end(st["ctx"])
 
 
+def group_broadcast_bytes(dist, raw, group=None, nbytes=128):
+    """`raw` (bytes on the group's first member, None elsewhere) -> the same bytes on every member of `group`.
+    `src` of dist.broadcast is a GLOBAL rank: a sub-group that does not contain global rank 0 (every query group but the first
+    of the 2-D grid) has to name its own first member."""
+    import torch
+    t = torch.zeros(nbytes, dtype=torch.uint8) if raw is None else torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(t, src=src, group=group)
+    return bytes(t.cpu().numpy().tobytes())
+
+
 class NativeComm:
     """RCCL communicator owned by the library (include/fastplaid.h fp_comm_*): rank 0 draws the 128-byte unique id, the caller's
     `broadcast(bytes_or_None) -> bytes` ships it (torch.distributed / MPI / a file -- any out-of-band channel), every rank joins."""
@@ -147,16 +160,8 @@ class NativeComm:
     @classmethod
     def from_torch_dist(cls, device_id: int, dist, group=None):
         """bootstrap through an initialised torch.distributed process group (the id travels as a CPU byte tensor)."""
-        import torch
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-
-        def bcast(raw):
-            t = torch.zeros(128, dtype=torch.uint8) if raw is None else torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
-            if dist.get_backend(group) == "nccl":
-                t = t.cuda()
-            dist.broadcast(t, src=0, group=group)
-            return bytes(t.cpu().numpy().tobytes())
-        return cls(device_id, world, rank, bcast)
+        return cls(device_id, world, rank, lambda raw: group_broadcast_bytes(dist, raw, group))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -130,6 +130,11 @@ def main():
         grid = sharded.plan_grid(world, D)
         d, g = grid[rank]
         groups = [dist.new_group([gg * D + dd for dd in range(D)]) for gg in range(world // D)]   # (every rank creates every group)
+        # the communicator bootstrap of the native path (NativeComm.from_torch_dist) over each sub-group: the group's first
+        # member's 128 bytes must reach its members -- also in the groups that do not contain global rank 0
+        mine = bytes([g * 16 + 1] * 128) if dist.get_rank(groups[g]) == 0 else None
+        got = sharded.group_broadcast_bytes(dist, mine, groups[g])
+        assert got == bytes([g * 16 + 1] * 128), (rank, g, got[:4])
         gb, ge = sharded.plan_shards(arr["doc_lengths"], D)[d]
         geng = OracleShardEngine(arr, gb, ge)
         gp, gs, gc = sharded.replicated_search(lambda qs: sharded.sharded_search(geng, qs, params, dist=dist, group=groups[g]), q, 20,

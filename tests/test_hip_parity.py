@@ -1124,6 +1124,41 @@ def test_maxsim_column_certification(fp, name):
     assert nflag_tot <= 0.05 * ncol_tot, f"{nflag_tot} of {ncol_tot} columns flagged"
 
 
+@pytest.mark.parametrize("Q", [70, 96, 100])
+def test_maxsim_columns_flag_rows_for_padded_query_lengths(fp, Q):
+    """fp_maxsim_columns with 64 < q_len <= 128 (the engine pads such queries to 128 columns): the caller's flag rows are
+    ceil(q_len / 32) words wide (fastplaid.h), not Qp / 32 -- q_len 70 and 96 are 3 words against 4 on the device.  Canary words
+    behind the buffers must survive, and the flags must still line up with the columns."""
+    import ctypes as C
+    from fast_plaid_amd import _native as N
+    z, arr = _load_golden("base_d128_nb4")
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    rng = np.random.default_rng(Q)
+    base = z["queries"].reshape(-1, z["queries"].shape[-1])
+    q = np.ascontiguousarray(base[rng.integers(0, base.shape[0], Q)], dtype=np.float16)
+    lens = arr["doc_lengths"]
+    pids = np.arange(len(lens), dtype=np.int64)
+    n, nw, pad = len(pids), (Q + 31) // 32, 64
+    scores = np.zeros(n, np.float32)
+    cm = np.zeros((n, Q), np.uint16)
+    unc = np.zeros(n, np.float32)
+    flags = np.full(n * nw + pad, 0xDEADBEEF, np.uint32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    N.check(N.lib().fp_maxsim_columns(hip._h, ptr(q), Q, int(q.shape[1]), ptr(pids), n, ptr(scores), ptr(cm), ptr(unc), ptr(flags)))
+    assert np.all(flags[n * nw:] == 0xDEADBEEF), "fp_maxsim_columns wrote past the [n, ceil(q_len / 32)] flag rows"
+    fl = flags[: n * nw].reshape(n, nw)
+    for i, pid in enumerate(pids.tolist()):
+        if lens[pid] == 0:
+            continue
+        want = orc.token_scores(q, pid).max(axis=1)
+        flagged = np.array([(int(fl[i, c // 32]) >> (c % 32)) & 1 for c in range(Q)], bool)
+        same = cm[i] == want.view(np.uint16)
+        assert np.all(same | flagged), f"doc {pid}: unflagged columns {np.nonzero(~same & ~flagged)[0].tolist()} differ"
+        if Q % 32:
+            assert int(fl[i, -1]) >> (Q % 32) == 0, "flag bits beyond q_len"
+
+
 def test_create_update_delete_vs_reference_restatement(fp, tmp_path):
     """SURVEY 8 rows f1 / f4 against the ATen restatement of the reference's directory writers (oracle/plaid_index_oracle_torch.py:
     rust/index/create.rs, update.rs, delete.rs), not against this repo's own one-shot compression: tests/golden/maintain/snapshots.npz holds
