@@ -121,8 +121,10 @@ struct HostBuf {
   }
 };
 
-enum { ST_UPLOAD = 0, ST_CENTROID, ST_PROBE, ST_IVF, ST_COMPACT, ST_APREP, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_REPAIR, ST_TOPK, ST_N };
-static const char* kStageNames[ST_N] = {"upload+pack", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
+enum { ST_UPLOAD = 0, ST_CENTROID, ST_S1MAIN, ST_PROBE, ST_IVF, ST_COMPACT, ST_APREP, ST_APPROX, ST_REFINE, ST_SELECT, ST_MAXSIM, ST_REPAIR, ST_TOPK, ST_N };
+// "S1 centroid_gemm" is exactly ONE kernel, the main pass of the centroid GEMM (round 5; until then the stage included the
+// sampled pre-pass and the floors, now "S1 prepass+floors": zero when level 0 is not prepared)
+static const char* kStageNames[ST_N] = {"upload+pack", "S1 prepass+floors", "S1 centroid_gemm", "S2 probe_topk", "S3 ivf_mark+count",
                                         "S3 compact",  "S4 prepare",       "S4 approx",     "S4 refine",
                                         "S5 select",   "S6+S7 maxsim",     "S7 order repair", "S8 topk+download"};
 // "S4 approx" is exactly ONE kernel -- k_l0_scan (level-0 bound of every candidate), k_approx_q8 (8-bit bounds of every
@@ -142,8 +144,9 @@ struct Scratch : ScratchGen {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats, qpad_s1;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats, qpad_s1, lz_state, lz_gpid, lz_gval;
   HostBuf h_out, h_small;
+  int lazy_fails = 0;           // batches whose lazy-S1 selection lists overflowed (run again eagerly); two of them switch the lazy form off for this scratch
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
   // Candidate-buffer capacity learnt from earlier batches of the same shape (0: none): with it, fp_search does not wait for the
@@ -217,7 +220,7 @@ struct Scratch : ScratchGen {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats, &qpad_s1})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats, &qpad_s1, &lz_state, &lz_gpid, &lz_gval})
       b->release();
     h_out.release();
     h_small.release();
@@ -251,6 +254,7 @@ struct fp_index {
 
 static thread_local float g_last_ms[ST_N];
 static thread_local bool g_have_ms = false;
+static thread_local int g_last_lazy = 0;      // the last fp_search batch ran S1's lazy form (1), the eager one (0), or was a replayed graph (-1)
 static thread_local uint64_t g_last_s1[4];   // FP_S1_STATS: S1's certification counters of the last call (flagged, changed, slow path, mode-2 unflagged differences)
 static bool s1_stats_enabled() { static const bool on = getenv("FP_S1_STATS") != nullptr; return on; }
 static thread_local int64_t g_last_counts[5];  // candidates, exact-scored docs, repaired docs, sub-batches, form of S4 (0 exact / 1 8-bit bounds / 2 level 0; -1: replayed graph)
@@ -263,8 +267,8 @@ struct OutLayout {
     nk = (size_t)B * (size_t)K;
     score_off = (nk * 8 + 255) & ~(size_t)255;
     cnt_off = (score_off + nk * 4 + 255) & ~(size_t)255;
-    stat_off = (cnt_off + n * 4 + 255) & ~(size_t)255;   // [1 + B] int64 statistics (survivor total, marked documents per query)
-    total = stat_off + (n + 1) * 8;
+    stat_off = (cnt_off + n * 4 + 255) & ~(size_t)255;   // [2 + B] int64 statistics (survivor total, marked documents per query, lazy-S1 overflow flag)
+    total = stat_off + (n + 2) * 8;
   }
   void scatter(const void* host, int64_t* pids, float* scores, int32_t* counts) const {
     const char* h = static_cast<const char*>(host);
@@ -748,6 +752,8 @@ struct Pipe {
   bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
   bool probe_prezeroed = false, selhist_prezeroed = false, l0hist_prezeroed = false;   // cleared by the batch's first kernel
   int s1_mode = 0;           // FpS1Exact::mode of this batch's S1
+  bool want_lazy = false;    // the caller allows S1's lazy form (fp_search / fp_search_device without subset, trace or probe fallback)
+  bool lazy = false;         // ... and this batch runs it (FpLazyS1)
 };
 
 // after a batch: the candidate capacity the next batch of this shape runs on (see run_front)
@@ -797,14 +803,24 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       P.l0hist_prezeroed = zl.add(s->l0_hist.p, fpk_l0_hist_bytes(B));
     }
   }
+  // S1's lazy form (FpLazyS1): where the threshold probe and the general selection serve the shape
+  static const int s1x_env = [] { const char* e = getenv("FP_S1_EXACT"); return e ? atoi(e) : 3; }();
+  P.lazy = P.want_lazy && s1x_env == 3 && sh.Qp <= 128 && fpk_probe_lazy_ok(D, sh, P.nchunk) && fpk_select_lazy_ok(sh) && D.ucodes != nullptr;
+  const size_t lz_bytes = ((size_t)(2 * B + 8) * 4 + 15) & ~(size_t)15;   // [B] slack | [B] gathered | flag, pad x 3 | stats x 4
+  const int lz_gcap = fpk_select_lazy_gcap(sh);
+  if (P.lazy) {
+    HIPCHK(s->lz_state.ensure(lz_bytes));
+    HIPCHK(s->lz_gpid.ensure((size_t)B * lz_gcap * 4));
+    HIPCHK(s->lz_gval.ensure((size_t)B * lz_gcap * 4));
+    if (!zl.add(s->lz_state.p, lz_bytes)) HIPCHK(hipMemsetAsync(s->lz_state.p, 0, lz_bytes, st));
+  }
   // S1 exact mode (FpS1Exact): certification window w0 |q_n| + kappa |x| around the MFMA result; FP_S1_EXACT=0 switches the
   // certification off (S then differs from the reference's matmul by one fp16 ulp in ~0.05 % of its entries), 2 re-evaluates
   // every entry (tests); FP_S1_W0_LOG2 / FP_S1_KAPPA_LOG2 move the window (defaults 2^-21.5 and 2^-20, x dim / 128 above 128)
-  static const int s1x_env = [] { const char* e = getenv("FP_S1_EXACT"); return e ? atoi(e) : 1; }();
   static const float s1x_w0 = [] { const char* e = getenv("FP_S1_W0_LOG2"); return std::exp2(e ? (float)atof(e) : -21.5f); }();
   static const float s1x_kappa = [] { const char* e = getenv("FP_S1_KAPPA_LOG2"); return std::exp2(e ? (float)atof(e) : -20.0f); }();
   const bool s1x_stats = s1_stats_enabled() && !s->capturing;
-  P.s1_mode = s1x_env < 0 ? 0 : (s1x_env > 2 ? 2 : s1x_env);
+  P.s1_mode = P.lazy ? 3 : (s1x_env <= 0 ? 0 : (s1x_env == 2 ? 2 : 1));   // (FP_S1_EXACT=3, the default: lazy where it applies, eager elsewhere)
   const float dim_scale = D.dim > 128 ? (float)D.dim / 128.0f : 1.0f;
   FpS1Exact xe{P.s1_mode, nullptr, s1x_kappa * dim_scale, nullptr};
   if (P.s1_mode) {
@@ -827,6 +843,13 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   }
   fpk_pack_queries(s->qin.as<uint16_t>(), s->qpad.as<uint16_t>(), B, sh.Q, sh.Qp, D.dim, st, &zl, P.s1_mode ? s->wcol.as<float>() : nullptr,
                    s1x_w0 * dim_scale * ix->cent_norm_max, D.cent_s1 ? s->qpad_s1.as<uint16_t>() : nullptr, D.dim_s1);
+  FpLazyS1 lzs{};
+  if (P.lazy) {
+    uint32_t* lzw = s->lz_state.as<uint32_t>();
+    lzs = FpLazyS1{s->wcol.as<float>(), xe.kappa, s->qpad.as<uint16_t>(), lzw, lzw + B, s->lz_gpid.as<int32_t>(), s->lz_gval.as<float>(), lz_gcap,
+                   reinterpret_cast<int32_t*>(lzw + 2 * B), s1x_stats ? lzw + 2 * B + 4 : nullptr};
+  }
+  const FpLazyS1* lz = P.lazy ? &lzs : nullptr;
   STAGE_DONE(ST_CENTROID);
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
@@ -873,10 +896,12 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
                   P.l0_hot ? std::min(0.02f, std::max(0.001f, (float)((double)std::max<int64_t>(D.N, 1) / (1.2 * (double)std::max<int64_t>(D.U, 1))))) : 0.f);
     if (Cpad > D.C) HIPCHK(hipMemsetAsync(s->l0_e8.p, 0, (size_t)B * Cpad, st));   // pad entries behind the table stay 0
     FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_gfl.as<uint16_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q};
+    STAGE_DONE(ST_S1MAIN);
     if (fpk_centroid_scores(D1, q_s1, s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex, &xe))
       return fail(FP_EUNSUPPORTED, "dim");
   } else {
     if (want_s8) HIPCHK(s->S8.ensure((size_t)B * D.C * sh.Qp));
+    STAGE_DONE(ST_S1MAIN);
     if (fpk_centroid_scores(D1, q_s1, s->S.as<uint16_t>(), B, sh.Qp, want_s8 ? s->S8.as<uint8_t>() : nullptr,
                             s->cmax128.as<uint16_t>(), st, 0, 1, nullptr, &xe))
       return fail(FP_EUNSUPPORTED, "dim");
@@ -910,7 +935,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   if (sh.n_probe >= 1) {
     if (fpk_probe(D, s->S.as<uint16_t>(), sh, has_subset ? s->allow.as<uint32_t>() : nullptr, s->partial.as<unsigned long long>(),
                   P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), s->cmax128.as<uint16_t>(), st,
-                  P.probe_prezeroed, !P.probe_no_fb, P.s1_mode != 0))
+                  P.probe_prezeroed, !P.probe_no_fb, P.s1_mode != 0, lz))
       return fail(FP_EUNSUPPORTED, "n_ivf_probe");
   } else {
     HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result
@@ -1031,12 +1056,12 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       // exact scores of the pilot group (about FP_L0_PILOT x keep documents per query; ties of UB0 at the cut can add more)
       // (each score also lands at the document's candidate position: a pilot member that survives is not scored again)
       fpk_approx(D, s->S.as<uint16_t>(), sh, nullptr, w.pilot_pid, std::min<int64_t>(M, 6 * (int64_t)B * sh.R), w.pilot_approx, st, w.npilot, pcap,
-                 w.cand_approx, w.pilot_idx, s->cand_off.as<int64_t>());
+                 w.cand_approx, w.pilot_idx, s->cand_off.as<int64_t>(), lz);
       fpk_l0_survivors(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
-                       s->surv_pid.as<int32_t>(), s->approx.as<float>(), st);
+                       s->surv_pid.as<int32_t>(), s->approx.as<float>(), st, lz ? lz->slack : nullptr);
       // survivors outside the pilot group (none when the threshold lies above the pilot cut, the usual case)
       fpk_approx(D, s->S.as<uint16_t>(), sh, s->surv_off.as<int64_t>(), w.xpid, std::min<int64_t>(M, 2 * (int64_t)B * sh.R), nullptr, st, w.nextra,
-                 INT64_MAX, s->approx.as<float>(), w.xdst, s->surv_off.as<int64_t>());
+                 INT64_MAX, s->approx.as<float>(), w.xdst, s->surv_off.as<int64_t>(), lz);
     } else {
       const int nch8 = sh.Qp / 32;
       HIPCHK(s->kq.ensure((size_t)M * 4 * (nch8 > 1 ? 1 + nch8 : 1)));
@@ -1046,7 +1071,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       STAGE_DONE(ST_REFINE);
       fpk_approx_q8_cut(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), M, s->q8hist.as<uint32_t>(), s->kq.as<uint32_t>(),
                         s->cut.as<int32_t>(), s->blkcnt2.as<int32_t>(), nblk2, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
-                        s->surv_pid.as<int32_t>(), st);
+                        s->surv_pid.as<int32_t>(), st, lz != nullptr);
     }
     sel_off = s->surv_off.as<int64_t>();
     sel_src = s->surv_pid.as<int32_t>();
@@ -1056,10 +1081,11 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     // grid sized for a few x R survivors per query (measured 1.7 x R at cfg2 after the 8-bit bounds); the kernel walks a
     // grid-stride loop if there are more
     if (P.approx_impl != 2)
-      fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), s->approx.as<float>(), st);
+      fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, std::min<int64_t>(M, 8 * (int64_t)B * sh.R), s->approx.as<float>(), st, nullptr, 0,
+                 nullptr, nullptr, nullptr, lz);
   } else {
     STAGE_DONE(ST_APPROX);
-    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st);
+    fpk_approx(D, s->S.as<uint16_t>(), sh, sel_off, sel_src, M, s->approx.as<float>(), st, nullptr, 0, nullptr, nullptr, nullptr, lz);
     STAGE_DONE(ST_REFINE);
   }
   STAGE_DONE(ST_SELECT);
@@ -1075,8 +1101,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st,
              /*short_lists: one workgroup per query; pays off when there are too few queries to fill the chip anyway (measured: B = 8
-               46 vs 53 us, B = 64 90 vs 71 us)*/ B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B),
-             P.selhist_prezeroed, s->ms_pref.as<int64_t>());
+               46 vs 53 us, B = 64 90 vs 71 us)*/ !lz && B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B),
+             P.selhist_prezeroed, s->ms_pref.as<int64_t>(), lz, &D);
+  if (lz && !s->fold_stats)   // device-resident I/O: the overflow flag travels by itself (host-buffer calls: with the result block)
+    HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, lz->flag, 4, hipMemcpyDeviceToHost, st));
   s->pref_ready = true;   // (whoever edits sel_cnt before S6 -- the sharded search's cut -- clears it)
   STAGE_DONE(ST_MAXSIM);
   return FP_OK;
@@ -1195,10 +1223,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
   int maxB = (int)std::max<size_t>(1, budget / perq);
   if (tr) maxB = 1;
   std::vector<int64_t> sub_off_local;
+  bool eager_retry = false;   // the previous attempt at this sub-batch overflowed a list of the lazy S1: this one runs the eager form
   for (int b0 = 0; b0 < nq; b0 += maxB) {
     const int B = std::min(maxB, nq - b0);
     Pipe P{};
     P.ix = ix; P.s = s; P.sh = make_shape(B, Q, p);
+    P.want_lazy = !tr && !has_subset && !s->probe_fb && !eager_retry && s->lazy_fails < 2;
+    eager_retry = false;
     P.exact_all = tr != nullptr;   // the trace reports the approximate score of every candidate
     hipStream_t st = s->st;
     const int64_t K = p->top_k;
@@ -1213,7 +1244,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
                           P.sh.R <= FP_MAX_SORT;   // (beyond it the final ranking allocates and synchronises: not capturable)
     const size_t qbytes = (size_t)B * Q * D.dim * 2;
     P.probe_no_fb = !tr && !s->probe_fb;
-    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)s->alloc_gen, s->probe_fb ? 2 : 1};
+    int64_t gkey[8] = {B, Q, p->n_ivf_probe, p->n_full_scores, p->top_k, s->spec_cap, (int64_t)s->alloc_gen, (s->probe_fb ? 2 : 1) + (P.want_lazy ? 4 : 0)};
     bool replayed = false;
     if (graph_ok && s->graph.valid && std::equal(gkey, gkey + 8, s->graph.key)) {
       memcpy(s->h_qin.p, queries, qbytes);
@@ -1278,7 +1309,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
                                        reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st,
                                        (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
                                        (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
-                                       s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr))
+                                       s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr,
+                                       P.lazy ? reinterpret_cast<const int32_t*>(s->lz_state.as<uint32_t>() + 2 * B) : nullptr))
       return trc < 0 ? fail(FP_EUNSUPPORTED, "n_queries * max(n_full_scores / 4, 1) >= 2^31 in one sub-batch of the final ranking")
                      : fail(FP_EHIP, "final ranking failed (hip error " + std::to_string(trc) + ")");
     if (dev_io) {
@@ -1330,8 +1362,14 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     if (s1_stats_enabled() && !replayed && !capture && s->s1stats.p) {   // diagnostics: blocking copy after the call's sync
       uint64_t h4[4] = {0, 0, 0, 0};
       HIPCHK(hipMemcpy(h4, s->s1stats.p, 32, hipMemcpyDeviceToHost));
+      if (P.lazy) {   // the lazy form's counters instead: {entries gathered by the selection, maybes recomputed, -, 3 = "lazy"}
+        uint32_t l4[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(l4, s->lz_state.as<uint32_t>() + 2 * B + 4, 16, hipMemcpyDeviceToHost));
+        h4[0] = l4[0]; h4[1] = l4[1]; h4[2] = 0; h4[3] = 0;
+      }
       for (int i = 0; i < 4; ++i) g_last_s1[i] = (b0 == 0 ? 0 : g_last_s1[i]) + h4[i];
     }
+    g_last_lazy = P.lazy ? 1 : (replayed ? -1 : 0);
     // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
     const int64_t M_true = *reinterpret_cast<const int64_t*>(s->h_small.p);
     if (P.probe_no_fb && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 16) != 0) {
@@ -1347,6 +1385,20 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       s->spec_cap = 0;
       b0 -= maxB;
       continue;
+    }
+    // S1's lazy form: a selection list overflowed (masses of near-tied approximate scores) -> the batch's results are void; run it
+    // again with the eager S1.  The flag came down with the result block (host buffers; 0 whenever the batch was not lazy -- a
+    // replayed graph included) or by its own copy (device-resident I/O).
+    {
+      const bool lz_failed = s->fold_stats
+                                 ? reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off)[1 + B] != 0
+                                 : (P.lazy && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 40) != 0);
+      if (lz_failed) {
+        s->lazy_fails++;
+        eager_retry = true;
+        b0 -= maxB;
+        continue;
+      }
     }
     learn_capacity(s, M_true);
     if (graph_ok) {
@@ -1503,8 +1555,9 @@ extern "C" int fp_last_search_counts(int64_t* out, int cap) {
 }
 
 extern "C" int fp_last_s1_counts(uint64_t* out, int cap) {
-  const int n = std::min(cap, 4);
-  for (int i = 0; i < n; ++i) out[i] = g_last_s1[i];
+  const int n = std::min(cap, 5);
+  for (int i = 0; i < n && i < 4; ++i) out[i] = g_last_s1[i];
+  if (n > 4) out[4] = (uint64_t)(int64_t)g_last_lazy;
   return n;
 }
 

@@ -158,11 +158,34 @@ struct FpS1Excess {
 // inside the kernel (centroid rows from the LDS tile, query rows from the MFMA A fragments), before the tile and its by-products
 // (excess bytes, 8-bit bins) leave.  S is then bit-identical to the reference's matmul.
 struct FpS1Exact {
-  int mode;                    // 0 off, 1 certify + repair, 2 (tests) re-evaluate EVERY entry and count the unflagged differences
+  int mode;                    // 0 off, 1 certify + repair, 2 (tests) re-evaluate EVERY entry and count the unflagged differences,
+                               // 3 lazy: upper candidates only, the consumers repair what they use (FpLazyS1 below)
   const float* wcol;           // [B*Qp] absolute window per query column: w0 |q_n| (0 for zero rows: their scores are exact zeros)
   float kappa;                 // relative part of the window
   unsigned long long* stats;   // nullable [4]: flagged entries, repaired values that differ from the MFMA's, entries beyond the
                                // LDS list (slow path), mode 2: unflagged differences
+};
+// S1's LAZY form (round 5; FpS1Exact::mode 3): S1 stores the upper candidate h(x + u) of EVERY score and runs no chain at all; a
+// stored value is the reference's or (rarely) one fp16 step above it.  The consumers settle only what they use:
+//   * the probe lowers its collection threshold by the window (s1_lower16) and re-evaluates the <= 64 collected scores of a
+//     column with the ascending chain before it ranks them (k_probe_merge);
+//   * the bound stages read upper bounds anyway (excess bytes, 8-bit bins);
+//   * k_approx sums the stored column maxima -- an UPPER bound A_up of the approximate score -- and records, per query, the
+//     largest slack A_up - A_lo any scored document can have (slack[b], float bits);
+//   * the selection gathers everything within the slack of the R-th largest A_up, keeps what lies above it by more than the slack
+//     and recomputes the others ("maybes", a few dozen per query) from scratch with ascending chains (k_sel_finish_lz), so that the
+//     selected SET equals the reference's; a list that overflows raises *flag and the caller runs the batch again eagerly.
+struct FpLazyS1 {
+  const float* wcol;        // [B*Qp] w0 |q_n| cmax (as FpS1Exact)
+  float kappa;
+  const uint16_t* qpad;     // [B*Qp][dim] packed queries (unpadded dim)
+  uint32_t* slack;          // [B] float bits, zeroed: max over the scored documents of their slack
+  uint32_t* gcount;         // [B] zeroed: entries gathered for the selection
+  int32_t* gpid;            // [B][gcap]
+  float* gval;              // [B][gcap]
+  int gcap;
+  int32_t* flag;            // zeroed; != 0: a list overflowed -> results of the batch are not to be used
+  uint32_t* stats;          // nullable [4]: gathered, maybes, recomputed values that changed, -
 };
 // the column maxima S1 emits (cmax) are taken over the UPPER candidates h(x + w): >= the exact maximum, at most one fp16 step above
 int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
@@ -174,7 +197,10 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
               bool prezeroed = false /*the region of fpk_probe_zero_region was cleared earlier in the stream*/,
               bool with_fallback = true /*false: a column with too many ties at its threshold leaves *fpk_probe_flag != 0 and NO cells;
                                           the caller reads the flag back and runs the batch again with the fallback*/,
-              bool cmax_upper = false /*cmax128 came from S1's exact mode: upper bounds, at most one fp16 step above an element*/);
+              bool cmax_upper = false /*cmax128 came from S1's exact mode: upper bounds, at most one fp16 step above an element*/,
+              const struct FpLazyS1* lz = nullptr /*S holds S1's lazy form (upper candidates everywhere): sound threshold + exact re-evaluation of the collected scores*/);
+// does this shape take the threshold probe with S1's column maxima (the only probe path the lazy form of S1 serves)?
+bool fpk_probe_lazy_ok(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);
 size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);
 // the counters + overflow flag the threshold probe expects zeroed (inside `partial`); false = this shape takes the other path
 bool fpk_probe_zero_region(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial, void** p, size_t* bytes);
@@ -197,7 +223,8 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 // given, else the whole CSR row.  Scores go to approx[row position] (if given) and/or scat[scat_off[b] + scat_idx[row position]].
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
                 const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt = nullptr, int64_t cap = 0,
-                float* scat = nullptr, const int32_t* scat_idx = nullptr, const int64_t* scat_off = nullptr);
+                float* scat = nullptr, const int32_t* scat_idx = nullptr, const int64_t* scat_off = nullptr,
+                const FpLazyS1* lz = nullptr /*S is S1's lazy form: the scores are upper bounds, lz->slack[b] collects the largest slack*/);
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
@@ -205,7 +232,8 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid,
                           int64_t M, uint32_t* kq, hipStream_t st);
 void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, uint32_t* q8hist, uint32_t* kq,
-                       int32_t* cut, int32_t* blkcnt, int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st);
+                       int32_t* cut, int32_t* blkcnt, int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid, hipStream_t st,
+                       bool lazy_bins = false /*the bins came from S1's lazy form*/);
 // level 0 of S4 (see fp_kernels.hip): scalar excess bound per centroid in LDS, pilot group, survivors
 struct FpL0Scratch {
   uint8_t* floors;      // [B][Qp]
@@ -256,13 +284,19 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st);
 int64_t fpk_l0_pilot_cap();
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
-                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st);
+                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st,
+                      const uint32_t* lz_slack = nullptr /*S1's lazy form: FpLazyS1::slack (the pilot scores are upper bounds)*/);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st,
                 bool short_lists = false /*lists of a few thousand entries: one workgroup per query does the whole radix select*/,
                 bool hist_prezeroed = false,
-                int64_t* pref = nullptr /*the last kernel also writes the [B + 1] prefix of sel_cnt here*/);
+                int64_t* pref = nullptr /*the last kernel also writes the [B + 1] prefix of sel_cnt here*/,
+                const FpLazyS1* lz = nullptr /*approx[] are upper bounds from S1's lazy form (general path only: !short_lists, R <= FP_MAX_SORT)*/,
+                const FpIndexDev* ix = nullptr /*needed with lz: the maybes are recomputed from the index*/);
+// S1's lazy form: can the selection serve this shape, and how many gathered entries per query does it want room for?
+bool fpk_select_lazy_ok(const FpSearchShape& sh);
+int fpk_select_lazy_gcap(const FpSearchShape& sh);
 // ---- fp_maxsim.hip ---------------------------------------------------------------------------
 // per-token norms of a freshly laid-out index (centroids / lut / codes / residuals set in `ix`)
 void fpk_token_norms(const FpIndexDev& ix, uint16_t* norms, hipStream_t st);
@@ -298,7 +332,8 @@ int fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local 
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,
                     int64_t stride, int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid /*[B][top_k]*/,
                     float* out_score, int32_t* out_cnt, hipStream_t st, const int64_t* stat_total = nullptr, const int32_t* stat_per_query = nullptr,
-                    int64_t* stat_out /*[1 + B]: statistics copied next to the results*/ = nullptr);
+                    int64_t* stat_out /*[2 + B]: statistics copied next to the results*/ = nullptr,
+                    const int32_t* stat_flag = nullptr /*-> stat_out[1 + B]*/);
 // sharded helpers (record layouts: include/fastplaid.h)
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
                      hipStream_t st, const int64_t* cand_total = nullptr, int64_t cand_cap = 0, int status = 0);

@@ -158,8 +158,29 @@ __device__ __forceinline__ uint32_t s1_certify(const f16v (&acc)[NA][NB], uint32
     *all_mask = 0u;
     return 0u;
   }
-  uint32_t A = 0u, M = 0u;
   const f2v kap = f2v{kappa, kappa};
+  if (mode == 3) {   // (wave-uniform) lazy form: the upper candidates h(x + u) only -- no flags, no list, no chains (FpS1Exact)
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int j0 = 0; j0 < 8; j0 += 4) {
+        f2v w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = wpair(a, j0 + j);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const f2v x = f2v{acc[a][b][2 * (j0 + jj)], acc[a][b][2 * (j0 + jj) + 1]};
+            const f2v up = x + (__builtin_elementwise_abs(x) * kap + w[jj]);
+            hw[a][b][j0 + jj] = s1_cvt_pk(up.x, up.y);
+          }
+      }
+    *all_mask = 0u;
+    return 0u;
+  }
+  uint32_t A = 0u, M = 0u;
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -215,6 +236,26 @@ __device__ __forceinline__ void s1_chain8(float& acc, const uint4 c, const uint4
                  : "+v"(acc)
                  : "v"(cw[t]), "v"(qw[t]));
 #endif
+}
+
+// ---- the lazy form (FpS1Exact mode 3): what a STORED value s = h(x + u) says about the reference's value t = h(chain) ------------
+// The chain result lies within [x - u, x + u] (the certification window), so t >= h(x - u); and s = h(x + u) puts x + u at or
+// above the midpoint between s and its fp16 predecessor.  Hence t >= RNE16(mid - 2 u) =: s1_lower16(s) <= t <= s.  u is
+// rebuilt from s (w + kappa |x|, |x| <= |s| (1 + 2^-10) + u: the factor 1.01 covers it), the fp32 subtraction is nudged down by
+// more than its own rounding error.  Zero query columns (w == 0) hold exact zeros.  The map is monotone in s.
+__device__ __forceinline__ uint16_t unmono16(uint32_t k) { return (k & 0x8000u) ? (uint16_t)(k ^ 0x8000u) : (uint16_t)~k; }
+__device__ __forceinline__ float s1_u2(float s_abs, float w, float kappa) { return 2.f * (w + 1.01f * kappa * s_abs) + 1e-30f; }
+__device__ __forceinline__ uint16_t s1_lower16(uint16_t stored, float w, float kappa) {
+  if (w == 0.f) return stored;
+  uint32_t k = mono16(stored);
+  if (k == 0u) return stored;
+  uint32_t kp = k - 1u;
+  if (kp == 0x7FFFu) kp = 0x7FFEu;   // (key 0x7FFF is -0, which mono16 folds into +0)
+  const float sf = (float)__builtin_bit_cast(half_t, stored), pf = (float)__builtin_bit_cast(half_t, unmono16(kp));
+  const float mid = 0.5f * sf + 0.5f * pf;   // exact in fp32
+  float lo = mid - s1_u2(__builtin_fabsf(sf), w, kappa);
+  lo = lo - __builtin_fabsf(lo) * 2.4e-7f - 1e-37f;
+  return __builtin_bit_cast(uint16_t, (half_t)lo);
 }
 
 // ---- epilogue of one 128 x 128 output tile, part 1: the fp16 tile (upper candidates) staged in LDS + the column maxima ----------
@@ -495,7 +536,7 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
         for (int j = 0; j < 8; ++j) hw[a][b][j] = s1_cvt_pk(acc[a][b][2 * j], acc[a][b][2 * j + 1]);
   }
   s1_stage<NWC>(hw, smem, tid, c0, C, cmax != nullptr);
-  if (xmode) {
+  if (xmode == 1 || xmode == 2) {
     const uint32_t Aw = A;
     if (xmode == 2) A = Aall;
     if (c0 + wc * (32 * NB) + l31 >= C) A = 0u;   // rows beyond the table are never written
@@ -664,7 +705,8 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     const uint32_t Aw = A;
     if (xe.mode == 2) A = Aall;
     uint32_t listed = 0u, flagged_total = 0u, lbase = 0u;
-    if (xe.mode) {
+    const bool chains = xe.mode == 1 || xe.mode == 2;   // (mode 3, the lazy form: nothing is re-evaluated here)
+    if (chains) {
       // list position of a lane's first entry = exclusive prefix of the lanes' counts (<= 32 each): one ballot per count bit
       const uint32_t cnt = (uint32_t)__popc(A);
       uint32_t off = 0u;
@@ -753,7 +795,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
       }
     }
     s1_stage<2, 4>(hw, cur, tidv, (int64_t)t * 128, C, cmax != nullptr);
-    if (xe.mode && flagged_total <= S1X_CAP && !xe.stats) {
+    if (chains && flagged_total <= S1X_CAP && !xe.stats) {
       // the re-evaluated values go over the staged upper candidates: the lane that ran an entry's chain writes it (the staging
       // stores of the whole wave are older in its LDS queue)
       for (uint32_t p0 = 0; p0 < listed; p0 += 64) {
@@ -764,7 +806,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
           *s1_staged_slot(cur, wr, wc * 64 + (pj >> 3) * 32 + (ls & 31), rr, ls >> 5) = res[idx];
         }
       }
-    } else if (xe.mode) {
+    } else if (chains) {
       // the general form (a wave with more flagged entries than its list holds -- never seen on unit vectors --, or the counters
       // are wanted): every lane walks ITS entries (list positions lbase, lbase + 1, ...); entries beyond the list are re-evaluated
       // here with the centroid row from global memory -- the tile's LDS copy is gone.
@@ -931,7 +973,9 @@ __global__ __launch_bounds__(256) void k_probe_partial(const uint16_t* __restric
 // one wave per (b, q) column: n_probe rounds of "largest key below the previous pick"
 __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __restrict__ partial, int Q, int Qp, int entries_stride,
                                                     int n_probe, int32_t* __restrict__ cells, const int32_t* __restrict__ flag,
-                                                    int run_if, const uint32_t* __restrict__ cnt /*nullable: valid entries per column*/) {
+                                                    int run_if, const uint32_t* __restrict__ cnt /*nullable: valid entries per column*/,
+                                                    const uint16_t* __restrict__ cent /*nullable: S1's lazy form, see below*/,
+                                                    const uint16_t* __restrict__ qpad, int D) {
   int entries = entries_stride;
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
@@ -947,6 +991,36 @@ __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __
   }
   const unsigned long long* src = partial + ((int64_t)b * Qp + q) * entries_stride;
   unsigned long long bound = ~0ull;
+  if (cent) {
+    // S1's lazy form: the collected scores are upper candidates h(x + u).  Every one of them (<= PROBE_CAP = 64: one per lane) is
+    // re-evaluated HERE with the reference's ascending chain, so that the top-n_probe below is taken over the reference's values
+    // (the collect pass took everything that can reach the true cut: k_probe_tau lowered its threshold by the window).
+    unsigned long long mine = 0ull;
+    if (lane < entries) {
+      const unsigned long long k0 = src[lane];
+      const uint32_t cix = 0xFFFFFFFFu - (uint32_t)k0;
+      const uint16_t* crow = cent + (int64_t)cix * D;
+      const uint16_t* qrow = qpad + ((int64_t)b * Qp + q) * D;
+      float ch = 0.f;
+      for (int k = 0; k < D; k += 8) s1_chain8(ch, *reinterpret_cast<const uint4*>(crow + k), *reinterpret_cast<const uint4*>(qrow + k));
+      mine = ((unsigned long long)mono16(__builtin_bit_cast(uint16_t, (half_t)ch)) << 32) | (k0 & 0xFFFFFFFFull);
+    }
+    for (int r = 0; r < n_probe; ++r) {
+      unsigned long long m = (mine < bound) ? mine : 0ull;
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) {
+        unsigned long long o = __shfl_xor(m, s, 64);
+        m = o > m ? o : m;
+      }
+      if (lane == 0) cells[((int64_t)b * Q + q) * n_probe + r] = m ? (int32_t)(0xFFFFFFFFu - (uint32_t)m) : -1;
+      if (m == 0ull) {
+        for (int r2 = r + 1; r2 < n_probe && lane == 0; ++r2) cells[((int64_t)b * Q + q) * n_probe + r2] = -1;
+        break;
+      }
+      bound = m;
+    }
+    return;
+  }
   for (int r = 0; r < n_probe; ++r) {
     unsigned long long m = 0ull;
     for (int i = lane; i < entries; i += 64) {
@@ -1205,7 +1279,8 @@ __global__ __launch_bounds__(256) void k_probe_chunkmax(const uint16_t* __restri
 // on registers (re-reading global memory every round cost 24 us at cfg2).
 template <int KPL>
 __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ cmax, int Q, int Qp, int nchunk, int n_probe,
-                                                  uint32_t* __restrict__ tau /*[B*Qp]*/, int upper /*the maxima are upper bounds, at most one fp16 step above an element*/) {
+                                                  uint32_t* __restrict__ tau /*[B*Qp]*/, int upper /*the maxima are upper bounds, at most one fp16 step above an element*/,
+                                                  const float* __restrict__ wcol /*nullable: S1's lazy form -- the column's window, tau is lowered by s1_lower16*/, float kappa) {
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
   const uint16_t* src = cmax + ((int64_t)b * Qp + q) * nchunk;
@@ -1235,16 +1310,20 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     uint32_t t = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
     // S1's exact mode takes the maxima over the upper candidates of the flagged entries: every chunk then holds an element of
     // at least the fp16 value one step BELOW its maximum, so that is what n_probe elements are guaranteed to reach
-    if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (key 0x7FFF is -0, which mono16 folds into +0)
+    // (lazy form: EVERY stored value is an upper candidate and the window may span several fp16 steps near zero -- the sound
+    // lower end of what an element stored as t can be is s1_lower16)
+    if (wcol) { if (t > 0u) t = mono16(s1_lower16(unmono16(t), wcol[(int64_t)b * Qp + q], kappa)); }
+    else if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (key 0x7FFF is -0, which mono16 folds into +0)
     tau[(int64_t)b * Qp + q] = t;
   }
 }
 
-static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st, int upper = 0) {
+static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st, int upper = 0,
+                             const float* wcol = nullptr, float kappa = 0.f) {
   const dim3 grid((unsigned)(sh.B * sh.Q));
-  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper);
-  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper);
-  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper);   // nchunk <= 4096
+  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa);
+  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa);
+  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa);   // nchunk <= 4096
 }
 
 __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
@@ -1353,6 +1432,10 @@ ProbeLayout probe_layout(const FpIndexDev& ix, const FpSearchShape& sh, int nchu
 }
 }  // namespace
 
+bool fpk_probe_lazy_ok(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk) {
+  const ProbeLayout L = probe_layout(ix, sh, nchunk, nullptr);
+  return L.threshold_ok && sh.n_probe >= 1 && (ix.C + 127) / 128 <= 4096;
+}
 bool fpk_probe_zero_region(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial, void** p, size_t* bytes) {
   const ProbeLayout L = probe_layout(ix, sh, nchunk, partial);
   *p = L.cnt;                     // (16-byte aligned: cols is a multiple of 32)
@@ -1366,7 +1449,7 @@ const int32_t* fpk_probe_flag(const FpIndexDev& ix, const FpSearchShape& sh, int
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
               unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells,
               const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st, bool prezeroed, bool with_fallback,
-              bool cmax_upper) {
+              bool cmax_upper, const FpLazyS1* lz) {
   const int64_t Cw = (ix.C + 31) / 32;
   const ProbeLayout L = probe_layout(ix, sh, nchunk, partial);
   const int NP = L.NP, nch2 = L.nch2;
@@ -1384,8 +1467,9 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     // tau is tighter, and the collect pass skips the 128-row sub-chunks that hold nothing >= tau in any of their 32 columns
     const int nch128 = (int)((ix.C + 127) / 128);
     const bool fused = cmax128 != nullptr && allow == nullptr && nch128 <= 4096;
+    if (lz && !fused) return -2;   // (the caller only asks for the lazy form where the fused threshold probe applies)
     if (fused) {
-      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper ? 1 : 0);
+      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper ? 1 : 0, lz ? lz->wcol : nullptr, lz ? lz->kappa : 0.f);
       hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag, cmax128, nch128);
     } else {
       hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);
@@ -1394,8 +1478,9 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
                          (const uint16_t*)nullptr, 0);
     }
     hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
-                       flag, 0, cnt);
+                       flag, 0, cnt, lz ? ix.centroids : (const uint16_t*)nullptr, lz ? lz->qpad : (const uint16_t*)nullptr, ix.dim);
   } else {
+    if (lz) return -2;
     (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
   }
   // fallback (its kernels exit at once unless the flag is set).  Without it a flagged batch has no cells at all (k_probe_merge
@@ -1414,7 +1499,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     default: launch_probe_partial<32>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
   }
   hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, fb_partial, sh.Q, sh.Qp, nchunk * 8 * NP, sh.n_probe,
-                     cells, flag, 1, (const uint32_t*)nullptr);
+                     cells, flag, 1, (const uint32_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, 0);
   }
   const int64_t n64 = (int64_t)sh.Q * sh.n_probe;
   if (n64 > 0x7FFFFFFFll / 4) return -1;
@@ -1831,13 +1916,24 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 // combined at the end -- a 33-code document is ONE step of row gathers instead of five dependent ones.  For the refine calls
 // of the bound stages (a few thousand documents per query: the chip is short of independent chains, not of lanes; measured at
 // cfg2, S4 refine: 0.457 ms with PPD 1, 0.397 ms with PPD 1 and sixteen times the workgroups, see fpk_approx).
-template <int PPD>
-__global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
+// LZ (S1's lazy form, FpLazyS1): S holds upper candidates, so the sum below is an UPPER bound A_up of the approximate score.  The
+// kernel also bounds how far below it the reference's score can lie: a stored column maximum s exceeds the true one by at most
+// slack(s) = ulp16(s) + 2 u2(s)  (s1_lower16: one fp16 step when the window is small against the step, the window plus a step
+// otherwise; ulp16 is clamped from below at 2^-14, the step at |s| = 2^-4), summed over the real columns -- and keeps the largest
+// such sum over the documents it scores in slack[b] (one guarded atomic per wave).
+__device__ __forceinline__ uint32_t ap_ulp16_pk(uint32_t m) {
+  uint32_t e = m & 0x7C007C00u, r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(e), "v"(0x2C002C00u));
+  return r - 0x28002800u;   // per half: 2^(E - 25) as fp16 bits, E >= 11 (no borrow between the halves)
+}
+template <int PPD, bool LZ = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                 float* __restrict__ approx, const int32_t* __restrict__ cnt, int64_t cap,
                                                 float* __restrict__ scat, const int32_t* __restrict__ scat_idx,
-                                                const int64_t* __restrict__ scat_off) {
+                                                const int64_t* __restrict__ scat_off, uint32_t* __restrict__ slack = nullptr,
+                                                const float* __restrict__ wcol = nullptr, float kappa = 0.f) {
   // candidate lists: rows start at cand_off[b] (CSR) or, without cand_off, at b * cap (fixed-capacity rows); a row holds
   // min(cnt[b], cap) entries when cnt is given, else the whole CSR row.  Results go to approx[row position] (if given) and/or
   // scat[scat_off[b] + scat_idx[row position]].
@@ -1859,6 +1955,17 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
   const int64_t stride = (int64_t)bx * CPB;
   const int nch = Qp / 32;
   int64_t i = (int64_t)bxi * CPB + grp / PPD;
+  float lz_w = 0.f, lz_max = 0.f;   // LZ: 4 w summed over the quad's real columns (+ the constant terms); the largest slack seen
+  if constexpr (LZ) {
+    for (int ch = 0; ch < nch; ++ch)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = ch * 32 + sub * 8 + j;
+        if (q < Q) lz_w += 4.f * wcol[(int64_t)b * Qp + q] + 4e-30f;
+      }
+    lz_w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_w), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    lz_w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_w), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  }
   // Software pipeline over the dependent chain  pid -> offsets -> codes -> rows:
   //   document metadata is fetched one document ahead, the next 8 codes (of this document, or
   //   the first 8 of the next one) are fetched while the current 8 row gathers are in flight,
@@ -1887,6 +1994,7 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     }
     const int32_t* cp = ucodes + u0;
     float total = 0.f;
+    float lz_s = 0.f;
     bool next_loaded = false;
     for (int ch = 0; ch < nch; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
@@ -1954,6 +2062,22 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
       AP_LANE_STEP(0xAA)
       AP_LANE_STEP(0xFF)
 #undef AP_LANE_STEP
+      if constexpr (LZ) {
+        const h2 u0 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m0))), u1 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m1)));
+        const h2 u2 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m2))), u3 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m3)));
+        const float k4 = 4.04f * kappa;
+        lz_s += ((q0 + 0 < Q) ? (float)u0.x : 0.f) + ((q0 + 1 < Q) ? (float)u0.y : 0.f) + ((q0 + 2 < Q) ? (float)u1.x : 0.f) +
+                ((q0 + 3 < Q) ? (float)u1.y : 0.f) + ((q0 + 4 < Q) ? (float)u2.x : 0.f) + ((q0 + 5 < Q) ? (float)u2.y : 0.f) +
+                ((q0 + 6 < Q) ? (float)u3.x : 0.f) + ((q0 + 7 < Q) ? (float)u3.y : 0.f) +
+                k4 * (__builtin_fabsf(c0) + __builtin_fabsf(c1) + __builtin_fabsf(c2) + __builtin_fabsf(c3) + __builtin_fabsf(c4) +
+                      __builtin_fabsf(c5) + __builtin_fabsf(c6) + __builtin_fabsf(c7));
+      }
+    }
+    if constexpr (LZ) {
+      lz_s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_s), 0xB1, 0xF, 0xF, false));
+      lz_s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_s), 0x4E, 0xF, 0xF, false));
+      lz_s += lz_w;
+      lz_max = lz_s > lz_max ? lz_s : lz_max;
     }
     if (!next_loaded && nlen > t0) {  // a quad without codes in this document never reaches the prefetch slot above
 #pragma unroll
@@ -1968,11 +2092,19 @@ __global__ __launch_bounds__(256) void k_approx(const uint16_t* __restrict__ S, 
     u0 = nu0;
     len = nlen;
   }
+  if constexpr (LZ) {
+#pragma unroll
+    for (int x = 32; x > 0; x >>= 1) {
+      const float o = __shfl_xor(lz_max, x, 64);
+      lz_max = o > lz_max ? o : lz_max;
+    }
+    if ((threadIdx.x & 63) == 0 && lz_max > __uint_as_float(slack[b])) atomicMax(&slack[b], __float_as_uint(lz_max));   // (non-negative floats order like their bits)
+  }
 }
 
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
                 const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt, int64_t cap, float* scat,
-                const int32_t* scat_idx, const int64_t* scat_off) {
+                const int32_t* scat_idx, const int64_t* scat_off, const FpLazyS1* lz) {
   if (M <= 0) return;
   // enough blocks to cover the largest per-query candidate list a few times over
   int64_t per_q = (M + sh.B - 1) / sh.B;
@@ -1988,12 +2120,21 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   // (an XCD-affine query assignment was measured slower when every candidate is scored: 8.3 vs 7.6 ms, round 1; and makes no
   // difference for the refine calls of the bound stages, ~6000 documents per query: 0.445 ms either way, round 3 -- their
   // ~200 k row gathers per query hardly repeat a row, FETCH_SIZE equals the logical bytes)
+  if (lz) {
+    if (wide)
+      hipLaunchKernelGGL((k_approx<4, true>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+                         ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, lz->slack, lz->wcol, lz->kappa);
+    else
+      hipLaunchKernelGGL((k_approx<1, true>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+                         ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, lz->slack, lz->wcol, lz->kappa);
+    return;
+  }
   if (wide)
-    hipLaunchKernelGGL(k_approx<4>, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off);
+    hipLaunchKernelGGL((k_approx<4, false>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, (uint32_t*)nullptr, (const float*)nullptr, 0.f);
   else
-    hipLaunchKernelGGL(k_approx<1>, dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off);
+    hipLaunchKernelGGL((k_approx<1, false>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
+                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, (uint32_t*)nullptr, (const float*)nullptr, 0.f);
 }
 
 // ============================================================================================
@@ -2367,7 +2508,7 @@ void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
 // (3)-(4): per-query cut from the histogram of the lower bounds, ordered survivors in surv_off [B+1] / surv_pid
 void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, uint32_t* q8hist /*[B][8192 * Qp/32]*/,
                        uint32_t* kq, int32_t* cut, int32_t* blkcnt, int nblk, int32_t* nsurv, int64_t* surv_off, int32_t* surv_pid,
-                       hipStream_t st) {
+                       hipStream_t st, bool lazy_bins) {
   const int B = sh.B;
   const int nch = sh.Qp / 32;
   const int bins = Q8_BINS_SUM * nch;
@@ -2376,7 +2517,9 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_q8_hist, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_q8_hist, dim3(Q8_HIST_BLOCKS, (unsigned)B), dim3(1024), (size_t)bins * 4, st, kq, cand_off, q8hist, bins);
-  hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, sh.Q, cut, bins);
+  // (S1's lazy form: the bins come from upper candidates, at most one bin above the true one per column (an fp16 step is below
+  // 1/128 wherever a bin is not clamped), so a document's TRUE lower bound is K_lo - Q at worst: the cut moves down by another Q)
+  hipLaunchKernelGGL(k_q8_cut, dim3((unsigned)B), dim3(1024), 0, st, q8hist, cand_off, sh.n_full, sh.R, lazy_bins ? 2 * sh.Q : sh.Q, cut, bins);
   hipLaunchKernelGGL(k_surv_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, kq, cand_off, cut, blkcnt, nblk);
   hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, nsurv, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr,
                      0, (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
@@ -3136,11 +3279,16 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
   }
 }
 
+// S1's lazy form: how far below an upper-bound score `a` a document's true approximate score can lie -- the recorded slack with a
+// margin for its own fp32 rounding and for the rounding of the two fp32 column sums (<= Q additions each, usually exact)
+__device__ __forceinline__ float lz_delta(float slack, float a, int Q) {
+  return slack * 1.01f + (float)Q * 2.4e-7f * (__builtin_fabsf(a) + 1.f);
+}
 // A_T = keep-th largest exact score of the pilot group (radix select over the monotone keys, 4 x 8 bits, LDS histogram)
 // -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).  One workgroup per query.
 __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int32_t* __restrict__ npilot,
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
-                                                 int32_t* __restrict__ cut) {
+                                                 int32_t* __restrict__ cut, const uint32_t* __restrict__ slack /*nullable: S1's lazy form*/) {
   __shared__ uint32_t h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -3186,7 +3334,10 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
     __syncthreads();
   }
   if (tid == 0) {
-    const float at = unmono32(s_prefix);
+    float at = unmono32(s_prefix);
+    // S1's lazy form: the pilot scores are upper bounds A_up; every pilot document's true score is at least A_up - slack[b] (the
+    // largest slack among the documents scored so far, i.e. the pilot group), so the keep-th largest TRUE score is at least this:
+    if (slack) at = at - lz_delta(__uint_as_float(slack[b]), at, Q);
     int32_t c = 0;
     if (at == at) {   // NaN scores: prune nothing
       const double t = floor(128.0 * (double)at + 99.0 * (double)Q) + 1.0;
@@ -3541,9 +3692,9 @@ int64_t fpk_l0_pilot_cap() { return L0_PILOT_MAX; }
 // level 0, second half (the pilot group's exact scores are in w.pilot_approx and, by candidate position, in w.cand_approx):
 // threshold, ordered survivors with the pilot members' scores copied, the others on the extra list (w.xpid / w.xdst / w.nextra)
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
-                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st) {
+                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st, const uint32_t* lz_slack) {
   const int B = sh.B;
-  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr);
+  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr, lz_slack);
   const bool one_launch = w.tickets && (int64_t)w.nblk * B <= FP_TICKET_MAX_WGS;
   hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.thr, w.cut, w.npilot, w.blkcnt,
                      w.blkcntx, w.nblk, one_launch ? w.tickets : (uint32_t*)nullptr, nsurv, w.nextra, B, surv_off);
@@ -3868,6 +4019,184 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
   }
 }
 
+// ---- selection over S1's lazy form (FpLazyS1): approx[] holds UPPER bounds A_up ------------------------------------------------
+// The radix select above ran on A_up: kstar = key of U, the keep-th largest A_up.  With D = the largest slack of any scored
+// document (lz_delta), the keep-th largest TRUE score T lies in [U - D, U], so
+//   * A_up <  U - D : certainly not selected (true score below T)            -> not even gathered;
+//   * A_up >  U + D : certainly selected (true score >= A_up - D > U >= T)   -> straight to the output;
+//   * the rest ("maybes", a few dozen per query): their TRUE scores are recomputed from scratch -- every code of the document
+//     against every query column with the reference's ascending fp32 chain, fp16 rounding, fp16 max, ascending fp32 sum, i.e.
+//     exactly the oracle's approximate score -- and the best keep - #certain of them by (score desc, id asc) complete the set.
+// The selected SET is then the reference's (its exact ties at the cut included); sel_approx holds A_up for the certain ones
+// (nobody reads it on this path).  gathered > gcap or maybes > LZ_MAYBE_MAX: *flag is raised and the caller runs the batch again
+// with the eager S1.
+#define LZ_MAYBE_MAX 1024
+__global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                       const int64_t* __restrict__ cand_off, uint32_t* __restrict__ st, int64_t R,
+                                                       int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
+                                                       const uint32_t* __restrict__ hist, const uint32_t* __restrict__ ext,
+                                                       const uint32_t* __restrict__ slack, uint32_t* __restrict__ gcount,
+                                                       int32_t* __restrict__ gpid, float* __restrict__ gval, int gcap, int Q) {
+  const int b = blockIdx.y;
+  uint32_t* s = st + (int64_t)b * 8;
+  const bool need = s[0] != 0;
+  uint32_t kstar = 0;
+  if (need) {
+    uint32_t k_rem = ext[(int64_t)b * 4 + 3];
+    kstar = ext[(int64_t)b * 4 + 2];
+    sel_scan_local<2>(hist + ((int64_t)2 * gridDim.y + b) * FP_SEL_BINS, kstar, k_rem);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { s[2] = kstar; s[3] = k_rem; }
+  }
+  const uint32_t keep = s[1];
+  const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  uint32_t thr = 0u;
+  if (need) {
+    const float U = unmono32(kstar);
+    const float lo = U - lz_delta(__uint_as_float(slack[b]), U, Q);
+    thr = (lo == lo) ? mono32(lo) : 0u;   // (NaN: gather everything -> overflow -> the eager form)
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = approx[beg + i];
+    if (!need) {  // everything is kept, already in ascending doc-id order
+      if (i < (int64_t)keep) { op[i] = cand_pid[beg + i]; oa[i] = a; }
+      continue;
+    }
+    if (mono32(a) >= thr) {
+      const uint32_t pos = atomicAdd(&gcount[b], 1u);
+      if (pos < (uint32_t)gcap) { gpid[(int64_t)b * gcap + pos] = cand_pid[beg + i]; gval[(int64_t)b * gcap + pos] = a; }
+    }
+  }
+}
+
+// the oracle's approximate score of document `pid` for query b, by one wave: lane = (column q of a 32-column group, code parity)
+__device__ __forceinline__ float lz_exact_approx(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, int D, int Q, int Qp, int b,
+                                                 int32_t pid, const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes, int lane) {
+  const int q = lane & 31, par = lane >> 5;
+  const int64_t u0 = uoff[pid];
+  const int len = (int)(uoff[pid + 1] - u0);
+  float total = 0.f;
+  for (int g = 0; g < Qp / 32; ++g) {
+    const uint16_t* qrow = qpad + ((int64_t)b * Qp + g * 32 + q) * D;
+    float m = NEG_MASK_F;
+    for (int t = par; t < len; t += 2) {
+      const uint16_t* crow = cent + (int64_t)ucodes[u0 + t] * D;
+      float ch = 0.f;
+      for (int k = 0; k < D; k += 8) s1_chain8(ch, *reinterpret_cast<const uint4*>(crow + k), *reinterpret_cast<const uint4*>(qrow + k));
+      const float v = (float)(half_t)ch;
+      m = v > m ? v : m;
+    }
+    const float o = __shfl_xor(m, 32, 64);
+    m = o > m ? o : m;
+    // ascending fp32 sum over the real columns (search.rs:401 as the oracle fixes it), the same in every lane
+    for (int j = 0; j < 32; ++j) {
+      const float v = __shfl(m, j, 64);
+      if (g * 32 + j < Q) total += v;
+    }
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ st, int64_t R, int32_t* __restrict__ sel_pid,
+                                                        float* __restrict__ sel_approx, const uint32_t* __restrict__ slack,
+                                                        const uint32_t* __restrict__ gcount, const int32_t* __restrict__ gpid,
+                                                        const float* __restrict__ gval, int gcap, int32_t* __restrict__ flag,
+                                                        const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, int D, int Q, int Qp,
+                                                        const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
+                                                        uint32_t* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_nin, s_nmay, s_bad;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  uint32_t* s = st + (int64_t)b * 8;
+  if (!s[0]) return;  // nothing selected away
+  const uint32_t keep = s[1];
+  const uint32_t ng_all = gcount[b];
+  const uint32_t ng = ng_all < (uint32_t)gcap ? ng_all : (uint32_t)gcap;
+  int kp2 = 2;
+  while (kp2 < (int)keep) kp2 <<= 1;
+  unsigned long long* kv = reinterpret_cast<unsigned long long*>(smem);                    // [kp2] the selection: id << 32 | score bits
+  unsigned long long* mk = kv + kp2;                                                        // [LZ_MAYBE_MAX] maybes: mono32(score) << 32 | ~id
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  const int32_t* gp = gpid + (int64_t)b * gcap;
+  const float* gv = gval + (int64_t)b * gcap;
+  if (tid == 0) { s_nin = 0u; s_nmay = 0u; s_bad = ng_all > (uint32_t)gcap ? 1u : 0u; }
+  for (int i = tid; i < kp2; i += 1024) kv[i] = ~0ull;
+  __syncthreads();
+  const float U = unmono32(s[2]);
+  const float hi = U + lz_delta(__uint_as_float(slack[b]), U, Q);
+  for (uint32_t i = tid; i < ng; i += 1024) {
+    const float a = gv[i];
+    const int32_t pid = gp[i];
+    if (a > hi) {
+      const uint32_t pos = atomicAdd(&s_nin, 1u);
+      if (pos < keep) kv[pos] = ((unsigned long long)(uint32_t)pid << 32) | (unsigned long long)__float_as_uint(a);
+      else s_bad = 1u;   // (cannot happen: fewer than keep scores exceed U)
+    } else {
+      const uint32_t pos = atomicAdd(&s_nmay, 1u);
+      if (pos < LZ_MAYBE_MAX) mk[pos] = (unsigned long long)(uint32_t)pid;   // (the score follows below)
+    }
+  }
+  __syncthreads();
+  const uint32_t nin = s_nin < keep ? s_nin : keep;
+  uint32_t nmay = s_nmay;
+  if (nmay > LZ_MAYBE_MAX) { nmay = LZ_MAYBE_MAX; if (tid == 0) s_bad = 1u; }
+  if (nin + nmay < keep && tid == 0) s_bad = 1u;   // (cannot happen unless a list overflowed: at least keep scores are >= U)
+  // the maybes' true scores: one wave per document
+  const int wave = tid >> 6, lane = tid & 63;
+  for (uint32_t m = (uint32_t)wave; m < nmay; m += 16u) {
+    const int32_t pid = (int32_t)(uint32_t)mk[m];
+    const float ex = lz_exact_approx(cent, qpad, D, Q, Qp, b, pid, uoff, ucodes, lane);
+    if (lane == 0) mk[m] = ((unsigned long long)mono32(ex) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)pid);
+  }
+  __syncthreads();
+  // best (keep - nin) maybes by (score desc, id asc)
+  {
+    const unsigned long long mine = (uint32_t)tid < nmay ? mk[tid] : 0ull;
+    __syncthreads();
+    const unsigned long long sorted = fp_sort1024_desc(mine, mk);
+    __syncthreads();
+    const uint32_t take = keep - nin;
+    if ((uint32_t)tid < take && (uint32_t)tid < nmay) {
+      const uint32_t pid = 0xFFFFFFFFu - (uint32_t)sorted;
+      kv[nin + tid] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(sorted >> 32)));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s_bad) *flag = 1;
+    if (stats) { atomicAdd(&stats[0], ng_all); atomicAdd(&stats[1], s_nmay); }
+  }
+  // whole selection ascending by doc id (the order every later stage expects)
+  if (kp2 == 1024) {
+    const unsigned long long sorted = ~fp_sort1024_desc(~kv[tid], kv);
+    kv[tid] = sorted;
+    __syncthreads();
+  } else {
+    for (int k = 2; k <= kp2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < kp2; i += 1024) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = kv[i], c = kv[ixj];
+            const bool up = ((i & k) == 0);
+            if ((a > c) == up) { kv[i] = c; kv[ixj] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  for (int i = tid; i < (int)keep; i += 1024) {
+    // (a failed batch -- s_bad -- may hold filler keys: clamp the ids so that nothing downstream indexes out of range; its
+    // results are discarded by the caller)
+    const unsigned long long k = kv[i];
+    op[i] = (k == ~0ull) ? 0 : (int32_t)(k >> 32);
+    oa[i] = __uint_as_float((uint32_t)k);
+  }
+}
+
 // k_sel_init + the three histogram / scan rounds + k_sel_gather in ONE workgroup per query, for lists of a few thousand entries
 // (the survivors of S4's bound stages): nine launches of ~5 us each become one.  Same selstate / output contract as the
 // separate kernels; k_sel_finish / k_sel_collect follow unchanged.
@@ -4033,11 +4362,22 @@ __global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) st[(int64_t)b * 8 + 7] = 1u;
 }
+bool fpk_select_lazy_ok(const FpSearchShape& sh) { return sh.R <= FP_MAX_SORT; }
+int fpk_select_lazy_gcap(const FpSearchShape& sh) {
+  static const int env = [] { const char* e = getenv("FP_LZ_GCAP"); return e ? atoi(e) : 0; }();   // tests: a small list forces the eager re-run
+  if (env > 0) return env;
+  return (int)std::min<int64_t>(2 * sh.R + 1024, 1 << 20);
+}
 size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t) + (size_t)B * 16; }   // three histograms per query + {prefix, k_rem} x 2
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
                 uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
-                bool short_lists, bool hist_prezeroed, int64_t* pref) {
+                bool short_lists, bool hist_prezeroed, int64_t* pref, const FpLazyS1* lz, const FpIndexDev* ixp) {
   const int B = sh.B;
+  const uint16_t* ix_cent = ixp ? ixp->centroids : nullptr;
+  const int ix_dim = ixp ? ixp->dim : 0;
+  const int64_t* ix_uoff = ixp ? ixp->uoff : nullptr;
+  const int32_t* ix_ucodes = ixp ? ixp->ucodes : nullptr;
+  if (lz && (short_lists || sh.R > FP_MAX_SORT || !ixp)) lz = nullptr;   // (callers do not ask for it there)
   if (short_lists) {
     hipLaunchKernelGGL(k_sel_front, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, sh.n_full, sh.R, selstate, sel_pid, sel_approx,
                        tie_pid, sel_cnt);
@@ -4052,6 +4392,25 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   }
   const bool big = sh.R > FP_MAX_SORT;   // beyond k_sel_finish's LDS sort: the ordered single-workgroup collection does the whole job
   if (!hist_prezeroed) (void)hipMemsetAsync(hist, 0, fpk_sel_hist_bytes(B), st);
+  if (lz) {   // (the caller asks for this only when !short_lists and !big)
+    uint32_t* ext = hist + (size_t)3 * B * FP_SEL_BINS;
+    dim3 gh(64, (unsigned)B);
+    hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
+    hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
+    hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
+    hipLaunchKernelGGL(k_sel_gather_lz, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
+                       hist, ext, lz->slack, lz->gcount, lz->gpid, lz->gval, lz->gcap, sh.Q);
+    static std::atomic<uint64_t> lds_ok3{0};
+    fp_allow_big_lds((const void*)k_sel_finish_lz, lds_ok3, 152 * 1024);
+    int kp2 = 2;
+    while (kp2 < (int)sh.R) kp2 <<= 1;
+    hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8 + (size_t)LZ_MAYBE_MAX * 8, st, selstate, sh.R, sel_pid,
+                       sel_approx, lz->slack, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, ix_cent, lz->qpad, ix_dim, sh.Q, sh.Qp, ix_uoff,
+                       ix_ucodes, lz->stats);
+    hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
+                       sel_approx, sel_cnt, pref, B);   // (s[7] == 0: only the count prefix)
+    return;
+  }
   uint32_t* ext = hist + (size_t)3 * B * FP_SEL_BINS;   // [B][4], behind the histograms (fpk_sel_hist_bytes)
   dim3 gh(64, (unsigned)B);
   hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
@@ -4087,13 +4446,17 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
                                                      int64_t stride, int npow2, int64_t top_k, int64_t pid_offset,
                                                      int64_t* __restrict__ out_pid, float* __restrict__ out_score,
                                                      int32_t* __restrict__ out_cnt, const int64_t* __restrict__ stat_total,
-                                                     const int32_t* __restrict__ stat_per_query, int64_t* __restrict__ stat_out) {
+                                                     const int32_t* __restrict__ stat_per_query, int64_t* __restrict__ stat_out,
+                                                     const int32_t* __restrict__ stat_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // statistics of the search that travel with the results (one copy to the host instead of three): [0] = *stat_total,
-  // [1 + b] = stat_per_query[b]
+  // [1 + b] = stat_per_query[b], [1 + B] = *stat_flag (the lazy S1's overflow flag)
   if (stat_out && threadIdx.x == 0) {
     stat_out[1 + blockIdx.x] = stat_per_query ? (int64_t)stat_per_query[blockIdx.x] : 0;
-    if (blockIdx.x == 0) stat_out[0] = stat_total ? *stat_total : 0;
+    if (blockIdx.x == 0) {
+      stat_out[0] = stat_total ? *stat_total : 0;
+      stat_out[1 + gridDim.x] = stat_flag ? (int64_t)*stat_flag : 0;
+    }
   }
   // all LDS in the dynamic region (a static __shared__ in front would mis-align the 8-byte keys)
   int* s_validp = reinterpret_cast<int*>(smem);
@@ -4150,24 +4513,25 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
   if (threadIdx.x == 0) out_cnt[b] = m;
 }
 
-__global__ void k_final_stats(const int64_t* __restrict__ stat_total, const int32_t* __restrict__ stat_per_query, int B, int64_t* __restrict__ stat_out) {
+__global__ void k_final_stats(const int64_t* __restrict__ stat_total, const int32_t* __restrict__ stat_per_query, int B, int64_t* __restrict__ stat_out,
+                              const int32_t* __restrict__ stat_flag) {
   for (int b = threadIdx.x; b < B; b += blockDim.x) stat_out[1 + b] = stat_per_query ? (int64_t)stat_per_query[b] : 0;
-  if (threadIdx.x == 0) stat_out[0] = stat_total ? *stat_total : 0;
+  if (threadIdx.x == 0) { stat_out[0] = stat_total ? *stat_total : 0; stat_out[1 + B] = stat_flag ? (int64_t)*stat_flag : 0; }
 }
 int fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
                    int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
-                   hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out) {
+                   hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out, const int32_t* stat_flag) {
   int np2 = next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
   if (stride > FP_MAX_SORT) {   // beyond the LDS sort: segmented device radix sort (rare: n_full_scores > 65536)
-    if (stat_out) hipLaunchKernelGGL(k_final_stats, dim3(1), dim3(256), 0, st, stat_total, stat_per_query, B, stat_out);
+    if (stat_out) hipLaunchKernelGGL(k_final_stats, dim3(1), dim3(256), 0, st, stat_total, stat_per_query, B, stat_out, stat_flag);
     // (allocates 2 * B * stride keys and synchronises; -1: B * stride does not fit its 32-bit segment offsets -- nothing was written)
     return fps_final_topk_big(score, pid_local, pid_global, cnt, stride, B, top_k, pid_offset, out_pid, out_score, out_cnt, st);
   }
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_topk, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,
-                     top_k, pid_offset, out_pid, out_score, out_cnt, stat_total, stat_per_query, stat_out);
+                     top_k, pid_offset, out_pid, out_score, out_cnt, stat_total, stat_per_query, stat_out, stat_flag);
   return 0;
 }
 

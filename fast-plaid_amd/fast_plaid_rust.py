@@ -342,10 +342,14 @@ def last_search_counts() -> dict:
 
 
 def last_s1_counts() -> dict:
-    """fp_last_s1_counts (FP_S1_STATS in the environment): the certification counters of S1."""
-    out = (C.c_uint64 * 4)()
-    N.lib().fp_last_s1_counts(C.cast(out, C.c_void_p), 4)
-    return dict(flagged=int(out[0]), changed=int(out[1]), slow_path=int(out[2]), unflagged_differences=int(out[3]))
+    """fp_last_s1_counts (FP_S1_STATS in the environment): the certification counters of S1 -- or, when the last batch ran S1's
+    lazy form (lazy == 1), flagged = entries the selection gathered, changed = maybes it recomputed from scratch.  lazy is
+    reported without FP_S1_STATS too (-1: the batch was a replayed graph)."""
+    out = (C.c_uint64 * 5)()
+    N.lib().fp_last_s1_counts(C.cast(out, C.c_void_p), 5)
+    lazy = int(out[4])
+    return dict(flagged=int(out[0]), changed=int(out[1]), slow_path=int(out[2]), unflagged_differences=int(out[3]),
+                lazy=lazy - (1 << 64) if lazy >= (1 << 63) else lazy)
 
 
 def export_index_arrays(index: PyLoadedIndex, centroids=None, bucket_weights=None) -> dict:

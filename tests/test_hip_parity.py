@@ -442,6 +442,22 @@ def test_without_tickets_and_with_every_score_reevaluated(fp):
         assert r.returncode == 0 and "Q8_OK" in r.stdout, str(extra) + r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("extra,expect", [({}, 1), ({"FP_APPROX_IMPL": "l0"}, 1), ({"FP_APPROX_IMPL": "q8"}, 1), ({"FP_APPROX_IMPL": "exact"}, 1),
+                                          ({"FP_LZ_GCAP": "3"}, 0), ({"FP_S1_EXACT": "1"}, 0), ({"FP_S1_STREAM": "0"}, 1)])
+def test_lazy_centroid_scores(fp, extra, expect):
+    """S1's lazy form (round 5: the centroid scores leave S1 as upper candidates h(x + u), no chain runs there; the probe
+    re-evaluates the handful of scores it ranks, the selection recomputes the few documents whose upper-bound score lies within
+    the slack of the cut) must give exactly what the eager form gives: fp_search (lazy) == fp_search_trace (eager) bit for bit and
+    the oracle's ids, for every form of S4, with both S1 kernels, with an unnormalised query and zero rows; a selection list that
+    overflows (FP_LZ_GCAP=3) sends the batch round again eagerly; FP_S1_EXACT=1 keeps everything eager."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LAZY_EXPECT=str(expect), **extra)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "lazy_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "LAZY_OK" in r.stdout, str(extra) + r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("kernel", ["stream", "one_tile"])
 def test_centroid_scores_exact_streaming_kernel(fp, kernel):
     """S1's exact mode under the traces, with the streaming kernel (the default for every table since round 4: 1 .. 8 tiles
