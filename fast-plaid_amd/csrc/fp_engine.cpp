@@ -144,7 +144,7 @@ struct Scratch : ScratchGen {
   DevBuf qin, qpad, S, partial, cells, ucells, ncells, allow, subbm, invalid, sub_ids, sub_off, bitmap, blkcnt, ncand,
       cand_off, cand_pid, approx, hist, selstate, sel_pid, sel_approx, sel_cnt, tie_pid, exact, out_pid, out_score, out_cnt, tmpf, tmpp,
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
-      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats, qpad_s1, lz_state, lz_gpid, lz_gval;
+      l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats, qpad_s1, lz_state, lz_gpid, lz_gval, lz_slackq;
   HostBuf h_out, h_small;
   int lazy_fails = 0;           // batches whose lazy-S1 selection lists overflowed (run again eagerly); two of them switch the lazy form off for this scratch
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
@@ -220,7 +220,7 @@ struct Scratch : ScratchGen {
     out_all.release();
     for (DevBuf* b : {&S8, &cmax128, &kq, &q8hist, &cut, &blkcnt2, &nsurv, &surv_off, &surv_pid, &l0_floors, &l0_F, &l0_e8, &l0_esc, &l0_ub,
                       &l0_hist, &l0_npilot, &l0_pilot_pid, &l0_pilot_approx, &l0_pilot_idx, &l0_capprox, &l0_thr, &l0_nextra, &l0_xpid, &l0_xdst, &l0_blkx, &Ssample, &l0_gfl, &u_cnt, &spec_total, &sh_lmarks, &sh_lnmark, &sh_x, &sh_xall, &ms_uncm, &ms_cm16, &ms_unc, &ms_flags, &ms_pref, &ms_marks,
-                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats, &qpad_s1, &lz_state, &lz_gpid, &lz_gval})
+                      &ms_nmark, &sh_rec, &sh_all, &tickets, &ms_flat, &l0_ubp, &wcol, &s1stats, &qpad_s1, &lz_state, &lz_gpid, &lz_gval, &lz_slackq})
       b->release();
     h_out.release();
     h_small.release();
@@ -805,13 +805,15 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   }
   // S1's lazy form (FpLazyS1): where the threshold probe and the general selection serve the shape
   static const int s1x_env = [] { const char* e = getenv("FP_S1_EXACT"); return e ? atoi(e) : 3; }();
-  P.lazy = P.want_lazy && s1x_env == 3 && sh.Qp <= 128 && fpk_probe_lazy_ok(D, sh, P.nchunk) && fpk_select_lazy_ok(sh) && D.ucodes != nullptr;
-  const size_t lz_bytes = ((size_t)(2 * B + 8) * 4 + 15) & ~(size_t)15;   // [B] slack | [B] gathered | flag, pad x 3 | stats x 4
+  P.lazy = P.want_lazy && s1x_env == 3 && sh.Qp <= 128 && D.C < (1ll << 24) && fpk_probe_lazy_ok(D, sh, P.nchunk) && fpk_select_lazy_ok(sh) &&
+           D.ucodes != nullptr;   // (C < 2^24: k_lz_exact's pair list packs code << 8 | column)
+  const size_t lz_bytes = ((size_t)(2 * B + 8) * 4 + 15) & ~(size_t)15;   // zeroed: [B] negative-maximum flags | [B] maybes | flag, pad x 3 | stats x 4
   const int lz_gcap = fpk_select_lazy_gcap(sh);
   if (P.lazy) {
     HIPCHK(s->lz_state.ensure(lz_bytes));
     HIPCHK(s->lz_gpid.ensure((size_t)B * lz_gcap * 4));
     HIPCHK(s->lz_gval.ensure((size_t)B * lz_gcap * 4));
+    HIPCHK(s->lz_slackq.ensure((size_t)2 * B * sh.Qp * 4));
     if (!zl.add(s->lz_state.p, lz_bytes)) HIPCHK(hipMemsetAsync(s->lz_state.p, 0, lz_bytes, st));
   }
   // S1 exact mode (FpS1Exact): certification window w0 |q_n| + kappa |x| around the MFMA result; FP_S1_EXACT=0 switches the
@@ -846,12 +848,14 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   FpLazyS1 lzs{};
   if (P.lazy) {
     uint32_t* lzw = s->lz_state.as<uint32_t>();
-    lzs = FpLazyS1{s->wcol.as<float>(), xe.kappa, s->qpad.as<uint16_t>(), lzw, lzw + B, s->lz_gpid.as<int32_t>(), s->lz_gval.as<float>(), lz_gcap,
+    lzs = FpLazyS1{s->wcol.as<float>(), xe.kappa, 1.0f / (s1x_w0 * dim_scale), s->qpad.as<uint16_t>(), nullptr, s->lz_slackq.as<float>(),
+                   s->lz_slackq.as<float>() + (size_t)B * sh.Qp, lzw, lzw + B, s->lz_gpid.as<int32_t>(), s->lz_gval.as<float>(), lz_gcap,
                    reinterpret_cast<int32_t*>(lzw + 2 * B), s1x_stats ? lzw + 2 * B + 4 : nullptr};
   }
   const FpLazyS1* lz = P.lazy ? &lzs : nullptr;
   STAGE_DONE(ST_CENTROID);
   HIPCHK(s->S.ensure((size_t)B * D.C * sh.Qp * 2));
+  lzs.S = s->S.as<uint16_t>();
   // by-products of S1: 8-bit bins for S4's bound stage (decided for real once the candidate count is known) and
   // per-128-centroid column maxima for the threshold probe
   // FP_APPROX_IMPL: exact | q8 | l0 force a form of S4 (tests); otherwise chosen below from the table size and the candidate count
@@ -1058,7 +1062,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
       fpk_approx(D, s->S.as<uint16_t>(), sh, nullptr, w.pilot_pid, std::min<int64_t>(M, 6 * (int64_t)B * sh.R), w.pilot_approx, st, w.npilot, pcap,
                  w.cand_approx, w.pilot_idx, s->cand_off.as<int64_t>(), lz);
       fpk_l0_survivors(sh, s->cand_off.as<int64_t>(), s->cand_pid.as<int32_t>(), w, s->nsurv.as<int32_t>(), s->surv_off.as<int64_t>(),
-                       s->surv_pid.as<int32_t>(), s->approx.as<float>(), st, lz ? lz->slack : nullptr);
+                       s->surv_pid.as<int32_t>(), s->approx.as<float>(), st, lz);
       // survivors outside the pilot group (none when the threshold lies above the pilot cut, the usual case)
       fpk_approx(D, s->S.as<uint16_t>(), sh, s->surv_off.as<int64_t>(), w.xpid, std::min<int64_t>(M, 2 * (int64_t)B * sh.R), nullptr, st, w.nextra,
                  INT64_MAX, s->approx.as<float>(), w.xdst, s->surv_off.as<int64_t>(), lz);
@@ -1365,7 +1369,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       if (P.lazy) {   // the lazy form's counters instead: {entries gathered by the selection, maybes recomputed, -, 3 = "lazy"}
         uint32_t l4[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(l4, s->lz_state.as<uint32_t>() + 2 * B + 4, 16, hipMemcpyDeviceToHost));
-        h4[0] = l4[0]; h4[1] = l4[1]; h4[2] = 0; h4[3] = 0;
+        h4[0] = l4[0]; h4[1] = l4[1]; h4[2] = l4[2]; h4[3] = l4[3];   // certain, maybes, most maybes of one query, (code, column) pairs re-evaluated
       }
       for (int i = 0; i < 4; ++i) g_last_s1[i] = (b0 == 0 ? 0 : g_last_s1[i]) + h4[i];
     }

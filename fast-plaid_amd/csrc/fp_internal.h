@@ -170,22 +170,26 @@ struct FpS1Exact {
 //   * the probe lowers its collection threshold by the window (s1_lower16) and re-evaluates the <= 64 collected scores of a
 //     column with the ascending chain before it ranks them (k_probe_merge);
 //   * the bound stages read upper bounds anyway (excess bytes, 8-bit bins);
-//   * k_approx sums the stored column maxima -- an UPPER bound A_up of the approximate score -- and records, per query, the
-//     largest slack A_up - A_lo any scored document can have (slack[b], float bits);
+//   * k_approx sums the stored column maxima -- an UPPER bound A_up of the approximate score; how far below it the reference's
+//     score can lie is bounded per query from the column maxima (tight / loose / negflag below);
 //   * the selection gathers everything within the slack of the R-th largest A_up, keeps what lies above it by more than the slack
 //     and recomputes the others ("maybes", a few dozen per query) from scratch with ascending chains (k_sel_finish_lz), so that the
 //     selected SET equals the reference's; a list that overflows raises *flag and the caller runs the batch again eagerly.
 struct FpLazyS1 {
   const float* wcol;        // [B*Qp] w0 |q_n| cmax (as FpS1Exact)
   float kappa;
+  float inv_w0;             // 1 / (w0 x dim scale): wcol * inv_w0 = |q_n| cmax, the bound on any |score| of the column
   const uint16_t* qpad;     // [B*Qp][dim] packed queries (unpadded dim)
-  uint32_t* slack;          // [B] float bits, zeroed: max over the scored documents of their slack
-  uint32_t* gcount;         // [B] zeroed: entries gathered for the selection
-  int32_t* gpid;            // [B][gcap]
-  float* gval;              // [B][gcap]
+  const uint16_t* S;        // [B][C][Qp] the stored scores (upper candidates)
+  float* tight;             // [B*Qp] per-column slack bound from the column's overall maximum (k_probe_tau); valid for non-negative maxima
+  float* loose;             // [B*Qp] ... from the norm bound: valid for any value
+  uint32_t* negflag;        // [B] zeroed; set by k_approx when a scored document has a negative column maximum
+  uint32_t* gcount;         // [B] zeroed: maybes gathered by the selection
+  int32_t* gpid;            // [B][gcap] their ids
+  float* gval;              // [B][gcap] ... and recomputed scores
   int gcap;
   int32_t* flag;            // zeroed; != 0: a list overflowed -> results of the batch are not to be used
-  uint32_t* stats;          // nullable [4]: gathered, maybes, recomputed values that changed, -
+  uint32_t* stats;          // nullable [4]: certain entries, maybes, -, -
 };
 // the column maxima S1 emits (cmax) are taken over the UPPER candidates h(x + w): >= the exact maximum, at most one fp16 step above
 int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S, int B, int Qp, uint8_t* S8, uint16_t* cmax,
@@ -224,7 +228,7 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off,
                 const int32_t* cand_pid, int64_t M, float* approx, hipStream_t st, const int32_t* cnt = nullptr, int64_t cap = 0,
                 float* scat = nullptr, const int32_t* scat_idx = nullptr, const int64_t* scat_off = nullptr,
-                const FpLazyS1* lz = nullptr /*S is S1's lazy form: the scores are upper bounds, lz->slack[b] collects the largest slack*/);
+                const FpLazyS1* lz = nullptr /*S is S1's lazy form: the scores are upper bounds; lz->negflag[b] is raised by a negative column maximum*/);
 // top-R selection by (approx desc, doc id asc); output in ascending doc id order
 // bound-and-refine front of S4 (see fp_kernels.hip): 8-bit bins of S, per-candidate bin sums, per-query cut, ordered survivors
 #define FP_SURV_CHUNK 2048
@@ -285,7 +289,7 @@ void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_
 int64_t fpk_l0_pilot_cap();
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
                       int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st,
-                      const uint32_t* lz_slack = nullptr /*S1's lazy form: FpLazyS1::slack (the pilot scores are upper bounds)*/);
+                      const FpLazyS1* lz = nullptr /*S1's lazy form: the pilot scores are upper bounds*/);
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st,

@@ -1280,12 +1280,16 @@ __global__ __launch_bounds__(256) void k_probe_chunkmax(const uint16_t* __restri
 template <int KPL>
 __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ cmax, int Q, int Qp, int nchunk, int n_probe,
                                                   uint32_t* __restrict__ tau /*[B*Qp]*/, int upper /*the maxima are upper bounds, at most one fp16 step above an element*/,
-                                                  const float* __restrict__ wcol /*nullable: S1's lazy form -- the column's window, tau is lowered by s1_lower16*/, float kappa) {
+                                                  const float* __restrict__ wcol /*nullable: S1's lazy form -- the column's window, tau is lowered by s1_lower16*/, float kappa,
+                                                  float* __restrict__ lz_tight /*[B*Qp], with wcol*/, float* __restrict__ lz_loose, float inv_w0) {
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
   const uint16_t* src = cmax + ((int64_t)b * Qp + q) * nchunk;
   if (nchunk < n_probe) {
-    if (lane == 0) tau[(int64_t)b * Qp + q] = 0u;
+    if (lane == 0) {
+      tau[(int64_t)b * Qp + q] = 0u;
+      if (wcol) { lz_tight[(int64_t)b * Qp + q] = __builtin_inff(); lz_loose[(int64_t)b * Qp + q] = __builtin_inff(); }   // (never with the lazy form: fpk_probe_lazy_ok)
+    }
     return;
   }
   uint32_t key[KPL];   // (mono16 << 12 | reversed chunk index): unique, chunks < 4096; 0 = no chunk
@@ -1294,7 +1298,7 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     const int i = lane + 64 * j;
     key[j] = (i < nchunk) ? ((mono16(src[i]) << 12) | (uint32_t)(nchunk - 1 - i)) : 0u;
   }
-  uint32_t bound = 0xFFFFFFFFu, m = 0;
+  uint32_t bound = 0xFFFFFFFFu, m = 0, m_first = 0;
   for (int r = 0; r < n_probe; ++r) {
     m = 0;
 #pragma unroll
@@ -1305,6 +1309,30 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
       m = o > m ? o : m;
     }
     bound = m;
+    if (r == 0) m_first = m;
+  }
+  if (wcol && lane == 0) {
+    // S1's lazy form, the selection's slack (FpLazyS1): a stored column maximum s of a document exceeds the reference's by at most
+    // ulp16(s) + 2 u2(s) (s1_lower16: one fp16 step while the window is small against the step, window + step otherwise; ulp16
+    // clamped from below at 2^-14).  tight: s <= the column's overall maximum (the first pick above), valid while s >= 0; loose: any
+    // |s| <= |q| |c|max = wcol / w0.  Zero columns hold exact zeros.
+    const float w = wcol[(int64_t)b * Qp + q];
+    float tg = 0.f, ls = 0.f;
+    if (w > 0.f) {
+      const uint16_t hmax = unmono16(m_first >> 12);
+      const float smax = __builtin_fabsf((float)__builtin_bit_cast(half_t, hmax));
+      uint32_t e = hmax & 0x7C00u;
+      e = (e < 0x2C00u ? 0x2C00u : e) - 0x2800u;
+      tg = (float)__builtin_bit_cast(half_t, (uint16_t)e) + 2.f * s1_u2(smax, w, kappa);
+      const float bq = w * inv_w0 * 1.002f;
+      int ex = 0;
+      (void)__builtin_frexpf(bq, &ex);   // bq = f * 2^ex, f in [0.5, 1): values below 2^ex have fp16 steps of at most 2^(ex - 11)
+      ex = ex - 11 < -14 ? -14 : ex - 11;
+      ls = __builtin_ldexpf(1.f, ex) + 2.f * s1_u2(bq, w, kappa);
+      if (!(ls >= tg)) ls = tg;   // (NaN / a maximum beyond the norm bound: keep the larger)
+    }
+    lz_tight[(int64_t)b * Qp + q] = tg;
+    lz_loose[(int64_t)b * Qp + q] = ls;
   }
   if (lane == 0) {
     uint32_t t = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
@@ -1319,11 +1347,15 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
 }
 
 static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st, int upper = 0,
-                             const float* wcol = nullptr, float kappa = 0.f) {
+                             const FpLazyS1* lz = nullptr) {
   const dim3 grid((unsigned)(sh.B * sh.Q));
-  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa);
-  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa);
-  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa);   // nchunk <= 4096
+  const float* wcol = lz ? lz->wcol : nullptr;
+  const float kappa = lz ? lz->kappa : 0.f, inv_w0 = lz ? lz->inv_w0 : 0.f;
+  float* tg = lz ? lz->tight : nullptr;
+  float* ls = lz ? lz->loose : nullptr;
+  if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa, tg, ls, inv_w0);
+  else if (nchunk <= 64 * 16) hipLaunchKernelGGL(k_probe_tau<16>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa, tg, ls, inv_w0);
+  else hipLaunchKernelGGL(k_probe_tau<64>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa, tg, ls, inv_w0);   // nchunk <= 4096
 }
 
 __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
@@ -1469,7 +1501,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     const bool fused = cmax128 != nullptr && allow == nullptr && nch128 <= 4096;
     if (lz && !fused) return -2;   // (the caller only asks for the lazy form where the fused threshold probe applies)
     if (fused) {
-      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper ? 1 : 0, lz ? lz->wcol : nullptr, lz ? lz->kappa : 0.f);
+      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper ? 1 : 0, lz);
       hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag, cmax128, nch128);
     } else {
       hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);
@@ -1916,24 +1948,17 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
 // combined at the end -- a 33-code document is ONE step of row gathers instead of five dependent ones.  For the refine calls
 // of the bound stages (a few thousand documents per query: the chip is short of independent chains, not of lanes; measured at
 // cfg2, S4 refine: 0.457 ms with PPD 1, 0.397 ms with PPD 1 and sixteen times the workgroups, see fpk_approx).
-// LZ (S1's lazy form, FpLazyS1): S holds upper candidates, so the sum below is an UPPER bound A_up of the approximate score.  The
-// kernel also bounds how far below it the reference's score can lie: a stored column maximum s exceeds the true one by at most
-// slack(s) = ulp16(s) + 2 u2(s)  (s1_lower16: one fp16 step when the window is small against the step, the window plus a step
-// otherwise; ulp16 is clamped from below at 2^-14, the step at |s| = 2^-4), summed over the real columns -- and keeps the largest
-// such sum over the documents it scores in slack[b] (one guarded atomic per wave).
-__device__ __forceinline__ uint32_t ap_ulp16_pk(uint32_t m) {
-  uint32_t e = m & 0x7C007C00u, r;
-  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(e), "v"(0x2C002C00u));
-  return r - 0x28002800u;   // per half: 2^(E - 25) as fp16 bits, E >= 11 (no borrow between the halves)
-}
+// LZ (S1's lazy form, FpLazyS1): S holds upper candidates, so the sum below is an UPPER bound A_up of the approximate score.  How far
+// the reference's score can lie below it is bounded per QUERY from the column maxima (k_probe_tau: lz_tight) -- valid as long as
+// every column maximum of every scored document is non-negative, which this kernel checks on its way (negflag[b] = 1 otherwise:
+// the consumers then take the bound that holds for any value, lz_loose).
 template <int PPD, bool LZ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_approx(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                 const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_pid,
                                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                                 float* __restrict__ approx, const int32_t* __restrict__ cnt, int64_t cap,
                                                 float* __restrict__ scat, const int32_t* __restrict__ scat_idx,
-                                                const int64_t* __restrict__ scat_off, uint32_t* __restrict__ slack = nullptr,
-                                                const float* __restrict__ wcol = nullptr, float kappa = 0.f) {
+                                                const int64_t* __restrict__ scat_off, uint32_t* __restrict__ negflag = nullptr) {
   // candidate lists: rows start at cand_off[b] (CSR) or, without cand_off, at b * cap (fixed-capacity rows); a row holds
   // min(cnt[b], cap) entries when cnt is given, else the whole CSR row.  Results go to approx[row position] (if given) and/or
   // scat[scat_off[b] + scat_idx[row position]].
@@ -1955,17 +1980,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int64_t stride = (int64_t)bx * CPB;
   const int nch = Qp / 32;
   int64_t i = (int64_t)bxi * CPB + grp / PPD;
-  float lz_w = 0.f, lz_max = 0.f;   // LZ: 4 w summed over the quad's real columns (+ the constant terms); the largest slack seen
-  if constexpr (LZ) {
-    for (int ch = 0; ch < nch; ++ch)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int q = ch * 32 + sub * 8 + j;
-        if (q < Q) lz_w += 4.f * wcol[(int64_t)b * Qp + q] + 4e-30f;
-      }
-    lz_w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_w), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-    lz_w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_w), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-  }
   // Software pipeline over the dependent chain  pid -> offsets -> codes -> rows:
   //   document metadata is fetched one document ahead, the next 8 codes (of this document, or
   //   the first 8 of the next one) are fetched while the current 8 row gathers are in flight,
@@ -1994,7 +2008,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     const int32_t* cp = ucodes + u0;
     float total = 0.f;
-    float lz_s = 0.f;
     bool next_loaded = false;
     for (int ch = 0; ch < nch; ++ch) {
       h2 m0 = neg2, m1 = neg2, m2 = neg2, m3 = neg2;
@@ -2062,22 +2075,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       AP_LANE_STEP(0xAA)
       AP_LANE_STEP(0xFF)
 #undef AP_LANE_STEP
-      if constexpr (LZ) {
-        const h2 u0 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m0))), u1 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m1)));
-        const h2 u2 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m2))), u3 = u32_as_h2(ap_ulp16_pk(h2_as_u32(m3)));
-        const float k4 = 4.04f * kappa;
-        lz_s += ((q0 + 0 < Q) ? (float)u0.x : 0.f) + ((q0 + 1 < Q) ? (float)u0.y : 0.f) + ((q0 + 2 < Q) ? (float)u1.x : 0.f) +
-                ((q0 + 3 < Q) ? (float)u1.y : 0.f) + ((q0 + 4 < Q) ? (float)u2.x : 0.f) + ((q0 + 5 < Q) ? (float)u2.y : 0.f) +
-                ((q0 + 6 < Q) ? (float)u3.x : 0.f) + ((q0 + 7 < Q) ? (float)u3.y : 0.f) +
-                k4 * (__builtin_fabsf(c0) + __builtin_fabsf(c1) + __builtin_fabsf(c2) + __builtin_fabsf(c3) + __builtin_fabsf(c4) +
-                      __builtin_fabsf(c5) + __builtin_fabsf(c6) + __builtin_fabsf(c7));
+      if constexpr (LZ) {   // (columns beyond Q are zero query rows: their maxima are +0)
+        if ((h2_as_u32(m0) | h2_as_u32(m1) | h2_as_u32(m2) | h2_as_u32(m3)) & 0x80008000u) negflag[b] = 1u;
       }
-    }
-    if constexpr (LZ) {
-      lz_s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_s), 0xB1, 0xF, 0xF, false));
-      lz_s += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lz_s), 0x4E, 0xF, 0xF, false));
-      lz_s += lz_w;
-      lz_max = lz_s > lz_max ? lz_s : lz_max;
     }
     if (!next_loaded && nlen > t0) {  // a quad without codes in this document never reaches the prefetch slot above
 #pragma unroll
@@ -2091,14 +2091,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     u0 = nu0;
     len = nlen;
-  }
-  if constexpr (LZ) {
-#pragma unroll
-    for (int x = 32; x > 0; x >>= 1) {
-      const float o = __shfl_xor(lz_max, x, 64);
-      lz_max = o > lz_max ? o : lz_max;
-    }
-    if ((threadIdx.x & 63) == 0 && lz_max > __uint_as_float(slack[b])) atomicMax(&slack[b], __float_as_uint(lz_max));   // (non-negative floats order like their bits)
   }
 }
 
@@ -2123,18 +2115,18 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   if (lz) {
     if (wide)
       hipLaunchKernelGGL((k_approx<4, true>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                         ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, lz->slack, lz->wcol, lz->kappa);
+                         ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, lz->negflag);
     else
       hipLaunchKernelGGL((k_approx<1, true>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                         ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, lz->slack, lz->wcol, lz->kappa);
+                         ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, lz->negflag);
     return;
   }
   if (wide)
     hipLaunchKernelGGL((k_approx<4, false>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, (uint32_t*)nullptr, (const float*)nullptr, 0.f);
+                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, (uint32_t*)nullptr);
   else
     hipLaunchKernelGGL((k_approx<1, false>), dim3((unsigned)bx, (unsigned)sh.B), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, cand_off, cand_pid,
-                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, (uint32_t*)nullptr, (const float*)nullptr, 0.f);
+                       ix.uoff, ix.ucodes, approx, cnt, cap, scat, scat_idx, scat_off, (uint32_t*)nullptr);
 }
 
 // ============================================================================================
@@ -3284,13 +3276,32 @@ __global__ __launch_bounds__(256) void k_l0_pilot(const uint16_t* __restrict__ u
 __device__ __forceinline__ float lz_delta(float slack, float a, int Q) {
   return slack * 1.01f + (float)Q * 2.4e-7f * (__builtin_fabsf(a) + 1.f);
 }
+// the slack of query b: sum over its real columns of the per-column bound (k_probe_tau) -- the tight one unless a scored document
+// had a negative column maximum (k_approx).  Called by every thread of a workgroup of >= 64 threads; `red` is one shared float.
+__device__ __forceinline__ float lz_query_slack(const float* __restrict__ tight, const float* __restrict__ loose, const uint32_t* __restrict__ negflag,
+                                                int b, int Q, int Qp, float* red) {
+  if (threadIdx.x < 64) {
+    const float* src = (negflag[b] ? loose : tight) + (int64_t)b * Qp;
+    float v = 0.f;
+    for (int q = (int)threadIdx.x; q < Q; q += 64) v += src[q];
+#pragma unroll
+    for (int x = 32; x > 0; x >>= 1) v += __shfl_xor(v, x, 64);
+    if (threadIdx.x == 0) *red = v;
+  }
+  __syncthreads();
+  return *red;
+}
 // A_T = keep-th largest exact score of the pilot group (radix select over the monotone keys, 4 x 8 bits, LDS histogram)
 // -> cut[b] = floor(128 A_T + 99 Q) + 1 (0 = keep everything).  One workgroup per query.
 __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot, const int32_t* __restrict__ npilot,
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
-                                                 int32_t* __restrict__ cut, const uint32_t* __restrict__ slack /*nullable: S1's lazy form*/) {
+                                                 int32_t* __restrict__ cut, const float* __restrict__ lz_tight /*nullable: S1's lazy form*/,
+                                                 const float* __restrict__ lz_loose, const uint32_t* __restrict__ lz_neg, int Qp) {
   __shared__ uint32_t h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
+  __shared__ float s_slack;
+  float qslack = 0.f;
+  if (lz_tight) qslack = lz_query_slack(lz_tight, lz_loose, lz_neg, blockIdx.x, Q, Qp, &s_slack);   // (before any thread leaves: it holds a barrier)
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t n = cand_off[b + 1] - cand_off[b];
   const int np = npilot[b];
@@ -3335,9 +3346,9 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
   }
   if (tid == 0) {
     float at = unmono32(s_prefix);
-    // S1's lazy form: the pilot scores are upper bounds A_up; every pilot document's true score is at least A_up - slack[b] (the
-    // largest slack among the documents scored so far, i.e. the pilot group), so the keep-th largest TRUE score is at least this:
-    if (slack) at = at - lz_delta(__uint_as_float(slack[b]), at, Q);
+    // S1's lazy form: the pilot scores are upper bounds A_up; every document's true score is at least A_up - the query's slack,
+    // so the keep-th largest TRUE score is at least this:
+    if (lz_tight) at = at - lz_delta(qslack, at, Q);
     int32_t c = 0;
     if (at == at) {   // NaN scores: prune nothing
       const double t = floor(128.0 * (double)at + 99.0 * (double)Q) + 1.0;
@@ -3692,9 +3703,10 @@ int64_t fpk_l0_pilot_cap() { return L0_PILOT_MAX; }
 // level 0, second half (the pilot group's exact scores are in w.pilot_approx and, by candidate position, in w.cand_approx):
 // threshold, ordered survivors with the pilot members' scores copied, the others on the extra list (w.xpid / w.xdst / w.nextra)
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
-                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st, const uint32_t* lz_slack) {
+                      int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st, const FpLazyS1* lz) {
   const int B = sh.B;
-  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr, lz_slack);
+  hipLaunchKernelGGL(k_l0_thr, dim3((unsigned)B), dim3(1024), 0, st, w.pilot_approx, w.npilot, cand_off, sh.n_full, sh.R, sh.Q, w.thr,
+                     lz ? lz->tight : (const float*)nullptr, lz ? lz->loose : (const float*)nullptr, lz ? lz->negflag : (const uint32_t*)nullptr, sh.Qp);
   const bool one_launch = w.tickets && (int64_t)w.nblk * B <= FP_TICKET_MAX_WGS;
   hipLaunchKernelGGL(k_l0_count, dim3((unsigned)w.nblk, (unsigned)B), dim3(256), 0, st, w.ub, cand_off, w.thr, w.cut, w.npilot, w.blkcnt,
                      w.blkcntx, w.nblk, one_launch ? w.tickets : (uint32_t*)nullptr, nsurv, w.nextra, B, surv_off);
@@ -4026,18 +4038,24 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
 //   * A_up >  U + D : certainly selected (true score >= A_up - D > U >= T)   -> straight to the output;
 //   * the rest ("maybes", a few dozen per query): their TRUE scores are recomputed from scratch -- every code of the document
 //     against every query column with the reference's ascending fp32 chain, fp16 rounding, fp16 max, ascending fp32 sum, i.e.
-//     exactly the oracle's approximate score -- and the best keep - #certain of them by (score desc, id asc) complete the set.
+//     exactly the oracle's approximate score (k_lz_exact) -- and the best keep - #certain of them by (score desc, id asc)
+//     complete the set (k_sel_finish_lz).
 // The selected SET is then the reference's (its exact ties at the cut included); sel_approx holds A_up for the certain ones
 // (nobody reads it on this path).  gathered > gcap or maybes > LZ_MAYBE_MAX: *flag is raised and the caller runs the batch again
 // with the eager S1.
 #define LZ_MAYBE_MAX 1024
+#define LZ_EX_BLOCKS 32   // k_lz_exact: workgroups (of four waves) per query
+// gather + classification: the certain ones go straight to the head of the selection (any order), the maybes' ids to gpid
 __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
                                                        const int64_t* __restrict__ cand_off, uint32_t* __restrict__ st, int64_t R,
                                                        int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
                                                        const uint32_t* __restrict__ hist, const uint32_t* __restrict__ ext,
-                                                       const uint32_t* __restrict__ slack, uint32_t* __restrict__ gcount,
-                                                       int32_t* __restrict__ gpid, float* __restrict__ gval, int gcap, int Q) {
+                                                       const float* __restrict__ lz_tight, const float* __restrict__ lz_loose,
+                                                       const uint32_t* __restrict__ lz_neg, uint32_t* __restrict__ gcount,
+                                                       int32_t* __restrict__ gpid, int gcap, int Q, int Qp) {
   const int b = blockIdx.y;
+  __shared__ float s_slack;
+  const float qslack = lz_query_slack(lz_tight, lz_loose, lz_neg, b, Q, Qp, &s_slack);
   uint32_t* s = st + (int64_t)b * 8;
   const bool need = s[0] != 0;
   uint32_t kstar = 0;
@@ -4051,11 +4069,12 @@ __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__
   const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
   int32_t* op = sel_pid + (int64_t)b * R;
   float* oa = sel_approx + (int64_t)b * R;
-  uint32_t thr = 0u;
+  uint32_t thr_lo = 0u, thr_hi = 0xFFFFFFFFu;
   if (need) {
     const float U = unmono32(kstar);
-    const float lo = U - lz_delta(__uint_as_float(slack[b]), U, Q);
-    thr = (lo == lo) ? mono32(lo) : 0u;   // (NaN: gather everything -> overflow -> the eager form)
+    const float d = lz_delta(qslack, U, Q);
+    const float lo = U - d, hi = U + d;
+    if (lo == lo && hi == hi) { thr_lo = mono32(lo); thr_hi = mono32(hi); }   // (NaN: everything is a maybe -> overflow -> the eager form)
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float a = approx[beg + i];
@@ -4063,56 +4082,160 @@ __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__
       if (i < (int64_t)keep) { op[i] = cand_pid[beg + i]; oa[i] = a; }
       continue;
     }
-    if (mono32(a) >= thr) {
+    const uint32_t key = mono32(a);
+    if (key > thr_hi) {
+      const uint32_t pos = atomicAdd(&s[5], 1u);
+      if (pos < keep) { op[pos] = cand_pid[beg + i]; oa[pos] = a; }
+    } else if (key >= thr_lo) {
       const uint32_t pos = atomicAdd(&gcount[b], 1u);
-      if (pos < (uint32_t)gcap) { gpid[(int64_t)b * gcap + pos] = cand_pid[beg + i]; gval[(int64_t)b * gcap + pos] = a; }
+      if (pos < (uint32_t)gcap) gpid[(int64_t)b * gcap + pos] = cand_pid[beg + i];
     }
   }
 }
 
-// the oracle's approximate score of document `pid` for query b, by one wave: lane = (column q of a 32-column group, code parity)
-__device__ __forceinline__ float lz_exact_approx(const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, int D, int Q, int Qp, int b,
-                                                 int32_t pid, const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes, int lane) {
-  const int q = lane & 31, par = lane >> 5;
-  const int64_t u0 = uoff[pid];
-  const int len = (int)(uoff[pid + 1] - u0);
-  float total = 0.f;
-  for (int g = 0; g < Qp / 32; ++g) {
-    const uint16_t* qrow = qpad + ((int64_t)b * Qp + g * 32 + q) * D;
-    float m = NEG_MASK_F;
-    for (int t = par; t < len; t += 2) {
-      const uint16_t* crow = cent + (int64_t)ucodes[u0 + t] * D;
-      float ch = 0.f;
-      for (int k = 0; k < D; k += 8) s1_chain8(ch, *reinterpret_cast<const uint4*>(crow + k), *reinterpret_cast<const uint4*>(qrow + k));
-      const float v = (float)(half_t)ch;
-      m = v > m ? v : m;
+// the oracle's approximate score of every maybe, one wave per document -- recomputing only what can matter.  For query column q
+// the true maximum over the document's codes is attained by an entry whose STORED value lies within the column's slack of the
+// stored maximum s (an entry stored below s - slack(s) is truly below s1_lower16(s) <= the true value of the stored argmax), and
+// that is one entry per column, rarely two.  So:
+//   1. the stored column maxima (the document's score rows of S: lane = (one of 16 codes, 8 columns), as in k_approx);
+//   2. the (code, column) pairs within the slack of their column's maximum -> an LDS list (~35 of a document's ~1000 entries);
+//   3. lane i re-evaluates pair i with the reference's ascending chain, both rows straight from L2 (32 loads in flight, then 128
+//      dependent v_fma_mix: the only serial part), fp16 rounding;
+//   4. LDS maxima per column, ascending fp32 sum over the real columns: exactly the oracle's value.
+// (Earlier forms, cfg2, ~84 maybes per query, every entry re-evaluated: rows from global memory per code 168 us per batch; lane =
+// code with the query row through the scalar cache 198 us; rows staged in LDS, two interleaved chains per lane 90 us -- LDS-bound.)
+#define LZ_PAIRS 256   // pair list per wave (a document with more -- masses of tied entries -- raises the batch's overflow flag)
+__global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ st, const uint32_t* __restrict__ gcount, const int32_t* __restrict__ gpid,
+                                                  float* __restrict__ gval, int gcap, const uint16_t* __restrict__ cent,
+                                                  const uint16_t* __restrict__ qpad, int D, int Q, int Qp, const int64_t* __restrict__ uoff,
+                                                  const int32_t* __restrict__ ucodes, const uint16_t* __restrict__ S, int64_t C,
+                                                  const float* __restrict__ wcol, float kappa, int32_t* __restrict__ flag, uint32_t* __restrict__ stats) {
+  __shared__ uint32_t s_pairs[4][LZ_PAIRS];      // code position << 8 | column
+  __shared__ uint32_t s_colmax[4][128];          // mono32 keys of the columns' true maxima
+  __shared__ uint32_t s_npair[4];
+  const int b = blockIdx.y;
+  if (!st[(int64_t)b * 8]) return;
+  const uint32_t nm0 = gcount[b];
+  const uint32_t nmay = nm0 < (uint32_t)gcap ? nm0 : (uint32_t)gcap;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+  const int ngrp = Qp / 32;
+  const uint16_t* Sb = S + (int64_t)b * C * Qp;
+  for (uint32_t m = wid; m < nmay && m < LZ_MAYBE_MAX; m += gridDim.x * 4u) {
+    const int32_t pid = gpid[(int64_t)b * gcap + m];
+    const int64_t u0 = uoff[pid];
+    const int len = (int)(uoff[pid + 1] - u0);
+    if (lane == 0) s_npair[wave] = 0u;
+    for (int j = lane; j < Qp; j += 64) s_colmax[wave][j] = mono32(NEG_MASK_F);
+    // steps 1 and 2 read the document's score rows the way k_approx does: lane = (one of 16 codes, 16-byte piece = 8 columns), so a
+    // 33-code document is three independent loads per lane and pass (a loop over the codes with one 2-byte load per lane and
+    // iteration was 17 dependent round trips per pass: 92 us per cfg2 batch)
+    const int cs = lane >> 2, pc = lane & 3;
+    for (int g = 0; g < ngrp; ++g) {
+      const uint16_t* Sg = Sb + g * 32 + pc * 8;
+      uint32_t mxp[4] = {0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u};   // packed fp16 -10000
+      for (int cb = 0; cb < len; cb += 64) {
+        const int32_t mycode = cb + lane < len ? ucodes[u0 + cb + lane] : 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int32_t code = __shfl(mycode, it * 16 + cs, 64);
+          if (cb + it * 16 + cs < len) {
+            const uint4 v = *reinterpret_cast<const uint4*>(Sg + (int64_t)code * Qp);
+            mxp[0] = pk_max_raw(mxp[0], v.x); mxp[1] = pk_max_raw(mxp[1], v.y); mxp[2] = pk_max_raw(mxp[2], v.z); mxp[3] = pk_max_raw(mxp[3], v.w);
+          }
+        }
+      }
+#pragma unroll
+      for (int x = 4; x < 64; x <<= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mxp[k] = pk_max_raw(mxp[k], shfl_xor_u32(mxp[k], x));
+      // 2. the entries within their column's slack of the maximum
+      float lo[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int col = g * 32 + pc * 8 + k;
+        const uint16_t hb = (uint16_t)(mxp[k >> 1] >> (16 * (k & 1)));
+        const float smax = (float)__builtin_bit_cast(half_t, hb);
+        const float w = wcol[(int64_t)b * Qp + col];
+        uint32_t e = hb & 0x7C00u;
+        e = (e < 0x2C00u ? 0x2C00u : e) - 0x2800u;
+        lo[k] = (w > 0.f) ? smax - ((float)__builtin_bit_cast(half_t, (uint16_t)e) + 2.f * s1_u2(__builtin_fabsf(smax), w, kappa)) * 1.0001f : smax;
+        if (col >= Q) lo[k] = __builtin_inff();   // (pad columns: no pairs)
+      }
+      for (int cb = 0; cb < len; cb += 64) {
+        const int32_t mycode = cb + lane < len ? ucodes[u0 + cb + lane] : 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int32_t code = __shfl(mycode, it * 16 + cs, 64);
+          const int t = cb + it * 16 + cs;
+          if (t < len) {
+            const uint4 v = *reinterpret_cast<const uint4*>(Sg + (int64_t)code * Qp);
+            const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float f = (float)__builtin_bit_cast(half_t, (uint16_t)(vw[k >> 1] >> (16 * (k & 1))));
+              if (f >= lo[k]) {
+                const uint32_t pos = atomicAdd(&s_npair[wave], 1u);
+                if (pos < LZ_PAIRS) s_pairs[wave][pos] = ((uint32_t)t << 8) | (uint32_t)(g * 32 + pc * 8 + k);
+              }
+            }
+          }
+        }
+      }
     }
-    const float o = __shfl_xor(m, 32, 64);
-    m = o > m ? o : m;
-    // ascending fp32 sum over the real columns (search.rs:401 as the oracle fixes it), the same in every lane
-    for (int j = 0; j < 32; ++j) {
-      const float v = __shfl(m, j, 64);
-      if (g * 32 + j < Q) total += v;
+    // (one wave: its LDS operations complete in order; the fence keeps the compiler from moving the reads above the writes)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint32_t np = s_npair[wave];
+    if (stats && lane == 0) atomicAdd(&stats[3], np);
+    if (np > LZ_PAIRS) { np = LZ_PAIRS; if (lane == 0) *flag = 1; }
+    // 3. one chain per lane and pair
+    for (uint32_t i0 = 0; i0 < np; i0 += 64) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      if (i < np) {
+        const uint32_t pr = s_pairs[wave][i];
+        const int t = (int)(pr >> 8), col = (int)(pr & 0xFFu);
+        const uint16_t* crow = cent + (int64_t)ucodes[u0 + t] * D;
+        const uint16_t* qrow = qpad + ((int64_t)b * Qp + col) * D;
+        float ch = 0.f;
+        for (int k0 = 0; k0 < D; k0 += 64) {   // eight 16-byte pieces of each row in flight
+          uint4 cv[8], qv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool in = k0 + j * 8 < D;
+            cv[j] = in ? *reinterpret_cast<const uint4*>(crow + k0 + j * 8) : make_uint4(0, 0, 0, 0);
+            qv[j] = in ? *reinterpret_cast<const uint4*>(qrow + k0 + j * 8) : make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (k0 + j * 8 < D) s1_chain8(ch, cv[j], qv[j]);
+        }
+        atomicMax(&s_colmax[wave][col], mono32((float)(half_t)ch));
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // 4. ascending fp32 sum over the real columns (search.rs:401 as the oracle fixes it), the same in every lane
+    float total = 0.f;
+    for (int j = 0; j < Q; ++j) total += unmono32(s_colmax[wave][j]);
+    if (lane == 0) gval[(int64_t)b * gcap + m] = total;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  return total;
 }
 
 __global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ st, int64_t R, int32_t* __restrict__ sel_pid,
-                                                        float* __restrict__ sel_approx, const uint32_t* __restrict__ slack,
-                                                        const uint32_t* __restrict__ gcount, const int32_t* __restrict__ gpid,
-                                                        const float* __restrict__ gval, int gcap, int32_t* __restrict__ flag,
-                                                        const uint16_t* __restrict__ cent, const uint16_t* __restrict__ qpad, int D, int Q, int Qp,
-                                                        const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
-                                                        uint32_t* __restrict__ stats) {
+                                                        float* __restrict__ sel_approx, const uint32_t* __restrict__ gcount,
+                                                        const int32_t* __restrict__ gpid, const float* __restrict__ gval, int gcap,
+                                                        int32_t* __restrict__ flag, uint32_t* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_nin, s_nmay, s_bad;
+  __shared__ uint32_t s_bad;
   const int b = blockIdx.x, tid = threadIdx.x;
   uint32_t* s = st + (int64_t)b * 8;
   if (!s[0]) return;  // nothing selected away
   const uint32_t keep = s[1];
-  const uint32_t ng_all = gcount[b];
-  const uint32_t ng = ng_all < (uint32_t)gcap ? ng_all : (uint32_t)gcap;
+  const uint32_t nm_all = gcount[b];
+  uint32_t nmay = nm_all < (uint32_t)gcap ? nm_all : (uint32_t)gcap;
+  if (nmay > LZ_MAYBE_MAX) nmay = LZ_MAYBE_MAX;
+  const uint32_t nin_all = s[5];
+  const uint32_t nin = nin_all < keep ? nin_all : keep;
   int kp2 = 2;
   while (kp2 < (int)keep) kp2 <<= 1;
   unsigned long long* kv = reinterpret_cast<unsigned long long*>(smem);                    // [kp2] the selection: id << 32 | score bits
@@ -4121,57 +4244,30 @@ __global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ s
   float* oa = sel_approx + (int64_t)b * R;
   const int32_t* gp = gpid + (int64_t)b * gcap;
   const float* gv = gval + (int64_t)b * gcap;
-  if (tid == 0) { s_nin = 0u; s_nmay = 0u; s_bad = ng_all > (uint32_t)gcap ? 1u : 0u; }
-  for (int i = tid; i < kp2; i += 1024) kv[i] = ~0ull;
-  __syncthreads();
-  const float U = unmono32(s[2]);
-  const float hi = U + lz_delta(__uint_as_float(slack[b]), U, Q);
-  for (uint32_t i = tid; i < ng; i += 1024) {
-    const float a = gv[i];
-    const int32_t pid = gp[i];
-    if (a > hi) {
-      const uint32_t pos = atomicAdd(&s_nin, 1u);
-      if (pos < keep) kv[pos] = ((unsigned long long)(uint32_t)pid << 32) | (unsigned long long)__float_as_uint(a);
-      else s_bad = 1u;   // (cannot happen: fewer than keep scores exceed U)
-    } else {
-      const uint32_t pos = atomicAdd(&s_nmay, 1u);
-      if (pos < LZ_MAYBE_MAX) mk[pos] = (unsigned long long)(uint32_t)pid;   // (the score follows below)
-    }
-  }
-  __syncthreads();
-  const uint32_t nin = s_nin < keep ? s_nin : keep;
-  uint32_t nmay = s_nmay;
-  if (nmay > LZ_MAYBE_MAX) { nmay = LZ_MAYBE_MAX; if (tid == 0) s_bad = 1u; }
-  if (nin + nmay < keep && tid == 0) s_bad = 1u;   // (cannot happen unless a list overflowed: at least keep scores are >= U)
-  // the maybes' true scores: one wave per document
-  const int wave = tid >> 6, lane = tid & 63;
-  for (uint32_t m = (uint32_t)wave; m < nmay; m += 16u) {
-    const int32_t pid = (int32_t)(uint32_t)mk[m];
-    const float ex = lz_exact_approx(cent, qpad, D, Q, Qp, b, pid, uoff, ucodes, lane);
-    if (lane == 0) mk[m] = ((unsigned long long)mono32(ex) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)pid);
-  }
+  // (more maybes than the lists hold, more certain ones than the selection -- impossible: fewer than keep scores exceed U --, or
+  // too few entries altogether -- impossible unless a list overflowed: at least keep scores are >= U)
+  if (tid == 0) s_bad = (nm_all > (uint32_t)gcap || nm_all > LZ_MAYBE_MAX || nin_all >= keep + 1u || nin + nmay < keep) ? 1u : 0u;
+  for (int i = tid; i < kp2; i += 1024)
+    kv[i] = ((uint32_t)i < nin) ? (((unsigned long long)(uint32_t)op[i] << 32) | (unsigned long long)__float_as_uint(oa[i])) : ~0ull;
+  const unsigned long long mine = (uint32_t)tid < nmay ? (((unsigned long long)mono32(gv[tid]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)gp[tid])) : 0ull;
   __syncthreads();
   // best (keep - nin) maybes by (score desc, id asc)
-  {
-    const unsigned long long mine = (uint32_t)tid < nmay ? mk[tid] : 0ull;
-    __syncthreads();
-    const unsigned long long sorted = fp_sort1024_desc(mine, mk);
-    __syncthreads();
-    const uint32_t take = keep - nin;
-    if ((uint32_t)tid < take && (uint32_t)tid < nmay) {
-      const uint32_t pid = 0xFFFFFFFFu - (uint32_t)sorted;
-      kv[nin + tid] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(sorted >> 32)));
-    }
+  const unsigned long long sorted = fp_sort1024_desc(mine, mk);
+  __syncthreads();
+  const uint32_t take = keep - nin;
+  if ((uint32_t)tid < take && (uint32_t)tid < nmay) {
+    const uint32_t pid = 0xFFFFFFFFu - (uint32_t)sorted;
+    kv[nin + tid] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(sorted >> 32)));
   }
   __syncthreads();
   if (tid == 0) {
     if (s_bad) *flag = 1;
-    if (stats) { atomicAdd(&stats[0], ng_all); atomicAdd(&stats[1], s_nmay); }
+    if (stats) { atomicAdd(&stats[0], nin_all); atomicAdd(&stats[1], nm_all); atomicMax(&stats[2], nm_all); }
   }
   // whole selection ascending by doc id (the order every later stage expects)
   if (kp2 == 1024) {
-    const unsigned long long sorted = ~fp_sort1024_desc(~kv[tid], kv);
-    kv[tid] = sorted;
+    const unsigned long long srt = ~fp_sort1024_desc(~kv[tid], kv);
+    kv[tid] = srt;
     __syncthreads();
   } else {
     for (int k = 2; k <= kp2; k <<= 1) {
@@ -4362,7 +4458,7 @@ __global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) st[(int64_t)b * 8 + 7] = 1u;
 }
-bool fpk_select_lazy_ok(const FpSearchShape& sh) { return sh.R <= FP_MAX_SORT; }
+bool fpk_select_lazy_ok(const FpSearchShape& sh) { return sh.R <= FP_MAX_SORT; }   // (and dim <= 256: k_lz_exact keeps a query row in registers -- the caller checks)
 int fpk_select_lazy_gcap(const FpSearchShape& sh) {
   static const int env = [] { const char* e = getenv("FP_LZ_GCAP"); return e ? atoi(e) : 0; }();   // tests: a small list forces the eager re-run
   if (env > 0) return env;
@@ -4399,14 +4495,15 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
     hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
     hipLaunchKernelGGL(k_sel_gather_lz, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
-                       hist, ext, lz->slack, lz->gcount, lz->gpid, lz->gval, lz->gcap, sh.Q);
+                       hist, ext, lz->tight, lz->loose, lz->negflag, lz->gcount, lz->gpid, lz->gcap, sh.Q, sh.Qp);
+    hipLaunchKernelGGL(k_lz_exact, dim3(LZ_EX_BLOCKS, (unsigned)B), dim3(256), 0, st, selstate, lz->gcount, lz->gpid, lz->gval, lz->gcap, ix_cent,
+                       lz->qpad, ix_dim, sh.Q, sh.Qp, ix_uoff, ix_ucodes, lz->S, ixp->C, lz->wcol, lz->kappa, lz->flag, lz->stats);
     static std::atomic<uint64_t> lds_ok3{0};
     fp_allow_big_lds((const void*)k_sel_finish_lz, lds_ok3, 152 * 1024);
     int kp2 = 2;
     while (kp2 < (int)sh.R) kp2 <<= 1;
     hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8 + (size_t)LZ_MAYBE_MAX * 8, st, selstate, sh.R, sel_pid,
-                       sel_approx, lz->slack, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, ix_cent, lz->qpad, ix_dim, sh.Q, sh.Qp, ix_uoff,
-                       ix_ucodes, lz->stats);
+                       sel_approx, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, lz->stats);
     hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
                        sel_approx, sel_cnt, pref, B);   // (s[7] == 0: only the count prefix)
     return;

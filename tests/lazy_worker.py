@@ -33,17 +33,20 @@ def main():
         spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=48, n_centroids=C, variable_len=True, seed=seed)
         arr = fp.synth.host_index_arrays(spec)
         q = fp.synth.make_queries(spec, arr["centroids"], B, Q)
-        if seed == 2:   # an unnormalised query and one whose second half is zero rows
+        expect = EXPECT
+        if seed == 2:   # an unnormalised query
             q = q.astype(np.float32)
             q[1] *= 7.5
-            q[2, Q // 2:] = 0
             q = q.astype(np.float16)
+        if seed == 5:   # a query whose second half is zero rows: its all-equal columns overflow the threshold probe's tie room, the
+            q[2, Q // 2:] = 0   # batch is run again with the register top-k fallback -- which reads S itself, hence eagerly
+            expect = 0
         idx = mk(arr)
         params = R.SearchParameters(2000, n_full, 25, n_probe)
         for rep in range(3):   # waited-for, speculative, speculative again
             pids, scores, counts = R.search_arrays(idx, q, params)
             lz = R.last_s1_counts()["lazy"]
-            assert lz == EXPECT, f"shape {seed} rep {rep}: lazy {lz}, expected {EXPECT}"
+            assert lz == expect, f"shape {seed} rep {rep}: lazy {lz}, expected {expect}"
             seen_lazy += int(lz == 1)
         for b in range(B):
             h = R.search_trace(idx, q[b], params)
