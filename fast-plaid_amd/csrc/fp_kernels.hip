@@ -4044,7 +4044,7 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
 // (nobody reads it on this path).  gathered > gcap or maybes > LZ_MAYBE_MAX: *flag is raised and the caller runs the batch again
 // with the eager S1.
 #define LZ_MAYBE_MAX 1024
-#define LZ_EX_BLOCKS 32   // k_lz_exact: workgroups (of four waves) per query
+#define LZ_EX_BLOCKS 64   // k_lz_exact: workgroups (of four waves) per query: a wave per maybe up to 256 of them
 // gather + classification: the certain ones go straight to the head of the selection (any order), the maybes' ids to gpid
 __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
                                                        const int64_t* __restrict__ cand_off, uint32_t* __restrict__ st, int64_t R,
@@ -4128,15 +4128,31 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
     if (lane == 0) s_npair[wave] = 0u;
     for (int j = lane; j < Qp; j += 64) s_colmax[wave][j] = mono32(NEG_MASK_F);
     // steps 1 and 2 read the document's score rows the way k_approx does: lane = (one of 16 codes, 16-byte piece = 8 columns), so a
-    // 33-code document is three independent loads per lane and pass (a loop over the codes with one 2-byte load per lane and
-    // iteration was 17 dependent round trips per pass: 92 us per cfg2 batch)
+    // 33-code document is three independent loads per lane (a loop over the codes with one 2-byte load per lane and iteration was
+    // 17 dependent round trips per pass: 92 us per cfg2 batch); documents of up to 64 codes keep the rows in registers for step 2
     const int cs = lane >> 2, pc = lane & 3;
+    const int32_t code0 = lane < len ? ucodes[u0 + lane] : 0;
+#pragma unroll 1
     for (int g = 0; g < ngrp; ++g) {
       const uint16_t* Sg = Sb + g * 32 + pc * 8;
       uint32_t mxp[4] = {0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u};   // packed fp16 -10000
-      for (int cb = 0; cb < len; cb += 64) {
-        const int32_t mycode = cb + lane < len ? ucodes[u0 + cb + lane] : 0;
+      uint4 keepv[4];
+      int32_t keepc[4];
 #pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        keepc[it] = __shfl(code0, it * 16 + cs, 64);
+        keepv[it] = make_uint4(0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u);
+        if (it * 16 + cs < len) keepv[it] = *reinterpret_cast<const uint4*>(Sg + (int64_t)keepc[it] * Qp);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        mxp[0] = pk_max_raw(mxp[0], keepv[it].x); mxp[1] = pk_max_raw(mxp[1], keepv[it].y);
+        mxp[2] = pk_max_raw(mxp[2], keepv[it].z); mxp[3] = pk_max_raw(mxp[3], keepv[it].w);
+      }
+#pragma unroll 1
+      for (int cb = 64; cb < len; cb += 64) {   // (documents of more than 64 codes)
+        const int32_t mycode = cb + lane < len ? ucodes[u0 + cb + lane] : 0;
+#pragma unroll 1
         for (int it = 0; it < 4; ++it) {
           const int32_t code = __shfl(mycode, it * 16 + cs, 64);
           if (cb + it * 16 + cs < len) {
@@ -4149,7 +4165,7 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
       for (int x = 4; x < 64; x <<= 1)
 #pragma unroll
         for (int k = 0; k < 4; ++k) mxp[k] = pk_max_raw(mxp[k], shfl_xor_u32(mxp[k], x));
-      // 2. the entries within their column's slack of the maximum
+      // 2. the entries within their column's slack of the maximum -> (code << 8 | column) pairs
       float lo[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -4162,24 +4178,31 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
         lo[k] = (w > 0.f) ? smax - ((float)__builtin_bit_cast(half_t, (uint16_t)e) + 2.f * s1_u2(__builtin_fabsf(smax), w, kappa)) * 1.0001f : smax;
         if (col >= Q) lo[k] = __builtin_inff();   // (pad columns: no pairs)
       }
-      for (int cb = 0; cb < len; cb += 64) {
-        const int32_t mycode = cb + lane < len ? ucodes[u0 + cb + lane] : 0;
+      // (compact code on purpose: this kernel runs a handful of waves once through straight-line code, i.e. at the speed of its
+      // instruction fetches -- 12 KB of code took 49 us whatever the work, ~260 ns per 64-byte line)
+      auto emit = [&](const uint4 v, const int32_t code) {
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        uint32_t mask = 0u;
 #pragma unroll
+        for (int k = 0; k < 8; ++k)
+          mask |= ((float)__builtin_bit_cast(half_t, (uint16_t)(vw[k >> 1] >> (16 * (k & 1)))) >= lo[k]) ? (1u << k) : 0u;
+        while (mask) {   // (rare: about one entry per column and document)
+          const int k = __builtin_ctz(mask);
+          mask &= mask - 1u;
+          const uint32_t pos = atomicAdd(&s_npair[wave], 1u);
+          if (pos < LZ_PAIRS) s_pairs[wave][pos] = ((uint32_t)code << 8) | (uint32_t)(g * 32 + pc * 8 + k);
+        }
+      };
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (it * 16 + cs < len) emit(keepv[it], keepc[it]);
+#pragma unroll 1
+      for (int cb = 64; cb < len; cb += 64) {
+        const int32_t mycode = cb + lane < len ? ucodes[u0 + cb + lane] : 0;
+#pragma unroll 1
         for (int it = 0; it < 4; ++it) {
           const int32_t code = __shfl(mycode, it * 16 + cs, 64);
-          const int t = cb + it * 16 + cs;
-          if (t < len) {
-            const uint4 v = *reinterpret_cast<const uint4*>(Sg + (int64_t)code * Qp);
-            const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float f = (float)__builtin_bit_cast(half_t, (uint16_t)(vw[k >> 1] >> (16 * (k & 1))));
-              if (f >= lo[k]) {
-                const uint32_t pos = atomicAdd(&s_npair[wave], 1u);
-                if (pos < LZ_PAIRS) s_pairs[wave][pos] = ((uint32_t)t << 8) | (uint32_t)(g * 32 + pc * 8 + k);
-              }
-            }
-          }
+          if (cb + it * 16 + cs < len) emit(*reinterpret_cast<const uint4*>(Sg + (int64_t)code * Qp), code);
         }
       }
     }
@@ -4188,25 +4211,27 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
     uint32_t np = s_npair[wave];
     if (stats && lane == 0) atomicAdd(&stats[3], np);
     if (np > LZ_PAIRS) { np = LZ_PAIRS; if (lane == 0) *flag = 1; }
-    // 3. one chain per lane and pair
+    // 3. one chain per lane and pair; up to 128 dims of both rows (sixteen 16-byte pieces each) in flight at a time
+#pragma unroll 1
     for (uint32_t i0 = 0; i0 < np; i0 += 64) {
       const uint32_t i = i0 + (uint32_t)lane;
       if (i < np) {
         const uint32_t pr = s_pairs[wave][i];
-        const int t = (int)(pr >> 8), col = (int)(pr & 0xFFu);
-        const uint16_t* crow = cent + (int64_t)ucodes[u0 + t] * D;
+        const int col = (int)(pr & 0xFFu);
+        const uint16_t* crow = cent + (int64_t)(pr >> 8) * D;
         const uint16_t* qrow = qpad + ((int64_t)b * Qp + col) * D;
         float ch = 0.f;
-        for (int k0 = 0; k0 < D; k0 += 64) {   // eight 16-byte pieces of each row in flight
-          uint4 cv[8], qv[8];
+#pragma unroll 1
+        for (int k0 = 0; k0 < D; k0 += 128) {
+          uint4 cv[16], qv[16];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < 16; ++j) {
             const bool in = k0 + j * 8 < D;
             cv[j] = in ? *reinterpret_cast<const uint4*>(crow + k0 + j * 8) : make_uint4(0, 0, 0, 0);
             qv[j] = in ? *reinterpret_cast<const uint4*>(qrow + k0 + j * 8) : make_uint4(0, 0, 0, 0);
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
+          for (int j = 0; j < 16; ++j)
             if (k0 + j * 8 < D) s1_chain8(ch, cv[j], qv[j]);
         }
         atomicMax(&s_colmax[wave][col], mono32((float)(half_t)ch));
@@ -4215,6 +4240,7 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // 4. ascending fp32 sum over the real columns (search.rs:401 as the oracle fixes it), the same in every lane
     float total = 0.f;
+#pragma unroll 1
     for (int j = 0; j < Q; ++j) total += unmono32(s_colmax[wave][j]);
     if (lane == 0) gval[(int64_t)b * gcap + m] = total;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
