@@ -250,6 +250,7 @@ struct fp_index {
   bool synthetic = false;
   int64_t n_hard_tokens = 0;   // tokens without a one-multiply reciprocal (k_token_rinv)
   float cent_norm_max = 1.f;   // largest centroid norm (>= 1): scales S1's certification window (FpS1Exact)
+  bool tickets_ok = true;      // the fence-free ticket chains passed their self-test on this index's device (finish_layout)
 };
 
 static thread_local float g_last_ms[ST_N];
@@ -386,8 +387,19 @@ struct StreamGuard {   // destroys the construction stream on every exit path
 // common tail of index construction: tokens sorted by code inside each document, per-token norms, per-document unique codes.
 // ix->d.{centroids, lut, codes, residuals, doc_off} are set.  Every device buffer is registered in ix->owned before its
 // producer's return code is looked at, so a failing build frees it with the index.
+// the self-test of the "last workgroup finishes the job" chains, once per device and process (fpk_ticket_selftest)
+static bool device_tickets_ok(int device, hipStream_t st) {
+  static std::mutex mu;
+  static int state[64];   // 0 unknown, 1 ok, 2 failed
+  std::lock_guard<std::mutex> g(mu);
+  int& s = state[device & 63];
+  if (s == 0) s = fpk_ticket_selftest(st) == 0 ? 1 : 2;
+  return s == 1;
+}
+
 static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   FpIndexDev& D = ix->d;
+  ix->tickets_ok = device_tickets_ok(ix->device, st);
   {
     uint16_t* perm = nullptr;
     const int src = fps_sort_docs(const_cast<int32_t*>(D.codes), const_cast<uint8_t*>(D.residuals), D.doc_off, D.N, D.T, maxlen, D.pr, &perm, st);
@@ -409,7 +421,7 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   // S1's zero-padded view of the centroid table (FpIndexDev::cent_s1)
   D.cent_s1 = nullptr;
   D.dim_s1 = D.dim;
-  static const bool pad_env = [] { const char* e2 = getenv("FP_S1_PAD"); return !(e2 && atoi(e2) == 0); }();
+  const bool pad_env = true;
   if (pad_env && D.dim < 256 && D.dim != 64 && D.dim != 128) {
     const int dp = D.dim < 64 ? 64 : (D.dim < 128 ? 128 : 256);
     uint16_t* cp = nullptr;
@@ -429,7 +441,7 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   if (fpk_maxsim6_shape(D.dim, D.nbits)) {
     // per-token reciprocals (from the rows still in the reference's byte order), then every row rewritten in the MaxSim kernel's
     // unit order IN PLACE, a slab of rows at a time through a bounded temporary
-    static const bool use_rinv = [] { const char* e2 = getenv("FP_MS_RINV"); return !(e2 && atoi(e2) == 0); }();
+    static const bool use_rinv = fp_test_opt("ms_rinv", 1) != 0;
     hipError_t e = hipSuccess;
     if (use_rinv) {
       uint32_t* rv = nullptr;
@@ -483,7 +495,7 @@ static int finish_layout(fp_index* ix, int maxlen, hipStream_t st) {
   if (D.C <= 8 * (1ll << 17) && (l0_forced || (D.C * 64 >= (2ll << 20) && D.U <= 64 * D.N))) {
     const int nr = (int)((D.C + (1ll << 17) - 1) >> 17);
     // lines of 4 pieces (24 codes) when a document has few codes per range: half the lanes, half the bytes per candidate and range
-    static const int ppl_env = [] { const char* e2 = getenv("FP_L0_PPL"); return e2 ? atoi(e2) : 0; }();
+    static const int ppl_env = (int)fp_test_opt("l0_ppl", 0);
     if (ppl_env == 4 || ppl_env == 8) D.l0_ppl = ppl_env;
     else if (nr > 1 && D.N > 0 && (double)D.U / ((double)D.N * nr) <= 14.0) D.l0_ppl = 4;
     // several ranges: ONE array of first lines, a document's ranges side by side (the scan then runs all ranges in one launch
@@ -603,6 +615,7 @@ extern "C" int64_t fp_index_device_bytes(const fp_index* ix) { return ix ? ix->b
 extern "C" int64_t fp_index_num_unique_codes(const fp_index* ix) { return ix ? ix->d.U : 0; }
 extern "C" int64_t fp_index_num_code_lines(const fp_index* ix) { return ix ? ix->d.n_lines * ix->d.l0_ppl / 8 : 0; }   // in 128-byte units
 extern "C" int64_t fp_index_num_hard_tokens(const fp_index* ix) { return ix ? ix->n_hard_tokens : 0; }
+extern "C" int32_t fp_index_tickets_ok(const fp_index* ix) { return ix && ix->tickets_ok ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------
 // synthetic device-resident corpora
@@ -758,7 +771,7 @@ struct Pipe {
 
 // after a batch: the candidate capacity the next batch of this shape runs on (see run_front)
 static void learn_capacity(Scratch* s, int64_t M_true) {
-  static const int pct = [] { const char* e = getenv("FP_SPEC_CAP_PCT"); const int v = e ? atoi(e) : 125; return v > 0 ? v : 125; }();   // tests: < 100 forces the re-run
+  static const int pct = [] { const int v = (int)fp_test_opt("spec_cap_pct", 125); return v > 0 ? v : 125; }();   // tests: < 100 forces the re-run
   const int64_t want = M_true * pct / 100 + 1024;
   if (want > s->spec_cap || pct < 100) s->spec_cap = want;
   s->spec_last = M_true;
@@ -784,7 +797,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // atomic exchanges and reads them back with device-scope atomic loads -- no fence, which is what makes it cheap, and which
   // relies on gfx950 keeping device-scope atomics coherent at L2 (checked by the tests on this part, outside the letter of the
   // HIP memory model).  FP_TICKETS=0 takes the plain count -> scan -> offsets launches instead.
-  static const bool tickets_on = [] { const char* e = getenv("FP_TICKETS"); return !(e && atoi(e) == 0); }();
+  static const bool tickets_env = [] { const char* e = getenv("FP_TICKETS"); return !(e && atoi(e) == 0); }();
+  const bool tickets_on = tickets_env && ix->tickets_ok;   // (the self-test of the index's device, fp_index_create)
   HIPCHK(s->hist.ensure(fpk_sel_hist_bytes(B)));
   {
     void* zp = nullptr;
@@ -819,8 +833,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // S1 exact mode (FpS1Exact): certification window w0 |q_n| + kappa |x| around the MFMA result; FP_S1_EXACT=0 switches the
   // certification off (S then differs from the reference's matmul by one fp16 ulp in ~0.05 % of its entries), 2 re-evaluates
   // every entry (tests); FP_S1_W0_LOG2 / FP_S1_KAPPA_LOG2 move the window (defaults 2^-21.5 and 2^-20, x dim / 128 above 128)
-  static const float s1x_w0 = [] { const char* e = getenv("FP_S1_W0_LOG2"); return std::exp2(e ? (float)atof(e) : -21.5f); }();
-  static const float s1x_kappa = [] { const char* e = getenv("FP_S1_KAPPA_LOG2"); return std::exp2(e ? (float)atof(e) : -20.0f); }();
+  static const float s1x_w0 = std::exp2((float)fp_test_opt("s1_w0_log2", -21.5));
+  static const float s1x_kappa = std::exp2((float)fp_test_opt("s1_kappa_log2", -20.0));
   const bool s1x_stats = s1_stats_enabled() && !s->capturing;
   P.s1_mode = P.lazy ? 3 : (s1x_env <= 0 ? 0 : (s1x_env == 2 ? 2 : 1));   // (FP_S1_EXACT=3, the default: lazy where it applies, eager elsewhere)
   const float dim_scale = D.dim > 128 ? (float)D.dim / 128.0f : 1.0f;
@@ -957,7 +971,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // host sync, ~30 us of idle GPU); later batches of the same shape run on with the capacity learnt so far (125 % of the largest
   // total seen) as M -- every kernel below takes its ranges from cand_off, M only sizes things.  A batch that exceeds the
   // capacity is emptied on the device (k_cand_offsets) and run again by the caller once the true total is known.
-  static const bool spec_env = [] { const char* e = getenv("FP_SPECULATE"); return !e || atoi(e) != 0; }();
+  const bool spec_env = true;
   const int64_t key[4] = {B, sh.Q, sh.n_probe, has_subset ? 1 : 0};
   if (P.allow_spec && (s->spec_key[0] != key[0] || s->spec_key[1] != key[1] || s->spec_key[2] != key[2] || s->spec_key[3] != key[3])) {
     s->spec_cap = 0;
@@ -1218,7 +1232,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
   const bool graph_env = g_graph_replay.load(std::memory_order_relaxed) != 0;
   const int Qp = fp_padded_qlen(Q);
   // sub-batch so that the centroid-score table stays within a budget
-  static const size_t budget_env = getenv("FP_S_BUDGET_KB") ? (size_t)atoll(getenv("FP_S_BUDGET_KB")) << 10 : 0;   // tests: force sub-batching
+  static const size_t budget_env = (size_t)fp_test_opt("s_budget_kb", 0) << 10;   // tests: force sub-batching
   const size_t perq = (size_t)D.C * Qp * 2;
   size_t free_b = 0, total_b = 0;
   if (!budget_env && (size_t)nq * perq > ((size_t)1 << 30))   // the driver call costs tens of microseconds: only when the table can exceed the floor of the budget
@@ -2193,7 +2207,7 @@ static int shard_search_batch(fp_index* ix, Scratch* s, fp_comm* comm, RcclApi* 
     }
     int32_t* d_flags = s->spec_total.as<int32_t>() + 2;   // (behind the 8 bytes of the candidate total)
     (void)hipMemsetAsync(d_flags, 0, 4, st);
-    static const int fail_at = [] { const char* e = getenv("FP_SHARD_FAIL_AT"); return e ? atoi(e) : 0; }();   // testing: a local failure in stage n
+    static const int fail_at = (int)fp_test_opt("shard_fail_at", 0);   // testing: a local failure in stage n
     // ---- front half (S1..S5 on the shard) ----
     bool have_front = false;
     if (fail_at == 1) note(fail(FP_EHIP, "injected failure in the front half (FP_SHARD_FAIL_AT=1)"));
@@ -2286,7 +2300,7 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   struct Rel { fp_index* ix; Scratch* s; ~Rel() { (void)hipStreamSynchronize(s->st); release(ix, s); } } rel{ix, s};
   // Sub-batches against a FIXED budget of the centroid-score table (every rank must split the batch identically, so the budget
   // may not depend on a rank's free memory as fp_search's does): 16 GiB, FP_SHARD_S_BUDGET_KB for tests
-  static const int64_t budget = [] { const char* e = getenv("FP_SHARD_S_BUDGET_KB"); return e ? atoll(e) * 1024 : (16ll << 30); }();
+  static const int64_t budget = [] { const double kb = fp_test_opt("shard_s_budget_kb", 0); return kb > 0 ? (int64_t)kb * 1024 : (16ll << 30); }();
   const int Qp = fp_padded_qlen(Q);
   const int64_t per_query = (int64_t)ix->d.C * Qp * 2;
   const int maxB = (int)std::max<int64_t>(1, std::min<int64_t>(nq, budget / std::max<int64_t>(per_query, 1)));

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include <stdint.h>
 
 #define FP_WAVE 64
@@ -98,8 +99,23 @@ static inline __host__ __device__ constexpr int fp_resid_logical(int p, int nbit
 // stay below 2^32, a larger launch silently wraps (seen at 10 M documents: 5.1e9 work-items).
 // Kernels whose natural grid scales with the index take this cap and walk a grid-stride loop.
 // FP_GRID_CAP=<blocks> (testing) lowers the cap so that small corpora exercise the loops.
+// FP_TEST="key=value,key=value,...": the knobs the TEST SUITE turns (forcing rare paths on small corpora, moving thresholds);
+// every key is listed with the test that uses it in INTEGRATION.md.  Numbers only; an absent key gives `def`.
+static inline double fp_test_opt(const char* key, double def) {
+  const char* e = getenv("FP_TEST");
+  if (!e) return def;
+  const size_t kl = strlen(key);
+  for (const char* p = e; *p;) {
+    const char* c = strchr(p, ',');
+    const size_t n = c ? (size_t)(c - p) : strlen(p);
+    if (n > kl + 1 && strncmp(p, key, kl) == 0 && p[kl] == '=') return atof(p + kl + 1);
+    if (!c) break;
+    p = c + 1;
+  }
+  return def;
+}
 static inline unsigned fp_grid_cap(int64_t blocks, int block_size) {
-  static const int64_t env_cap = getenv("FP_GRID_CAP") ? atoll(getenv("FP_GRID_CAP")) : 0;
+  static const int64_t env_cap = (int64_t)fp_test_opt("grid_cap", 0);
   int64_t cap = 0xFFFFFFFFll / block_size;
   if (env_cap > 0 && env_cap < cap) cap = env_cap;
   return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
@@ -377,6 +393,8 @@ void fpk_reconstruct(const FpIndexDev& ix, const int64_t* tok_idx /*[n] global t
                      hipStream_t st);
 
 void fpk_selftest_arith(unsigned long long* out_dev /*[2], zeroed*/, hipStream_t st);
+// the fence-free "last workgroup finishes the job" pattern checked on this device: 0 = holds (synchronises `st`)
+int fpk_ticket_selftest(hipStream_t st);
 
 // ---- fp_synth.hip ----------------------------------------------------------------------------
 struct FpSynthParams {

@@ -111,9 +111,6 @@ __device__ __forceinline__ uint8_t l0_encode(uint32_t e, bool inf, uint32_t* __r
   return (uint8_t)(L0_ESC_BASE + slot);
 }
 #define S1_TILE 128
-#ifndef S1_ABL
-#define S1_ABL 0   // timing-only ablations of the S1 epilogue (tools/abl_run.sh): 1 no write-out, 2 direct 8-byte stores, 3 no excess math
-#endif
 // Epilogue of one 128 x 128 output tile (shared by the two S1 kernels): fp16 tile staged through LDS so that S leaves with
 // 16 B per lane, plus the by-products (column maxima, 8-bit bins or the level-0 excess byte).
 // query index and first column of the four 32-column groups of a 128-column tile (wave-uniform; Qp is a multiple of 32, so a
@@ -220,22 +217,12 @@ __device__ __forceinline__ int s1_col_of(int rr, int hi) { return (rr & 3) + 8 *
 // v_fma_mix_f32 takes the halves in place; left to the compiler the pair becomes v_dot2, which rounds differently)
 __device__ __forceinline__ void s1_chain8(float& acc, const uint4 c, const uint4 q) {
   const uint32_t cw[4] = {c.x, c.y, c.z, c.w}, qw[4] = {q.x, q.y, q.z, q.w};
-#ifndef S1X_NOP
-#define S1X_NOP 1   // 0 (experiments): no wait state between the dependent v_fma_mix instructions
-#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-#if S1X_NOP
     asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\ts_nop 0\n\t"
                  "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]\n\ts_nop 0"
                  : "+v"(acc)
                  : "v"(cw[t]), "v"(qw[t]));
-#else
-    asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]\n\t"
-                 "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]"
-                 : "+v"(acc)
-                 : "v"(cw[t]), "v"(qw[t]));
-#endif
 }
 
 // ---- the lazy form (FpS1Exact mode 3): what a STORED value s = h(x + u) says about the reference's value t = h(chain) ------------
@@ -343,11 +330,6 @@ __device__ __forceinline__ void s1_writeout(unsigned char* smem, const int tid, 
   const int clt = tid >> 2, ch = tid & 3;
   const uint32_t lane_s = (uint32_t)(clt * Qp + ch * 8);                        // halves, within the pass's block of S
   const uint32_t lane_o = (uint32_t)(clt * 64 + ((ch ^ ((clt >> 2) & 3)) * 16));       // bytes, within the pass's block of the staged tile
-#if S1_ABL == 1 || S1_ABL == 2
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) eacc[it] = 0u;
-  if (Qp < 0)   // timing only: no write-out
-#endif
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     eacc[it] = 0u;
@@ -359,11 +341,11 @@ __device__ __forceinline__ void s1_writeout(unsigned char* smem, const int tid, 
     // (the floors are fetched before the store is issued: the memory counter is in order, so a load behind the store would make
     // its consumer wait for the store's acknowledgement)
     uint4 gw = make_uint4(0, 0, 0, 0);
-    if (ex.e8 && S1_ABL != 3) gw = *reinterpret_cast<const uint4*>(ex.gfl + (bq * Qp + q0) + (uint32_t)(ch * 8));
+    if (ex.e8) gw = *reinterpret_cast<const uint4*>(ex.gfl + (bq * Qp + q0) + (uint32_t)(ch * 8));
     const uint4 v = *reinterpret_cast<const uint4*>(Os + (g * 128 + cl0) * 64 + lane_o);
     uint16_t* Sblk = S + ((bq * C + c0 + cl0) * Qp + q0);   // (uniform)
     *reinterpret_cast<uint4*>(Sblk + lane_s) = v;
-    if (ex.e8 && S1_ABL != 3) {
+    if (ex.e8) {
       // S4 level 0's table entry, straight from the tile (instead of writing the 8-bit bins and reading them back):
       // e(c) = sum over the query's real columns of max(0, bin - floor_q); the floors come from a sampled pre-pass.
       // Packed fp16 throughout: 128 x, its floor, the clamp at bin 255 (floor = 155) and the difference to g = floor_q - 100
@@ -575,9 +557,6 @@ __global__ __launch_bounds__(128 * NWC) void k_centroid_scores(const uint16_t* _
 // after an LDS-writing load it knows of with vmcnt(0), which would serialise the prefetch with the MFMA phase; here the one wait
 // sits in the epilogue in front of the tile's stores and the barrier at the top of the loop publishes the buffer.
 // (One-tile-per-workgroup form above: 64 KB of operands per tile in two serialised round trips, 201 us without its write-out.)
-#ifndef S1_LAUNDER
-#define S1_LAUNDER 1
-#endif
 // one of the two LDS buffers: the operand tile (128 rows of DK halves; the staged output tile and, behind it at 32 KiB, the epilogue's
 // column-maximum scratch reuse the space) -- 33 KiB up to dim 128, 65 KiB at dim 256 (one workgroup per CU then)
 static constexpr int s1_buf_bytes(int dk) { return (128 * dk * 2 > 4 * 128 * 64 ? 128 * dk * 2 : 4 * 128 * 64) + 4 * 128 * 2; }
@@ -607,9 +586,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
   // position jcol ^ (row % CH) of its LDS row (what the MFMA loop's reads undo)
   auto prefetch = [&](int tile, uint32_t buf_off) {
     int tidp = tid;
-#if S1_LAUNDER
     asm volatile("" : "+v"(tidp));   // (per-piece offsets recomputed per tile instead of living in registers -- or scratch -- across the loop)
-#endif
     const uint32_t rbase = (uint32_t)(tidp / CH);
     const uint32_t jcol = (uint32_t)(tidp % CH);
     const int64_t c0 = (int64_t)tile * 128;
@@ -656,9 +633,7 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     // where the exact mode's chains leave no registers for them and they would be spilled: a scratch reload waits with vmcnt(0),
     // i.e. for the prefetch just issued)
     int tidv = tid;
-#if S1_LAUNDER
     asm volatile("" : "+v"(tidv));
-#endif
     const int lane = tidv & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tidv >> 6), wr = wave >> 1, wc = wave & 1;   // (scalar registers)
     uint16_t* lst = reinterpret_cast<uint16_t*>(smem + 2 * S1_BUF + 512) + wave * (2 * S1X_CAP);   // entries
@@ -684,14 +659,12 @@ void k_centroid_scores_stream(const uint16_t* __restrict__ cent, const uint16_t*
     // across the loop: with them hoisted the kernel spills, and a scratch reload's vmcnt(0) would wait for the prefetch)
     int tn = tile_n;
     S1Groups G = G0;
-#if S1_LAUNDER
     asm volatile("" : "+s"(tn));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       asm volatile("" : "+s"(G.bq[g]));
       asm volatile("" : "+s"(G.q0[g]));
     }
-#endif
     // ---- certification + exact re-evaluation of the flagged entries (FpS1Exact).  The centroid tile is still in LDS and the
     // query rows are in the A fragments: lane (n, hi) holds the chunks 2 ks + hi of column n, so a lane that re-evaluates column
     // n' fetches them with ds_bpermute from lanes n' and n' + 32.  The wave first lists its flagged entries (round-robin over the
@@ -881,8 +854,7 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
   // batches too since round 4, because its exact mode repairs from the LDS tile where the one-tile kernel fetches both rows of
   // every flagged score from L2 (cfg2's table, S1 stage: B = 1 79 -> 52 us, B = 4 143 -> 71 us, B = 8 120 -> 99 us)
   static const int stream_env = [] { const char* e = getenv("FP_S1_STREAM"); return e ? atoi(e) : 1; }();   // 0: one tile per workgroup; n > 1: tiles per workgroup
-  static const int64_t stream_min = [] { const char* e = getenv("FP_S1_STREAM_MIN"); return e ? atoll(e) : 1ll; }();   // tiles below which the one-tile kernel runs (experiments)
-  if ((D == 128 || D == 64 || D == 256) && stream_env && n_rows <= 0 && (int64_t)nch * grid.y >= stream_min) {
+  if ((D == 128 || D == 64 || D == 256) && stream_env && n_rows <= 0) {
     const int nrt = (int)grid.y;
     const int64_t tiles = (int64_t)nch * grid.y;
     const int nct = stream_env > 1 ? stream_env : (int)std::min<int64_t>(8, std::max<int64_t>(1, tiles / 512));
@@ -900,14 +872,8 @@ int fpk_centroid_scores(const FpIndexDev& ix, const uint16_t* qpad, uint16_t* S,
       hipLaunchKernelGGL(k_centroid_scores_stream<64>, dim3(nwg), dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, nct, nrt, ex, xe);
     return 0;
   }
-  static const int nwc_env = [] { const char* e = getenv("FP_S1_WAVES"); return (e && atoi(e) == 4) ? 2 : 4; }();   // FP_S1_WAVES=4: 2 x 2 waves (round 1)
-  const int nwc = xe.mode ? 4 : nwc_env;   // (the exact mode's flag word covers 32 accumulators per lane)
-  static const int xcd_env = [] { const char* e = getenv("FP_S1_XCD"); return e ? atoi(e) : 0; }();   // 1: XCD-aware tile order (measured 315 vs 297 us: the memory-side cache already serves the re-reads)
-  int nrt = 0;
-  if (xcd_env && grid.y > 1 && (int64_t)((nch + 7) / 8) * 8 * grid.y < (1ll << 31)) {
-    nrt = (int)grid.y;
-    grid = dim3((unsigned)(((nch + 7) / 8) * 8 * nrt), 1);
-  }
+  const int nwc = 4;   // eight waves (4 x 2); the 2 x 2-wave layout of round 1 and the XCD-aware tile order (315 vs 297 us) are gone
+  const int nrt = 0;
   if (D % 64 == 0) {
     const size_t lds = std::max<size_t>(2 * 128 * 64 * 2, out_lds);
     if (nwc == 4) hipLaunchKernelGGL((k_centroid_scores<64, 4>), grid, dim3(512), lds, st, ix.centroids, qpad, S, C, Ntot, Qp, S8, cmax, nch, D, rs, ex, nrt, xe);
@@ -1725,6 +1691,44 @@ __device__ __forceinline__ bool fp_ticket_last(uint32_t* ctr, uint32_t expect) {
   __syncthreads();
   return s_last != 0u;
 }
+// Self-test of exactly this publish / ticket / read pattern (run once per device at the first index creation, fp_engine.cpp): every
+// workgroup publishes a round-dependent value over a poisoned slot and draws a ticket; the last one reads ALL slots back.  A part
+// (or a driver) on which device-scope atomics were not coherent at one point would show stale slots here -- the engine then takes
+// the plain count -> scan -> offsets launches for good (what FP_TICKETS=0 selects by hand).
+__global__ __launch_bounds__(256) void k_ticket_selftest(int32_t* __restrict__ slots, uint32_t* __restrict__ ctr, int32_t* __restrict__ bad, int round) {
+  const int n = (int)gridDim.x;
+  if (threadIdx.x == 0) fp_publish(slots + blockIdx.x, (int32_t)((blockIdx.x * 2654435761u) ^ (uint32_t)round) | 1);
+  if (!fp_ticket_last(ctr + round, (uint32_t)n)) return;
+  int wrong = 0;
+  for (int i = (int)threadIdx.x; i < n; i += 256)
+    if (fp_read_published(slots + i) != ((int32_t)(((uint32_t)i * 2654435761u) ^ (uint32_t)round) | 1)) ++wrong;
+  if (wrong) atomicAdd(bad, wrong);
+  if (threadIdx.x == 0) atomicAdd(bad + 1, 1);   // rounds that reached their last workgroup
+}
+__global__ void k_ticket_poison(int32_t* __restrict__ slots, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) slots[i] = 0;   // (a published value is never 0: bit 0 is set)
+}
+// 0 = the pattern holds on this device; != 0: stale reads, missing rounds or a HIP error
+int fpk_ticket_selftest(hipStream_t st) {
+  constexpr int N = 1024, ROUNDS = 16;   // more workgroups than fit the chip at once: several waves of them per round
+  int32_t* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), (size_t)(N + ROUNDS + 2) * 4) != hipSuccess) return -1;
+  int32_t* slots = buf;
+  uint32_t* ctr = reinterpret_cast<uint32_t*>(buf + N);
+  int32_t* bad = buf + N + ROUNDS;
+  (void)hipMemsetAsync(ctr, 0, (size_t)(ROUNDS + 2) * 4, st);
+  for (int r = 0; r < ROUNDS; ++r) {
+    hipLaunchKernelGGL(k_ticket_poison, dim3(N / 256), dim3(256), 0, st, slots, N);
+    hipLaunchKernelGGL(k_ticket_selftest, dim3(N), dim3(256), 0, st, slots, ctr, bad, r);
+  }
+  int32_t h[2] = {-1, -1};
+  const hipError_t e1 = hipMemcpyAsync(h, bad, 8, hipMemcpyDeviceToHost, st);
+  const hipError_t e2 = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return (h[0] == 0 && h[1] == ROUNDS) ? 0 : 1;
+}
 // exclusive scan of the published v[0..nblk) in place by a 256-thread workgroup; returns the total
 __device__ __forceinline__ int fp_scan_counts_256(int32_t* v, int nblk, int* s /*[256] LDS*/) {
   int base = 0;
@@ -1930,9 +1934,6 @@ void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32
                      cand_off, cand_pid);
 }
 
-#ifndef AP_ABL
-#define AP_ABL 0  // k_approx ablation bits (timing only): 1 no row gathers, 2 synthetic codes
-#endif
 // ============================================================================================
 // S4  approximate scores  approx[d] = sum_q max_{c in codes(d)} S[c, q]   (fp16 max, fp32 sum).
 // The stage is gather-LATENCY bound (candidate -> its code list -> one 64-byte score row per
@@ -2018,22 +2019,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       for (int t = t0; t < len; t += TSTEP) {
         uint4 v[8];
-#if AP_ABL & 1
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = make_uint4(code[k], code[k] * 3, code[k] * 5, code[k] * 7);
-#else
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code[k] * Qp);
-#endif
         // next codes while the rows are in flight (max is idempotent: the tail re-reads the last code)
         if (t + TSTEP < len) {
-#if AP_ABL & 2
-#pragma unroll
-          for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)(code[k] * 2654435761u + k)) % (uint32_t)C);
-#else
 #pragma unroll
           for (int k = 0; k < 8; ++k) code[k] = cp[(t + TSTEP + k < len) ? (t + TSTEP + k) : (len - 1)];
-#endif
         } else if (ch == nch - 1 && nlen > t0) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) code[k] = ucodes[nu0 + ((t0 + k < nlen) ? t0 + k : (nlen - 1))];
@@ -2101,10 +2092,9 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
   // enough blocks to cover the largest per-query candidate list a few times over
   int64_t per_q = (M + sh.B - 1) / sh.B;
   // PPD 4 when the lists are short (the refine calls: at most a few x R documents per query)
-  static const int ppd_env = [] { const char* e = getenv("FP_APPROX_PPD"); return e ? atoi(e) : 0; }();   // 1 / 4: force
-  const bool wide = ppd_env ? ppd_env == 4 : per_q <= 16 * sh.R;
+  const bool wide = per_q <= 16 * sh.R;
   const int cpb = wide ? 16 : 64;
-  static const int bxmul = [] { const char* e = getenv("FP_APPROX_BXMUL"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();   // block slots per expected candidate
+  const int bxmul = 2;   // block slots per expected candidate
   int64_t bx = (per_q * bxmul + cpb - 1) / cpb;
   if (bx > (wide ? 4096 : 2048)) bx = wide ? 4096 : 2048;
   if (bx < 1) bx = 1;
@@ -2151,9 +2141,6 @@ void fpk_approx(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh
 //       candidates exactly (tests: fp_search == fp_search_trace, which keeps the all-exact path).
 // ============================================================================================
 #define Q8_OFFSET 100
-#ifndef Q8_ABL
-#define Q8_ABL 0  // timing-only ablations of k_approx_q8: 1 no byte-max arithmetic, 2 synthetic codes
-#endif
 #define Q8_BINS_SUM 8192   // 32 columns x 255 < 8192
 
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
@@ -2238,29 +2225,19 @@ __global__ __launch_bounds__(512) void k_approx_q8(const uint8_t* __restrict__ S
       uint4 v[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const uint4*>(Sb + (int64_t)code[k] * 32);
-#if Q8_ABL & 2
-#pragma unroll
-      for (int k = 0; k < 8; ++k) code[k] = (int32_t)(((uint32_t)code[k] * 2654435761u + (uint32_t)k) % (uint32_t)C);
-#else
       if (t + TSTEP < len) {
         load_codes(cp, t + TSTEP, len, code);
       } else if (tfirst < nlen) {
         load_codes(ucodes + nu0, tfirst, nlen, code);
       }
-#endif
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#if Q8_ABL & 1
-#pragma unroll
-        for (int j = 0; j < 4; ++j) me[j] ^= w[j];
-#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           me[j] = pk_max_u16(me[j], w[j] & 0x00FF00FFu);
           mo[j] = pk_max_u16(mo[j], (w[j] >> 8) & 0x00FF00FFu);
         }
-#endif
       }
     }
     if (tfirst >= len && tfirst < nlen) load_codes(ucodes + nu0, tfirst, nlen, code);  // this pair had no group in this list
@@ -2468,7 +2445,7 @@ void fpk_approx_q8_bounds(const FpIndexDev& ix, const uint8_t* S8, const FpSearc
   // 4.53/4.63 ms), more when one query would otherwise not fill the chip (~1280 resident workgroups x 128 pairs; long
   // documents, small shards).  One workgroup pass per query wherever possible: a grid cap of 2048 costs 0.5 ms, and
   // longer-lived workgroups (2/4/8 candidates per pair: 6.6/8.3/10.3 ms at 1 pair) put several queries' slices in flight.
-  static const int ppd_env = getenv("FP_Q8_PPD") ? atoi(getenv("FP_Q8_PPD")) : 0;
+  static const int ppd_env = (int)fp_test_opt("q8_ppd", 0);
   const int64_t per_q = (M + B - 1) / B;
   const int64_t groups = ix.N > 0 ? (ix.U / ix.N + 7) / 8 : 1;   // average code groups per document
   int ppd = 1;
@@ -2716,7 +2693,7 @@ __device__ __forceinline__ uint32_t l0_u16(const uint4& v, int k) {
 // LPC = lanes per candidate = 16-byte pieces per code line: 8 (128-byte lines, 48 codes: one line per document for tables of one
 // range) or 4 (64-byte lines, 24 codes: tables of several ranges, where a document has ~8 codes per range and 8 lanes per
 // candidate would spend three quarters of their lookups on empty pieces).
-template <int ABL /*timing experiments only: 1 no table lookups, 2 no line loads*/, int LPC>
+template <int LPC>
 __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8, int64_t Cpad, int64_t tab_off, int tab_bytes,
                                                   const uint32_t* __restrict__ esc,
                                                   const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
@@ -2802,7 +2779,6 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
   const int64_t nlast = n - 1;
   auto pos = [&](int64_t at) -> int64_t { return at + kq < nlast ? at + kq : nlast; };
   auto load_line = [&](uint32_t line) -> uint4 {
-    if (ABL & 2) return make_uint4(line * 2654435761u & 0x1FFFFu, line * 40503u & 0x1FFFFu, line * 7919u & 0x1FFFFu, 0x06000000u | (line & 0xFFFFu));
     if (pair) return pcodes[((int64_t)line * pstr + (rng & ~1)) * 4 + sub];
     return pcodes[((int64_t)line * pstr + rng) * LPC + sub];
   };
@@ -2863,16 +2839,11 @@ __global__ __launch_bounds__(1024) void k_l0_scan(const uint8_t* __restrict__ e8
       for (int k = 0; k < L0_UNROLL; ++k)
         if (i + k < n) prev[k] = ubrow[i + k];
     }
-    if (ABL & 1) {
 #pragma unroll
-      for (int k = 0; k < L0_UNROLL; ++k) sums[k] = (pc[k].x ^ pc[k].y ^ pc[k].z ^ pc[k].w) & 7u;
-    } else {
+    for (int k = 0; k < L0_UNROLL; ++k) sums[k] = piece(pc[k]);   // straight-line: all 24 table reads of the lane in flight together
+    if (pair) {
 #pragma unroll
-      for (int k = 0; k < L0_UNROLL; ++k) sums[k] = piece(pc[k]);   // straight-line: all 24 table reads of the lane in flight together
-      if (pair) {
-#pragma unroll
-        for (int k = 0; k < L0_UNROLL; ++k) sums[k] = active ? sums[k] : 0u;
-      }
+      for (int k = 0; k < L0_UNROLL; ++k) sums[k] = active ? sums[k] : 0u;
     }
     uint32_t red[L0_UNROLL];
 #pragma unroll
@@ -3563,15 +3534,15 @@ void fpk_l0h_scan(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& 
 // floors (+ their sum) from the bins of a centroid sample: S8s is [B][nch][ns][32], the bins of the centroids 0, stride, 2 stride, ...
 // (fpk_l0_sample_plan), exactly the sample k_l0_floor takes from a full table
 void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride) {
-  static const int64_t want = [] { const char* e = getenv("FP_L0_SAMPLE"); const int64_t v = e ? atoll(e) : L0_SAMPLE_PRE; return v >= 256 && v <= L0_SAMPLE ? v : L0_SAMPLE_PRE; }();
+  const int64_t want = L0_SAMPLE_PRE;
   *stride = ix.C > want ? ix.C / want : 1;
   *n_rows = (ix.C + *stride - 1) / *stride;
 }
 void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, uint16_t* gfl,
                    hipStream_t st, float hot_tail) {
   const int nch = sh.Qp / 32;
-  static const float tail0 = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
-  static const float tailh = [] { const char* e = getenv("FP_L0H_TAIL"); const float v = e ? (float)atof(e) : 0.f; return (v > 0.f && v < 0.5f) ? v : 0.f; }();   // (0: the caller's)
+  static const float tail0 = [] { const float v = (float)fp_test_opt("l0_tail", 0.025); return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
+  static const float tailh = [] { const float v = (float)fp_test_opt("l0h_tail", 0.0); return (v > 0.f && v < 0.5f) ? v : 0.f; }();   // (0: the caller's)
   const float tail = hot_tail > 0.f ? (tailh > 0.f ? tailh : hot_tail) : tail0;
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
@@ -3589,7 +3560,7 @@ void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape
   const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
   if (!hist_prezeroed) (void)hipMemsetAsync(w.hist, 0, fpk_l0_hist_bytes(B), st);
   if (!S8) return;
-  static const float tail = [] { const char* e = getenv("FP_L0_TAIL"); const float v = e ? (float)atof(e) : 0.025f; return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
+  static const float tail = [] { const float v = (float)fp_test_opt("l0_tail", 0.025); return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum, w.esc,
@@ -3603,33 +3574,24 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   const int B = sh.B;
   const int64_t Cpad = (ix.C + 15) & ~(int64_t)15;
   static std::atomic<uint64_t> ok8{0}, ok4{0};
-  fp_allow_big_lds((const void*)k_l0_scan<0, 8>, ok8, 160 * 1024);
-  fp_allow_big_lds((const void*)k_l0_scan<0, 4>, ok4, 160 * 1024);
+  fp_allow_big_lds((const void*)k_l0_scan<8>, ok8, 160 * 1024);
+  fp_allow_big_lds((const void*)k_l0_scan<4>, ok4, 160 * 1024);
   const int64_t per_q = (M + B - 1) / B;
   // each workgroup copies the table (up to 128 KiB) into LDS first: candidates per workgroup (measured at cfg2: 256 / 512 / 1024 /
   // 2048 / 4096 -> 1.99 / 1.76 / 1.60 / 1.51 / 1.51 ms with the first version of the kernel)
-  static const int cpw = [] { const char* e = getenv("FP_L0_CPW"); const int v = e ? atoi(e) : 4096; return v >= 256 ? v : 4096; }();
+  const int cpw = 4096;
   int64_t bx = (per_q + cpw - 1) / cpw;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
   // measured at cfg2: XCD-affine 0.674 ms, plain (chunk, query) grid 0.565 ms -- the table copies are the smaller effect; with
   // the plain grid the workgroups of ~4 queries sweep the corpus together on all XCDs and share the code lines in the
   // memory-side cache.  Experiment only: FP_L0_XCD=1.
-  static const int affine_env = [] { const char* e = getenv("FP_L0_XCD"); return e ? atoi(e) : 0; }();
+  const int affine_env = 0;
   // (also tried, round 3: query-fastest dispatch order, so that the 256 resident workgroups belong to all 64 queries and walk the
   // same stretch of the corpus together -- lines shared in L2 instead of read once per query: 0.98 ms against 0.56 ms, and
   // fewer, longer workgroups made it worse still; profiles/r03_l0_order_lab.txt)
   const int affine = (affine_env && B % 8 == 0 && bx * (int64_t)B < (1ll << 31)) ? 1 : 0;
   const dim3 grid = affine ? dim3((unsigned)(bx * B)) : dim3((unsigned)bx, (unsigned)B);
-#ifdef FP_ABLATIONS   // timing-only variants of the scan (results are wrong): built only with -DFP_ABLATIONS, never in the shipped library
-  static const int abl = [] { const char* e = getenv("FP_L0_ABL"); return e ? atoi(e) : 0; }();
-  static std::atomic<uint64_t> ok2a{0}, ok2b{0}, ok2c{0};
-  if (abl & 3) {
-    fp_allow_big_lds((const void*)k_l0_scan<1, 8>, ok2a, 160 * 1024);
-    fp_allow_big_lds((const void*)k_l0_scan<2, 8>, ok2b, 160 * 1024);
-    fp_allow_big_lds((const void*)k_l0_scan<3, 8>, ok2c, 160 * 1024);
-  }
-#endif
   FpL0Multi mr{};
   mr.nr = ix.n_ranges;
   mr.ub_stride = w.ub_stride;
@@ -3641,16 +3603,16 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
   // scan).  The nr workgroups of a chunk are dealt to the SAME XCD (ids 8 apart) back to back, so they run together and the
   // second range's line is an L2 hit.  Each writes its partial sums to its own array; k_l0_combine adds F and the parts and
   // builds the histogram.  FP_L0_MULTI=0: one launch per range, accumulating in place (the form before round 3's end).
-  static const int multi_env = [] { const char* e = getenv("FP_L0_MULTI"); return e ? atoi(e) : 1; }();
+  const int multi_env = 1;
   if (ix.n_ranges > 1 && multi_env && w.ub_parts && ((bx + 7) & ~7ll) * ix.n_ranges * (int64_t)B < 0x7FFFFFFFll) {
     const dim3 g1((unsigned)(((bx + 7) & ~7ll) * ix.n_ranges * B));
-    static const int pair_env = [] { const char* e = getenv("FP_L0_PAIR"); return e ? atoi(e) : 0; }();   // (measured slower at cfg3: 61.0 vs 46.9 ms -- experiment only)
+    const int pair_env = 0;   // (lines read as 128-byte pairs of ranges: measured slower at cfg3, 61.0 vs 46.9 ms)
     mr.pair = (pair_env && ix.l0_ppl == 4 && ix.n_ranges % 2 == 0) ? 1 : 0;
     if (ix.l0_ppl == 4 && !mr.pair)
-      hipLaunchKernelGGL((k_l0_scan<0, 4>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
+      hipLaunchKernelGGL((k_l0_scan<4>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
                          (const int32_t*)nullptr, ix.pcodes, w.ub_parts, w.hist, 1, 0, (int)bx, 2, mr);
     else
-      hipLaunchKernelGGL((k_l0_scan<0, 8>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
+      hipLaunchKernelGGL((k_l0_scan<8>), g1, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, (int64_t)0, 0, w.esc, w.Fsum, cand_off, cand_pid,
                          (const int32_t*)nullptr, ix.pcodes, w.ub_parts, w.hist, 1, 0, (int)bx, 2, mr);
     int64_t cb = (per_q + 16383) / 16384;
     if (cb > 256) cb = 256;
@@ -3663,34 +3625,24 @@ void fpk_l0_scan(const FpIndexDev& ix, const FpSearchShape& sh, const int64_t* c
     const int64_t off = (int64_t)r * FP_L0_RANGE;
     const int tb = (int)std::min<int64_t>(FP_L0_RANGE, Cpad - off);
     mr.seq_r = r;
-#define L0_LAUNCH(A_, L_) \
-    hipLaunchKernelGGL((k_l0_scan<A_, L_>), grid, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
+#define L0_LAUNCH(L_) \
+    hipLaunchKernelGGL((k_l0_scan<L_>), grid, dim3(1024), fpk_l0_lds_bytes(ix), st, w.e8, Cpad, off, tb, w.esc, w.Fsum, cand_off, \
                        cand_pid, ix.poff_r[r], ix.pcodes, w.ub, w.hist, r == 0 ? 1 : 0, r == ix.n_ranges - 1 ? 1 : 0, (int)bx, affine, mr)
-#ifdef FP_ABLATIONS
-    if (ix.l0_ppl == 8 && (abl & 3)) {
-      switch (abl & 3) {
-        case 1: L0_LAUNCH(1, 8); break;
-        case 2: L0_LAUNCH(2, 8); break;
-        default: L0_LAUNCH(3, 8); break;
-      }
-      continue;
-    }
-#endif
-    if (ix.l0_ppl == 4) L0_LAUNCH(0, 4);
-    else L0_LAUNCH(0, 8);
+    if (ix.l0_ppl == 4) L0_LAUNCH(4);
+    else L0_LAUNCH(8);
 #undef L0_LAUNCH
   }
 }
 
 void fpk_l0_pilot(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M, FpL0Scratch& w, hipStream_t st) {
   const int B = sh.B;
-  static const int mult = [] { const char* e = getenv("FP_L0_PILOT"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 16 ? v : 4; }();
+  static const int mult = [] { const int v = (int)fp_test_opt("l0_pilot", 4); return v >= 1 && v <= 16 ? v : 4; }();
   hipLaunchKernelGGL(k_l0_topcut, dim3((unsigned)B), dim3(1024), 0, st, w.hist, cand_off, sh.n_full, sh.R, mult, w.Fsum, w.cut, w.npilot);
   const int64_t per_q = (M + B - 1) / B;
   // candidates per workgroup: every workgroup ends with one atomic on its query's counter, and the B counters share a cache
   // line -- device-scope atomics on one line retire at ~6 ns each, whatever the address (8192 / 16384 / 32768 / 65536 per
   // workgroup at cfg2: 28.3 / 19.8 / 25.7 / 42.3 us; k_l0_count reads the same 42 MB without the atomics in 12.7 us)
-  static const int cpb = [] { const char* e = getenv("FP_L0_PILOT_CPB"); const int v = e ? atoi(e) : 16384; return v >= 2048 ? v : 16384; }();
+  const int cpb = 16384;
   int64_t bx = (per_q + cpb - 1) / cpb;
   if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
@@ -4486,7 +4438,7 @@ __global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
 }
 bool fpk_select_lazy_ok(const FpSearchShape& sh) { return sh.R <= FP_MAX_SORT; }   // (and dim <= 256: k_lz_exact keeps a query row in registers -- the caller checks)
 int fpk_select_lazy_gcap(const FpSearchShape& sh) {
-  static const int env = [] { const char* e = getenv("FP_LZ_GCAP"); return e ? atoi(e) : 0; }();   // tests: a small list forces the eager re-run
+  static const int env = (int)fp_test_opt("lz_gcap", 0);   // tests: a small list forces the eager re-run
   if (env > 0) return env;
   return (int)std::min<int64_t>(2 * sh.R + 1024, 1 << 20);
 }
@@ -4925,7 +4877,7 @@ int fpk_shard_global_cut(const void* all_rec1, int G, int B, int64_t R, int64_t 
   const int np2 = next_pow2(n < 2 ? 2 : n);
   const int rp2 = next_pow2((int)(R < 2 ? 2 : R));
   const size_t lds = (size_t)np2 * 8 + (size_t)rp2 * 4 + 16;
-  static const bool force_big = getenv("FP_SHARD_BIG") && atoi(getenv("FP_SHARD_BIG")) != 0;   // testing: the sort-free paths for every size
+  static const bool force_big = fp_test_opt("shard_big", 0) != 0;   // testing: the sort-free paths for every size
   if (lds > 160 * 1024 || force_big) {
     if ((int64_t)G * R >= 0x7FFFFFFFll) return -1;
     hipLaunchKernelGGL(k_shard_cut_big, dim3((unsigned)B), dim3(1024), 0, st, static_cast<const ShardRec1*>(all_rec1), G, B, R, pid_lo, pid_hi, sel_pid,
@@ -4992,7 +4944,7 @@ int fpk_shard_union(const void* all_rec2, int G, int B, int64_t R, int64_t* u_pi
                     int32_t* u_cnt, hipStream_t st) {
   const int n = (int)(G * R);
   const int np2 = next_pow2(n < 2 ? 2 : n);
-  static const bool force_big = getenv("FP_SHARD_BIG") && atoi(getenv("FP_SHARD_BIG")) != 0;
+  static const bool force_big = fp_test_opt("shard_big", 0) != 0;
   if ((size_t)np2 * 8 > 160 * 1024 || force_big) {
     if ((int64_t)G * R >= 0x7FFFFFFFll) return -1;
     hipLaunchKernelGGL(k_shard_union_big, dim3((unsigned)B), dim3(1024), 0, st, static_cast<const ShardRec2*>(all_rec2), G, B, R, u_pid, u_score, u_src,
@@ -5443,7 +5395,7 @@ size_t fpk_compress_work_bytes(int64_t T) { return (size_t)T * (4 + 4 + 4 + 4 * 
 
 static int assign_codes(const uint16_t* emb, int64_t T, const uint16_t* cent, int64_t C, int D, float cmaxabs, int32_t* codes32, void* work,
                         hipStream_t st) {
-  static const int impl_env = [] { const char* e = getenv("FP_ASSIGN_IMPL"); return (e && e[0] == 'e') ? 1 : 0; }();   // "exact": VALU kernel only
+  static const int impl_env = fp_test_opt("assign_exact", 0) != 0 ? 1 : 0;   // the all-VALU exact kernel only (tools/bench_compress.py)
   const unsigned eblocks = fp_grid_cap((T + 63) / 64, 256);
   if ((int64_t)eblocks * 64 < T) return -2;   // callers chunk far below this
   auto exact = [&]() {

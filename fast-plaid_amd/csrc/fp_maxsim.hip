@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_token_rinv(const uint16_t* __restrict__
 
 void fpk_token_rinv(const FpIndexDev& ix, uint32_t* rinv, unsigned long long* n_hard_dev, hipStream_t st) {
   if (ix.T <= 0) return;
-  static const int hard_every = [] { const char* e = getenv("FP_MS_RINV_HARD_EVERY"); return e ? atoi(e) : 0; }();
+  static const int hard_every = (int)fp_test_opt("ms_rinv_hard_every", 0);
   hipLaunchKernelGGL(k_token_rinv, dim3(fp_grid_cap((ix.T + 255) / 256, 256)), dim3(256), 0, st, ix.centroids, ix.lut, ix.codes, ix.residuals,
                      ix.norms, ix.dim, ix.nbits, ix.T, rinv, n_hard_dev, hard_every);
 }
@@ -418,11 +418,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
       uint32_t e[NE];
       uint32_t rw[RW];
       // ---- loads of this chunk (exhausted streams read row 0 of the arrays: harmless) ----
-#if defined(FP_MS_ABL) && (FP_MS_ABL == 1 || FP_MS_ABL == 5)
-      ms_load_token<D, NBITS>(a.resid, a.cent, valid ? tok_row() : 0, 0, rw, e);   // timing-only ablation: no scattered centroid gather
-#else
       ms_load_token<D, NBITS>(a.resid, a.cent, valid ? tok_row() : 0, valid ? code : 0, rw, e);
-#endif
       const float nf = (float)__builtin_bit_cast(half_t, nrm);
       // ---- this chunk's bookkeeping, then step the stream and prefetch the next code / norm ----
       const int c_t0 = t0, c_len = len, c_r = r;
@@ -437,24 +433,11 @@ __global__ __launch_bounds__(MS_THREADS) void k_maxsim5(const MsArgs a) {
         if (valid) { const long long rr = tok_row(); code = a.codes[rr]; nrm = a.norms[rr]; }
       }
       // ---- e = h(cent + w);  e^ = h(fl32(e / n)) through the compensated reciprocal product (fp_selftest_arith out[0]) ----
-#if !defined(FP_MS_ABL) || FP_MS_ABL != 3
       ms_decode<D, NBITS>(laneoff, rw, e);
-#else
-#pragma unroll
-      for (int i = 0; i < RW; ++i) e[i] ^= rw[i];
-#endif
       float r_hi, r_lo;
       recip2(nf, r_hi, r_lo);
-#if !defined(FP_MS_ABL) || FP_MS_ABL == 1 || FP_MS_ABL == 3
 #pragma unroll
       for (int i = 0; i < NE; i += 2) norm_pair2(e[i], e[i + 1], r_hi, r_lo);
-#elif FP_MS_ABL == 4 || FP_MS_ABL == 5   // timing-only: one v_fma_mixlo/hi per element
-#pragma unroll
-      for (int i = 0; i < NE; ++i)
-        asm volatile("v_fma_mixlo_f16 %0, %0, %1, 0 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %0, %1, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(e[i]) : "v"(r_hi + r_lo));
-#else
-      e[0] ^= __float_as_uint(r_hi + r_lo);
-#endif
       // ---- MFMA: acc0 rows = lower stream's tokens, acc1 rows = upper stream's tokens ----
       f16v acc0[NCH], acc1[NCH];
 #pragma unroll
@@ -793,13 +776,7 @@ __global__ __launch_bounds__(ms6_waves(KS4, NCH, NBITS) * 64) __attribute__((amd
       if constexpr (LB % 16 == 0) {
 #pragma unroll
         for (int i = 0; i < LB / 16; ++i) {
-#ifdef FP_MS6_NT   // experiment: the residual stream with the non-temporal hint (read once: keep it out of the L2's way)
-          typedef uint32_t ms_u4v __attribute__((ext_vector_type(4)));
-          const ms_u4v t = __builtin_nontemporal_load(reinterpret_cast<const ms_u4v*>(rp + 16 * i));
-          const uint4 v = make_uint4(t.x, t.y, t.z, t.w);
-#else
           const uint4 v = *reinterpret_cast<const uint4*>(rp + 16 * i);
-#endif
           bf.rw[4 * i] = v.x; bf.rw[4 * i + 1] = v.y; bf.rw[4 * i + 2] = v.z; bf.rw[4 * i + 3] = v.w;
         }
       } else if constexpr (LB % 8 == 0) {
@@ -831,13 +808,7 @@ __global__ __launch_bounds__(ms6_waves(KS4, NCH, NBITS) * 64) __attribute__((amd
 
     auto compute = [&](const Ms6Step& st, Ms6Buf<KS4, NBITS>& bf, uint32_t nrm) {
       // e = h(cent + w);  e^ = h(fl32(e / n))
-#if !defined(FP_MS6_ABL) || (FP_MS6_ABL != 2 && FP_MS6_ABL != 4)
       ms6_decode<NBITS, RW, NE>(laneoff, bf.rw, bf.e);
-#else
-#pragma unroll
-      for (int i = 0; i < RW; ++i) bf.e[i] ^= bf.rw[i];   // timing-only ablation: no decode
-#endif
-#if !defined(FP_MS6_ABL) || FP_MS6_ABL == 3
       if (a.rinv && !__any((int)(nrm >> 31))) {   // one multiply per value by the token's stored reciprocal
         const float r = __uint_as_float(nrm);
 #pragma unroll
@@ -850,15 +821,8 @@ __global__ __launch_bounds__(ms6_waves(KS4, NCH, NBITS) * 64) __attribute__((amd
 #pragma unroll
         for (int i = 0; i < NE; i += 2) norm_pair2(bf.e[i], bf.e[i + 1], r_hi, r_lo);
       }
-#else
-      bf.e[0] ^= nrm;   // timing-only ablation: no normalisation
-#endif
       // MFMA: D[row = token][col], this lane's rows 4 g + i
       f4v acc[NC16];
-#if defined(FP_MS6_ABL) && (FP_MS6_ABL == 3 || FP_MS6_ABL == 4)
-#pragma unroll
-      for (int c = 0; c < NC16; ++c) acc[c] = f4v{__uint_as_float(bf.e[c]), __uint_as_float(bf.e[4 + c]), __uint_as_float(bf.e[8 + c]), __uint_as_float(bf.e[12 + c])};   // timing-only: no MFMA / fragment reads
-#else
 #pragma unroll
       for (int c = 0; c < NC16; ++c) {
 #pragma unroll
@@ -869,7 +833,6 @@ __global__ __launch_bounds__(ms6_waves(KS4, NCH, NBITS) * 64) __attribute__((amd
           else acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq, acc[c], 0, 0, 0);
         }
       }
-#endif
       const bool partial = st.t0 + 16 > st.len;
 #pragma unroll
       for (int c = 0; c < NC16; ++c) {
@@ -1341,9 +1304,9 @@ static void launch_maxsim6(const FpIndexDev& ix, const uint16_t* qpad, const FpS
     if ((int64_t)g * waves > tot_max) g = (int)std::max<int64_t>(1, (tot_max + waves - 1) / waves);
     return g;
   };
-  static const float eps_env = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  const float eps_env = 1.9073486e-06f;   // 2^-19
   const float eps_rel = eps_env * (ix.dim > 128 ? (float)ix.dim / 128.f : 1.f);   // (the window was measured at dim 128; the reorder noise grows with the number of terms)
-  static const int xcd = [] { const char* e = getenv("FP_MS_XCD"); return e ? atoi(e) : 0; }();
+  const int xcd = 0;   // (a query's documents on one XCD: measured -1 us, round 3)
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
            Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, ix.rinv, xcd};
   static std::atomic<uint64_t> ok1{0}, ok2{0};
@@ -1372,7 +1335,7 @@ static void launch_maxsim5(const FpIndexDev& ix, const uint16_t* qpad, const FpS
   const int64_t tot_max = (int64_t)sh.B * Rcap;
   int grid = ms_num_cus();
   if ((int64_t)grid * MS_WAVES > tot_max) grid = (int)std::max<int64_t>(1, (tot_max + MS_WAVES - 1) / MS_WAVES);
-  static const float eps_env = [] { const char* e = getenv("FP_MAXSIM_EPS"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 1.9073486e-06f; }();   // 2^-19
+  const float eps_env = 1.9073486e-06f;   // 2^-19
   const float eps_rel = eps_env * (ix.dim > 128 ? (float)ix.dim / 128.f : 1.f);   // (the window was measured at dim 128; the reorder noise grows with the number of terms)
   MsArgs a{ix.centroids, ix.lut, ix.codes, ix.norms, ix.residuals, ix.doc_off, qpad, sel_pid, pref, exact, aux.cm16, aux.unc, aux.uncm, aux.flags,
            Rcap, sh.B, sh.Q, sh.Qp, 0, 0, eps_rel, nullptr, 0};

@@ -124,6 +124,11 @@ class PyLoadedIndex:
         """tokens whose normalisation has no one-multiply reciprocal (k_token_rinv): their steps take the compensated path"""
         return int(N.lib().fp_index_num_hard_tokens(self._h))
 
+    @property
+    def tickets_ok(self):
+        """the fence-free "last workgroup finishes" launches passed their self-test on this index's device (else: plain launch chains)"""
+        return bool(N.lib().fp_index_tickets_ok(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib().fp_index_destroy(self._h)

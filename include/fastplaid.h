@@ -95,6 +95,9 @@ int64_t fp_index_num_unique_codes(const fp_index* index);
 int64_t fp_index_num_code_lines(const fp_index* index);
 /* tokens whose normalisation has no one-multiply reciprocal (the MaxSim kernel takes the compensated path for their steps) */
 int64_t fp_index_num_hard_tokens(const fp_index* index);
+/* 1 when the fence-free "last workgroup finishes the job" launches passed their self-test on the index's device at creation (they
+ * then replace the count -> scan -> offsets launch chains), 0 when the plain chains are used -- results are the same. */
+int32_t fp_index_tickets_ok(const fp_index* index);
 
 /* ---- search: `pysearch` (rust/lib.rs:195-223) -> search_many (search.rs:219-288) ----- */
 /* queries: host [n_queries, q_len, dim] f16.  subset_offsets NULL = no subset; otherwise

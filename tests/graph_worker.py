@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fptest_env import test_opt  # noqa: E402
+
 import fast_plaid_amd as fp  # noqa: E402
 
 
@@ -44,7 +47,7 @@ def main():
         pids, scores, counts = R.search_arrays(dev, q, params)
         alt.append((params, q, pids.copy(), scores.copy(), counts.copy()))
     replays = R.graph_replay_count() - before
-    if not os.environ.get("FP_SPEC_CAP_PCT"):   # (the forced-overflow run never keeps a capacity: nothing to replay)
+    if not test_opt("spec_cap_pct"):   # (the forced-overflow run never keeps a capacity: nothing to replay)
         assert replays >= 24, replays   # 30 calls - 3 shapes x 2 warm-up forms
     for params, q, pids, scores, counts in alt:
         for b in range(q.shape[0]):

@@ -1,5 +1,5 @@
 """GPU worker for tests/test_hip_parity.py::test_index_build_with_capped_grids: runs with
-FP_GRID_CAP=3 so every index-build kernel whose grid scales with the corpus walks its
+FP_TEST=grid_cap=3 so every index-build kernel whose grid scales with the corpus walks its
 grid-stride loop many times (the path a > 2^32 work-item launch takes at 10 M documents)."""
 import os
 import sys
@@ -10,13 +10,16 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fptest_env import test_opt  # noqa: E402
+
 import fast_plaid_amd as fp  # noqa: E402
 import plaid_oracle as OC  # noqa: E402
 from parity import check_trace  # noqa: E402
 
 
 def main():
-    assert os.environ.get("FP_GRID_CAP") == "3"
+    assert test_opt("grid_cap") == "3"
     R = fp.fast_plaid_rust
     # device generator + sort + unique + IVF build == numpy twin
     spec = fp.synth.SynthSpec(n_docs=3000, doc_len=48, n_centroids=512, variable_len=True, seed=42)
@@ -41,9 +44,9 @@ def main():
     for idx in (dev, hip):
         for b in range(3):
             check_trace(R.search_trace(idx, q[b], params), orc.search_trace(q[b], 20, 256, 4), 32, 4, 256, 20)
-    # FP_S_BUDGET_KB (set by the test next to FP_GRID_CAP): the batch is cut into sub-batches of the centroid-score table's
+    # s_budget_kb (set by the test next to grid_cap in FP_TEST): the batch is cut into sub-batches of the centroid-score table's
     # budget; results must not depend on the cut
-    if os.environ.get("FP_S_BUDGET_KB"):
+    if test_opt("s_budget_kb"):
         qb = fp.synth.make_queries(spec, host["centroids"], 23, 32)
         pids, scores, counts = R.search_arrays(hip, qb, params)
         assert R.last_search_counts()["sub_batches"] > 1, "the budget did not force sub-batching"

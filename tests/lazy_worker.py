@@ -1,7 +1,7 @@
 """GPU worker for tests/test_hip_parity.py::test_lazy_centroid_scores: S1's lazy form (FpLazyS1, fp_internal.h -- upper candidates
 stored, the probe / the selection settle what they use) under fp_search against the EAGER form under fp_search_trace (every score
 certified and repaired inside S1) and against the oracle.  LAZY_EXPECT=1: the batches must report the lazy form; 0: the eager one
-(FP_S1_EXACT=1, or FP_LZ_GCAP so small that every batch overflows its selection list and is run again eagerly)."""
+(FP_S1_EXACT=1, or FP_TEST=lz_gcap=.. so small that every batch overflows its selection list and is run again eagerly)."""
 import os
 import sys
 

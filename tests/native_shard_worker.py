@@ -2,7 +2,7 @@
 by the library on its own stream) with ONE rank over RCCL -- all a single-GPU box allows, since RCCL wants a GPU per rank; the
 multi-rank protocol itself is covered through the staged entry points (shard_gpu_worker.py, shard_mp_worker.py, gloo tests).
 One rank must reproduce fp_search exactly, batch after batch of the same shape, so from the second batch on the front half runs
-on the learnt candidate capacity; with FP_SPEC_CAP_PCT=50 (set by the test) every such batch overflows, says so in the first
+on the learnt candidate capacity; with FP_TEST=spec_cap_pct=50 (set by the test) every such batch overflows, says so in the first
 exchange and is run again."""
 import os
 import sys
@@ -13,6 +13,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fptest_env import test_opt  # noqa: E402
 
 import fast_plaid_amd as fp  # noqa: E402
 from fast_plaid_amd import sharded  # noqa: E402
@@ -26,7 +29,7 @@ def main():
     host = fp.synth.host_index_arrays(spec)
     index = R.construct_synthetic_index(spec, "cuda:0", centroids=host["centroids"])
     comm = sharded.NativeComm.from_torch_dist(index.device_id, dist)
-    if os.environ.get("FP_SHARD_FAIL_AT"):
+    if test_opt("shard_fail_at"):
         # a stage that fails locally must neither hang nor return results: every collective is still issued, the failure travels in
         # the status word of the next exchange, and the call raises after its final sync; the communicator stays usable
         params = R.SearchParameters(2000, 512, 50, 4)

@@ -15,6 +15,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fptest_env import test_opt  # noqa: E402
+
 import fast_plaid_amd as fp  # noqa: E402
 import plaid_oracle as OC  # noqa: E402
 
@@ -61,7 +64,7 @@ def main():
                 n_scores += n
             _same_order_modulo_ref_ties(pids[b, :n], ref[b][0], dict(zip(np.asarray(ref[b][0]).tolist(), np.asarray(ref[b][1]).tolist())))
             n_lists += 1
-        if os.environ.get("FP_MS_RINV_HARD_EVERY") and fp.fast_plaid_rust is R and dim % 32 == 0 and not (dim == 96 and nbits == 2):
+        if test_opt("ms_rinv_hard_every") and fp.fast_plaid_rust is R and dim % 32 == 0 and not (dim == 96 and nbits == 2):
             assert idx.n_hard_tokens > 0, (dim, nbits)   # the forced exact-path tokens were really marked
     print("REPAIR_OK mode", mode, "scores", n_scores, "lists", n_lists)
 

@@ -3,7 +3,7 @@
 fp_search sizes S4 / S5 from the candidate total of EARLIER batches of the same shape instead of waiting for the current one
 in the middle of the pipeline; a batch that exceeds the learnt capacity is emptied on the device and run again.  This worker
 drives both outcomes: repeated batches (the capacity holds), batches whose totals grow (re-run), and -- with
-FP_SPEC_CAP_PCT=50 set by the test -- a capacity that is always too small (every batch after the first is run twice).  Every
+FP_TEST=spec_cap_pct=50 set by the test -- a capacity that is always too small (every batch after the first is run twice).  Every
 result must equal fp_search_trace, which never speculates."""
 import os
 import sys

@@ -8,6 +8,7 @@ import pytest
 
 import plaid_oracle as OC
 from conftest import GOLDEN_DIR, golden_cases
+from fptest_env import with_test_opts
 from parity import SCORE_TOL, check_final, check_trace, ulp_diff_f16 as parity_ulp
 
 pytestmark = pytest.mark.gpu
@@ -350,15 +351,25 @@ def test_probe_fallback_path_forced(fp):
     assert r.returncode == 0 and "PROBE_FALLBACK_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_ticket_chain_selftest_passes_on_this_device(fp):
+    """the 'last workgroup finishes the job' launches publish counts with device-scope atomic exchanges and read them back with
+    device-scope atomic loads, no fence -- behaviour outside the letter of the HIP memory model.  The library checks exactly
+    that pattern on the index's device at the first index creation (1024 workgroups x 16 rounds over poisoned slots) and takes
+    the plain launch chains if it ever fails; on this part it must pass (FP_TICKETS=0 covers the other branch)."""
+    z, arr = _load_golden("base_d128_nb4")
+    hip = _hip_index(fp, arr)
+    assert hip.tickets_ok
+
+
 def test_index_build_with_capped_grids(fp):
     """HIP dispatches wrap silently beyond 2^32 work-items (hit at 10 M documents); the
-    index-build kernels therefore cap their grids and loop.  FP_GRID_CAP=3 forces those loops on
+    index-build kernels therefore cap their grids and loop.  FP_TEST=grid_cap=3 forces those loops on
     a small corpus; results must still equal the numpy twin / the oracle.  The same worker also forces the batch
-    to be cut into sub-batches (FP_S_BUDGET_KB) and checks that results do not depend on the cut."""
+    to be cut into sub-batches (s_budget_kb) and checks that results do not depend on the cut."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FP_GRID_CAP="3", FP_S_BUDGET_KB="200")   # 512 centroids x 32 x 2 B = 32 KiB per query -> sub-batches of 6
+    env = with_test_opts(grid_cap=3, s_budget_kb=200)   # 512 centroids x 32 x 2 B = 32 KiB per query -> sub-batches of 6
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "grid_cap_worker.py")], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "GRID_CAP_OK" in r.stdout, r.stdout + r.stderr
@@ -368,13 +379,13 @@ def test_index_build_with_capped_grids(fp):
 def test_candidate_capacity_speculation(fp, cap_pct, impl):
     """fp_search sizes S4 / S5 from the candidate totals of earlier batches of the same shape instead of waiting for the
     current total in the middle of the pipeline; a batch above the learnt capacity is emptied on the device and run again.
-    FP_SPEC_CAP_PCT=50 makes the capacity half of the last total, so every batch after a shape's first takes the re-run."""
+    FP_TEST=spec_cap_pct=50 makes the capacity half of the last total, so every batch after a shape's first takes the re-run."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     if cap_pct:
-        env["FP_SPEC_CAP_PCT"] = cap_pct
+        env = with_test_opts(env, spec_cap_pct=cap_pct)
     if impl:
         env["FP_APPROX_IMPL"] = impl
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "spec_worker.py")], capture_output=True, text=True, timeout=600, env=env)
@@ -385,7 +396,7 @@ def test_candidate_capacity_speculation(fp, cap_pct, impl):
 def test_bound_and_refine_forced(fp, ppd):
     """S4's bound-and-refine form (8-bit bins of S -> per-candidate bounds -> exact rescoring of
     the survivors) forced on small corpora via FP_APPROX_IMPL=q8, for every lane-pairs-per-candidate
-    instantiation of the bound kernel (FP_Q8_PPD): fp_search must equal fp_search_trace (which
+    instantiation of the bound kernel (FP_TEST=q8_ppd=..): fp_search must equal fp_search_trace (which
     scores every candidate exactly) bit for bit -- fixtures, pruned synthetic corpora, Q < 32,
     out-of-range score values, the odd random shapes."""
     import subprocess
@@ -393,7 +404,7 @@ def test_bound_and_refine_forced(fp, ppd):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FP_APPROX_IMPL="q8")
     if ppd != "auto":
-        env["FP_Q8_PPD"] = ppd
+        env = with_test_opts(env, q8_ppd=ppd)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
@@ -402,14 +413,14 @@ def test_bound_and_refine_forced(fp, ppd):
 def test_level0_forced(fp, tail, pilot, ppl):
     """S4's level-0 form (per-centroid excess table in LDS -> upper bound of every candidate from its code list alone ->
     pilot group scored exactly -> threshold -> survivors scored exactly) forced on small corpora via FP_APPROX_IMPL=l0, for
-    several floor quantiles (FP_L0_TAIL) and pilot-group sizes (FP_L0_PILOT): fp_search must equal fp_search_trace (which
+    several floor quantiles (FP_TEST l0_tail) and pilot-group sizes (l0_pilot): fp_search must equal fp_search_trace (which
     scores every candidate exactly) bit for bit on the same inputs as the 8-bit bound stage's test."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FP_APPROX_IMPL="l0", FP_L0_TAIL=tail, FP_L0_PILOT=pilot)
+    env = with_test_opts(dict(os.environ, FP_APPROX_IMPL="l0"), l0_tail=tail, l0_pilot=pilot)
     if ppl:   # code lines of 4 / 8 pieces whatever the table size (4: documents of more than 24 codes take the multi-line path)
-        env["FP_L0_PPL"] = ppl
+        env = with_test_opts(env, l0_ppl=ppl)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "Q8_OK" in r.stdout, r.stdout + r.stderr
 
@@ -423,7 +434,7 @@ def test_level0_hot_form_forced(fp):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for tail in ("0.004", "0.05"):
-        env = dict(os.environ, FP_APPROX_IMPL="l0h", FP_L0H_TAIL=tail)
+        env = with_test_opts(dict(os.environ, FP_APPROX_IMPL="l0h"), l0h_tail=tail)
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "q8_worker.py")], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0 and "Q8_OK" in r.stdout, tail + r.stdout + r.stderr
 
@@ -443,13 +454,13 @@ def test_without_tickets_and_with_every_score_reevaluated(fp):
 
 
 @pytest.mark.parametrize("extra,expect", [({}, 1), ({"FP_APPROX_IMPL": "l0"}, 1), ({"FP_APPROX_IMPL": "q8"}, 1), ({"FP_APPROX_IMPL": "exact"}, 1),
-                                          ({"FP_LZ_GCAP": "3"}, 0), ({"FP_S1_EXACT": "1"}, 0), ({"FP_S1_STREAM": "0"}, 1)])
+                                          ({"FP_TEST": "lz_gcap=3"}, 0), ({"FP_S1_EXACT": "1"}, 0), ({"FP_S1_STREAM": "0"}, 1)])
 def test_lazy_centroid_scores(fp, extra, expect):
     """S1's lazy form (round 5: the centroid scores leave S1 as upper candidates h(x + u), no chain runs there; the probe
     re-evaluates the handful of scores it ranks, the selection recomputes the few documents whose upper-bound score lies within
     the slack of the cut) must give exactly what the eager form gives: fp_search (lazy) == fp_search_trace (eager) bit for bit and
     the oracle's ids, for every form of S4, with both S1 kernels, with an unnormalised query and zero rows; a selection list that
-    overflows (FP_LZ_GCAP=3) sends the batch round again eagerly; FP_S1_EXACT=1 keeps everything eager."""
+    overflows (FP_TEST=lz_gcap=3) sends the batch round again eagerly; FP_S1_EXACT=1 keeps everything eager."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -478,7 +489,7 @@ def test_centroid_scores_exact_streaming_kernel(fp, kernel):
     assert any("'flagged': 0," not in ln for ln in lines), "the certification flagged nothing: the exact mode did not run"
 
 
-@pytest.mark.parametrize("mode,extra", [("2", {}), ("1", {}), ("2", {"FP_MS_RINV_HARD_EVERY": "5"}), ("2", {"FP_MS_RINV": "0"})])
+@pytest.mark.parametrize("mode,extra", [("2", {}), ("1", {}), ("2", {"FP_TEST": "ms_rinv_hard_every=5"}), ("2", {"FP_TEST": "ms_rinv=0"})])
 def test_maxsim_repair_vs_oracle(fp, mode, extra):
     """exact-order repair of the MFMA MaxSim pass (tests/repair_worker.py): with every flagged document repaired
     (FP_MAXSIM_REPAIR=2) every returned score equals the oracle's bit for bit over thirteen dim/nbits/q_len shapes; with the
@@ -985,16 +996,16 @@ def test_sharded_equals_unsharded(fp, big):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_gpu_worker.py")], capture_output=True, text=True,
-                       timeout=600, env=dict(os.environ, FP_SHARD_BIG=big))
+                       timeout=600, env=with_test_opts(shard_big=big))
     assert r.returncode == 0 and "SHARDED_GPU_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("cap_pct,extra", [("", {}), ("50", {}), ("", {"FP_SHARD_BIG": "1"}), ("50", {"FP_SHARD_S_BUDGET_KB": "128"}),
-                                           ("", {"FP_SHARD_FAIL_AT": "1"}), ("", {"FP_SHARD_FAIL_AT": "2"}), ("", {"FP_SHARD_FAIL_AT": "3"})])
+@pytest.mark.parametrize("cap_pct,extra", [("", {}), ("50", {}), ("", {"shard_big": "1"}), ("50", {"shard_s_budget_kb": "128"}),
+                                           ("", {"shard_fail_at": "1"}), ("", {"shard_fail_at": "2"}), ("", {"shard_fail_at": "3"})])
 def test_native_rccl_shard_search_one_rank(fp, cap_pct, extra):
     """fp_shard_search with one rank over RCCL (a single-GPU box allows no more) reproduces fp_search exactly, also when the
     learnt candidate capacity is forced too small and the batch is run again after the overflow mark of the first exchange;
-    with the sort-free cut / union of large unions forced (FP_SHARD_BIG); split into sub-batches by a tiny budget of the
+    with the sort-free cut / union of large unions forced (FP_TEST=shard_big=1); split into sub-batches by a tiny budget of the
     centroid-score table; and with a failure injected into each stage (the call raises, no collective is skipped)."""
     import socket
     import subprocess
@@ -1006,8 +1017,8 @@ def test_native_rccl_shard_search_one_rank(fp, cap_pct, extra):
     s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if cap_pct:
-        env["FP_SPEC_CAP_PCT"] = cap_pct
-    env.update(extra)
+        env = with_test_opts(env, spec_cap_pct=cap_pct)
+    env = with_test_opts(env, **extra)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "native_shard_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NATIVE_SHARD_OK" in r.stdout, r.stdout + r.stderr
 

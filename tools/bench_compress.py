@@ -13,4 +13,4 @@ for C, T in ((8192, 1 << 18), (131072, 1 << 18)):
     cut = np.linspace(-0.05, 0.05, 15).astype(np.float16)
     CR.compress(cent, cut, emb[:4096], 4)
     t = time.perf_counter(); codes, res = CR.compress(cent, cut, emb, 4); dt = time.perf_counter() - t
-    print("C=%d T=%d: %.3f s  %.2f Mtok/s  %.1f TFLOP/s useful (2 T C D / time; FP_ASSIGN_IMPL=exact forces the all-VALU kernel)" % (C, T, dt, T / dt / 1e6, 2.0 * T * C * 128 / dt / 1e12))
+    print("C=%d T=%d: %.3f s  %.2f Mtok/s  %.1f TFLOP/s useful (2 T C D / time; FP_TEST=assign_exact=1 forces the all-VALU kernel)" % (C, T, dt, T / dt / 1e6, 2.0 * T * C * 128 / dt / 1e12))

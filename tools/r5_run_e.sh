@@ -2,7 +2,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 T=${1:-r5e}
 ( LAZY_EXPECT=1 timeout 600 python tests/lazy_worker.py 2>&1 | tail -2
-  for v in "FP_APPROX_IMPL=l0 LAZY_EXPECT=1" "FP_APPROX_IMPL=q8 LAZY_EXPECT=1" "FP_APPROX_IMPL=exact LAZY_EXPECT=1" "FP_LZ_GCAP=3 LAZY_EXPECT=0" "FP_S1_EXACT=1 LAZY_EXPECT=0" "FP_S1_STREAM=0 LAZY_EXPECT=1"; do
+  for v in "FP_APPROX_IMPL=l0 LAZY_EXPECT=1" "FP_APPROX_IMPL=q8 LAZY_EXPECT=1" "FP_APPROX_IMPL=exact LAZY_EXPECT=1" "FP_TEST=lz_gcap=3 LAZY_EXPECT=0" "FP_S1_EXACT=1 LAZY_EXPECT=0" "FP_S1_STREAM=0 LAZY_EXPECT=1"; do
     echo "== $v"; env $v timeout 600 python tests/lazy_worker.py 2>&1 | tail -2
   done ) > $OUT/${T}_lazy_worker.log 2>&1
 grep -c LAZY_OK $OUT/${T}_lazy_worker.log; grep -v LAZY_OK $OUT/${T}_lazy_worker.log | grep -v "^==" | tail -5

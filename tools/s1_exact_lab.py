@@ -1,5 +1,5 @@
 """S1 exact-mode lab (GPU): S of fp_search_trace against the C oracle, bit for bit, on goldens and synthetic corpora; run it with
-FP_S1_STREAM_MIN=1 to put the streaming kernel under the traces, FP_S1_EXACT=0/1/2, FP_S1_STATS=1 for the counters."""
+FP_S1_EXACT=0/1/2, FP_S1_STATS=1 for the counters."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

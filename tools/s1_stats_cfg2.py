@@ -1,4 +1,4 @@
-"""S1 certification counters and stage times on BASELINE cfg2 (GPU).  Usage: [FP_S1_EXACT=0|1|2] [FP_S1_W0_LOG2=-21] FP_S1_STATS=1
+"""S1 certification counters and stage times on BASELINE cfg2 (GPU).  Usage: [FP_S1_EXACT=0|1|2|3] [FP_TEST=s1_w0_log2=-21] FP_S1_STATS=1
 python tools/s1_stats_cfg2.py [batches] [docs] [dim]"""
 import os, sys, time
 import numpy as np

@@ -10,5 +10,5 @@ cd ${GRAFT_REPO_ROOT:-.}
 for s in $SCALES; do
   w0=$(python -c "print(-21.5 - $s)"); ka=$(python -c "print(-20.0 - $s)")
   echo "## window scale 2^-$s: w0 = 2^$w0, kappa = 2^$ka"
-  FP_S1_EXACT=2 FP_S1_STATS=1 FP_S1_W0_LOG2=$w0 FP_S1_KAPPA_LOG2=$ka timeout 200 python tools/s1_stats_cfg2.py $NB $DOCS $DIM 2>&1 | tail -1
+  FP_S1_EXACT=2 FP_S1_STATS=1 FP_TEST="s1_w0_log2=$w0,s1_kappa_log2=$ka" timeout 200 python tools/s1_stats_cfg2.py $NB $DOCS $DIM 2>&1 | tail -1
 done
