@@ -275,3 +275,33 @@ def test_index_directory_oracle_roundtrip():
                 assert v == json.loads(bytes(w).decode()), fn
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_prepare_search_matches_the_reference_python():
+    """tests/golden/prepare_search.npz holds what the REFERENCE's own FastPlaid._prepare_search (python/fast_plaid/search/
+    fast_plaid.py:743-795, imported from /root/reference in the build container by tests/golden/make_prepare_search_golden.py)
+    returned for seeded inputs: a list of 2-D / 3-D query tensors zero-padded to the longest, a 3-D tensor passed through, and
+    every subset form (flat list, per-query lists, an int, the empty list, a list of the wrong length).  This repository's
+    FastPlaid._prepare_search must hand the same padded queries (cast to fp16, as fast_plaid.py:241 does before the native
+    boundary) and the same normalised subsets to the native search."""
+    import types
+    from fast_plaid_amd import search
+    z = np.load(os.path.join(ROOT, "tests", "golden", "prepare_search.npz"))
+    me = types.SimpleNamespace(index=None, devices=["cpu"], indices={"cpu": object()})
+    prep = lambda q, s: search.FastPlaid._prepare_search(me, q, s)   # noqa: E731
+    qa = [z[f"a_in_{i}"] for i in range(4)]
+    q3, sub = prep(qa, None)
+    assert sub is None and q3.dtype == np.float16
+    assert np.array_equal(q3, z["a_out"].astype(np.float16))
+    q3, _ = prep(z["b_in"], None)
+    assert np.array_equal(q3, z["b_out"].astype(np.float16))
+    forms = {"flat": [7, 3, 3, 11], "perq": [[1], [2, 2, 5], [], [9, 8]], "int": 6, "empty": []}
+    for name, sv in forms.items():
+        _, sub = prep(qa, sv)
+        assert (sub is None) == bool(z[f"sub_{name}_none"]), name
+        if sub is not None:
+            assert [len(x) for x in sub] == z[f"sub_{name}_lens"].tolist(), name
+            assert [int(v) for x in sub for v in x] == z[f"sub_{name}_flat"].tolist(), name
+    assert bool(z["sub_badlen_raises"])
+    with pytest.raises(ValueError):
+        prep(qa, [[1], [2]])
