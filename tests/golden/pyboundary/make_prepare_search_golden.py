@@ -1,4 +1,4 @@
-"""Generates tests/golden/prepare_search.npz  (run in the build container only; reads /root/reference).
+"""Generates tests/golden/pyboundary/prepare_search.npz  (run in the build container only; reads /root/reference).
 
 What is pinned: the Python-side normalisation in front of the native boundary ("Python caller to reproduce"):
 the REFERENCE's own `FastPlaid._prepare_search` (python/fast_plaid/search/fast_plaid.py:743-795) -- zero-padding of a list of

@@ -278,15 +278,15 @@ def test_index_directory_oracle_roundtrip():
 
 
 def test_prepare_search_matches_the_reference_python():
-    """tests/golden/prepare_search.npz holds what the REFERENCE's own FastPlaid._prepare_search (python/fast_plaid/search/
-    fast_plaid.py:743-795, imported from /root/reference in the build container by tests/golden/make_prepare_search_golden.py)
+    """tests/golden/pyboundary/prepare_search.npz holds what the REFERENCE's own FastPlaid._prepare_search (python/fast_plaid/search/
+    fast_plaid.py:743-795, imported from /root/reference in the build container by tests/golden/pyboundary/make_prepare_search_golden.py)
     returned for seeded inputs: a list of 2-D / 3-D query tensors zero-padded to the longest, a 3-D tensor passed through, and
     every subset form (flat list, per-query lists, an int, the empty list, a list of the wrong length).  This repository's
     FastPlaid._prepare_search must hand the same padded queries (cast to fp16, as fast_plaid.py:241 does before the native
     boundary) and the same normalised subsets to the native search."""
     import types
     from fast_plaid_amd import search
-    z = np.load(os.path.join(ROOT, "tests", "golden", "prepare_search.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "pyboundary", "prepare_search.npz"))
     me = types.SimpleNamespace(index=None, devices=["cpu"], indices={"cpu": object()})
     prep = lambda q, s: search.FastPlaid._prepare_search(me, q, s)   # noqa: E731
     qa = [z[f"a_in_{i}"] for i in range(4)]
