@@ -3993,9 +3993,8 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
 //     exactly the oracle's approximate score (k_lz_exact) -- and the best keep - #certain of them by (score desc, id asc)
 //     complete the set (k_sel_finish_lz).
 // The selected SET is then the reference's (its exact ties at the cut included); sel_approx holds A_up for the certain ones
-// (nobody reads it on this path).  gathered > gcap or maybes > LZ_MAYBE_MAX: *flag is raised and the caller runs the batch again
+// (nobody reads it on this path).  More maybes than the list holds (gcap = max(1024, R)): *flag is raised and the caller runs the batch again
 // with the eager S1.
-#define LZ_MAYBE_MAX 1024
 #define LZ_EX_BLOCKS 64   // k_lz_exact: workgroups (of four waves) per query: a wave per maybe up to 256 of them
 // gather + classification: the certain ones go straight to the head of the selection (any order), the maybes' ids to gpid
 __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
@@ -4073,7 +4072,7 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
   const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
   const int ngrp = Qp / 32;
   const uint16_t* Sb = S + (int64_t)b * C * Qp;
-  for (uint32_t m = wid; m < nmay && m < LZ_MAYBE_MAX; m += gridDim.x * 4u) {
+  for (uint32_t m = wid; m < nmay; m += gridDim.x * 4u) {
     const int32_t pid = gpid[(int64_t)b * gcap + m];
     const int64_t u0 = uoff[pid];
     const int len = (int)(uoff[pid + 1] - u0);
@@ -4210,32 +4209,59 @@ __global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ s
   if (!s[0]) return;  // nothing selected away
   const uint32_t keep = s[1];
   const uint32_t nm_all = gcount[b];
-  uint32_t nmay = nm_all < (uint32_t)gcap ? nm_all : (uint32_t)gcap;
-  if (nmay > LZ_MAYBE_MAX) nmay = LZ_MAYBE_MAX;
+  const uint32_t nmay = nm_all < (uint32_t)gcap ? nm_all : (uint32_t)gcap;
   const uint32_t nin_all = s[5];
   const uint32_t nin = nin_all < keep ? nin_all : keep;
   int kp2 = 2;
   while (kp2 < (int)keep) kp2 <<= 1;
   unsigned long long* kv = reinterpret_cast<unsigned long long*>(smem);                    // [kp2] the selection: id << 32 | score bits
-  unsigned long long* mk = kv + kp2;                                                        // [LZ_MAYBE_MAX] maybes: mono32(score) << 32 | ~id
+  unsigned long long* mk = kv + kp2;                                                        // [max(1024, pow2(gcap))] maybes: mono32(score) << 32 | ~id
   int32_t* op = sel_pid + (int64_t)b * R;
   float* oa = sel_approx + (int64_t)b * R;
   const int32_t* gp = gpid + (int64_t)b * gcap;
   const float* gv = gval + (int64_t)b * gcap;
   // (more maybes than the lists hold, more certain ones than the selection -- impossible: fewer than keep scores exceed U --, or
   // too few entries altogether -- impossible unless a list overflowed: at least keep scores are >= U)
-  if (tid == 0) s_bad = (nm_all > (uint32_t)gcap || nm_all > LZ_MAYBE_MAX || nin_all >= keep + 1u || nin + nmay < keep) ? 1u : 0u;
+  if (tid == 0) s_bad = (nm_all > (uint32_t)gcap || nin_all >= keep + 1u || nin + nmay < keep) ? 1u : 0u;
   for (int i = tid; i < kp2; i += 1024)
     kv[i] = ((uint32_t)i < nin) ? (((unsigned long long)(uint32_t)op[i] << 32) | (unsigned long long)__float_as_uint(oa[i])) : ~0ull;
-  const unsigned long long mine = (uint32_t)tid < nmay ? (((unsigned long long)mono32(gv[tid]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)gp[tid])) : 0ull;
-  __syncthreads();
   // best (keep - nin) maybes by (score desc, id asc)
-  const unsigned long long sorted = fp_sort1024_desc(mine, mk);
-  __syncthreads();
   const uint32_t take = keep - nin;
-  if ((uint32_t)tid < take && (uint32_t)tid < nmay) {
-    const uint32_t pid = 0xFFFFFFFFu - (uint32_t)sorted;
-    kv[nin + tid] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(sorted >> 32)));
+  auto mkey = [&](uint32_t i) -> unsigned long long {
+    return i < nmay ? (((unsigned long long)mono32(gv[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)gp[i])) : 0ull;
+  };
+  if (nmay <= 1024u) {   // (the usual case: a few dozen) one key per thread, shuffle network
+    const unsigned long long mine = mkey((uint32_t)tid);
+    __syncthreads();
+    const unsigned long long sorted = fp_sort1024_desc(mine, mk);
+    __syncthreads();
+    if ((uint32_t)tid < take && (uint32_t)tid < nmay) {
+      const uint32_t pid = 0xFFFFFFFFu - (uint32_t)sorted;
+      kv[nin + tid] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(sorted >> 32)));
+    }
+  } else {               // large rerank lists: bitonic sort in LDS
+    int mp2 = 2048;
+    while (mp2 < (int)nmay) mp2 <<= 1;
+    for (int i = tid; i < mp2; i += 1024) mk[i] = mkey((uint32_t)i);
+    __syncthreads();
+    for (int k = 2; k <= mp2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < mp2; i += 1024) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long x = mk[i], y = mk[ixj];
+            const bool desc = ((i & k) == 0);
+            if ((x < y) == desc) { mk[i] = y; mk[ixj] = x; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t i = tid; i < take && i < nmay; i += 1024) {
+      const unsigned long long sorted = mk[i];
+      const uint32_t pid = 0xFFFFFFFFu - (uint32_t)sorted;
+      kv[nin + i] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(sorted >> 32)));
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -4436,11 +4462,12 @@ __global__ void k_sel_force_collect(uint32_t* __restrict__ st, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) st[(int64_t)b * 8 + 7] = 1u;
 }
-bool fpk_select_lazy_ok(const FpSearchShape& sh) { return sh.R <= FP_MAX_SORT; }   // (and dim <= 256: k_lz_exact keeps a query row in registers -- the caller checks)
-int fpk_select_lazy_gcap(const FpSearchShape& sh) {
+// the selection and the maybes' sort share the LDS of one workgroup: (pow2(R) + max(1024, pow2(maybe capacity))) x 8 bytes
+bool fpk_select_lazy_ok(const FpSearchShape& sh) { return sh.R <= 8192; }
+int fpk_select_lazy_gcap(const FpSearchShape& sh) {   // room for the maybes of one query (their number grows with the density of scores at the cut, i.e. with R)
   static const int env = (int)fp_test_opt("lz_gcap", 0);   // tests: a small list forces the eager re-run
   if (env > 0) return env;
-  return (int)std::min<int64_t>(2 * sh.R + 1024, 1 << 20);
+  return (int)std::max<int64_t>(1024, fp_next_pow2((int)sh.R));
 }
 size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t) + (size_t)B * 16; }   // three histograms per query + {prefix, k_rem} x 2
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
@@ -4480,7 +4507,9 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     fp_allow_big_lds((const void*)k_sel_finish_lz, lds_ok3, 152 * 1024);
     int kp2 = 2;
     while (kp2 < (int)sh.R) kp2 <<= 1;
-    hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8 + (size_t)LZ_MAYBE_MAX * 8, st, selstate, sh.R, sel_pid,
+    int mp2 = 1024;
+    while (mp2 < lz->gcap) mp2 <<= 1;
+    hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8 + (size_t)mp2 * 8, st, selstate, sh.R, sel_pid,
                        sel_approx, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, lz->stats);
     hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
                        sel_approx, sel_cnt, pref, B);   // (s[7] == 0: only the count prefix)
