@@ -953,7 +953,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   if (sh.n_probe >= 1) {
     if (fpk_probe(D, s->S.as<uint16_t>(), sh, has_subset ? s->allow.as<uint32_t>() : nullptr, s->partial.as<unsigned long long>(),
                   P.nchunk, s->cells.as<int32_t>(), s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), s->cmax128.as<uint16_t>(), st,
-                  P.probe_prezeroed, !P.probe_no_fb, P.s1_mode != 0, lz))
+                  P.probe_prezeroed, !P.probe_no_fb, P.s1_mode != 0 ? &xe : nullptr, lz))
       return fail(FP_EUNSUPPORTED, "n_ivf_probe");
   } else {
     HIPCHK(hipMemsetAsync(s->ncells.p, 0, (size_t)B * 4, st));  // topk(0) -> no cells -> empty result

@@ -217,7 +217,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
               bool prezeroed = false /*the region of fpk_probe_zero_region was cleared earlier in the stream*/,
               bool with_fallback = true /*false: a column with too many ties at its threshold leaves *fpk_probe_flag != 0 and NO cells;
                                           the caller reads the flag back and runs the batch again with the fallback*/,
-              bool cmax_upper = false /*cmax128 came from S1's exact mode: upper bounds, at most one fp16 step above an element*/,
+              const FpS1Exact* cmax_upper = nullptr /*cmax128 came from S1's exact mode: maxima over the upper candidates; the threshold is lowered by the window (wcol, kappa)*/,
               const struct FpLazyS1* lz = nullptr /*S holds S1's lazy form (upper candidates everywhere): sound threshold + exact re-evaluation of the collected scores*/);
 // does this shape take the threshold probe with S1's column maxima (the only probe path the lazy form of S1 serves)?
 bool fpk_probe_lazy_ok(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk);

@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
   if (nchunk < n_probe) {
     if (lane == 0) {
       tau[(int64_t)b * Qp + q] = 0u;
-      if (wcol) { lz_tight[(int64_t)b * Qp + q] = __builtin_inff(); lz_loose[(int64_t)b * Qp + q] = __builtin_inff(); }   // (never with the lazy form: fpk_probe_lazy_ok)
+      if (wcol && lz_tight) { lz_tight[(int64_t)b * Qp + q] = __builtin_inff(); lz_loose[(int64_t)b * Qp + q] = __builtin_inff(); }   // (never with the lazy form: fpk_probe_lazy_ok)
     }
     return;
   }
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     bound = m;
     if (r == 0) m_first = m;
   }
-  if (wcol && lane == 0) {
+  if (wcol && lz_tight && lane == 0) {
     // S1's lazy form, the selection's slack (FpLazyS1): a stored column maximum s of a document exceeds the reference's by at most
     // ulp16(s) + 2 u2(s) (s1_lower16: one fp16 step while the window is small against the step, window + step otherwise; ulp16
     // clamped from below at 2^-14).  tight: s <= the column's overall maximum (the first pick above), valid while s >= 0; loose: any
@@ -1304,19 +1304,22 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     uint32_t t = m >> 12;  // mono16 of the n_probe-th largest chunk maximum
     // S1's exact mode takes the maxima over the upper candidates of the flagged entries: every chunk then holds an element of
     // at least the fp16 value one step BELOW its maximum, so that is what n_probe elements are guaranteed to reach
-    // (lazy form: EVERY stored value is an upper candidate and the window may span several fp16 steps near zero -- the sound
-    // lower end of what an element stored as t can be is s1_lower16)
+    // The maxima S1 emits are taken over upper candidates h(x + u) (of the flagged entries in the eager form, of every entry in the
+    // lazy one), and near zero the window u spans several fp16 steps: the sound lower end of what an element stored as t can be is
+    // s1_lower16 (round 4 stepped one fp16 value down, which undershoots for |x| < ~2^-10).
     if (wcol) { if (t > 0u) t = mono16(s1_lower16(unmono16(t), wcol[(int64_t)b * Qp + q], kappa)); }
-    else if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (key 0x7FFF is -0, which mono16 folds into +0)
+    else if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (no window given: one step; key 0x7FFF is -0, which mono16 folds into +0)
     tau[(int64_t)b * Qp + q] = t;
   }
 }
 
-static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st, int upper = 0,
+static void launch_probe_tau(const uint16_t* cmax, const FpSearchShape& sh, int nchunk, uint32_t* tau, hipStream_t st,
+                             const FpS1Exact* up = nullptr /*the maxima are S1's upper candidates: the threshold is lowered by the window*/,
                              const FpLazyS1* lz = nullptr) {
   const dim3 grid((unsigned)(sh.B * sh.Q));
-  const float* wcol = lz ? lz->wcol : nullptr;
-  const float kappa = lz ? lz->kappa : 0.f, inv_w0 = lz ? lz->inv_w0 : 0.f;
+  const int upper = up ? 1 : 0;
+  const float* wcol = lz ? lz->wcol : (up ? up->wcol : nullptr);
+  const float kappa = lz ? lz->kappa : (up ? up->kappa : 0.f), inv_w0 = lz ? lz->inv_w0 : 0.f;
   float* tg = lz ? lz->tight : nullptr;
   float* ls = lz ? lz->loose : nullptr;
   if (nchunk <= 64 * 4) hipLaunchKernelGGL(k_probe_tau<4>, grid, dim3(64), 0, st, cmax, sh.Q, sh.Qp, nchunk, sh.n_probe, tau, upper, wcol, kappa, tg, ls, inv_w0);
@@ -1447,7 +1450,7 @@ const int32_t* fpk_probe_flag(const FpIndexDev& ix, const FpSearchShape& sh, int
 int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const uint32_t* allow,
               unsigned long long* partial, int nchunk, int32_t* cells, int32_t* ucells, int32_t* ncells,
               const uint16_t* cmax128 /*nullable: [B*Qp][ceil(C/128)] from S1*/, hipStream_t st, bool prezeroed, bool with_fallback,
-              bool cmax_upper, const FpLazyS1* lz) {
+              const FpS1Exact* cmax_upper, const FpLazyS1* lz) {
   const int64_t Cw = (ix.C + 31) / 32;
   const ProbeLayout L = probe_layout(ix, sh, nchunk, partial);
   const int NP = L.NP, nch2 = L.nch2;
@@ -1467,7 +1470,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     const bool fused = cmax128 != nullptr && allow == nullptr && nch128 <= 4096;
     if (lz && !fused) return -2;   // (the caller only asks for the lazy form where the fused threshold probe applies)
     if (fused) {
-      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper ? 1 : 0, lz);
+      launch_probe_tau(cmax128, sh, nch128, tau, st, cmax_upper, lz);
       hipLaunchKernelGGL(k_probe_collect, grid, dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, allow, Cw, tau, cnt, cand, flag, cmax128, nch128);
     } else {
       hipLaunchKernelGGL(k_probe_chunkmax, grid, dim3(256), 0, st, S, ix.C, sh.Qp, nch2, allow, Cw, cmax);

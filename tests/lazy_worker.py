@@ -38,6 +38,11 @@ def main():
             q = q.astype(np.float32)
             q[1] *= 7.5
             q = q.astype(np.float16)
+        if seed == 3:   # a query of tiny norm: its scores sit where fp16 is finest and S1's window spans several fp16 steps (the
+            q = q.astype(np.float32)   # probe threshold and the selection's slack must follow the window, not "one step")
+            q[3] *= 0.002
+            q[4] *= 0.03
+            q = q.astype(np.float16)
         if seed == 5:   # a query whose second half is zero rows: its all-equal columns overflow the threshold probe's tie room, the
             q[2, Q // 2:] = 0   # batch is run again with the register top-k fallback -- which reads S itself, hence eagerly
             expect = 0
