@@ -268,8 +268,8 @@ struct OutLayout {
     nk = (size_t)B * (size_t)K;
     score_off = (nk * 8 + 255) & ~(size_t)255;
     cnt_off = (score_off + nk * 4 + 255) & ~(size_t)255;
-    stat_off = (cnt_off + n * 4 + 255) & ~(size_t)255;   // [2 + B] int64 statistics (survivor total, marked documents per query, lazy-S1 overflow flag)
-    total = stat_off + (n + 2) * 8;
+    stat_off = (cnt_off + n * 4 + 255) & ~(size_t)255;   // [4 + B] int64 statistics (survivor total, marked documents per query, lazy-S1 overflow flag, candidate total, probe overflow flag)
+    total = stat_off + (n + 4) * 8;
   }
   void scatter(const void* host, int64_t* pids, float* scores, int32_t* counts) const {
     const char* h = static_cast<const char*>(host);
@@ -765,6 +765,7 @@ struct Pipe {
   bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
   bool probe_prezeroed = false, selhist_prezeroed = false, l0hist_prezeroed = false;   // cleared by the batch's first kernel
   int s1_mode = 0;           // FpS1Exact::mode of this batch's S1
+  bool total_folded = false; // the candidate total / probe flag come down with the result block (no copy of their own)
   bool want_lazy = false;    // the caller allows S1's lazy form (fp_search / fp_search_device without subset, trace or probe fallback)
   bool lazy = false;         // ... and this batch runs it (FpLazyS1)
 };
@@ -988,7 +989,10 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   // total (8 bytes) and, at byte 16, the probe flag: one copy.  (Bytes 8..15 of the pinned block are rewritten by the survivor
   // total's copy further down when there is one.)
   if (sh.n_probe < 1) HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(d_total) + 16, 0, 4, st));
-  HIPCHK(hipMemcpyAsync(s->h_small.p, d_total, 24, hipMemcpyDeviceToHost, st));
+  // (a speculative host-buffer search reads them after its final sync only: they travel in the result block's statistics instead,
+  // one copy node and its ~10 us of dispatch less)
+  P.total_folded = P.spec && s->fold_stats;
+  if (!P.total_folded) HIPCHK(hipMemcpyAsync(s->h_small.p, d_total, 24, hipMemcpyDeviceToHost, st));
   STAGE_DONE(ST_COMPACT);
   int64_t M;
   if (P.spec) {
@@ -1120,7 +1124,8 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
              s->tie_pid.as<int32_t>(), st,
              /*short_lists: one workgroup per query; pays off when there are too few queries to fill the chip anyway (measured: B = 8
                46 vs 53 us, B = 64 90 vs 71 us)*/ !lz && B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B),
-             P.selhist_prezeroed, s->ms_pref.as<int64_t>(), lz, &D);
+             P.selhist_prezeroed, s->ms_pref.as<int64_t>(), lz, &D,
+             /*list length per query: the bound stages leave a few x R survivors, otherwise every candidate*/ sel_src != s->cand_pid.as<int32_t>() ? 8 * sh.R : (B > 0 ? M / B : 0));
   if (lz && !s->fold_stats)   // device-resident I/O: the overflow flag travels by itself (host-buffer calls: with the result block)
     HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, lz->flag, 4, hipMemcpyDeviceToHost, st));
   s->pref_ready = true;   // (whoever edits sel_cnt before S6 -- the sharded search's cut -- clears it)
@@ -1328,7 +1333,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
                                        (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
                                        (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
                                        s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr,
-                                       P.lazy ? reinterpret_cast<const int32_t*>(s->lz_state.as<uint32_t>() + 2 * B) : nullptr))
+                                       P.lazy ? reinterpret_cast<const int32_t*>(s->lz_state.as<uint32_t>() + 2 * B) : nullptr,
+                                       P.total_folded ? s->spec_total.as<int64_t>() : nullptr))
       return trc < 0 ? fail(FP_EUNSUPPORTED, "n_queries * max(n_full_scores / 4, 1) >= 2^31 in one sub-batch of the final ranking")
                      : fail(FP_EHIP, "final ranking failed (hip error " + std::to_string(trc) + ")");
     if (dev_io) {
@@ -1389,8 +1395,11 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     }
     g_last_lazy = P.lazy ? 1 : (replayed ? -1 : 0);
     // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
-    const int64_t M_true = *reinterpret_cast<const int64_t*>(s->h_small.p);
-    if (P.probe_no_fb && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 16) != 0) {
+    const int64_t* stat_blk = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
+    const int64_t M_true = P.total_folded ? stat_blk[2 + B] : *reinterpret_cast<const int64_t*>(s->h_small.p);
+    const bool probe_ovf = P.total_folded ? stat_blk[3 + B] != 0
+                                          : *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 16) != 0;
+    if (P.probe_no_fb && probe_ovf) {
       // some column had more ties at its probe threshold than the candidate lists hold: the device probed nothing (k_probe_merge);
       // run the batch again with the register top-k fallback, and keep it enqueued for this scratch from now on
       s->probe_fb = true;

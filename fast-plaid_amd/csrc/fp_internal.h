@@ -313,7 +313,8 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
                 bool hist_prezeroed = false,
                 int64_t* pref = nullptr /*the last kernel also writes the [B + 1] prefix of sel_cnt here*/,
                 const FpLazyS1* lz = nullptr /*approx[] are upper bounds from S1's lazy form (general path only: !short_lists, R <= FP_MAX_SORT)*/,
-                const FpIndexDev* ix = nullptr /*needed with lz: the maybes are recomputed from the index*/);
+                const FpIndexDev* ix = nullptr /*needed with lz: the maybes are recomputed from the index*/,
+                int64_t est_per_query = 0 /*expected list length per query (sizes the grids; 0 = unknown)*/);
 // S1's lazy form: can the selection serve this shape, and how many gathered entries per query does it want room for?
 bool fpk_select_lazy_ok(const FpSearchShape& sh);
 int fpk_select_lazy_gcap(const FpSearchShape& sh);
@@ -352,8 +353,9 @@ int fpk_final_topk(const float* score /*[B][stride]*/, const int32_t* pid_local 
                     const int64_t* pid_global /*[B][stride] or null*/, const int32_t* cnt /*[B] or null -> stride*/,
                     int64_t stride, int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid /*[B][top_k]*/,
                     float* out_score, int32_t* out_cnt, hipStream_t st, const int64_t* stat_total = nullptr, const int32_t* stat_per_query = nullptr,
-                    int64_t* stat_out /*[2 + B]: statistics copied next to the results*/ = nullptr,
-                    const int32_t* stat_flag = nullptr /*-> stat_out[1 + B]*/);
+                    int64_t* stat_out /*[4 + B]: statistics copied next to the results*/ = nullptr,
+                    const int32_t* stat_flag = nullptr /*-> stat_out[1 + B]*/,
+                    const int64_t* stat_cand = nullptr /*S3's {total, -, probe flag} block -> stat_out[2 + B], [3 + B]*/);
 // sharded helpers (record layouts: include/fastplaid.h)
 void fpk_shard_pack1(const float* sel_approx, const int32_t* sel_pid, const int32_t* sel_cnt, int B, int64_t R, int64_t pid_offset, void* rec1,
                      hipStream_t st, const int64_t* cand_total = nullptr, int64_t cand_cap = 0, int status = 0);

@@ -1578,30 +1578,40 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   for (int cb = 0; cb < nc_all; cb += maxcells) {
   const int nc = (nc_all - cb) < maxcells ? (nc_all - cb) : maxcells;
   __syncthreads();   // the previous chunk's lo_s / pre are no longer read
-  // phase 1: per-cell [lo, lo+len) and exclusive prefix of the lengths
+  // phase 1: per-cell [lo, lo+len) and exclusive prefix of the lengths.  With the per-tile range search, TWO threads per cell: one
+  // finds the list's first entry >= tile_lo, its neighbour the first >= tile_hi (the two searches one after the other were ~20
+  // dependent L2 round trips, a quarter of this workgroup's life)
   uint32_t base = 0;
-  for (int start = 0; start < nc; start += 1024) {
-    const int j = start + tid;
+  const int cpr = search ? 512 : 1024;            // cells per round
+  const int sl = search ? (tid >> 1) : tid;       // this thread's cell slot in the round
+  const int which = search ? (tid & 1) : 0;
+  for (int start = 0; start < nc; start += cpr) {
+    const int j = start + sl;
     uint32_t len = 0;
     long long lo = 0;
     if (j < nc) {
       const int32_t cell = ucells[(int64_t)b * ucstride + cb + j];
       if (cell >= 0 && cell < P) {
         long long beg = ivf_off[cell], end = ivf_off[cell + 1];
-        if (search) {   // (both bounds in one four-way search, six independent loads per round trip: S3 0.107 -> 0.134 ms, round 3 -- not the bottleneck)
+        if (search) {
+          const int32_t target = which ? tile_hi : tile_lo;
           long long l = beg, h = end;
-          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < tile_lo) l = m + 1; else h = m; }
-          beg = l;
-          h = end;
-          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < tile_hi) l = m + 1; else h = m; }
-          end = l;
+          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < target) l = m + 1; else h = m; }
+          beg = l;   // which == 0: the range's start; which == 1: its end
         }
         lo = beg;
         len = (uint32_t)(end - beg);
       }
-      lo_s[j] = lo;
     }
-    s_scan[tid] = len;
+    if (search) {   // (lanes 2k, 2k + 1 hold the same cell; both valid or both not)
+      const long long other = (long long)(((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)((unsigned long long)lo >> 32), 1, 64) << 32) |
+                                          (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)lo, 1, 64));
+      len = (which == 0 && j < nc) ? (uint32_t)(other - lo) : 0u;
+      if (which == 0) s_scan[sl] = len; else s_scan[512 + sl] = 0u;
+    } else {
+      s_scan[tid] = len;
+    }
+    if (which == 0 && j < nc) lo_s[j] = lo;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
       uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
@@ -1609,7 +1619,7 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
       s_scan[tid] += v;
       __syncthreads();
     }
-    if (j < nc) pre[j] = base + s_scan[tid] - len;
+    if (which == 0 && j < nc) pre[j] = base + s_scan[sl] - len;
     const uint32_t tot = s_scan[1023];
     __syncthreads();
     base += tot;
@@ -3745,6 +3755,8 @@ __global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ appr
   uint32_t* s = st + (int64_t)b * 8;
   uint32_t* e = ext + (int64_t)b * 4;
   const int64_t beg = cand_off[b], end = cand_off[b + 1];
+  const int64_t i_pre = beg + (int64_t)blockIdx.x * 256 + threadIdx.x;   // (fetched ahead of the previous pass's scan: see k_sel_gather_lz)
+  const float a_pre = i_pre < end ? approx[i_pre] : 0.f;
   uint32_t prefix = 0;
   if (PASS == 0) {
     const int64_t n = end - beg;
@@ -3772,8 +3784,8 @@ __global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ appr
   __shared__ uint32_t h[FP_SEL_BINS];
   for (int i = threadIdx.x; i < FP_SEL_BINS; i += 256) h[i] = 0;
   __syncthreads();
-  for (int64_t i = beg + (int64_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (int64_t)gridDim.x * 256) {
-    uint32_t k = mono32(approx[i]);
+  for (int64_t i = i_pre; i < end; i += (int64_t)gridDim.x * 256) {
+    uint32_t k = mono32(i == i_pre ? a_pre : approx[i]);
     bool match = (PASS == 0) ? true : ((k >> (SHIFT + WIDTH)) == prefix);
     if (match) atomicAdd(&h[(k >> SHIFT) & ((1u << WIDTH) - 1)], 1u);
   }
@@ -3853,13 +3865,8 @@ __device__ __forceinline__ void sel_collect_body(const float* __restrict__ appro
 
 // The selection's last kernel also leaves the prefix of the per-query rerank counts that S6 maps its work items with (workgroup
 // 0 writes pref[0..B]) -- one launch less in front of MaxSim.
-__global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
-                                                      const int64_t* __restrict__ cand_off, const uint32_t* __restrict__ st,
-                                                      int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
-                                                      const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref /*nullable*/, int B) {
-  sel_collect_body(approx, cand_pid, cand_off, st, R, sel_pid, sel_approx);
-  if (!pref || blockIdx.x != 0) return;   // (sel_cnt is final before this kernel starts: k_sel_hist<0> / k_sel_front wrote it)
-  __syncthreads();
+// exclusive prefix of the queries' selection counts (what S6 maps its work with), by one workgroup of 1024 threads
+__device__ __forceinline__ void sel_count_prefix(const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref, int B) {
   __shared__ long long sp[1024];
   long long base = 0;
   if (threadIdx.x == 0) pref[0] = 0;
@@ -3878,6 +3885,15 @@ __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ 
     if (i < B) pref[i + 1] = base + sp[threadIdx.x];
     base += sp[1023];
   }
+}
+__global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
+                                                      const int64_t* __restrict__ cand_off, const uint32_t* __restrict__ st,
+                                                      int64_t R, int32_t* __restrict__ sel_pid, float* __restrict__ sel_approx,
+                                                      const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref /*nullable*/, int B) {
+  sel_collect_body(approx, cand_pid, cand_off, st, R, sel_pid, sel_approx);
+  if (!pref || blockIdx.x != 0) return;   // (sel_cnt is final before this kernel starts: k_sel_hist<0> / k_sel_front wrote it)
+  __syncthreads();
+  sel_count_prefix(sel_cnt, pref, B);
 }
 
 // parallel gather: elements above the threshold go straight to the output (any order), elements
@@ -3998,7 +4014,7 @@ __global__ __launch_bounds__(1024) void k_sel_finish(uint32_t* __restrict__ st, 
 // The selected SET is then the reference's (its exact ties at the cut included); sel_approx holds A_up for the certain ones
 // (nobody reads it on this path).  More maybes than the list holds (gcap = max(1024, R)): *flag is raised and the caller runs the batch again
 // with the eager S1.
-#define LZ_EX_BLOCKS 64   // k_lz_exact: workgroups (of four waves) per query: a wave per maybe up to 256 of them
+#define LZ_EX_BLOCKS 32   // k_lz_exact: workgroups (of four waves) per query: a wave per maybe up to 128 of them (FP_TEST lz_exb)
 // gather + classification: the certain ones go straight to the head of the selection (any order), the maybes' ids to gpid
 __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,
                                                        const int64_t* __restrict__ cand_off, uint32_t* __restrict__ st, int64_t R,
@@ -4009,6 +4025,13 @@ __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__
                                                        int32_t* __restrict__ gpid, int gcap, int Q, int Qp) {
   const int b = blockIdx.y;
   __shared__ float s_slack;
+  // a thread's first element is fetched before the prologue (slack, threshold scan): the kernel is a chain of dependent first-touch
+  // loads, and with one element per thread this takes the two at its end off the chain
+  const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
+  const int64_t i_pre = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float a_pre = 0.f;
+  int32_t p_pre = 0;
+  if (i_pre < n) { a_pre = approx[beg + i_pre]; p_pre = cand_pid[beg + i_pre]; }
   const float qslack = lz_query_slack(lz_tight, lz_loose, lz_neg, b, Q, Qp, &s_slack);
   uint32_t* s = st + (int64_t)b * 8;
   const bool need = s[0] != 0;
@@ -4020,7 +4043,6 @@ __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) { s[2] = kstar; s[3] = k_rem; }
   }
   const uint32_t keep = s[1];
-  const int64_t beg = cand_off[b], n = cand_off[b + 1] - beg;
   int32_t* op = sel_pid + (int64_t)b * R;
   float* oa = sel_approx + (int64_t)b * R;
   uint32_t thr_lo = 0u, thr_hi = 0xFFFFFFFFu;
@@ -4030,19 +4052,36 @@ __global__ __launch_bounds__(256) void k_sel_gather_lz(const float* __restrict__
     const float lo = U - d, hi = U + d;
     if (lo == lo && hi == hi) { thr_lo = mono32(lo); thr_hi = mono32(hi); }   // (NaN: everything is a maybe -> overflow -> the eager form)
   }
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float a = approx[beg + i];
+  // (one atomic per wave and class instead of one per element: the ~1000 certain documents of a query all draw their slots from
+  // one address, and same-address device atomics retire at ~6 - 10 ns apiece)
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i0 + lane;
+    const bool valid = i < n;
+    const bool first = i == i_pre;
+    const float a = first ? a_pre : (valid ? approx[beg + i] : 0.f);
     if (!need) {  // everything is kept, already in ascending doc-id order
-      if (i < (int64_t)keep) { op[i] = cand_pid[beg + i]; oa[i] = a; }
+      if (valid && i < (int64_t)keep) { op[i] = first ? p_pre : cand_pid[beg + i]; oa[i] = a; }
       continue;
     }
     const uint32_t key = mono32(a);
-    if (key > thr_hi) {
-      const uint32_t pos = atomicAdd(&s[5], 1u);
-      if (pos < keep) { op[pos] = cand_pid[beg + i]; oa[pos] = a; }
-    } else if (key >= thr_lo) {
-      const uint32_t pos = atomicAdd(&gcount[b], 1u);
-      if (pos < (uint32_t)gcap) gpid[(int64_t)b * gcap + pos] = cand_pid[beg + i];
+    const bool in = valid && key > thr_hi;
+    const bool mb = valid && !in && key >= thr_lo;
+    const unsigned long long m_in = __ballot(in), m_mb = __ballot(mb);
+    if (m_in) {
+      uint32_t base = 0u;
+      if (lane == __builtin_ctzll(m_in)) base = atomicAdd(&s[5], (uint32_t)__builtin_popcountll(m_in));
+      base = __shfl(base, __builtin_ctzll(m_in), 64);
+      const uint32_t pos = base + (uint32_t)__builtin_popcountll(m_in & lt);
+      if (in && pos < keep) { op[pos] = first ? p_pre : cand_pid[beg + i]; oa[pos] = a; }
+    }
+    if (m_mb) {
+      uint32_t base = 0u;
+      if (lane == __builtin_ctzll(m_mb)) base = atomicAdd(&gcount[b], (uint32_t)__builtin_popcountll(m_mb));
+      base = __shfl(base, __builtin_ctzll(m_mb), 64);
+      const uint32_t pos = base + (uint32_t)__builtin_popcountll(m_mb & lt);
+      if (mb && pos < (uint32_t)gcap) gpid[(int64_t)b * gcap + pos] = first ? p_pre : cand_pid[beg + i];
     }
   }
 }
@@ -4067,15 +4106,18 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
   __shared__ uint32_t s_pairs[4][LZ_PAIRS];      // code position << 8 | column
   __shared__ uint32_t s_colmax[4][128];          // mono32 keys of the columns' true maxima
   __shared__ uint32_t s_npair[4];
-  const int b = blockIdx.y;
+  // grid (queries, workgroups per query): the workgroups that have a maybe -- the first ~20 of a query's -- come FIRST in dispatch
+  // order for all queries, the empty ones drain behind them (with the query as the slow index every round of resident
+  // workgroups was two thirds empty ones: at 176 registers a CU holds two, and 4096 of them took eight rounds)
+  const int b = blockIdx.x;
   if (!st[(int64_t)b * 8]) return;
   const uint32_t nm0 = gcount[b];
   const uint32_t nmay = nm0 < (uint32_t)gcap ? nm0 : (uint32_t)gcap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t wid = blockIdx.x * 4u + (uint32_t)wave;
+  const uint32_t wid = blockIdx.y * 4u + (uint32_t)wave;
   const int ngrp = Qp / 32;
   const uint16_t* Sb = S + (int64_t)b * C * Qp;
-  for (uint32_t m = wid; m < nmay; m += gridDim.x * 4u) {
+  for (uint32_t m = wid; m < nmay; m += gridDim.y * 4u) {
     const int32_t pid = gpid[(int64_t)b * gcap + m];
     const int64_t u0 = uoff[pid];
     const int len = (int)(uoff[pid + 1] - u0);
@@ -4176,16 +4218,16 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
         const uint16_t* qrow = qpad + ((int64_t)b * Qp + col) * D;
         float ch = 0.f;
 #pragma unroll 1
-        for (int k0 = 0; k0 < D; k0 += 128) {
-          uint4 cv[16], qv[16];
+        for (int k0 = 0; k0 < D; k0 += 64) {   // (64 dims of both rows in flight: 16 loads, ~110 registers, four waves per SIMD)
+          uint4 cv[8], qv[8];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
+          for (int j = 0; j < 8; ++j) {
             const bool in = k0 + j * 8 < D;
             cv[j] = in ? *reinterpret_cast<const uint4*>(crow + k0 + j * 8) : make_uint4(0, 0, 0, 0);
             qv[j] = in ? *reinterpret_cast<const uint4*>(qrow + k0 + j * 8) : make_uint4(0, 0, 0, 0);
           }
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
+          for (int j = 0; j < 8; ++j)
             if (k0 + j * 8 < D) s1_chain8(ch, cv[j], qv[j]);
         }
         atomicMax(&s_colmax[wave][col], mono32((float)(half_t)ch));
@@ -4204,11 +4246,15 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
 __global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ st, int64_t R, int32_t* __restrict__ sel_pid,
                                                         float* __restrict__ sel_approx, const uint32_t* __restrict__ gcount,
                                                         const int32_t* __restrict__ gpid, const float* __restrict__ gval, int gcap,
-                                                        int32_t* __restrict__ flag, uint32_t* __restrict__ stats) {
+                                                        int32_t* __restrict__ flag, uint32_t* __restrict__ stats,
+                                                        const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref /*nullable*/, int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_bad;
   const int b = blockIdx.x, tid = threadIdx.x;
   uint32_t* s = st + (int64_t)b * 8;
+  // (the count prefix k_sel_collect writes in the eager form: sel_cnt is final since k_sel_hist<0>; the lazy form never takes the
+  // ordered collection -- an overflow voids the batch -- so that launch is not enqueued here)
+  if (pref && b == 0) { sel_count_prefix(sel_cnt, pref, B); __syncthreads(); }
   if (!s[0]) return;  // nothing selected away
   const uint32_t keep = s[1];
   const uint32_t nm_all = gcount[b];
@@ -4475,8 +4521,26 @@ int fpk_select_lazy_gcap(const FpSearchShape& sh) {   // room for the maybes of 
 size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t) + (size_t)B * 16; }   // three histograms per query + {prefix, k_rem} x 2
 void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
                 uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
-                bool short_lists, bool hist_prezeroed, int64_t* pref, const FpLazyS1* lz, const FpIndexDev* ixp) {
+                bool short_lists, bool hist_prezeroed, int64_t* pref, const FpLazyS1* lz, const FpIndexDev* ixp, int64_t est_per_query) {
   const int B = sh.B;
+  // workgroups per query of the histogram / gather passes: every one of them zeroes and flushes a 2048-bin histogram and repeats
+  // the previous pass's scan, so a list of a few thousand survivors wants a handful, not 64 (grid-stride loops: any number works)
+  unsigned gx = 64;
+  if (est_per_query > 0) {
+    const int64_t w = (est_per_query + 1023) / 1024;
+    gx = (unsigned)(w < 4 ? 4 : w > 64 ? 64 : w);
+  }
+  gx = (unsigned)fp_test_opt("sel_gx", gx);
+  if (gx < 1) gx = 1;
+  // the gather: one element per thread where the chip has room (its prologue is the same in every workgroup, but its loop ends in
+  // dependent loads and a slot atomic per wave)
+  unsigned gg = 64;
+  if (est_per_query > 0) {
+    const int64_t w = (est_per_query + 255) / 256;
+    gg = (unsigned)(w < 4 ? 4 : w > 64 ? 64 : w);
+  }
+  gg = (unsigned)fp_test_opt("sel_gg", gg);
+  if (gg < 1) gg = 1;
   const uint16_t* ix_cent = ixp ? ixp->centroids : nullptr;
   const int ix_dim = ixp ? ixp->dim : 0;
   const int64_t* ix_uoff = ixp ? ixp->uoff : nullptr;
@@ -4498,13 +4562,14 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   if (!hist_prezeroed) (void)hipMemsetAsync(hist, 0, fpk_sel_hist_bytes(B), st);
   if (lz) {   // (the caller asks for this only when !short_lists and !big)
     uint32_t* ext = hist + (size_t)3 * B * FP_SEL_BINS;
-    dim3 gh(64, (unsigned)B);
+    dim3 gh(gx, (unsigned)B);
     hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
     hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
     hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
-    hipLaunchKernelGGL(k_sel_gather_lz, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
+    hipLaunchKernelGGL(k_sel_gather_lz, dim3(gg, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
                        hist, ext, lz->tight, lz->loose, lz->negflag, lz->gcount, lz->gpid, lz->gcap, sh.Q, sh.Qp);
-    hipLaunchKernelGGL(k_lz_exact, dim3(LZ_EX_BLOCKS, (unsigned)B), dim3(256), 0, st, selstate, lz->gcount, lz->gpid, lz->gval, lz->gcap, ix_cent,
+    static const int lz_exb = (int)fp_test_opt("lz_exb", LZ_EX_BLOCKS);
+    hipLaunchKernelGGL(k_lz_exact, dim3((unsigned)B, (unsigned)(lz_exb < 1 ? 1 : lz_exb)), dim3(256), 0, st, selstate, lz->gcount, lz->gpid, lz->gval, lz->gcap, ix_cent,
                        lz->qpad, ix_dim, sh.Q, sh.Qp, ix_uoff, ix_ucodes, lz->S, ixp->C, lz->wcol, lz->kappa, lz->flag, lz->stats);
     static std::atomic<uint64_t> lds_ok3{0};
     fp_allow_big_lds((const void*)k_sel_finish_lz, lds_ok3, 152 * 1024);
@@ -4513,13 +4578,11 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     int mp2 = 1024;
     while (mp2 < lz->gcap) mp2 <<= 1;
     hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8 + (size_t)mp2 * 8, st, selstate, sh.R, sel_pid,
-                       sel_approx, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, lz->stats);
-    hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
-                       sel_approx, sel_cnt, pref, B);   // (s[7] == 0: only the count prefix)
+                       sel_approx, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, lz->stats, sel_cnt, pref, B);
     return;
   }
   uint32_t* ext = hist + (size_t)3 * B * FP_SEL_BINS;   // [B][4], behind the histograms (fpk_sel_hist_bytes)
-  dim3 gh(64, (unsigned)B);
+  dim3 gh(gx, (unsigned)B);
   hipLaunchKernelGGL(k_sel_hist<0>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
   hipLaunchKernelGGL(k_sel_hist<1>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
   hipLaunchKernelGGL(k_sel_hist<2>, gh, dim3(256), 0, st, approx, cand_off, selstate, hist, ext, sh.n_full, sh.R, sel_cnt);
@@ -4527,7 +4590,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     hipLaunchKernelGGL(k_sel_scan_final, dim3((unsigned)B), dim3(256), 0, st, hist, selstate, ext, B);
     hipLaunchKernelGGL(k_sel_force_collect, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, selstate, B);
   } else {
-    hipLaunchKernelGGL(k_sel_gather, dim3(64, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
+    hipLaunchKernelGGL(k_sel_gather, dim3(gg, (unsigned)B), dim3(256), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
                        tie_pid, hist, ext);
   }
   if (!big) {
@@ -4554,7 +4617,7 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
                                                      int64_t* __restrict__ out_pid, float* __restrict__ out_score,
                                                      int32_t* __restrict__ out_cnt, const int64_t* __restrict__ stat_total,
                                                      const int32_t* __restrict__ stat_per_query, int64_t* __restrict__ stat_out,
-                                                     const int32_t* __restrict__ stat_flag) {
+                                                     const int32_t* __restrict__ stat_flag, const int64_t* __restrict__ stat_cand) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // statistics of the search that travel with the results (one copy to the host instead of three): [0] = *stat_total,
   // [1 + b] = stat_per_query[b], [1 + B] = *stat_flag (the lazy S1's overflow flag)
@@ -4563,6 +4626,9 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
     if (blockIdx.x == 0) {
       stat_out[0] = stat_total ? *stat_total : 0;
       stat_out[1 + gridDim.x] = stat_flag ? (int64_t)*stat_flag : 0;
+      // S3's block {candidate total, -, the probe's overflow flag (int32 at byte 16)}: saves the host-buffer search a copy node
+      stat_out[2 + gridDim.x] = stat_cand ? stat_cand[0] : 0;
+      stat_out[3 + gridDim.x] = stat_cand ? (int64_t) * reinterpret_cast<const int32_t*>(stat_cand + 2) : 0;
     }
   }
   // all LDS in the dynamic region (a static __shared__ in front would mis-align the 8-byte keys)
@@ -4621,24 +4687,30 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
 }
 
 __global__ void k_final_stats(const int64_t* __restrict__ stat_total, const int32_t* __restrict__ stat_per_query, int B, int64_t* __restrict__ stat_out,
-                              const int32_t* __restrict__ stat_flag) {
+                              const int32_t* __restrict__ stat_flag, const int64_t* __restrict__ stat_cand) {
   for (int b = threadIdx.x; b < B; b += blockDim.x) stat_out[1 + b] = stat_per_query ? (int64_t)stat_per_query[b] : 0;
-  if (threadIdx.x == 0) { stat_out[0] = stat_total ? *stat_total : 0; stat_out[1 + B] = stat_flag ? (int64_t)*stat_flag : 0; }
+  if (threadIdx.x == 0) {
+    stat_out[0] = stat_total ? *stat_total : 0;
+    stat_out[1 + B] = stat_flag ? (int64_t)*stat_flag : 0;
+    stat_out[2 + B] = stat_cand ? stat_cand[0] : 0;
+    stat_out[3 + B] = stat_cand ? (int64_t) * reinterpret_cast<const int32_t*>(stat_cand + 2) : 0;
+  }
 }
 int fpk_final_topk(const float* score, const int32_t* pid_local, const int64_t* pid_global, const int32_t* cnt, int64_t stride,
                    int B, int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt,
-                   hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out, const int32_t* stat_flag) {
+                   hipStream_t st, const int64_t* stat_total, const int32_t* stat_per_query, int64_t* stat_out, const int32_t* stat_flag,
+                   const int64_t* stat_cand) {
   int np2 = next_pow2((int)stride);
   if (np2 < 2) np2 = 2;
   if (stride > FP_MAX_SORT) {   // beyond the LDS sort: segmented device radix sort (rare: n_full_scores > 65536)
-    if (stat_out) hipLaunchKernelGGL(k_final_stats, dim3(1), dim3(256), 0, st, stat_total, stat_per_query, B, stat_out, stat_flag);
+    if (stat_out) hipLaunchKernelGGL(k_final_stats, dim3(1), dim3(256), 0, st, stat_total, stat_per_query, B, stat_out, stat_flag, stat_cand);
     // (allocates 2 * B * stride keys and synchronises; -1: B * stride does not fit its 32-bit segment offsets -- nothing was written)
     return fps_final_topk_big(score, pid_local, pid_global, cnt, stride, B, top_k, pid_offset, out_pid, out_score, out_cnt, st);
   }
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_final_topk, lds_ok, 144 * 1024);
   hipLaunchKernelGGL(k_final_topk, dim3((unsigned)B), dim3(1024), (size_t)np2 * 8 + 16, st, score, pid_local, pid_global, cnt, stride, np2,
-                     top_k, pid_offset, out_pid, out_score, out_cnt, stat_total, stat_per_query, stat_out, stat_flag);
+                     top_k, pid_offset, out_pid, out_score, out_cnt, stat_total, stat_per_query, stat_out, stat_flag, stat_cand);
   return 0;
 }
 
