@@ -3281,14 +3281,20 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
                                                  const int64_t* __restrict__ cand_off, int64_t n_full, int64_t R, int Q,
                                                  int32_t* __restrict__ cut, const float* __restrict__ lz_tight /*nullable: S1's lazy form*/,
                                                  const float* __restrict__ lz_loose, const uint32_t* __restrict__ lz_neg, int Qp) {
-  __shared__ uint32_t h[256], sfx[256];
+  __shared__ uint32_t h[256], s_wtot[4];
   __shared__ uint32_t s_prefix, s_rem;
   __shared__ float s_slack;
-  float qslack = 0.f;
-  if (lz_tight) qslack = lz_query_slack(lz_tight, lz_loose, lz_neg, blockIdx.x, Q, Qp, &s_slack);   // (before any thread leaves: it holds a barrier)
   const int b = blockIdx.x, tid = threadIdx.x;
+  // the first four scores of every thread (a pilot group of 4 R = 4096) are fetched once, ahead of the slack's dependent loads, and
+  // kept in registers for the four passes
+  const float* pv = pilot + (int64_t)b * L0_PILOT_MAX;
+  float pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pre[k] = pv[tid + 1024 * k];   // (unconditional: rows have L0_PILOT_MAX slots; masked by np below)
   const int64_t n = cand_off[b + 1] - cand_off[b];
   const int np = npilot[b];
+  float qslack = 0.f;
+  if (lz_tight) qslack = lz_query_slack(lz_tight, lz_loose, lz_neg, blockIdx.x, Q, Qp, &s_slack);   // (before any thread leaves: it holds a barrier)
   int64_t keep = n;
   if (n_full < keep) keep = n_full;
   if (R < keep) keep = R;
@@ -3296,32 +3302,50 @@ __global__ __launch_bounds__(1024) void k_l0_thr(const float* __restrict__ pilot
     if (tid == 0) cut[b] = 0;
     return;
   }
-  const float* pv = pilot + (int64_t)b * L0_PILOT_MAX;
   if (tid == 0) { s_prefix = 0u; s_rem = (uint32_t)keep; }
+  const int lane = tid & 63, wave = tid >> 6;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     if (tid < 256) h[tid] = 0u;
     __syncthreads();
     const uint32_t prefix = s_prefix;
-    for (int i = tid; i < np; i += 1024) {
-      const uint32_t k = mono32(pv[i]);
-      if (pass == 0 || (k >> (shift + 8)) == prefix) atomicAdd(&h[(k >> shift) & 0xFFu], 1u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // (scores of one query share their leading bits: the lanes whose digit equals the first active lane's go in with ONE atomic)
+      const uint32_t key = mono32(pre[k]);
+      const bool on = tid + 1024 * k < np && (pass == 0 || (key >> (shift + 8)) == prefix);
+      const uint32_t dg = (key >> shift) & 0xFFu;
+      const unsigned long long act = __ballot(on);
+      if (act) {
+        const uint32_t d0 = (uint32_t)__shfl((int)dg, __builtin_ctzll(act), 64);
+        const unsigned long long same = __ballot(on && dg == d0);
+        if (lane == __builtin_ctzll(act)) atomicAdd(&h[d0], (uint32_t)__builtin_popcountll(same));
+        if (on && dg != d0) atomicAdd(&h[dg], 1u);
+      }
+    }
+    for (int i = tid + 4096; i < np; i += 1024) {
+      const uint32_t key = mono32(pv[i]);
+      if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
-    // the largest digit d with #{digit >= d} >= rem (d = 0 if none): inclusive suffix sums of the 256 bins
+    // the largest digit d with #{digit >= d} >= rem (d = 0 if none): inclusive suffix sums of the 256 bins -- a wave scan in each
+    // of the first four waves plus their totals (a Hillis-Steele scan in LDS was sixteen barriers per pass)
     const uint32_t rem = s_rem;
     const uint32_t own = tid < 256 ? h[tid] : 0u;
-    if (tid < 256) sfx[tid] = own;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      const uint32_t v = (tid < 256 && tid + off < 256) ? sfx[tid + off] : 0u;
-      __syncthreads();
-      if (tid < 256) sfx[tid] += v;
-      __syncthreads();
-    }
+    uint32_t sfx = own;
     if (tid < 256) {
-      const uint32_t above = sfx[tid] - own;
-      if (above < rem && (sfx[tid] >= rem || tid == 0)) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_down((int)sfx, off, 64);
+        if (lane + off < 64) sfx += v;
+      }
+      if (lane == 0) s_wtot[wave] = sfx;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      for (int w = wave + 1; w < 4; ++w) sfx += s_wtot[w];
+      const uint32_t above = sfx - own;
+      if (above < rem && (sfx >= rem || tid == 0)) {
         s_prefix = (prefix << 8) | (uint32_t)tid;
         s_rem = rem - above;
       }
@@ -4251,34 +4275,60 @@ __global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ s
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_bad;
   const int b = blockIdx.x, tid = threadIdx.x;
-  uint32_t* s = st + (int64_t)b * 8;
   // (the count prefix k_sel_collect writes in the eager form: sel_cnt is final since k_sel_hist<0>; the lazy form never takes the
-  // ordered collection -- an overflow voids the batch -- so that launch is not enqueued here)
-  if (pref && b == 0) { sel_count_prefix(sel_cnt, pref, B); __syncthreads(); }
-  if (!s[0]) return;  // nothing selected away
-  const uint32_t keep = s[1];
-  const uint32_t nm_all = gcount[b];
+  // ordered collection -- an overflow voids the batch -- so that launch is not enqueued here.  A workgroup of its own, behind the
+  // queries': inside one of theirs its ten scan rounds were the kernel's critical path)
+  if (b == B) {
+    if (pref) sel_count_prefix(sel_cnt, pref, B);
+    return;
+  }
+  uint32_t* s = st + (int64_t)b * 8;
+  int32_t* op = sel_pid + (int64_t)b * R;
+  float* oa = sel_approx + (int64_t)b * R;
+  const int32_t* gp = gpid + (int64_t)b * gcap;
+  const float* gv = gval + (int64_t)b * gcap;
+  // every first-touch load up front, unconditionally (slots past the counts hold stale values and are masked below): one round
+  // trip instead of counts -> lists
+  const uint32_t need = s[0], keep = s[1], nin_all = s[5], nm_all = gcount[b];
+  const int32_t p_op = (int64_t)tid < R ? op[tid] : 0;
+  const float p_oa = (int64_t)tid < R ? oa[tid] : 0.f;
+  const int32_t p_gp = tid < gcap ? gp[tid] : 0;
+  const float p_gv = tid < gcap ? gv[tid] : 0.f;
+  if (!need) return;  // nothing selected away
   const uint32_t nmay = nm_all < (uint32_t)gcap ? nm_all : (uint32_t)gcap;
-  const uint32_t nin_all = s[5];
   const uint32_t nin = nin_all < keep ? nin_all : keep;
   int kp2 = 2;
   while (kp2 < (int)keep) kp2 <<= 1;
   unsigned long long* kv = reinterpret_cast<unsigned long long*>(smem);                    // [kp2] the selection: id << 32 | score bits
   unsigned long long* mk = kv + kp2;                                                        // [max(1024, pow2(gcap))] maybes: mono32(score) << 32 | ~id
-  int32_t* op = sel_pid + (int64_t)b * R;
-  float* oa = sel_approx + (int64_t)b * R;
-  const int32_t* gp = gpid + (int64_t)b * gcap;
-  const float* gv = gval + (int64_t)b * gcap;
   // (more maybes than the lists hold, more certain ones than the selection -- impossible: fewer than keep scores exceed U --, or
   // too few entries altogether -- impossible unless a list overflowed: at least keep scores are >= U)
   if (tid == 0) s_bad = (nm_all > (uint32_t)gcap || nin_all >= keep + 1u || nin + nmay < keep) ? 1u : 0u;
-  for (int i = tid; i < kp2; i += 1024)
-    kv[i] = ((uint32_t)i < nin) ? (((unsigned long long)(uint32_t)op[i] << 32) | (unsigned long long)__float_as_uint(oa[i])) : ~0ull;
+  for (int i = tid; i < kp2; i += 1024) {
+    const int32_t pi = i < 1024 ? p_op : op[i];
+    const float ai = i < 1024 ? p_oa : oa[i];
+    kv[i] = ((uint32_t)i < nin) ? (((unsigned long long)(uint32_t)pi << 32) | (unsigned long long)__float_as_uint(ai)) : ~0ull;
+  }
   // best (keep - nin) maybes by (score desc, id asc)
   const uint32_t take = keep - nin;
   auto mkey = [&](uint32_t i) -> unsigned long long {
-    return i < nmay ? (((unsigned long long)mono32(gv[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)gp[i])) : 0ull;
+    const int32_t pi = i < 1024u ? p_gp : gp[i];
+    const float vi = i < 1024u ? p_gv : gv[i];
+    return i < nmay ? (((unsigned long long)mono32(vi) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)pi)) : 0ull;
   };
+  if (nmay <= 256u) {    // (the usual case: a few dozen) rank by counting: every key against every other, broadcast reads of LDS
+    const unsigned long long mine = mkey((uint32_t)tid);   // (tid < 1024: the prefetched slot is this thread's own)
+    if ((uint32_t)tid < nmay) mk[tid] = mine;
+    __syncthreads();
+    if ((uint32_t)tid < nmay) {
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nmay; ++j) rank += mk[j] > mine ? 1u : 0u;   // (keys are distinct: the ids are)
+      if (rank < take) {
+        const uint32_t pid = 0xFFFFFFFFu - (uint32_t)mine;
+        kv[nin + rank] = ((unsigned long long)pid << 32) | (unsigned long long)__float_as_uint(unmono32((uint32_t)(mine >> 32)));
+      }
+    }
+  } else
   if (nmay <= 1024u) {   // (the usual case: a few dozen) one key per thread, shuffle network
     const unsigned long long mine = mkey((uint32_t)tid);
     __syncthreads();
@@ -4577,7 +4627,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     while (kp2 < (int)sh.R) kp2 <<= 1;
     int mp2 = 1024;
     while (mp2 < lz->gcap) mp2 <<= 1;
-    hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8 + (size_t)mp2 * 8, st, selstate, sh.R, sel_pid,
+    hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B + (pref ? 1u : 0u)), dim3(1024), (size_t)kp2 * 8 + (size_t)mp2 * 8, st, selstate, sh.R, sel_pid,
                        sel_approx, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, lz->stats, sel_cnt, pref, B);
     return;
   }
@@ -4619,6 +4669,15 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
                                                      const int32_t* __restrict__ stat_per_query, int64_t* __restrict__ stat_out,
                                                      const int32_t* __restrict__ stat_flag, const int64_t* __restrict__ stat_cand) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  // a thread's first element before anything else, unconditionally (slots past the count are masked below): the count, the
+  // statistics and the lists are then ONE round of first-touch loads instead of three dependent ones
+  const int64_t o_pre = (int64_t)b * stride + threadIdx.x;
+  const bool in_pre = (int64_t)threadIdx.x < stride;
+  const int64_t idg_pre = (in_pre && !pid_local) ? pid_global[o_pre] : 0;
+  const int32_t idl_pre = (in_pre && pid_local) ? pid_local[o_pre] : 0;
+  const float s_pre = in_pre ? score[o_pre] : 0.f;
+  const int n = cnt ? cnt[b] : (int)stride;
   // statistics of the search that travel with the results (one copy to the host instead of three): [0] = *stat_total,
   // [1 + b] = stat_per_query[b], [1 + B] = *stat_flag (the lazy S1's overflow flag)
   if (stat_out && threadIdx.x == 0) {
@@ -4634,16 +4693,16 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
   // all LDS in the dynamic region (a static __shared__ in front would mis-align the 8-byte keys)
   int* s_validp = reinterpret_cast<int*>(smem);
   unsigned long long* v = reinterpret_cast<unsigned long long*>(smem + 16);
-  const int b = blockIdx.x;
-  const int n = cnt ? cnt[b] : (int)stride;
   if (threadIdx.x == 0) *s_validp = 0;
   __syncthreads();
   int myvalid = 0;
   for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
     unsigned long long key = 0ull;
     if (i < n) {
-      int64_t id = pid_local ? (int64_t)pid_local[(int64_t)b * stride + i] + pid_offset : pid_global[(int64_t)b * stride + i];
-      float s = score[(int64_t)b * stride + i];
+      const bool first = i == (int)threadIdx.x;
+      int64_t id = pid_local ? (int64_t)(first ? idl_pre : pid_local[(int64_t)b * stride + i]) + pid_offset
+                             : (first ? idg_pre : pid_global[(int64_t)b * stride + i]);
+      float s = first ? s_pre : score[(int64_t)b * stride + i];
       if (id >= 0) {  // id < 0 = padding entry of a sharded buffer
         key = ((unsigned long long)mono32(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)id);
         ++myvalid;
@@ -4651,7 +4710,12 @@ __global__ __launch_bounds__(1024) void k_final_topk(const float* __restrict__ s
     }
     v[i] = key;
   }
-  atomicAdd(s_validp, myvalid);
+  {   // (one LDS atomic per wave: 1024 of them on one address were microseconds)
+    int wv = myvalid;
+#pragma unroll
+    for (int x = 32; x > 0; x >>= 1) wv += __shfl_xor(wv, x, 64);
+    if ((threadIdx.x & 63) == 0 && wv) atomicAdd(s_validp, wv);
+  }
   __syncthreads();
   if (npow2 == 1024 && blockDim.x == 1024) {   // one key per thread: shuffle-based network
     const unsigned long long sorted = fp_sort1024_desc(v[threadIdx.x], v);

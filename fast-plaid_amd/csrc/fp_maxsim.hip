@@ -1028,6 +1028,68 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
   const int b = blockIdx.x;
   const int n = cnt[b];
   if (threadIdx.x == 0) { s_any = 0; s_n = 0; }
+  if (npow2 == 1024 && blockDim.x == 1024) {
+    // One document per thread (the usual rerank list).  Everything the kernel reads from global memory is fetched up front in slot
+    // order (the budgets used to be gathered through the sorted slots twice: two more dependent round trips), and the two scans
+    // are wave scans plus one combine over the sixteen wave totals (Hillis-Steele over 1024 elements was twenty barriers).
+    __shared__ float s_u[1024], s_um[1024], s_wl[16], s_wh[16];
+    const int i = (int)threadIdx.x, lane = i & 63, wave = i >> 6;
+    const int64_t o = (int64_t)b * stride + i;
+    const float sc = i < n ? score[o] : 0.f;
+    const float u0 = i < n ? unc[o] : 0.f;
+    const float um0 = (uncm && i < n) ? uncm[o] : u0;
+    s_u[i] = u0;
+    s_um[i] = um0;
+    __syncthreads();   // (also orders the s_any / s_n reset)
+    if (i < n && u0 > 0.f) s_any = 1;
+    __syncthreads();
+    if (s_any) {   // (uniform)
+      const unsigned long long key0 = i < n ? (((unsigned long long)mono32(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i)) : 0ull;
+      const unsigned long long key = fp_sort1024_desc(key0, v);
+      const float inf = __builtin_inff();
+      const int slot = (int)(0xFFFFFFFFu - (uint32_t)key);
+      const float si = unmono32((uint32_t)(key >> 32));
+      float u = 0.f, um = 0.f, l = inf, h = -inf;
+      if (i < n) {
+        u = s_u[slot];
+        um = s_um[slot];
+        l = si - um;
+        h = si + (uncm ? u - um : u);
+      }
+      // inclusive prefix-min of l / suffix-max of h inside the wave
+      float pl = l, ph = h;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float a = __shfl_up(pl, off, 64), c = __shfl_down(ph, off, 64);
+        if (lane >= off) pl = __builtin_fminf(pl, a);
+        if (lane + off < 64) ph = __builtin_fmaxf(ph, c);
+      }
+      if (lane == 63) s_wl[wave] = pl;
+      if (lane == 0) s_wh[wave] = ph;
+      __syncthreads();
+      float bl = inf, bh = -inf;
+      for (int w = 0; w < wave; ++w) bl = __builtin_fminf(bl, s_wl[w]);
+      for (int w = wave + 1; w < 16; ++w) bh = __builtin_fmaxf(bh, s_wh[w]);
+      lo[i] = __builtin_fminf(pl, bl);
+      hi[i] = __builtin_fmaxf(ph, bh);
+      __syncthreads();
+      const int kk = (int)(top_k < n ? top_k : n);   // emitted positions [0, kk)
+      const float lmin_top = kk > 0 ? lo[kk - 1] : inf;
+      if (i < n && u > 0.f) {
+        const float up = uncm ? u - um : u;
+        bool conflict;
+        if (i < kk) {
+          const float lmin = i > 0 ? lo[i - 1] : inf;
+          const float hmax = i + 1 < 1024 ? hi[i + 1] : -inf;
+          conflict = !(si + up < lmin) || !(si - um > hmax);
+          conflict = conflict || um > 0.00095f || up > 0.00095f;   // (see the general path below)
+        } else {
+          conflict = !(si + up < lmin_top);
+        }
+        if (conflict) marks[(int64_t)b * stride + atomicAdd(&s_n, 1)] = slot;
+      }
+    }
+  } else {
   __syncthreads();
   int any = 0;
   for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
@@ -1113,6 +1175,7 @@ __global__ __launch_bounds__(1024) void k_final_mark(const float* __restrict__ s
       }
       if (conflict) marks[(int64_t)b * stride + atomicAdd(&s_n, 1)] = slot;
     }
+  }
   }
   __syncthreads();
   if (threadIdx.x == 0) nmark[b] = s_n;
