@@ -964,7 +964,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->bitmap.ensure((size_t)B * P.W * 4));
   // k_ivf_mark writes every word of the bitmap (tiles are built in LDS): no memset needed
   fpk_ivf_mark(D, s->ucells.as<int32_t>(), s->ncells.as<int32_t>(), sh.Q * np, B, s->bitmap.as<uint32_t>(), P.W, st);
-  P.nblk = (int)((P.W + 1023) / 1024);
+  P.nblk = (int)((P.W + fpk_cand_words_per_block() - 1) / fpk_cand_words_per_block());
   HIPCHK(s->blkcnt.ensure((size_t)B * P.nblk * 4));
   HIPCHK(s->ncand.ensure((size_t)B * 4));
   HIPCHK(s->cand_off.ensure((size_t)(B + 1) * 8));

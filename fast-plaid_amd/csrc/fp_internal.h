@@ -236,6 +236,7 @@ void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t
                     int64_t cap /*0: none*/, int32_t* invalid_rw, int64_t* total_out /*{total, -, int32 probe flag at byte 16}*/,
                     uint32_t* tickets = nullptr /*[B + 1] zeroed counters -> one launch instead of three*/,
                     const int32_t* probe_flag = nullptr);
+int fpk_cand_words_per_block();   // bitmap words one workgroup of the candidate counting / compaction kernels covers
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkcnt /*exclusive-scanned*/, int nblk, const int64_t* cand_off, int32_t* cand_pid,
                       hipStream_t st);

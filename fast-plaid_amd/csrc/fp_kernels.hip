@@ -945,6 +945,8 @@ __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __
   int entries = entries_stride;
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
+  // (S1's lazy form: a lane's collected entry is fetched together with the flag and the count, not behind them)
+  const unsigned long long k0_pre = (cent && lane < entries_stride) ? partial[((int64_t)b * Qp + q) * entries_stride + lane] : 0ull;
   if (flag && ((*flag != 0) != (run_if != 0))) {
     // the threshold path gave up (a column overflowed its list): no cells, unless the fallback that follows writes them
     if (run_if == 0)
@@ -963,12 +965,24 @@ __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __
     // (the collect pass took everything that can reach the true cut: k_probe_tau lowered its threshold by the window).
     unsigned long long mine = 0ull;
     if (lane < entries) {
-      const unsigned long long k0 = src[lane];
+      const unsigned long long k0 = k0_pre;
       const uint32_t cix = 0xFFFFFFFFu - (uint32_t)k0;
       const uint16_t* crow = cent + (int64_t)cix * D;
       const uint16_t* qrow = qpad + ((int64_t)b * Qp + q) * D;
       float ch = 0.f;
-      for (int k = 0; k < D; k += 8) s1_chain8(ch, *reinterpret_cast<const uint4*>(crow + k), *reinterpret_cast<const uint4*>(qrow + k));
+#pragma unroll 1
+      for (int k0d = 0; k0d < D; k0d += 64) {   // 64 dims of both rows in flight (a load pair per chain step was 16 dependent round trips)
+        uint4 cv[8], qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool in = k0d + j * 8 < D;
+          cv[j] = in ? *reinterpret_cast<const uint4*>(crow + k0d + j * 8) : make_uint4(0, 0, 0, 0);
+          qv[j] = in ? *reinterpret_cast<const uint4*>(qrow + k0d + j * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (k0d + j * 8 < D) s1_chain8(ch, cv[j], qv[j]);
+      }
       mine = ((unsigned long long)mono16(__builtin_bit_cast(uint16_t, (half_t)ch)) << 32) | (k0 & 0xFFFFFFFFull);
     }
     for (int r = 0; r < n_probe; ++r) {
@@ -1133,6 +1147,64 @@ __global__ __launch_bounds__(256) void k_cells_from_bitmap(const uint32_t* __res
 }
 
 // LDS bitonic sort (ascending) of n <= cap int32 values, then unique.  one block per query.
+// the same through a bitmap over the centroid ids in LDS (tables up to 2^18 centroids: 32 KiB): mark, then read the set bits back
+// in order -- four barriers instead of the ~50 of the sort + scan below (a one-query search spends ~10 us in that kernel)
+#define CELLS_BM_MAXC (1 << 18)
+__global__ __launch_bounds__(256) void k_cells_unique_bm(const int32_t* __restrict__ cells, int n, int64_t C,
+                                                         int32_t* __restrict__ ucells, int32_t* __restrict__ ncells) {
+  __shared__ uint32_t bm[CELLS_BM_MAXC / 32];
+  __shared__ int wtot[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int32_t* src = cells + (int64_t)b * n;
+  const int nw = (int)((C + 31) / 32);                  // words in use
+  const int wpt = (nw + 255) / 256;                     // consecutive words per thread
+  int32_t pre[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pre[k] = tid + 256 * k < n ? src[tid + 256 * k] : -1;   // (in flight while the bitmap is cleared)
+  for (int i = tid; i < nw; i += 256) bm[i] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (pre[k] >= 0 && pre[k] < C) atomicOr(&bm[pre[k] >> 5], 1u << (pre[k] & 31));
+  for (int i = tid + 1024; i < n; i += 256) {
+    const int32_t x = src[i];
+    if (x >= 0 && x < C) atomicOr(&bm[x >> 5], 1u << (x & 31));
+  }
+  __syncthreads();
+  const int w0 = tid * wpt;
+  int cnt = 0;
+  for (int k = 0; k < wpt; ++k)
+    if (w0 + k < nw) cnt += __popc(bm[w0 + k]);
+  const int lane = tid & 63, wave = tid >> 6;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int t = wtot[w];
+    before += w < wave ? t : 0;
+    total += t;
+  }
+  int pos = before + incl - cnt;
+  int32_t* out = ucells + (int64_t)b * n;
+  for (int k = 0; k < wpt; ++k) {
+    if (w0 + k >= nw) break;
+    uint32_t w = bm[w0 + k];
+    while (w) {
+      const int bit = __ffs(w) - 1;
+      out[pos++] = (w0 + k) * 32 + bit;
+      w &= w - 1;
+    }
+  }
+  if (tid == 0) ncells[b] = total;
+}
+
 __global__ __launch_bounds__(256) void k_cells_unique(const int32_t* __restrict__ cells, int n, int npow2,
                                                       int32_t* __restrict__ ucells, int32_t* __restrict__ ncells) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1258,6 +1330,7 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     }
     return;
   }
+  const float w_pre = wcol ? wcol[(int64_t)b * Qp + q] : 0.f;   // (in flight with the maxima: its consumers sit behind the selection)
   uint32_t key[KPL];   // (mono16 << 12 | reversed chunk index): unique, chunks < 4096; 0 = no chunk
 #pragma unroll
   for (int j = 0; j < KPL; ++j) {
@@ -1282,7 +1355,7 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     // ulp16(s) + 2 u2(s) (s1_lower16: one fp16 step while the window is small against the step, window + step otherwise; ulp16
     // clamped from below at 2^-14).  tight: s <= the column's overall maximum (the first pick above), valid while s >= 0; loose: any
     // |s| <= |q| |c|max = wcol / w0.  Zero columns hold exact zeros.
-    const float w = wcol[(int64_t)b * Qp + q];
+    const float w = w_pre;
     float tg = 0.f, ls = 0.f;
     if (w > 0.f) {
       const uint16_t hmax = unmono16(m_first >> 12);
@@ -1307,7 +1380,7 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     // The maxima S1 emits are taken over upper candidates h(x + u) (of the flagged entries in the eager form, of every entry in the
     // lazy one), and near zero the window u spans several fp16 steps: the sound lower end of what an element stored as t can be is
     // s1_lower16 (round 4 stepped one fp16 value down, which undershoots for |x| < ~2^-10).
-    if (wcol) { if (t > 0u) t = mono16(s1_lower16(unmono16(t), wcol[(int64_t)b * Qp + q], kappa)); }
+    if (wcol) { if (t > 0u) t = mono16(s1_lower16(unmono16(t), w_pre, kappa)); }
     else if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (no window given: one step; key 0x7FFF is -0, which mono16 folds into +0)
     tau[(int64_t)b * Qp + q] = t;
   }
@@ -1358,11 +1431,28 @@ __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restric
   for (int j = 0; j < 8; ++j) tq[j] = (q0 + j < Q) ? tau[(int64_t)b * Qp + q0 + j] : 0xFFFFFFFFu;  // pad columns collect nothing
   const uint16_t* Sb = S + ((int64_t)b * C) * Qp + q0;
   const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
-  for (int i = 0; i < PROBE_CHUNK / 64; ++i) {
-    if (!((live >> (i >> 1)) & 1u)) continue;
+  // (the rows of a live sub-chunk pair are fetched together, four loads in flight per thread: one load per iteration in front of
+  // its compares left the kernel at 3.2 TB/s on the ~22 % of S it reads)
+  constexpr int NIT = PROBE_CHUNK / 64;
+#pragma unroll 1
+  for (int i0 = 0; i0 < NIT; i0 += 4) {
+    if (!((live >> (i0 >> 1)) & 3u)) continue;   // (uniform: two sub-chunks per group of four iterations)
+    uint4 vv[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k;
+      const int64_t c = (int64_t)chunk * PROBE_CHUNK + i * 64 + rl;
+      ok[k] = ((live >> (i >> 1)) & 1u) && c < C && !(al && !((al[c >> 5] >> (c & 31)) & 1u));
+      vv[k] = make_uint4(0, 0, 0, 0);
+      if (ok[k]) vv[k] = *reinterpret_cast<const uint4*>(Sb + c * Qp);
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!ok[k]) continue;
+    const int i = i0 + k;
     const int64_t c = (int64_t)chunk * PROBE_CHUNK + i * 64 + rl;
-    if (c >= C || (al && !((al[c >> 5] >> (c & 31)) & 1u))) continue;
-    const uint4 v = *reinterpret_cast<const uint4*>(Sb + c * Qp);
+    const uint4 v = vv[k];
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1377,6 +1467,7 @@ __global__ __launch_bounds__(256) void k_probe_collect(const uint16_t* __restric
           *flag = 1;
       }
     }
+  }
   }
 }
 
@@ -1507,7 +1598,11 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
   const int n = (int)n64;
   if (n <= FP_MAX_CELLS) {
     const int np2 = next_pow2(n);
-    hipLaunchKernelGGL(k_cells_unique, dim3((unsigned)sh.B), dim3(256), (size_t)np2 * 4, st, cells, n, np2, ucells, ncells);
+    static const bool cells_bm = fp_test_opt("cells_bm", 1) != 0;
+    if (cells_bm && ix.C <= CELLS_BM_MAXC)
+      hipLaunchKernelGGL(k_cells_unique_bm, dim3((unsigned)sh.B), dim3(256), 0, st, cells, n, ix.C, ucells, ncells);
+    else
+      hipLaunchKernelGGL(k_cells_unique, dim3((unsigned)sh.B), dim3(256), (size_t)np2 * 4, st, cells, n, np2, ucells, ncells);
   } else {   // more probed cells than the LDS sort holds: mark them in a bitmap over the centroid ids and read it back in order
     uint32_t* bm = reinterpret_cast<uint32_t*>(flag + 4);   // [B][Cw] behind the flag (fpk_probe_scratch_bytes)
     (void)hipMemsetAsync(bm, 0, (size_t)sh.B * Cw * 4, st);
@@ -1676,8 +1771,11 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
 }
 
 // ---- ordered compaction of the bitmaps ------------------------------------------------------
-#define CAND_WPT 4                           // words per thread
-#define CAND_WPB (256 * CAND_WPT)            // words per block
+// words per thread / per workgroup of the counting and compaction kernels: 2 / 512 (16384 documents: at the ~33 % candidate
+// density of cfg2 a workgroup's ids fit ONE pass through its 8192-id LDS stage; with 4 / 1024 they took two passes, each of
+// which walks every set bit) -- FP_TEST cand_wpt=4 brings the larger workgroups back
+static int cand_wpt() { static const int v = (int)fp_test_opt("cand_wpt", 2) == 4 ? 4 : 2; return v; }
+int fpk_cand_words_per_block() { return 256 * cand_wpt(); }
 // ---- "last workgroup finishes the job": the count -> scan -> offsets chains below were three or four launches of which only the
 // first has real work; each extra launch is ~4.5 us of dispatch tail (40 % of a one-query search was such tails).  Every
 // workgroup publishes its count, then takes a ticket; the one that draws the last ticket of its query scans the query's
@@ -1795,11 +1893,13 @@ __device__ __forceinline__ void fp_offsets_256(int32_t* ncand, int B, int64_t* c
 }
 
 // ctr != nullptr: fused form -- also leaves blkcnt scanned (exclusive, per query), ncand, cand_off and *total_out
+template <int CAND_WPT>
 __global__ __launch_bounds__(256) void k_cand_count(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
                                                     const int32_t* invalid, int64_t W, int32_t* blkcnt, int nblk,
                                                     uint32_t* ctr = nullptr, int32_t* ncand = nullptr, int B = 0, int64_t* cand_off = nullptr,
                                                     int64_t cap = 0, int32_t* invalid_rw = nullptr, int64_t* total_out = nullptr,
                                                     const int32_t* probe_flag = nullptr) {
+  constexpr int CAND_WPB = 256 * CAND_WPT;
   const int b = blockIdx.y;
   int cnt = 0;
   if (!(invalid && invalid[b])) {
@@ -1869,12 +1969,13 @@ __global__ __launch_bounds__(256) void k_cand_offsets(int32_t* ncand, int B, int
 void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W, int32_t* blkcnt,
                     int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st, int64_t cap, int32_t* invalid_rw, int64_t* total_out,
                     uint32_t* ctr, const int32_t* probe_flag) {
+  const auto count_kernel = cand_wpt() == 4 ? k_cand_count<4> : k_cand_count<2>;
   if (ctr && (int64_t)nblk * B <= FP_TICKET_MAX_WGS) {
-    hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, ctr, ncand, B,
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, ctr, ncand, B,
                        cand_off, cap, invalid_rw, total_out, probe_flag);
     return;
   }
-  hipLaunchKernelGGL(k_cand_count, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, (uint32_t*)nullptr,
+  hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, (uint32_t*)nullptr,
                      (int32_t*)nullptr, 0, (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
   if (ctr) {
     hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand, (int32_t*)nullptr, (int32_t*)nullptr, ctr + B, B,
@@ -1886,13 +1987,16 @@ void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t
   hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(256), 0, st, ncand, B, cand_off, cap, invalid_rw, total_out, probe_flag);
 }
 
+template <int CAND_WPT>
 __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
                                                       const int32_t* __restrict__ invalid, int64_t W,
                                                       const int32_t* __restrict__ blkoff, int nblk,
                                                       const int64_t* __restrict__ cand_off, int32_t* __restrict__ cand_pid) {
-  // a block covers CAND_WPB words = 32768 documents; its ids are expanded into LDS in order and then written out
-  // coalesced (the per-thread `cand_pid[pos++] = ...` stores it replaces ran at 0.85 TB/s: 108 us for 84 MB)
-  __shared__ int32_t stage[CAND_WPB * 32 / 4];   // 8192 ids (32 KiB) per pass
+  // a block covers CAND_WPB words; its ids are expanded into LDS in order and then written out coalesced (the per-thread
+  // `cand_pid[pos++] = ...` stores it replaces ran at 0.85 TB/s: 108 us for 84 MB)
+  constexpr int CAND_WPB = 256 * CAND_WPT;
+  constexpr int STAGE = 8192;                      // ids (32 KiB) per pass
+  __shared__ int32_t stage[STAGE];
   const int b = blockIdx.y;
   if (invalid && invalid[b]) return;
   const int64_t w0 = (int64_t)blockIdx.x * CAND_WPB + threadIdx.x * CAND_WPT;
@@ -1908,20 +2012,29 @@ __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict
     }
     cnt += __popc(x[k]);
   }
-  __shared__ int s[256];
-  s[threadIdx.x] = cnt;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-    __syncthreads();
-    s[threadIdx.x] += t;
-    __syncthreads();
-  }
-  const int total = s[255];
-  const int mine0 = s[threadIdx.x] - cnt;          // rank of this thread's first id inside the block
+  // (independent of the scan below: in flight with the bitmap words)
   int32_t* out = cand_pid + cand_off[b] + blkoff[(int64_t)b * nblk + blockIdx.x];
-  constexpr int STAGE = CAND_WPB * 32 / 4;
-  for (int base = 0; base < total; base += STAGE) {   // at most 4 passes (density 100 %)
+  // inclusive scan of the threads' counts: inside a wave by shuffles, across the four waves through LDS (one barrier; the
+  // shared-memory scan it replaces was sixteen)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  __shared__ int wtot[4];
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int t = wtot[w];
+    before += w < wave ? t : 0;
+    total += t;
+  }
+  const int mine0 = before + incl - cnt;          // rank of this thread's first id inside the block
+  for (int base = 0; base < total; base += STAGE) {   // one pass up to 8192 ids
     int pos = mine0;
 #pragma unroll
     for (int k = 0; k < CAND_WPT; ++k) {
@@ -1943,7 +2056,8 @@ __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict
 
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkoff, int nblk, const int64_t* cand_off, int32_t* cand_pid, hipStream_t st) {
-  hipLaunchKernelGGL(k_cand_compact, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkoff, nblk,
+  const auto compact_kernel = cand_wpt() == 4 ? k_cand_compact<4> : k_cand_compact<2>;
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkoff, nblk,
                      cand_off, cand_pid);
 }
 
@@ -4155,6 +4269,9 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
 #pragma unroll 1
     for (int g = 0; g < ngrp; ++g) {
       const uint16_t* Sg = Sb + g * 32 + pc * 8;
+      float wv[8];   // (the columns' windows: fetched with the score rows, used behind their reduction)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wv[k] = wcol[(int64_t)b * Qp + g * 32 + pc * 8 + k];
       uint32_t mxp[4] = {0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u, 0xF0E2F0E2u};   // packed fp16 -10000
       uint4 keepv[4];
       int32_t keepc[4];
@@ -4192,7 +4309,7 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
         const int col = g * 32 + pc * 8 + k;
         const uint16_t hb = (uint16_t)(mxp[k >> 1] >> (16 * (k & 1)));
         const float smax = (float)__builtin_bit_cast(half_t, hb);
-        const float w = wcol[(int64_t)b * Qp + col];
+        const float w = wv[k];
         uint32_t e = hb & 0x7C00u;
         e = (e < 0x2C00u ? 0x2C00u : e) - 0x2800u;
         lo[k] = (w > 0.f) ? smax - ((float)__builtin_bit_cast(half_t, (uint16_t)e) + 2.f * s1_u2(__builtin_fabsf(smax), w, kappa)) * 1.0001f : smax;

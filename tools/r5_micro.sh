@@ -15,4 +15,4 @@ PY
 cd /tmp && export TMPDIR=/tmp
 FP_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o run -- python $R/bench.py --steps 8 --warmup 3 --cpu-queries 0 > $OUT/${TAG}_prof.log 2>&1
 python $R/tools/summarize_prof.py $(ls $OUT/${TAG}_prof/*/run_kernel_stats.csv $OUT/${TAG}_prof/run_kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats.csv "bench.py --steps 8 --warmup 3, FP_GRAPH=0"
-grep -E "k_lz_exact|k_sel_|k_ivf_mark|copyBuffer|k_final|k_cand" $OUT/${TAG}_kernel_stats.csv
+grep -E "k_lz_exact|k_sel_|k_ivf_mark|k_final|k_cand|k_probe|k_l0_thr" $OUT/${TAG}_kernel_stats.csv
