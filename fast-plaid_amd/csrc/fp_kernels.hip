@@ -1760,7 +1760,8 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
   const int maxcells = ucstride < FP_MAX_CELLS ? ucstride : FP_MAX_CELLS;   // probed cells per pass of the kernel
   // tile size: the largest that still gives the chip ~4 workgroups per CU (measured at cfg2: B=64 -> 2048 words 0.11 ms vs 8192 words 0.26 ms; B=8 -> 512 words 0.04 vs 0.22 ms)
   int tw = MARK_TILE_WORDS_MAX;
-  while (tw > 512 && ((W + tw - 1) / tw) * B < 1024) tw >>= 1;
+  static const int64_t want_wgs = (int64_t)fp_test_opt("ivf_wgs", 1024);
+  while (tw > 512 && ((W + tw - 1) / tw) * B < want_wgs) tw >>= 1;
   const int ntile = (int)((W + tw - 1) / tw);
   const size_t lds = (size_t)tw * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
   static std::atomic<uint64_t> lds_ok{0};

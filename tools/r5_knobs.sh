@@ -1,0 +1,12 @@
+#!/bin/bash
+# bench line + stage times under a list of FP_TEST settings:  bash tools/r5_knobs.sh "ivf_wgs=512" "ivf_wgs=2048" ...
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; cd $R; mkdir -p $OUT
+for v in "" "$@"; do
+  FP_TEST="$v" timeout 300 python bench.py --cpu-queries 0 --steps 30 --warmup 5 > $OUT/knob.json 2> $OUT/knob.err
+  python - "$v" <<PY
+import json, sys
+d = json.load(open("$OUT/knob.json"))
+st = d["stages_ms"]
+print("%-22s ms/step %.4f p50 %.4f | %s" % (sys.argv[1] or "(default)", d["ms_per_step"], d["p50_ms"], " ".join("%s %.4f" % (k.split()[0] + k.split()[1][:4], v) for k, v in st.items())))
+PY
+done
