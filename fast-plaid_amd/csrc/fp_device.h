@@ -129,6 +129,32 @@ static inline void fp_allow_big_lds(const void* fn, std::atomic<uint64_t>& done,
 
 
 #if defined(__HIPCC__)
+// Inclusive prefix sum over a whole workgroup (blockDim.x = 64 * nwaves <= 1024, every thread calls it): inside a wave by lane
+// shuffles, across the waves through their totals in LDS (`wt`, [16]).  Two barriers -- the shared-memory Hillis-Steele loops it
+// replaces were two per STEP (twenty for 1024 threads), and the kernels that scan are one-shot kernels whose time is such chains.
+// *total (optional) receives the sum over the workgroup.  `wt` may be reused as soon as the call returns.
+template <typename T>
+__device__ __forceinline__ T fp_block_scan_incl(T v, T* wt, T* total = nullptr) {
+  const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+  T incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T y = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += y;
+  }
+  if (lane == 63) wt[wave] = incl;
+  __syncthreads();
+  T before = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    const T t = wt[w];
+    before += w < wave ? t : (T)0;
+    tot += t;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return before + incl;
+}
+
 // Bitonic sort of 1024 64-bit keys, one per thread of a 1024-thread workgroup, descending: returns the key of rank threadIdx.x.
 // Exchanges inside a wave go through lane shuffles (45 of the 55 stages: no barrier), the ten stages with partners in other
 // waves through `lds` ([1024] keys).  Same network as the all-LDS loops it replaces (k_final_topk / k_final_mark /

@@ -1649,23 +1649,49 @@ void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int6
 //              tiles: lists are short and L2-resident);
 // search == 1: each list's sub-range for this tile is found by binary search first (many
 //              tiles / long lists).
+// the lists' skip table (FpIndexDev::ivf_skip), built once per index: one thread per (cell, boundary)
+__global__ __launch_bounds__(256) void k_ivf_skip_build(const int64_t* __restrict__ ivf_off, const int32_t* __restrict__ ivf_pids, int64_t P,
+                                                        int nskip, int shift, int32_t* __restrict__ skip) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P * nskip) return;
+  const int64_t cell = i / nskip;
+  const int t = (int)(i % nskip);
+  const int64_t beg = ivf_off[cell], end = ivf_off[cell + 1];
+  const int64_t target = (int64_t)t << shift;
+  int64_t l = beg, h = end;
+  if (t == nskip - 1) l = end;   // (the last boundary lies at or beyond the corpus: the whole list)
+  else
+    while (l < h) { const int64_t m = (l + h) >> 1; if ((int64_t)ivf_pids[m] < target) l = m + 1; else h = m; }
+  skip[i] = (int32_t)(l - beg);
+}
+void fpk_ivf_skip_build(const int64_t* ivf_off, const int32_t* ivf_pids, int64_t P, int nskip, int shift, int32_t* skip, hipStream_t st) {
+  const int64_t n = P * nskip;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_ivf_skip_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ivf_off, ivf_pids, P, nskip, shift, skip);
+}
+
 #define MARK_TILE_WORDS_MAX 8192   // 32 KiB of LDS bitmap = 262144 documents per tile
 __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
                                                    int maxcells /*cells per pass (LDS capacity)*/, int ucstride /*row stride of ucells*/,
                                                    const int64_t* __restrict__ ivf_off,
                                                    const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
-                                                   int64_t W, int search, int tw) {
+                                                   int64_t W, int search, int tw, const int32_t* __restrict__ skip /*nullable*/, int nskip,
+                                                   int skip_shift) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                              // [tw]
   long long* lo_s = reinterpret_cast<long long*>(smem + (size_t)tw * 4);      // [maxcells]
   uint32_t* pre = reinterpret_cast<uint32_t*>(smem + (size_t)tw * 4 + (size_t)maxcells * 8);  // [maxcells + 1]
   __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_wtot[16];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int64_t word0 = (int64_t)blockIdx.x * tw;
   const int32_t tile_lo = (int32_t)(word0 * 32);
   const int64_t tile_hi64 = (word0 + tw) * 32;
   const int32_t tile_hi = tile_hi64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tile_hi64;
+  // (the first round's cell of this thread is fetched with the cell count, not behind it: slots past the count are masked below)
+  const int sl0 = search ? (tid >> 1) : tid;
+  const int32_t cell_pre = sl0 < ucstride ? ucells[(int64_t)b * ucstride + sl0] : -1;
   for (int i = tid; i < tw; i += 1024) tile[i] = 0u;
   const int nc_all = ncells[b];
   const int lane = tid & 63, wave = tid >> 6;
@@ -1685,13 +1711,25 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
     uint32_t len = 0;
     long long lo = 0;
     if (j < nc) {
-      const int32_t cell = ucells[(int64_t)b * ucstride + cb + j];
+      const int32_t cell = (cb == 0 && start == 0) ? cell_pre : ucells[(int64_t)b * ucstride + cb + j];
       if (cell >= 0 && cell < P) {
         long long beg = ivf_off[cell], end = ivf_off[cell + 1];
         if (search) {
           const int32_t target = which ? tile_hi : tile_lo;
           long long l = beg, h = end;
-          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < target) l = m + 1; else h = m; }
+          bool exact = false;
+          if (skip) {   // the index's skip table narrows the search to one granule of the list, or answers it (aligned tiles)
+            const int t = (int)((uint32_t)target >> skip_shift);
+            if (t >= nskip - 1) { l = end; exact = true; }
+            else {
+              const int32_t* sk = skip + (int64_t)cell * nskip + t;
+              h = beg + sk[1];
+              l = beg + sk[0];
+              exact = ((uint32_t)target & ((1u << skip_shift) - 1u)) == 0u;
+            }
+          }
+          if (!exact)
+            while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < target) l = m + 1; else h = m; }
           beg = l;   // which == 0: the range's start; which == 1: its end
         }
         lo = beg;
@@ -1708,16 +1746,31 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
     }
     if (which == 0 && j < nc) lo_s[j] = lo;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
+    // inclusive scan of the 1024 slots: inside a wave by shuffles, across the sixteen waves through their totals (two barriers;
+    // the shared-memory scan it replaces was twenty, with sixteen waves each)
+    {
+      const uint32_t v0 = s_scan[tid];
+      uint32_t incl = v0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += y;
+      }
+      if (lane == 63) s_wtot[wave] = incl;
       __syncthreads();
-      s_scan[tid] += v;
+      uint32_t before = 0u, tot = 0u;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const uint32_t t = s_wtot[w];
+        before += w < wave ? t : 0u;
+        tot += t;
+      }
+      s_scan[tid] = before + incl;
       __syncthreads();
+      if (which == 0 && j < nc) pre[j] = base + s_scan[sl] - len;
+      __syncthreads();   // (s_scan is rewritten by the next round)
+      base += tot;
     }
-    if (which == 0 && j < nc) pre[j] = base + s_scan[sl] - len;
-    const uint32_t tot = s_scan[1023];
-    __syncthreads();
-    base += tot;
   }
   if (tid == 0) pre[nc] = base;
   __syncthreads();
@@ -1767,8 +1820,9 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_ivf_mark, lds_ok, 144 * 1024);
   const int search = ntile > 8 ? 1 : 0;
+  static const bool use_skip = fp_test_opt("ivf_skip", 1) != 0;
   hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ucstride, ix.ivf_off,
-                     ix.ivf_pids, ix.P, bitmap, W, search, tw);
+                     ix.ivf_pids, ix.P, bitmap, W, search, tw, use_skip ? ix.ivf_skip : nullptr, ix.ivf_nskip, ix.ivf_skip_shift);
 }
 
 // ---- ordered compaction of the bitmaps ------------------------------------------------------
@@ -1847,39 +1901,26 @@ __device__ __forceinline__ int fp_scan_counts_256(int32_t* v, int nblk, int* s /
   for (int start = 0; start < nblk; start += 256) {
     const int i = start + (int)threadIdx.x;
     const int x = (i < nblk) ? fp_read_published(v + i) : 0;
-    __syncthreads();
-    s[threadIdx.x] = x;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      const int t = ((int)threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nblk) v[i] = base + s[threadIdx.x] - x;
-    base += s[255];
+    int tot = 0;
+    __syncthreads();   // (the caller may still be reading s)
+    const int incl = fp_block_scan_incl<int>(x, s, &tot);
+    if (i < nblk) v[i] = base + incl - x;
+    base += tot;
   }
   return base;
 }
 // cand_off[0..B] from the per-query totals; cap / invalid / total_out as k_cand_offsets below; a 256-thread workgroup
 __device__ __forceinline__ void fp_offsets_256(int32_t* ncand, int B, int64_t* cand_off, int64_t cap, int32_t* invalid, int64_t* total_out,
                                                const int32_t* probe_flag) {
-  __shared__ long long so[256];
+  __shared__ long long so[16];
   long long base = 0;
   for (int start = 0; start < B; start += 256) {
     const int i = start + (int)threadIdx.x;
     const long long x = (i < B) ? (long long)fp_read_published(ncand + i) : 0ll;
-    __syncthreads();
-    so[threadIdx.x] = x;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      const long long t = ((int)threadIdx.x >= off) ? so[threadIdx.x - off] : 0ll;
-      __syncthreads();
-      so[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < B) cand_off[i] = base + so[threadIdx.x] - x;
-    base += so[255];
+    long long tot = 0;
+    const long long incl = fp_block_scan_incl<long long>(x, so, &tot);
+    if (i < B) cand_off[i] = base + incl - x;
+    base += tot;
   }
   const bool over = cap > 0 && base > cap;
   if (over)
@@ -3252,7 +3293,7 @@ __global__ __launch_bounds__(256) void k_l0_combine(const uint16_t* __restrict__
 __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__ hist, const int64_t* __restrict__ cand_off, int64_t n_full,
                                                     int64_t R, int mult, const uint32_t* __restrict__ Fsum, int32_t* __restrict__ cut,
                                                     int32_t* __restrict__ npilot) {
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[16];
   __shared__ int s_k;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int64_t n = cand_off[b + 1] - cand_off[b];
@@ -3276,16 +3317,12 @@ __global__ __launch_bounds__(1024) void k_l0_topcut(const uint32_t* __restrict__
     own[k] = hg[tid * BPT + k];
     loc += own[k];
   }
-  part[tid] = loc;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // inclusive suffix scan
-    const uint32_t v = (tid + off < 1024) ? part[tid + off] : 0u;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  const uint32_t above = part[tid] - loc;
-  if (above < (uint32_t)want && part[tid] >= (uint32_t)want) {
+  // inclusive suffix sums from the prefix sums and the total
+  uint32_t tot_all = 0;
+  const uint32_t pincl = fp_block_scan_incl<uint32_t>(loc, part, &tot_all);
+  const uint32_t sfx_incl = tot_all - pincl + loc;
+  const uint32_t above = sfx_incl - loc;
+  if (above < (uint32_t)want && sfx_incl >= (uint32_t)want) {
     uint32_t acc = above;
     int kk = tid * BPT;
 #pragma unroll
@@ -3854,18 +3891,10 @@ __device__ __forceinline__ void sel_scan_local(const uint32_t* __restrict__ g, u
   uint32_t sum = 0;
 #pragma unroll
   for (int j = 0; j < PER; ++j) { loc[j] = g[NB - 1 - (threadIdx.x * PER + j)]; sum += loc[j]; }
-  __shared__ uint32_t sc[256];
+  __shared__ uint32_t sc[16];
   __shared__ uint32_t s_out[2];
-  sc[threadIdx.x] = sum;
   if (threadIdx.x == 0) { s_out[0] = prefix << WIDTH; s_out[1] = k_rem; }
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    uint32_t t = ((int)threadIdx.x >= off) ? sc[threadIdx.x - off] : 0;
-    __syncthreads();
-    sc[threadIdx.x] += t;
-    __syncthreads();
-  }
-  const uint32_t incl = sc[threadIdx.x], excl = incl - sum;
+  const uint32_t incl = fp_block_scan_incl<uint32_t>(sum, sc), excl = incl - sum;   // (its barriers also order s_out)
   if (excl < k_rem && incl >= k_rem) {  // exactly one thread
     uint32_t cum = excl;
 #pragma unroll
@@ -4006,23 +4035,16 @@ __device__ __forceinline__ void sel_collect_body(const float* __restrict__ appro
 // 0 writes pref[0..B]) -- one launch less in front of MaxSim.
 // exclusive prefix of the queries' selection counts (what S6 maps its work with), by one workgroup of 1024 threads
 __device__ __forceinline__ void sel_count_prefix(const int32_t* __restrict__ sel_cnt, int64_t* __restrict__ pref, int B) {
-  __shared__ long long sp[1024];
+  __shared__ long long sp[16];
   long long base = 0;
   if (threadIdx.x == 0) pref[0] = 0;
   for (int start = 0; start < B; start += 1024) {
     const int i = start + (int)threadIdx.x;
     const long long x = (i < B) ? (long long)sel_cnt[i] : 0ll;
-    __syncthreads();
-    sp[threadIdx.x] = x;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const long long t = ((int)threadIdx.x >= off) ? sp[threadIdx.x - off] : 0ll;
-      __syncthreads();
-      sp[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < B) pref[i + 1] = base + sp[threadIdx.x];
-    base += sp[1023];
+    long long tot = 0;
+    const long long incl = fp_block_scan_incl<long long>(x, sp, &tot);
+    if (i < B) pref[i + 1] = base + incl;
+    base += tot;
   }
 }
 __global__ __launch_bounds__(1024) void k_sel_collect(const float* __restrict__ approx, const int32_t* __restrict__ cand_pid,

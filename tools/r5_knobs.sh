@@ -7,6 +7,6 @@ for v in "" "$@"; do
 import json, sys
 d = json.load(open("$OUT/knob.json"))
 st = d["stages_ms"]
-print("%-22s ms/step %.4f p50 %.4f | %s" % (sys.argv[1] or "(default)", d["ms_per_step"], d["p50_ms"], " ".join("%s %.4f" % (k.split()[0] + k.split()[1][:4], v) for k, v in st.items())))
+print("%-22s ms/step %.4f p50 %.4f | %s" % (sys.argv[1] or "(default)", d["ms_per_step"], d["p50_ms"], " ".join("%s %.3f" % (k.split()[0], v) for k, v in st.items())))
 PY
 done
