@@ -1683,6 +1683,7 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   uint32_t* pre = reinterpret_cast<uint32_t*>(smem + (size_t)tw * 4 + (size_t)maxcells * 8);  // [maxcells + 1]
   __shared__ uint32_t s_scan[1024];
   __shared__ uint32_t s_wtot[16];
+  __shared__ uint16_t s_cs[1024];   // cell of every 2^gshift-th position of the concatenated stream
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int64_t word0 = (int64_t)blockIdx.x * tw;
@@ -1775,22 +1776,42 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
   if (tid == 0) pre[nc] = base;
   __syncthreads();
   const uint32_t total = base;
-  // phase 2: walk the concatenated stream, 512 elements per wave-chunk
+  // phase 2: walk the concatenated stream, 512 elements per wave-chunk, EIGHT CONSECUTIVE elements per lane.  Where a lane's
+  // elements lie -- which cell, at which offset -- comes from LDS gathers, and those were the kernel: with consecutive lanes on
+  // consecutive elements every element paid ~4 of them (cell advance, list start, prefix), 44 of the kernel's 80 us at cfg2
+  // (timing-only ablation: no atomics -18 us, no list loads -19 us, no walk at all -64 us).  Now a lane looks its first
+  // element's cell up in a table of the stream's cells at every 2^gshift-th position (built here, one search per entry), steps
+  // forward to it, and keeps {next boundary, list address - stream position} in registers until it crosses into the next list.
+  int gshift = 6;
+  while (((total >> gshift) + 1u) > 1024u) ++gshift;
+  const uint32_t nent = (total >> gshift) + 1u;
+  if ((uint32_t)tid < nent && total > 0u) {
+    const uint32_t p0 = (uint32_t)tid << gshift;
+    int l = 0, h = nc;   // last cell with pre[cell] <= p0
+    while (h - l > 1) { const int m = (l + h) >> 1; if (pre[m] <= p0) l = m; else h = m; }
+    s_cs[tid] = (uint16_t)l;
+  }
+  __syncthreads();
   for (uint32_t c0 = (uint32_t)wave * 512u; c0 < total; c0 += 16u * 512u) {
-    int cell = 0;
-    {  // last cell with pre[cell] <= c0
-      int l = 0, h = nc;
-      while (h - l > 1) { int m = (l + h) >> 1; if (pre[m] <= c0) l = m; else h = m; }
-      cell = l;
-    }
+    const uint32_t g0 = c0 + (uint32_t)lane * 8u;
     int32_t pid[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const uint32_t g = c0 + (uint32_t)k * 64u + (uint32_t)lane;
-      pid[k] = -1;
-      if (g < total) {
-        while (g >= pre[cell + 1]) ++cell;
-        pid[k] = ivf_pids[lo_s[cell] + (long long)(g - pre[cell])];
+    for (int k = 0; k < 8; ++k) pid[k] = -1;
+    if (g0 < total) {
+      int cell = (int)s_cs[g0 >> gshift];
+      uint32_t nb = pre[cell + 1];
+      while (g0 >= nb) { ++cell; nb = pre[cell + 1]; }   // (empty lists are stepped over too: their boundaries coincide)
+      long long adj = lo_s[cell] - (long long)pre[cell];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t g = g0 + (uint32_t)k;
+        if (g < total) {
+          if (g >= nb) {
+            do { ++cell; nb = pre[cell + 1]; } while (g >= nb);
+            adj = lo_s[cell] - (long long)pre[cell];
+          }
+          pid[k] = ivf_pids[adj + (long long)g];
+        }
       }
     }
 #pragma unroll
