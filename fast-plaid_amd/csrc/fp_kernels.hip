@@ -1849,9 +1849,9 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
 // ---- ordered compaction of the bitmaps ------------------------------------------------------
 // words per thread / per workgroup of the counting and compaction kernels: 2 / 512 (16384 documents: at the ~33 % candidate
 // density of cfg2 a workgroup's ids fit ONE pass through its 8192-id LDS stage; with 4 / 1024 they took two passes, each of
-// which walks every set bit) -- FP_TEST cand_wpt=4 brings the larger workgroups back
-static int cand_wpt() { static const int v = (int)fp_test_opt("cand_wpt", 2) == 4 ? 4 : 2; return v; }
-int fpk_cand_words_per_block() { return 256 * cand_wpt(); }
+// which walks every set bit: 46 against 31 us)
+#define CAND_WPT_N 2
+int fpk_cand_words_per_block() { return 256 * CAND_WPT_N; }
 // ---- "last workgroup finishes the job": the count -> scan -> offsets chains below were three or four launches of which only the
 // first has real work; each extra launch is ~4.5 us of dispatch tail (40 % of a one-query search was such tails).  Every
 // workgroup publishes its count, then takes a ticket; the one that draws the last ticket of its query scans the query's
@@ -2032,7 +2032,7 @@ __global__ __launch_bounds__(256) void k_cand_offsets(int32_t* ncand, int B, int
 void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W, int32_t* blkcnt,
                     int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st, int64_t cap, int32_t* invalid_rw, int64_t* total_out,
                     uint32_t* ctr, const int32_t* probe_flag) {
-  const auto count_kernel = cand_wpt() == 4 ? k_cand_count<4> : k_cand_count<2>;
+  const auto count_kernel = k_cand_count<CAND_WPT_N>;
   if (ctr && (int64_t)nblk * B <= FP_TICKET_MAX_WGS) {
     hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, ctr, ncand, B,
                        cand_off, cap, invalid_rw, total_out, probe_flag);
@@ -2119,7 +2119,7 @@ __global__ __launch_bounds__(256) void k_cand_compact(const uint32_t* __restrict
 
 void fpk_cand_compact(const uint32_t* bitmap, const uint32_t* subbm, const int32_t* invalid, int B, int64_t W,
                       const int32_t* blkoff, int nblk, const int64_t* cand_off, int32_t* cand_pid, hipStream_t st) {
-  const auto compact_kernel = cand_wpt() == 4 ? k_cand_compact<4> : k_cand_compact<2>;
+  const auto compact_kernel = k_cand_compact<CAND_WPT_N>;
   hipLaunchKernelGGL(compact_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkoff, nblk,
                      cand_off, cand_pid);
 }

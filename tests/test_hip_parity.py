@@ -473,13 +473,18 @@ def test_without_tickets_and_with_every_score_reevaluated(fp):
 
 
 @pytest.mark.parametrize("extra,expect", [({}, 1), ({"FP_APPROX_IMPL": "l0"}, 1), ({"FP_APPROX_IMPL": "q8"}, 1), ({"FP_APPROX_IMPL": "exact"}, 1),
-                                          ({"FP_TEST": "lz_gcap=3"}, 0), ({"FP_S1_EXACT": "1"}, 0), ({"FP_S1_STREAM": "0"}, 1)])
+                                          ({"FP_TEST": "lz_gcap=3"}, 0), ({"FP_S1_EXACT": "1"}, 0), ({"FP_S1_STREAM": "0"}, 1),
+                                          # the paths the launch-tail pass left as fallbacks (IVF range cuts by search alone, probed cells
+                                          # through the sort) and odd grid sizes for the selection / the maybes / the IVF tiles
+                                          ({"FP_TEST": "ivf_skip=0,cells_bm=0,sel_gx=3,sel_gg=5,lz_exb=3,ivf_wgs=4096"}, 1),
+                                          ({"FP_TEST": "sel_gx=64,sel_gg=64,lz_exb=64,ivf_wgs=64"}, 1)])
 def test_lazy_centroid_scores(fp, extra, expect):
     """S1's lazy form (round 5: the centroid scores leave S1 as upper candidates h(x + u), no chain runs there; the probe
     re-evaluates the handful of scores it ranks, the selection recomputes the few documents whose upper-bound score lies within
     the slack of the cut) must give exactly what the eager form gives: fp_search (lazy) == fp_search_trace (eager) bit for bit and
     the oracle's ids, for every form of S4, with both S1 kernels, with an unnormalised query and zero rows; a selection list that
-    overflows (FP_TEST=lz_gcap=3) sends the batch round again eagerly; FP_S1_EXACT=1 keeps everything eager."""
+    overflows (FP_TEST=lz_gcap=3) sends the batch round again eagerly; FP_S1_EXACT=1 keeps everything eager.  The last two
+    variants run the same comparison over the fallback paths and other grid sizes of round 5's small kernels."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
