@@ -351,7 +351,6 @@ static hipError_t dev_alloc(fp_index* ix, T** p, size_t n) {
   *p = reinterpret_cast<T*>(q);
   return hipSuccess;
 }
-static void build_ivf_skip(fp_index* ix, hipStream_t st);
 
 static int upload_narrow(const int64_t* host, int32_t* dev, int64_t n, hipStream_t st) {
   // chunked i64 -> i32 through a device staging buffer
@@ -592,29 +591,8 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   ICHK(hipStreamSynchronize(st));
 #undef ICHK
   D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
-  build_ivf_skip(ix, st);
   *out = ix;
   return FP_OK;
-}
-
-// the IVF lists' skip table (FpIndexDev::ivf_skip): at most ~33 boundaries per list, granules of at least 65536 documents (the
-// tile S3 marks with at cfg2's batch size), kept only while it stays under an eighth of the lists themselves + 64 MB
-static void build_ivf_skip(fp_index* ix, hipStream_t st) {
-  FpIndexDev& D = ix->d;
-  D.ivf_skip = nullptr; D.ivf_nskip = 0; D.ivf_skip_shift = 0;
-  if (!ix->has_ivf || D.P <= 0 || D.N <= 0 || !D.ivf_off || !D.ivf_pids) return;
-  int shift = 16;
-  while (((D.N + (1ll << shift) - 1) >> shift) > 32) ++shift;
-  const int nskip = (int)((D.N + (1ll << shift) - 1) >> shift) + 1;
-  int64_t tot = 0;
-  if (hipMemcpy(&tot, D.ivf_off + D.P, 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
-  const int64_t bytes = D.P * nskip * 4;
-  if (bytes > tot * 4 / 8 + (64ll << 20)) return;
-  int32_t* sk = nullptr;
-  if (dev_alloc(ix, &sk, (size_t)(D.P * nskip)) != hipSuccess) { (void)hipGetLastError(); return; }   // (no table: S3 searches)
-  fpk_ivf_skip_build(D.ivf_off, D.ivf_pids, D.P, nskip, shift, sk, st);
-  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return; }
-  D.ivf_skip = sk; D.ivf_nskip = nskip; D.ivf_skip_shift = shift;
 }
 
 extern "C" void fp_index_destroy(fp_index* ix) {
@@ -701,7 +679,6 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
 #undef ICHK
   ix->has_ivf = true;
   D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
-  build_ivf_skip(ix, st);
   *out = ix;
   return FP_OK;
 }

@@ -68,12 +68,6 @@ struct FpIndexDev {
   // `centroids` (dim 64 / 128 / 256, and dims above 256, which stay on the one-tile kernel).
   const uint16_t* cent_s1;
   int dim_s1;
-  // skip table of the IVF lists (round 5): ivf_skip[cell * ivf_nskip + t] = number of the cell's entries with a document id below
-  // t << ivf_skip_shift (t = 0 .. ivf_nskip - 1; the last one = the list's length).  S3 cuts every probed list to its document
-  // tile with it instead of two ten-step binary searches per (cell, tile) -- the searches were most of a marking workgroup's life.
-  // nullptr: no table (S3 searches).
-  const int32_t* ivf_skip;
-  int ivf_nskip, ivf_skip_shift;
 };
 
 // Native unit order of a token's residual bytes (k_maxsim6): a unit = 8 dims = nbits bytes; unit u = 4 s + g (k-step s of 32 dims,
@@ -440,7 +434,5 @@ int fps_final_topk_big(const float* score, const int32_t* pid_local, const int64
                        int64_t top_k, int64_t pid_offset, int64_t* out_pid, float* out_score, int32_t* out_cnt, hipStream_t st);
 // Builds the IVF (per-cell ascending unique local doc ids) from the per-document unique codes.
 // Allocates *ivf_pids (hipMalloc) and fills ivf_off_dev [P+1].  Returns 0 or a hipError.
-// (device) the skip table of the IVF lists: skip [P][nskip] as described at FpIndexDev::ivf_skip
-void fpk_ivf_skip_build(const int64_t* ivf_off, const int32_t* ivf_pids, int64_t P, int nskip, int shift, int32_t* skip, hipStream_t st);
 int fps_build_ivf(const int32_t* ucodes, const int64_t* uoff_dev, int64_t n_docs, int64_t U, int64_t P, int32_t** ivf_pids,
                   int64_t* ivf_total, int64_t* ivf_off_dev, hipStream_t st);

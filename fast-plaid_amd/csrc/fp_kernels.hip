@@ -1649,50 +1649,23 @@ void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int6
 //              tiles: lists are short and L2-resident);
 // search == 1: each list's sub-range for this tile is found by binary search first (many
 //              tiles / long lists).
-// the lists' skip table (FpIndexDev::ivf_skip), built once per index: one thread per (cell, boundary)
-__global__ __launch_bounds__(256) void k_ivf_skip_build(const int64_t* __restrict__ ivf_off, const int32_t* __restrict__ ivf_pids, int64_t P,
-                                                        int nskip, int shift, int32_t* __restrict__ skip) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= P * nskip) return;
-  const int64_t cell = i / nskip;
-  const int t = (int)(i % nskip);
-  const int64_t beg = ivf_off[cell], end = ivf_off[cell + 1];
-  const int64_t target = (int64_t)t << shift;
-  int64_t l = beg, h = end;
-  if (t == nskip - 1) l = end;   // (the last boundary lies at or beyond the corpus: the whole list)
-  else
-    while (l < h) { const int64_t m = (l + h) >> 1; if ((int64_t)ivf_pids[m] < target) l = m + 1; else h = m; }
-  skip[i] = (int32_t)(l - beg);
-}
-void fpk_ivf_skip_build(const int64_t* ivf_off, const int32_t* ivf_pids, int64_t P, int nskip, int shift, int32_t* skip, hipStream_t st) {
-  const int64_t n = P * nskip;
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_ivf_skip_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ivf_off, ivf_pids, P, nskip, shift, skip);
-}
-
 #define MARK_TILE_WORDS_MAX 8192   // 32 KiB of LDS bitmap = 262144 documents per tile
 __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ ucells, const int32_t* __restrict__ ncells,
                                                    int maxcells /*cells per pass (LDS capacity)*/, int ucstride /*row stride of ucells*/,
                                                    const int64_t* __restrict__ ivf_off,
                                                    const int32_t* __restrict__ ivf_pids, int64_t P, uint32_t* __restrict__ bitmap,
-                                                   int64_t W, int search, int tw, const int32_t* __restrict__ skip /*nullable*/, int nskip,
-                                                   int skip_shift) {
+                                                   int64_t W, int search, int tw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                              // [tw]
   long long* lo_s = reinterpret_cast<long long*>(smem + (size_t)tw * 4);      // [maxcells]
   uint32_t* pre = reinterpret_cast<uint32_t*>(smem + (size_t)tw * 4 + (size_t)maxcells * 8);  // [maxcells + 1]
   __shared__ uint32_t s_scan[1024];
-  __shared__ uint32_t s_wtot[16];
-  __shared__ uint16_t s_cs[1024];   // cell of every 2^gshift-th position of the concatenated stream
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int64_t word0 = (int64_t)blockIdx.x * tw;
   const int32_t tile_lo = (int32_t)(word0 * 32);
   const int64_t tile_hi64 = (word0 + tw) * 32;
   const int32_t tile_hi = tile_hi64 > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)tile_hi64;
-  // (the first round's cell of this thread is fetched with the cell count, not behind it: slots past the count are masked below)
-  const int sl0 = search ? (tid >> 1) : tid;
-  const int32_t cell_pre = sl0 < ucstride ? ucells[(int64_t)b * ucstride + sl0] : -1;
   for (int i = tid; i < tw; i += 1024) tile[i] = 0u;
   const int nc_all = ncells[b];
   const int lane = tid & 63, wave = tid >> 6;
@@ -1712,25 +1685,13 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
     uint32_t len = 0;
     long long lo = 0;
     if (j < nc) {
-      const int32_t cell = (cb == 0 && start == 0) ? cell_pre : ucells[(int64_t)b * ucstride + cb + j];
+      const int32_t cell = ucells[(int64_t)b * ucstride + cb + j];
       if (cell >= 0 && cell < P) {
         long long beg = ivf_off[cell], end = ivf_off[cell + 1];
         if (search) {
           const int32_t target = which ? tile_hi : tile_lo;
           long long l = beg, h = end;
-          bool exact = false;
-          if (skip) {   // the index's skip table narrows the search to one granule of the list, or answers it (aligned tiles)
-            const int t = (int)((uint32_t)target >> skip_shift);
-            if (t >= nskip - 1) { l = end; exact = true; }
-            else {
-              const int32_t* sk = skip + (int64_t)cell * nskip + t;
-              h = beg + sk[1];
-              l = beg + sk[0];
-              exact = ((uint32_t)target & ((1u << skip_shift) - 1u)) == 0u;
-            }
-          }
-          if (!exact)
-            while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < target) l = m + 1; else h = m; }
+          while (l < h) { long long m = (l + h) >> 1; if (ivf_pids[m] < target) l = m + 1; else h = m; }
           beg = l;   // which == 0: the range's start; which == 1: its end
         }
         lo = beg;
@@ -1747,71 +1708,36 @@ __global__ __launch_bounds__(1024) void k_ivf_mark(const int32_t* __restrict__ u
     }
     if (which == 0 && j < nc) lo_s[j] = lo;
     __syncthreads();
-    // inclusive scan of the 1024 slots: inside a wave by shuffles, across the sixteen waves through their totals (two barriers;
-    // the shared-memory scan it replaces was twenty, with sixteen waves each)
-    {
-      const uint32_t v0 = s_scan[tid];
-      uint32_t incl = v0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += y;
-      }
-      if (lane == 63) s_wtot[wave] = incl;
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
       __syncthreads();
-      uint32_t before = 0u, tot = 0u;
-#pragma unroll
-      for (int w = 0; w < 16; ++w) {
-        const uint32_t t = s_wtot[w];
-        before += w < wave ? t : 0u;
-        tot += t;
-      }
-      s_scan[tid] = before + incl;
+      s_scan[tid] += v;
       __syncthreads();
-      if (which == 0 && j < nc) pre[j] = base + s_scan[sl] - len;
-      __syncthreads();   // (s_scan is rewritten by the next round)
-      base += tot;
     }
+    if (which == 0 && j < nc) pre[j] = base + s_scan[sl] - len;
+    const uint32_t tot = s_scan[1023];
+    __syncthreads();
+    base += tot;
   }
   if (tid == 0) pre[nc] = base;
   __syncthreads();
   const uint32_t total = base;
-  // phase 2: walk the concatenated stream, 512 elements per wave-chunk, EIGHT CONSECUTIVE elements per lane.  Where a lane's
-  // elements lie -- which cell, at which offset -- comes from LDS gathers, and those were the kernel: with consecutive lanes on
-  // consecutive elements every element paid ~4 of them (cell advance, list start, prefix), 44 of the kernel's 80 us at cfg2
-  // (timing-only ablation: no atomics -18 us, no list loads -19 us, no walk at all -64 us).  Now a lane looks its first
-  // element's cell up in a table of the stream's cells at every 2^gshift-th position (built here, one search per entry), steps
-  // forward to it, and keeps {next boundary, list address - stream position} in registers until it crosses into the next list.
-  int gshift = 6;
-  while (((total >> gshift) + 1u) > 1024u) ++gshift;
-  const uint32_t nent = (total >> gshift) + 1u;
-  if ((uint32_t)tid < nent && total > 0u) {
-    const uint32_t p0 = (uint32_t)tid << gshift;
-    int l = 0, h = nc;   // last cell with pre[cell] <= p0
-    while (h - l > 1) { const int m = (l + h) >> 1; if (pre[m] <= p0) l = m; else h = m; }
-    s_cs[tid] = (uint16_t)l;
-  }
-  __syncthreads();
+  // phase 2: walk the concatenated stream, 512 elements per wave-chunk
   for (uint32_t c0 = (uint32_t)wave * 512u; c0 < total; c0 += 16u * 512u) {
-    const uint32_t g0 = c0 + (uint32_t)lane * 8u;
+    int cell = 0;
+    {  // last cell with pre[cell] <= c0
+      int l = 0, h = nc;
+      while (h - l > 1) { int m = (l + h) >> 1; if (pre[m] <= c0) l = m; else h = m; }
+      cell = l;
+    }
     int32_t pid[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pid[k] = -1;
-    if (g0 < total) {
-      int cell = (int)s_cs[g0 >> gshift];
-      uint32_t nb = pre[cell + 1];
-      while (g0 >= nb) { ++cell; nb = pre[cell + 1]; }   // (empty lists are stepped over too: their boundaries coincide)
-      long long adj = lo_s[cell] - (long long)pre[cell];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const uint32_t g = g0 + (uint32_t)k;
-        if (g < total) {
-          if (g >= nb) {
-            do { ++cell; nb = pre[cell + 1]; } while (g >= nb);
-            adj = lo_s[cell] - (long long)pre[cell];
-          }
-          pid[k] = ivf_pids[adj + (long long)g];
-        }
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t g = c0 + (uint32_t)k * 64u + (uint32_t)lane;
+      pid[k] = -1;
+      if (g < total) {
+        while (g >= pre[cell + 1]) ++cell;
+        pid[k] = ivf_pids[lo_s[cell] + (long long)(g - pre[cell])];
       }
     }
 #pragma unroll
@@ -1834,16 +1760,14 @@ void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* nc
   const int maxcells = ucstride < FP_MAX_CELLS ? ucstride : FP_MAX_CELLS;   // probed cells per pass of the kernel
   // tile size: the largest that still gives the chip ~4 workgroups per CU (measured at cfg2: B=64 -> 2048 words 0.11 ms vs 8192 words 0.26 ms; B=8 -> 512 words 0.04 vs 0.22 ms)
   int tw = MARK_TILE_WORDS_MAX;
-  static const int64_t want_wgs = (int64_t)fp_test_opt("ivf_wgs", 1024);
-  while (tw > 512 && ((W + tw - 1) / tw) * B < want_wgs) tw >>= 1;
+  while (tw > 512 && ((W + tw - 1) / tw) * B < 1024) tw >>= 1;
   const int ntile = (int)((W + tw - 1) / tw);
   const size_t lds = (size_t)tw * 4 + (size_t)maxcells * 8 + (size_t)(maxcells + 1) * 4 + 16;
   static std::atomic<uint64_t> lds_ok{0};
   fp_allow_big_lds((const void*)k_ivf_mark, lds_ok, 144 * 1024);
   const int search = ntile > 8 ? 1 : 0;
-  static const bool use_skip = fp_test_opt("ivf_skip", 1) != 0;
   hipLaunchKernelGGL(k_ivf_mark, dim3((unsigned)ntile, (unsigned)B), dim3(1024), lds, st, ucells, ncells, maxcells, ucstride, ix.ivf_off,
-                     ix.ivf_pids, ix.P, bitmap, W, search, tw, use_skip ? ix.ivf_skip : nullptr, ix.ivf_nskip, ix.ivf_skip_shift);
+                     ix.ivf_pids, ix.P, bitmap, W, search, tw);
 }
 
 // ---- ordered compaction of the bitmaps ------------------------------------------------------
@@ -1956,19 +1880,22 @@ __device__ __forceinline__ void fp_offsets_256(int32_t* ncand, int B, int64_t* c
 }
 
 // ctr != nullptr: fused form -- also leaves blkcnt scanned (exclusive, per query), ncand, cand_off and *total_out
+// One workgroup counts TWO consecutive compaction blocks (waves 0 - 1 the first, waves 2 - 3 the second: 2 x CAND_WPT words per
+// thread): halving the compaction blocks to 512 words doubled this kernel's workgroups, and at cfg3 (156 k of them) that cost
+// more than the compaction gained.  nblk = compaction blocks per query; the grid is ceil(nblk / 2) x B.
 template <int CAND_WPT>
 __global__ __launch_bounds__(256) void k_cand_count(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ subbm,
                                                     const int32_t* invalid, int64_t W, int32_t* blkcnt, int nblk,
                                                     uint32_t* ctr = nullptr, int32_t* ncand = nullptr, int B = 0, int64_t* cand_off = nullptr,
                                                     int64_t cap = 0, int32_t* invalid_rw = nullptr, int64_t* total_out = nullptr,
                                                     const int32_t* probe_flag = nullptr) {
-  constexpr int CAND_WPB = 256 * CAND_WPT;
+  constexpr int WPT2 = 2 * CAND_WPT;
   const int b = blockIdx.y;
   int cnt = 0;
   if (!(invalid && invalid[b])) {
-    const int64_t w0 = (int64_t)blockIdx.x * CAND_WPB + threadIdx.x * CAND_WPT;
+    const int64_t w0 = (int64_t)blockIdx.x * (256 * WPT2) + threadIdx.x * WPT2;   // (threads 0 .. 127: the first 256 * CAND_WPT words)
 #pragma unroll
-    for (int k = 0; k < CAND_WPT; ++k) {
+    for (int k = 0; k < WPT2; ++k) {
       int64_t w = w0 + k;
       if (w < W) {
         uint32_t x = bitmap[(int64_t)b * W + w];
@@ -1978,18 +1905,25 @@ __global__ __launch_bounds__(256) void k_cand_count(const uint32_t* __restrict__
     }
   }
   __shared__ int s[256];
-  s[threadIdx.x] = cnt;
+#pragma unroll
+  for (int x = 32; x > 0; x >>= 1) cnt += __shfl_xor(cnt, x, 64);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-    __syncthreads();
-  }
+  const int c0 = s[0] + s[1], c1 = s[2] + s[3];
+  const int k0 = 2 * (int)blockIdx.x;
+  const bool two = k0 + 1 < nblk;
   if (!ctr) {
-    if (threadIdx.x == 0) blkcnt[(int64_t)b * nblk + blockIdx.x] = s[0];
+    if (threadIdx.x == 0) {
+      blkcnt[(int64_t)b * nblk + k0] = c0;
+      if (two) blkcnt[(int64_t)b * nblk + k0 + 1] = c1;
+    }
     return;
   }
-  if (threadIdx.x == 0) fp_publish(blkcnt + (int64_t)b * nblk + blockIdx.x, s[0]);
-  if (!fp_ticket_last(ctr + b, (uint32_t)nblk)) return;
+  if (threadIdx.x == 0) {
+    fp_publish(blkcnt + (int64_t)b * nblk + k0, c0);
+    if (two) fp_publish(blkcnt + (int64_t)b * nblk + k0 + 1, c1);
+  }
+  if (!fp_ticket_last(ctr + b, gridDim.x)) return;
   const int total = fp_scan_counts_256(blkcnt + (int64_t)b * nblk, nblk, s);
   if (threadIdx.x == 0) fp_publish(ncand + b, total);
   if (!fp_ticket_last(ctr + B, (uint32_t)B)) return;
@@ -2033,12 +1967,13 @@ void fpk_cand_count(const uint32_t* bitmap, const uint32_t* subbm, const int32_t
                     int nblk, int32_t* ncand, int64_t* cand_off, hipStream_t st, int64_t cap, int32_t* invalid_rw, int64_t* total_out,
                     uint32_t* ctr, const int32_t* probe_flag) {
   const auto count_kernel = k_cand_count<CAND_WPT_N>;
-  if (ctr && (int64_t)nblk * B <= FP_TICKET_MAX_WGS) {
-    hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, ctr, ncand, B,
+  const unsigned ngrid = (unsigned)((nblk + 1) / 2);   // (a counting workgroup covers two compaction blocks)
+  if (ctr && (int64_t)ngrid * B <= FP_TICKET_MAX_WGS) {
+    hipLaunchKernelGGL(count_kernel, dim3(ngrid, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, ctr, ncand, B,
                        cand_off, cap, invalid_rw, total_out, probe_flag);
     return;
   }
-  hipLaunchKernelGGL(count_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, (uint32_t*)nullptr,
+  hipLaunchKernelGGL(count_kernel, dim3(ngrid, (unsigned)B), dim3(256), 0, st, bitmap, subbm, invalid, W, blkcnt, nblk, (uint32_t*)nullptr,
                      (int32_t*)nullptr, 0, (int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (int64_t*)nullptr, (const int32_t*)nullptr);
   if (ctr) {
     hipLaunchKernelGGL(k_cand_scan, dim3((unsigned)B), dim3(256), 0, st, blkcnt, nblk, ncand, (int32_t*)nullptr, (int32_t*)nullptr, ctr + B, B,

@@ -474,10 +474,10 @@ def test_without_tickets_and_with_every_score_reevaluated(fp):
 
 @pytest.mark.parametrize("extra,expect", [({}, 1), ({"FP_APPROX_IMPL": "l0"}, 1), ({"FP_APPROX_IMPL": "q8"}, 1), ({"FP_APPROX_IMPL": "exact"}, 1),
                                           ({"FP_TEST": "lz_gcap=3"}, 0), ({"FP_S1_EXACT": "1"}, 0), ({"FP_S1_STREAM": "0"}, 1),
-                                          # the paths the launch-tail pass left as fallbacks (IVF range cuts by search alone, probed cells
-                                          # through the sort) and odd grid sizes for the selection / the maybes / the IVF tiles
-                                          ({"FP_TEST": "ivf_skip=0,cells_bm=0,sel_gx=3,sel_gg=5,lz_exb=3,ivf_wgs=4096"}, 1),
-                                          ({"FP_TEST": "sel_gx=64,sel_gg=64,lz_exb=64,ivf_wgs=64"}, 1)])
+                                          # the path the launch-tail pass left as a fallback (probed cells through the sort) and odd grid
+                                          # sizes for the selection / the maybes
+                                          ({"FP_TEST": "cells_bm=0,sel_gx=3,sel_gg=5,lz_exb=3"}, 1),
+                                          ({"FP_TEST": "sel_gx=64,sel_gg=64,lz_exb=64"}, 1)])
 def test_lazy_centroid_scores(fp, extra, expect):
     """S1's lazy form (round 5: the centroid scores leave S1 as upper candidates h(x + u), no chain runs there; the probe
     re-evaluates the handful of scores it ranks, the selection recomputes the few documents whose upper-bound score lies within

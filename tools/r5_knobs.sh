@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench line + stage times under a list of FP_TEST settings:  bash tools/r5_knobs.sh "ivf_wgs=512" "ivf_wgs=2048" ...
+# bench line + stage times under a list of FP_TEST settings:  bash tools/r5_knobs.sh "sel_gx=4" "sel_gx=16" ...
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; cd $R; mkdir -p $OUT
 for v in "" "$@"; do
   FP_TEST="$v" timeout 300 python bench.py --cpu-queries 0 --steps 30 --warmup 5 > $OUT/knob.json 2> $OUT/knob.err
