@@ -1276,6 +1276,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         P.spec = true;
         P.M = s->spec_cap;
         P.used_q8 = s->graph.used_q8;
+        P.total_folded = true;   // (a graph is only ever kept from a speculative host-buffer batch: its candidate total and probe flag are in the result block)
         s->fold_stats = true;
         s->ms_marked_now = s->graph.marked;
         replayed = true;

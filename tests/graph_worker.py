@@ -53,7 +53,28 @@ def main():
         for b in range(q.shape[0]):
             t = R.search_trace(dev, q[b], params)
             assert counts[b] == len(t["pids"]) and np.array_equal(pids[b, : counts[b]], t["pids"]) and np.array_equal(scores[b, : counts[b]], t["scores"])
-    print("GRAPH_OK replays", replays)
+    # an overflow on a REPLAYED batch: the capacity of a new shape is learnt from batches of all-zero queries (every token probes the
+    # same few lowest-numbered cells: a small candidate total), then a batch of real queries -- many times the candidates -- arrives
+    # through the captured graph.  The device empties such a batch; the host must see the true total (it travels in the result
+    # block: the graph has no copy node of its own for it) and run the batch again.
+    params = R.SearchParameters(2000, 512, 50, 4)
+    qz = np.zeros((4, 32, host["centroids"].shape[1]), np.float16)
+    for _ in range(5):
+        R.search_arrays(dev, qz, params)
+    small = R.last_search_counts()["candidates"]
+    before = R.graph_replay_count()
+    R.search_arrays(dev, qz, params)
+    replayed_small = R.graph_replay_count() - before
+    q = fp.synth.make_queries(spec, host["centroids"], 4, 32, seed=77)
+    pids, scores, counts = R.search_arrays(dev, q, params)
+    big = R.last_search_counts()["candidates"]
+    for b in range(4):
+        t = R.search_trace(dev, q[b], params)
+        assert counts[b] == len(t["pids"]) and len(t["pids"]) > 0, (b, counts[b], len(t["pids"]))
+        assert np.array_equal(pids[b, : counts[b]], t["pids"]) and np.array_equal(scores[b, : counts[b]], t["scores"])
+    if not test_opt("spec_cap_pct"):
+        assert replayed_small == 1 and big > 2 * small, (replayed_small, small, big)
+    print("GRAPH_OK replays", replays, "overflow on a replayed batch:", small, "->", big)
 
 
 if __name__ == "__main__":
