@@ -4401,15 +4401,16 @@ __global__ __launch_bounds__(1024) void k_sel_finish_lz(uint32_t* __restrict__ s
   // too few entries altogether -- impossible unless a list overflowed: at least keep scores are >= U)
   if (tid == 0) s_bad = (nm_all > (uint32_t)gcap || nin_all >= keep + 1u || nin + nmay < keep) ? 1u : 0u;
   for (int i = tid; i < kp2; i += 1024) {
-    const int32_t pi = i < 1024 ? p_op : op[i];
-    const float ai = i < 1024 ? p_oa : oa[i];
-    kv[i] = ((uint32_t)i < nin) ? (((unsigned long long)(uint32_t)pi << 32) | (unsigned long long)__float_as_uint(ai)) : ~0ull;
+    const bool have = (uint32_t)i < nin;   // (slots past the row's R entries exist in kv only: kp2 is R rounded up to a power of two)
+    const int32_t pi = i < 1024 ? p_op : (have ? op[i] : 0);
+    const float ai = i < 1024 ? p_oa : (have ? oa[i] : 0.f);
+    kv[i] = have ? (((unsigned long long)(uint32_t)pi << 32) | (unsigned long long)__float_as_uint(ai)) : ~0ull;
   }
   // best (keep - nin) maybes by (score desc, id asc)
   const uint32_t take = keep - nin;
   auto mkey = [&](uint32_t i) -> unsigned long long {
-    const int32_t pi = i < 1024u ? p_gp : gp[i];
-    const float vi = i < 1024u ? p_gv : gv[i];
+    const int32_t pi = i < 1024u ? p_gp : (i < nmay ? gp[i] : 0);
+    const float vi = i < 1024u ? p_gv : (i < nmay ? gv[i] : 0.f);
     return i < nmay ? (((unsigned long long)mono32(vi) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)pi)) : 0ull;
   };
   if (nmay <= 256u) {    // (the usual case: a few dozen) rank by counting: every key against every other, broadcast reads of LDS

@@ -28,7 +28,8 @@ def main():
     R.set_graph_replay(False)   # (a replayed graph reports lazy == -1; the graph path has its own test)
     seen_lazy = 0
     shapes = ((30000, 4096, 32, 512, 8, 24, 1), (20000, 2048, 20, 64, 4, 17, 2), (30000, 65536, 32, 256, 8, 20, 3),
-              (20000, 2048, 70, 256, 8, 18, 4), (8000, 512, 7, 32, 2, 3, 5), (25000, 262144, 32, 256, 8, 19, 6))
+              (20000, 2048, 70, 256, 8, 18, 4), (8000, 512, 7, 32, 2, 3, 5), (25000, 262144, 32, 256, 8, 19, 6),
+              (30000, 4096, 32, 6000, 8, 9, 7))   # (the last: a rerank list of 1500, not a power of two and beyond one key per thread)
     for (n_docs, C, Q, n_full, n_probe, B, seed) in shapes:
         spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=48, n_centroids=C, variable_len=True, seed=seed)
         arr = fp.synth.host_index_arrays(spec)
