@@ -104,3 +104,36 @@ def test_lazy_selection_equals_the_exact_one_unit_queries():
 def test_lazy_selection_equals_the_exact_one_scaled_queries():
     for seed, scale in ((2, 6.0), (3, 0.004)):   # an unnormalised query batch; a tiny-norm one (scores where fp16 is finest)
         _run(seed, scale)
+
+
+def test_lazy_probe_threshold_collects_the_reference_top_n():
+    """the probe under the lazy form (k_probe_tau / k_probe_collect / k_probe_merge): tau = the n_probe-th largest 128-centroid
+    chunk maximum of the STORED column, lowered by s1_lower16; everything stored at or above it is collected and re-evaluated.
+    Claim: the reference's top n_probe of the column (value desc, centroid id asc) is among the collected."""
+    from test_lazy_bounds_cpu import f16_bits_to_f32, s1_lower16
+    rng = np.random.default_rng(5)
+    C, D, Q, n_probe = 16384, 64, 16, 8
+    cent = rng.standard_normal((C, D)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    cent = cent.astype(np.float16)
+    for scale in (1.0, 0.003, 9.0):
+        q = rng.standard_normal((Q, D)).astype(np.float32)
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True) * scale).astype(np.float16)
+        q[3] = 0                                                         # a zero row: exact zeros, window 0
+        chain = _chain(cent, q)
+        t = chain.astype(np.float16)
+        qn = np.linalg.norm(q.astype(np.float32), axis=1).astype(np.float32)
+        w = (W0 * qn * np.float32(np.linalg.norm(cent.astype(np.float32), axis=1).max())).astype(np.float32)
+        u_c = (w[None, :] + KAPPA * np.abs(chain)).astype(np.float32)
+        x = (chain + (rng.uniform(-0.5, 0.5, chain.shape) * u_c).astype(np.float32)).astype(np.float32)
+        s = (x + (w[None, :] + KAPPA * np.abs(x)).astype(np.float32)).astype(np.float32).astype(np.float16)
+        for col in range(Q):
+            sc, tc = s[:, col], t[:, col].astype(np.float64)
+            chunk_max = sc.reshape(C // 128, 128).max(axis=1)
+            tau = np.sort(chunk_max)[::-1][n_probe - 1]
+            low = f16_bits_to_f32(s1_lower16(np.array([tau]).view(np.uint16), np.array([w[col]], np.float32), KAPPA))[0]
+            collected = np.nonzero(sc.astype(np.float32) >= low)[0]
+            ref = np.lexsort((np.arange(C), -tc))[:n_probe]
+            assert set(ref.tolist()) <= set(collected.tolist()), (scale, col, tau, low)
+            if w[col] > 0:
+                assert len(collected) < 4096, (scale, col, len(collected))   # ... and it stays a short list
