@@ -146,7 +146,8 @@ struct Scratch : ScratchGen {
       tok_idx, recon, out_all, S8, cmax128, kq, q8hist, cut, blkcnt2, nsurv, surv_off, surv_pid, l0_floors, l0_F, l0_e8, l0_esc, l0_ub,
       l0_hist, l0_npilot, l0_pilot_pid, l0_pilot_approx, l0_pilot_idx, l0_capprox, l0_thr, l0_nextra, l0_xpid, l0_xdst, l0_blkx, Ssample, l0_gfl, u_cnt, spec_total, sh_lmarks, sh_lnmark, sh_x, sh_xall, ms_uncm, ms_cm16, ms_unc, ms_flags, ms_pref, ms_marks, ms_nmark, sh_rec, sh_all, tickets, ms_flat, l0_ubp, wcol, s1stats, qpad_s1, lz_state, lz_gpid, lz_gval, lz_slackq;
   HostBuf h_out, h_small;
-  int lazy_fails = 0;           // batches whose lazy-S1 selection lists overflowed (run again eagerly); two of them switch the lazy form off for this scratch
+  int lazy_fails = 0;           // batches whose lazy-S1 selection lists overflowed (run again eagerly); two of them switch the lazy form off for this scratch (post_batch: for a stretch of batches, not for good)
+  int lazy_clean = 0, lazy_off_batches = 0;
   bool ms_repairable = false;   // the last run_maxsim produced budgets / flags (fast-path shape, repair enabled)
   bool ms_have_marks = false;   // h_small + 64 holds the per-query marked counts of the last batch
   // Candidate-buffer capacity learnt from earlier batches of the same shape (0: none): with it, fp_search does not wait for the
@@ -258,7 +259,7 @@ static thread_local bool g_have_ms = false;
 static thread_local int g_last_lazy = 0;      // the last fp_search batch ran S1's lazy form (1), the eager one (0), or was a replayed graph (-1)
 static thread_local uint64_t g_last_s1[4];   // FP_S1_STATS: S1's certification counters of the last call (flagged, changed, slow path, mode-2 unflagged differences)
 static bool s1_stats_enabled() { static const bool on = getenv("FP_S1_STATS") != nullptr; return on; }
-static thread_local int64_t g_last_counts[5];  // candidates, exact-scored docs, repaired docs, sub-batches, form of S4 (0 exact / 1 8-bit bounds / 2 level 0; -1: replayed graph)
+static thread_local int64_t g_last_counts[6];  // candidates, exact-scored docs, repaired docs, sub-batches, form of S4 (0 exact / 1 8-bit bounds / 2 level 0; -1: replayed graph), lazy-S1 overflows the scratch remembers (>= 2: lazy form off)
 
 // results of one (sub-)batch in one device block: ids | scores | counts
 struct OutLayout {
@@ -279,6 +280,15 @@ struct OutLayout {
   }
 };
 
+static Scratch* new_scratch() {
+  Scratch* s = new Scratch();
+  if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
+    delete s;
+    return nullptr;
+  }
+  for (auto& e : s->ev) (void)hipEventCreate(&e);
+  return s;
+}
 static Scratch* acquire(fp_index* ix) {
   {
     std::lock_guard<std::mutex> g(ix->mu);
@@ -288,13 +298,7 @@ static Scratch* acquire(fp_index* ix) {
       return s;
     }
   }
-  Scratch* s = new Scratch();
-  if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess) {
-    delete s;
-    return nullptr;
-  }
-  for (auto& e : s->ev) (void)hipEventCreate(&e);
-  return s;
+  return new_scratch();
 }
 static void release(fp_index* ix, Scratch* s) {
   std::lock_guard<std::mutex> g(ix->mu);
@@ -1202,6 +1206,161 @@ static FpSearchShape make_shape(int B, int Q, const fp_search_params* p) {
   return sh;
 }
 
+// One sub-batch of fp_search / fp_search_device / fp_search_trace enqueued on its scratch's stream: query upload, S1 .. S8, the
+// result block's download (host buffers: into s->h_out) or the copies into the caller's device buffers.  Nothing in here waits
+// for the device when the batch runs on a learnt candidate capacity (P.spec is set then).
+static int enqueue_batch(Pipe& P, const uint16_t* q_src, hipMemcpyKind q_kind, const fp_search_params* p, const OutLayout& ol,
+                         const int64_t* sids, const int64_t* soff /*B+1 rebased*/, bool has_subset, bool trace, int64_t* dev_pids,
+                         float* dev_scores, int32_t* dev_counts) {
+  fp_index* ix = P.ix;
+  Scratch* s = P.s;
+  const FpIndexDev& D = ix->d;
+  hipStream_t st = s->st;
+  const int B = P.sh.B;
+  const int64_t K = p->top_k;
+  const bool dev_io = dev_pids != nullptr;
+  const size_t qbytes = (size_t)B * P.sh.Q * D.dim * 2;
+  STAGE_DONE(ST_UPLOAD);
+  HIPCHK(s->qin.ensure(qbytes));
+  HIPCHK(hipMemcpyAsync(s->qin.p, q_src, qbytes, q_kind, st));
+  s->fold_stats = !dev_io;
+  s->ms_marked_now = false;
+  P.allow_spec = !trace && !has_subset;   // (subset searches: the candidate total follows the subset sizes, not the shape)
+  if (int rc = run_front(P, sids, soff, has_subset)) return rc;
+  // S6+S7
+  const int64_t R = P.sh.R;
+  if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true, true)) return rc;
+  STAGE_DONE(ST_TOPK);
+  // S8
+  HIPCHK(s->out_all.ensure(ol.total));
+  HIPCHK(s->h_out.ensure(ol.total));
+  char* od = s->out_all.as<char>();
+  if (const int trc = fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
+                                     reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st,
+                                     (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
+                                     (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
+                                     s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr,
+                                     P.lazy ? reinterpret_cast<const int32_t*>(s->lz_state.as<uint32_t>() + 2 * B) : nullptr,
+                                     P.total_folded ? s->spec_total.as<int64_t>() : nullptr))
+    return trc < 0 ? fail(FP_EUNSUPPORTED, "n_queries * max(n_full_scores / 4, 1) >= 2^31 in one sub-batch of the final ranking")
+                   : fail(FP_EHIP, "final ranking failed (hip error " + std::to_string(trc) + ")");
+  if (dev_io) {
+    HIPCHK(hipMemcpyAsync(dev_pids, od, ol.nk * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(dev_scores, od + ol.score_off, ol.nk * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(dev_counts, od + ol.cnt_off, ol.n * 4, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
+  }
+  STAGE_DONE(ST_N);   // (a capture records no stage events: its call reports zeros)
+  return FP_OK;
+}
+
+// After the final sync of a sub-batch: the flags that void it, the learnt capacity, the graph bookkeeping, the call's counters
+// and stage times.  POST_RETRY*: the batch must be run again (the state that makes the second attempt differ is already set).
+enum { POST_DONE = 0, POST_RETRY = 1, POST_RETRY_EAGER = 2 };
+struct BatchFlags { int64_t M_true; bool probe_ovf, lz_failed; };
+// where the three words come from: the result block's statistics (speculative host-buffer batches and everything replayed) or the
+// small copies of their own (first batches, device-resident I/O)
+static BatchFlags batch_flags(const Scratch* s, const Pipe& P, const OutLayout& ol) {
+  const int B = P.sh.B;
+  const char* hs = static_cast<const char*>(s->h_small.p);
+  const int64_t* stv = (s->fold_stats || P.total_folded) ? reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off) : nullptr;
+  BatchFlags f;
+  f.M_true = P.total_folded ? stv[2 + B] : *reinterpret_cast<const int64_t*>(hs);
+  f.probe_ovf = P.total_folded ? stv[3 + B] != 0 : *reinterpret_cast<const int32_t*>(hs + 16) != 0;
+  // S1's lazy form: the flag is 0 whenever the batch was not lazy (a replayed graph included)
+  f.lz_failed = s->fold_stats ? stv[1 + B] != 0 : (P.lazy && *reinterpret_cast<const int32_t*>(hs + 40) != 0);
+  return f;
+}
+static int post_batch(Scratch* s, const Pipe& P, const OutLayout& ol, bool replayed, bool capture, bool graph_ok, const int64_t (&gkey)[8],
+                      bool first_sub_batch, bool stage_times = true) {
+  const int B = P.sh.B;
+  g_last_lazy = P.lazy ? 1 : (replayed ? -1 : 0);
+  const BatchFlags f = batch_flags(s, P, ol);
+  const int64_t M_true = f.M_true;
+  if (P.probe_no_fb && f.probe_ovf) {
+    // some column had more ties at its probe threshold than the candidate lists hold: the device probed nothing (k_probe_merge);
+    // run the batch again with the register top-k fallback, and keep it enqueued for this scratch from now on
+    s->probe_fb = true;
+    return POST_RETRY;
+  }
+  if (P.spec && M_true > P.M) {
+    // more candidates than the capacity learnt from earlier batches: the device emptied the batch (k_cand_offsets); run it again,
+    // this time waiting for the total
+    s->spec_cap = 0;
+    return POST_RETRY;
+  }
+  // S1's lazy form: a selection list overflowed (masses of near-tied approximate scores) -> the batch's results are void; run it
+  // again with the eager S1.  Two such batches switch the lazy form off for the scratch -- not for good: after FP_LAZY_RETRY_AFTER
+  // batches it is tried again (one overflowing batch then switches it off for the next stretch), and a run of clean lazy batches
+  // forgets an old overflow.
+  if (f.lz_failed) {
+    s->lazy_fails++;
+    s->lazy_clean = 0;
+    s->lazy_off_batches = 0;
+    return POST_RETRY_EAGER;
+  }
+  if (P.lazy || (replayed && P.want_lazy)) {
+    if (s->lazy_fails == 1 && ++s->lazy_clean >= 64) s->lazy_fails = 0;
+  } else if (s->lazy_fails >= 2 && ++s->lazy_off_batches >= 256) {
+    s->lazy_fails = 1;
+    s->lazy_off_batches = 0;
+    s->lazy_clean = 0;
+  }
+  learn_capacity(s, M_true);
+  if (graph_ok) {
+    // remember what this call ran on: the next call may capture if it has the same shape, the capacity is still the one THIS
+    // call sized every buffer for, and nothing was (re)allocated since
+    if (P.spec && std::equal(gkey, gkey + 5, s->graph.last)) s->graph.warm++;
+    else s->graph.warm = P.spec ? 1 : 0;
+    std::copy(gkey, gkey + 8, s->graph.last);
+    s->graph.last[5] = P.spec ? P.M : 0;
+    s->graph.last[6] = (int64_t)s->alloc_gen;
+  }
+  if (first_sub_batch) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
+  g_last_counts[4] = replayed ? -1 : (P.approx_impl == 2 && P.l0_hot ? 3 : P.approx_impl);
+  g_last_counts[0] += M_true;
+  g_last_counts[3] += 1;
+  g_last_counts[5] = s->lazy_fails;
+  if (s->fold_stats) {   // the statistics came down with the results
+    const int64_t* stv = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
+    // Level 0 is worth its scan only while it prunes: a corpus whose documents' code sets overlap every query (survivors above a
+    // quarter of the candidates in two batches running) is switched to the 8-bit bound stage for this scratch, for good (the
+    // selection is the same in every form of S4, only the time differs)
+    if (P.approx_impl == 2 && M_true > 0) {
+      int& poor = P.l0_hot ? s->l0h_poor : s->l0_poor;
+      if (stv[0] * 4 > M_true) poor = std::min(poor + 1, 4);
+      else poor = 0;
+    }
+    g_last_counts[1] += P.used_q8 ? stv[0] : M_true;
+    for (int i = 0; i < B; ++i) g_last_counts[2] += stv[1 + i];
+  } else
+    g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : M_true;
+  if (!s->fold_stats && s->ms_have_marks) {
+    const int32_t* nm = reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 64);
+    for (int i = 0; i < B; ++i) g_last_counts[2] += nm[i];
+    s->ms_have_marks = false;
+  }
+  if (!stage_times) return POST_DONE;
+  if (replayed || capture) {   // a graph launch records no stage events
+    for (int i = 0; i < ST_N; ++i) g_last_ms[i] = 0.f;
+    g_have_ms = true;
+  } else if (first_sub_batch) {
+    for (int i = 0; i < ST_N; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) != hipSuccess) ms = 0.f;
+      g_last_ms[i] = ms;
+    }
+    g_have_ms = true;
+  } else {
+    for (int i = 0; i < ST_N; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) == hipSuccess) g_last_ms[i] += ms;
+    }
+  }
+  return POST_DONE;
+}
+
 // dev_io: `queries` and the three outputs are DEVICE pointers on the index's GPU (fp_search_device); subsets stay host-side.
 static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_t Q, const fp_search_params* p,
                        const int64_t* subset_ids, const int64_t* subset_off, int64_t* out_pids, float* out_scores,
@@ -1307,45 +1466,20 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       }
     }
     if (!replayed) {
-    STAGE_DONE(ST_UPLOAD);
-    HIPCHK(s->qin.ensure(qbytes));
-    HIPCHK(hipMemcpyAsync(s->qin.p, capture ? static_cast<const uint16_t*>(s->h_qin.p) : queries + (size_t)b0 * Q * D.dim, qbytes,
-                          dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     const int64_t* sids = nullptr;
     if (has_subset) {
       sub_off_local.resize((size_t)B + 1);
       for (int i = 0; i <= B; ++i) sub_off_local[i] = subset_off[b0 + i] - subset_off[b0];
       sids = subset_ids + subset_off[b0];
     }
-    s->fold_stats = !dev_io;
-    s->ms_marked_now = false;
-    P.allow_spec = tr == nullptr && !has_subset;   // (subset searches: the candidate total follows the subset sizes, not the shape)
-    if (int rc = run_front(P, sids, has_subset ? sub_off_local.data() : nullptr, has_subset)) return rc;
-    // S6+S7
-    const int64_t R = P.sh.R;
-    if (int rc = run_maxsim(ix, s, P.sh, R, p->top_k, 1, true, true)) return rc;
-    STAGE_DONE(ST_TOPK);
-    // S8
-    HIPCHK(s->out_all.ensure(ol.total));
-    HIPCHK(s->h_out.ensure(ol.total));
-    char* od = s->out_all.as<char>();
-    if (const int trc = fpk_final_topk(s->exact.as<float>(), s->sel_pid.as<int32_t>(), nullptr, s->sel_cnt.as<int32_t>(), R, B, K, D.pid_offset,
-                                       reinterpret_cast<int64_t*>(od), reinterpret_cast<float*>(od + ol.score_off), reinterpret_cast<int32_t*>(od + ol.cnt_off), st,
-                                       (s->fold_stats && P.used_q8) ? s->surv_off.as<int64_t>() + B : nullptr,
-                                       (s->fold_stats && s->ms_marked_now) ? s->ms_nmark.as<int32_t>() : nullptr,
-                                       s->fold_stats ? reinterpret_cast<int64_t*>(od + ol.stat_off) : nullptr,
-                                       P.lazy ? reinterpret_cast<const int32_t*>(s->lz_state.as<uint32_t>() + 2 * B) : nullptr,
-                                       P.total_folded ? s->spec_total.as<int64_t>() : nullptr))
-      return trc < 0 ? fail(FP_EUNSUPPORTED, "n_queries * max(n_full_scores / 4, 1) >= 2^31 in one sub-batch of the final ranking")
-                     : fail(FP_EHIP, "final ranking failed (hip error " + std::to_string(trc) + ")");
+    if (int rc = enqueue_batch(P, capture ? static_cast<const uint16_t*>(s->h_qin.p) : queries + (size_t)b0 * Q * D.dim,
+                               dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, p, ol, sids, has_subset ? sub_off_local.data() : nullptr,
+                               has_subset, tr != nullptr, dev_io ? out_pids + (size_t)b0 * K : nullptr, dev_io ? out_scores + (size_t)b0 * K : nullptr,
+                               dev_io ? out_counts + b0 : nullptr))
+      return rc;
     if (dev_io) {
-      HIPCHK(hipMemcpyAsync(out_pids + (size_t)b0 * K, od, ol.nk * 8, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(out_scores + (size_t)b0 * K, od + ol.score_off, ol.nk * 4, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(out_counts + b0, od + ol.cnt_off, ol.n * 4, hipMemcpyDeviceToDevice, st));
-      STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));   // results are complete in HBM when the call returns
     } else {
-      HIPCHK(hipMemcpyAsync(s->h_out.p, od, ol.total, hipMemcpyDeviceToHost, st));
       if (capture) {
         // nothing has run yet: close the capture, keep the executable graph if the call was what a replay needs (speculative, no
         // buffer moved), and launch it -- or fall back to the plain path for this batch
@@ -1379,7 +1513,6 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         }
         g_graph_replays.fetch_add(1, std::memory_order_relaxed);   // (the capturing call is itself served by the graph's first launch)
       }
-      STAGE_DONE(ST_N);
       HIPCHK(hipStreamSynchronize(st));
     }
     }   // !replayed
@@ -1394,87 +1527,12 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
       }
       for (int i = 0; i < 4; ++i) g_last_s1[i] = (b0 == 0 ? 0 : g_last_s1[i]) + h4[i];
     }
-    g_last_lazy = P.lazy ? 1 : (replayed ? -1 : 0);
-    // the candidate total of this batch (copied to pinned memory right after S3; complete by the sync above)
-    const int64_t* stat_blk = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
-    const int64_t M_true = P.total_folded ? stat_blk[2 + B] : *reinterpret_cast<const int64_t*>(s->h_small.p);
-    const bool probe_ovf = P.total_folded ? stat_blk[3 + B] != 0
-                                          : *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 16) != 0;
-    if (P.probe_no_fb && probe_ovf) {
-      // some column had more ties at its probe threshold than the candidate lists hold: the device probed nothing (k_probe_merge);
-      // run the batch again with the register top-k fallback, and keep it enqueued for this scratch from now on
-      s->probe_fb = true;
-      b0 -= maxB;
-      continue;
-    }
-    if (P.spec && M_true > P.M) {
-      // more candidates than the capacity learnt from earlier batches: the device emptied the batch (k_cand_offsets); run it again,
-      // this time waiting for the total
-      s->spec_cap = 0;
-      b0 -= maxB;
-      continue;
-    }
-    // S1's lazy form: a selection list overflowed (masses of near-tied approximate scores) -> the batch's results are void; run it
-    // again with the eager S1.  The flag came down with the result block (host buffers; 0 whenever the batch was not lazy -- a
-    // replayed graph included) or by its own copy (device-resident I/O).
     {
-      const bool lz_failed = s->fold_stats
-                                 ? reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off)[1 + B] != 0
-                                 : (P.lazy && *reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 40) != 0);
-      if (lz_failed) {
-        s->lazy_fails++;
-        eager_retry = true;
+      const int act = post_batch(s, P, ol, replayed, capture, graph_ok, gkey, b0 == 0);
+      if (act != POST_DONE) {   // a flag came down with the batch: its results are void, run it again
+        eager_retry = act == POST_RETRY_EAGER;
         b0 -= maxB;
         continue;
-      }
-    }
-    learn_capacity(s, M_true);
-    if (graph_ok) {
-      // remember what this call ran on: the next call may capture if it has the same shape, the capacity is still the one THIS
-      // call sized every buffer for, and nothing was (re)allocated since
-      if (P.spec && std::equal(gkey, gkey + 5, s->graph.last)) s->graph.warm++;
-      else s->graph.warm = P.spec ? 1 : 0;
-      std::copy(gkey, gkey + 8, s->graph.last);
-      s->graph.last[5] = P.spec ? P.M : 0;
-      s->graph.last[6] = (int64_t)s->alloc_gen;
-    }
-    if (b0 == 0) g_last_counts[0] = g_last_counts[1] = g_last_counts[2] = g_last_counts[3] = 0;
-    g_last_counts[4] = replayed ? -1 : (P.approx_impl == 2 && P.l0_hot ? 3 : P.approx_impl);
-    g_last_counts[0] += M_true;
-    g_last_counts[3] += 1;
-    if (s->fold_stats) {   // the statistics came down with the results
-      const int64_t* stv = reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_out.p) + ol.stat_off);
-      // Level 0 is worth its scan only while it prunes: a corpus whose documents' code sets overlap every query (survivors above a
-      // quarter of the candidates in two batches running) is switched to the 8-bit bound stage for this scratch, for good (the
-      // selection is the same in every form of S4, only the time differs)
-      if (P.approx_impl == 2 && M_true > 0) {
-        int& poor = P.l0_hot ? s->l0h_poor : s->l0_poor;
-        if (stv[0] * 4 > M_true) poor = std::min(poor + 1, 4);
-        else poor = 0;
-      }
-      g_last_counts[1] += P.used_q8 ? stv[0] : M_true;
-      for (int i = 0; i < B; ++i) g_last_counts[2] += stv[1 + i];
-    } else
-    g_last_counts[1] += P.used_q8 ? *reinterpret_cast<const int64_t*>(static_cast<const char*>(s->h_small.p) + 8) : M_true;
-    if (!s->fold_stats && s->ms_have_marks) {
-      const int32_t* nm = reinterpret_cast<const int32_t*>(static_cast<const char*>(s->h_small.p) + 64);
-      for (int i = 0; i < B; ++i) g_last_counts[2] += nm[i];
-      s->ms_have_marks = false;
-    }
-    if (replayed || capture) {   // a graph launch records no stage events
-      for (int i = 0; i < ST_N; ++i) g_last_ms[i] = 0.f;
-      g_have_ms = true;
-    } else if (b0 == 0) {
-      for (int i = 0; i < ST_N; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) != hipSuccess) ms = 0.f;
-        g_last_ms[i] = ms;
-      }
-      g_have_ms = true;
-    } else {
-      for (int i = 0; i < ST_N; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) == hipSuccess) g_last_ms[i] += ms;
       }
     }
     if (tr) {  // B == 1
@@ -1577,7 +1635,7 @@ extern "C" int fp_search_trace(const fp_index* index, const uint16_t* query, int
 }
 
 extern "C" int fp_last_search_counts(int64_t* out, int cap) {
-  int n = std::min(cap, 5);
+  int n = std::min(cap, 6);
   for (int i = 0; i < n; ++i) out[i] = g_last_counts[i];
   return n;
 }

@@ -340,10 +340,11 @@ def maxsim_columns(index: PyLoadedIndex, query_f16, pids) -> dict:
 
 
 def last_search_counts() -> dict:
-    out = (C.c_int64 * 5)()
-    N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 5)
+    out = (C.c_int64 * 6)()
+    N.lib().fp_last_search_counts(C.cast(out, C.c_void_p), 6)
     return dict(candidates=int(out[0]), approx_exact=int(out[1]), repaired=int(out[2]), sub_batches=int(out[3]),
-                s4_form={0: "exact", 1: "q8", 2: "l0", 3: "l0h", -1: "replayed graph"}.get(int(out[4]), "?"))
+                s4_form={0: "exact", 1: "q8", 2: "l0", 3: "l0h", -1: "replayed graph"}.get(int(out[4]), "?"),
+                lazy_overflows=int(out[5]))
 
 
 def last_s1_counts() -> dict:

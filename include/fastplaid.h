@@ -106,16 +106,29 @@ int32_t fp_index_tickets_ok(const fp_index* index);
  * out_counts [n_queries] = results per query = min(top_k, max(n_full/4,1), candidates)
  * (search.rs:614, :666); rows are sorted by descending score; the slots [count, top_k) of
  * a row hold id -1 and score 0.  A query whose per-query search fails in the reference
- * (search.rs:268 `.unwrap_or_default()`) gets count 0 (its row is left untouched).
+ * (search.rs:268 `.unwrap_or_default()`) gets count 0 and a row of -1 / 0 like any other unused slot; the calls that return
+ * before anything is enqueued (n_queries == 0, top_k == 0, an empty index, n_ivf_probe > n_centroids without a subset) write
+ * the counts only.
  *
- * What is exact.  The returned ids are the reference's, in the reference's order (documents whose reference scores are
- * EXACTLY equal may come in another order: the reference's own tie order is implementation-defined; ours is id ascending).
- * Every stage up to the rerank list reproduces the reference bit for bit (centroid scores, probed cells, candidates,
- * approximate scores).  The returned MaxSim SCORES are within 1e-3 of the reference's: the MFMA pass can round one query
- * column of a document one fp16 step away (<= 4.9e-4); only the documents whose rank could depend on that -- the near-tied
- * ones -- are re-evaluated in the reference's summation order (their scores are then the reference's bit for bit), the
- * others keep the MFMA score.  FP_MAXSIM_REPAIR=2 in the environment re-evaluates every flagged document: every returned
- * score is then the reference's. */
+ * What is exact, and on what evidence.  The returned ids are the reference's, in the reference's order (documents whose
+ * reference scores are EXACTLY equal may come in another order: the reference's own tie order is implementation-defined; ours
+ * is id ascending).  Probed cells, candidate sets and the rerank set are the reference's; fp_search_trace additionally
+ * reproduces the centroid scores and every candidate's approximate score bit for bit (fp_search itself stores upper
+ * candidates of the centroid scores and settles exactly the entries its decisions depend on: see fp_last_s1_counts).  The
+ * returned MaxSim SCORES are within 1e-3 of the reference's: the MFMA pass can round one query column of a document one fp16
+ * step away (<= 4.9e-4); only the documents whose rank could depend on that -- the near-tied ones -- are re-evaluated in the
+ * reference's summation order (their scores are then the reference's bit for bit), the others keep the MFMA score.
+ * FP_MAXSIM_REPAIR=2 in the environment re-evaluates every flagged document: every returned score is then the reference's.
+ *
+ * This rests on two CERTIFICATION WINDOWS that are empirical margins, not worst-case bounds.  An fp32 MFMA result is taken as
+ * "the reference's ascending fp32 chain rounds to the same fp16 value" when it lies further from every fp16 rounding boundary
+ * than w0 |q| c_max + kappa |x| (centroid scores: w0 = 2^-21.5, kappa = 2^-20) resp. 2^-19 |q_col| (MaxSim column maxima); the
+ * worst-case reordering error of a D-term fp32 sum, D 2^-24 sum |a_k b_k|, is ~2^-17 at D = 128 and would flag far more.
+ * Measured: 0 unflagged differences in 12.9 G centroid scores and 12.8 M column maxima, the first unflagged difference appears
+ * at a QUARTER of the shipped centroid window (profiles/r04_s1_window_sweep.txt, r04_cert_stats.jsonl).  So "identical ids"
+ * holds with overwhelming probability on data like the tested corpora, not by construction; an adversarially built input is
+ * not covered.  FP_TEST=s1_w0_log2=..,s1_kappa_log2=.. widen the centroid window (cost: more entries re-evaluated).
+ */
 int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
               const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets,
               int64_t* out_pids, float* out_scores, int32_t* out_counts);
@@ -162,16 +175,28 @@ uint64_t fp_graph_replay_count(void);
  * summed over queries (S3 output), out[1] = candidates that reached the exact approximate-score
  * kernel (== out[0] unless a bound stage pruned), out[2] = documents whose near-tied final score was re-evaluated in the
  * reference's summation order (exact-order repair), out[3] = sub-batches, out[4] = the form of S4 the last sub-batch ran
- * (0 every candidate scored exactly, 1 8-bit bound stage, 2 level 0, 3 level 0 over the hot codes; -1 when the call was a graph replay).  Returns entries written. */
+ * (0 every candidate scored exactly, 1 8-bit bound stage, 2 level 0, 3 level 0 over the hot codes; -1 when the call was a graph
+ * replay), out[5] = lazy-S1 list overflows the scratch that served the call remembers (>= 2: S1's lazy form is off for it, to
+ * be tried again after 256 batches).  Returns entries written (cap >= 6 for all). */
 int fp_last_search_counts(int64_t* out, int cap);
 
-/* Centroid scores (S1, search.rs:491) are exact: every fp32 MFMA result that lies within a certification window of an fp16
- * rounding boundary -- the only place where the reference's ascending fp32 chain can round differently -- is re-evaluated with
- * that chain inside the kernel, so S, and with it every later stage, equals the reference's bit for bit.  With FP_S1_STATS set in
- * the environment (diagnostics: it also switches the graph replay off) the counters of the most recent fp_search on this thread
- * are kept: out[0] = flagged entries, out[1] = re-evaluated entries whose value is not the upper candidate that was staged,
- * out[2] = entries that overflowed a wave's list (re-evaluated on the slow path), out[3] = FP_S1_EXACT=2 only (every entry is
- * re-evaluated): entries the window did NOT flag whose chain value differs from the MFMA's -- must be 0.  Returns entries written. */
+/* Centroid scores (S1, search.rs:491).  Every fp32 MFMA result x is certified against the fp16 rounding boundaries with the
+ * window u = w0 |q| c_max + kappa |x| (see fp_search).  FP_S1_EXACT in the environment picks what happens to the entries inside
+ * the window: 3 (default) = LAZY form wherever the threshold probe and the general selection serve the shape (no subset,
+ * n_ivf_probe <= 32, q_len <= 128, n_full_scores / 4 <= 8192, fewer than 2^24 centroids): S holds h(x + u) for EVERY entry -- the
+ * reference's value or slightly above it, with a lower bound computable from the stored value alone -- and the consumers whose
+ * decisions depend on exact values (the probe's ranking, the rerank selection) re-evaluate with the reference's ascending chain
+ * exactly the entries that can change them; probed cells, candidates, the selected set and the results are the reference's.
+ * Elsewhere, and always with 1 = EAGER form (fp_search_trace, subsets, the sharded search's staged protocol): the flagged
+ * entries are re-evaluated inside the kernel and S itself equals the reference's bit for bit.  2 = every entry re-evaluated
+ * (tests), 0 = no certification (S differs from the reference's by one fp16 ulp in ~0.05 % of its entries).
+ * With FP_S1_STATS set (diagnostics: it also switches the graph replay off) the counters of the most recent fp_search on this
+ * thread are kept.  Eager batch: out[0] = flagged entries, out[1] = re-evaluated entries whose value is not the upper candidate
+ * that was staged, out[2] = entries that overflowed a wave's list (slow path), out[3] = FP_S1_EXACT=2 only: entries the window
+ * did NOT flag whose chain value differs from the MFMA's -- must be 0.  Lazy batch: out[0] = documents the selection took as
+ * certain, out[1] = "maybes" whose approximate score was recomputed exactly, out[2] = the most maybes of one query, out[3] =
+ * (code, column) pairs re-evaluated.  out[4] (kept without FP_S1_STATS too) = 1 the last batch ran the lazy form, 0 the eager
+ * one, -1 it was a replayed graph.  Returns entries written (cap >= 5 for all). */
 int fp_last_s1_counts(uint64_t* out, int cap);
 
 /* Diagnostic / test entry point: the MFMA pass of the exact stage (S6+S7) on the given documents for ONE query, before the
