@@ -1123,13 +1123,14 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   HIPCHK(s->sel_cnt.ensure((size_t)B * 4));
   HIPCHK(s->tie_pid.ensure((size_t)B * sh.R * 4));
   HIPCHK(s->ms_pref.ensure((size_t)(B + 1) * 8));
-  fpk_select(sh, sel_off, sel_src, s->approx.as<float>(), s->hist.as<uint32_t>(),
+  if (fpk_select(sh, sel_off, sel_src, s->approx.as<float>(), s->hist.as<uint32_t>(),
              s->selstate.as<uint32_t>(), s->sel_pid.as<int32_t>(), s->sel_approx.as<float>(), s->sel_cnt.as<int32_t>(),
              s->tie_pid.as<int32_t>(), st,
              /*short_lists: one workgroup per query; pays off when there are too few queries to fill the chip anyway (measured: B = 8
                46 vs 53 us, B = 64 90 vs 71 us)*/ !lz && B <= 16 && sh.R <= FP_MAX_SORT && (P.approx_impl != 0 || M <= 16384ll * B),
              P.selhist_prezeroed, s->ms_pref.as<int64_t>(), lz, &D,
-             /*list length per query: the bound stages leave a few x R survivors, otherwise every candidate*/ sel_src != s->cand_pid.as<int32_t>() ? 8 * sh.R : (B > 0 ? M / B : 0));
+             /*list length per query: the bound stages leave a few x R survivors, otherwise every candidate*/ sel_src != s->cand_pid.as<int32_t>() ? 8 * sh.R : (B > 0 ? M / B : 0)))
+    return fail(FP_EINVAL, "internal: the lazy selection was asked for on a shape it does not serve");
   if (lz && !s->fold_stats)   // device-resident I/O: the overflow flag travels by itself (host-buffer calls: with the result block)
     HIPCHK(hipMemcpyAsync(static_cast<char*>(s->h_small.p) + 40, lz->flag, 4, hipMemcpyDeviceToHost, st));
   s->pref_ready = true;   // (whoever edits sel_cnt before S6 -- the sharded search's cut -- clears it)

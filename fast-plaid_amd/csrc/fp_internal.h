@@ -307,7 +307,7 @@ int64_t fpk_l0_pilot_cap();
 void fpk_l0_survivors(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, FpL0Scratch& w, int32_t* nsurv,
                       int64_t* surv_off, int32_t* surv_pid, float* surv_approx, hipStream_t st,
                       const FpLazyS1* lz = nullptr /*S1's lazy form: the pilot scores are upper bounds*/);
-void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
+int fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx,
                 uint32_t* hist /*[3][B][BINS]*/, uint32_t* selstate /*[B][8]*/, int32_t* sel_pid /*[B][R]*/,
                 float* sel_approx /*[B][R]*/, int32_t* sel_cnt /*[B]*/, int32_t* tie_pid /*[B][R] scratch*/, hipStream_t st,
                 bool short_lists = false /*lists of a few thousand entries: one workgroup per query does the whole radix select*/,

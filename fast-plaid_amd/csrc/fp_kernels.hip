@@ -941,16 +941,22 @@ __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __
                                                     int n_probe, int32_t* __restrict__ cells, const int32_t* __restrict__ flag,
                                                     int run_if, const uint32_t* __restrict__ cnt /*nullable: valid entries per column*/,
                                                     const uint16_t* __restrict__ cent /*nullable: S1's lazy form, see below*/,
-                                                    const uint16_t* __restrict__ qpad, int D) {
+                                                    const uint16_t* __restrict__ qpad, int D,
+                                                    const float* __restrict__ wcol /*nullable: the columns' certification windows (0 = an all-zero query row)*/) {
   int entries = entries_stride;
   const int b = blockIdx.x / Q, q = blockIdx.x % Q;
   const int lane = threadIdx.x;
+  const bool zero_row = wcol && !(wcol[(int64_t)b * Qp + q] > 0.f);
   // (S1's lazy form: a lane's collected entry is fetched together with the flag and the count, not behind them)
   const unsigned long long k0_pre = (cent && lane < entries_stride) ? partial[((int64_t)b * Qp + q) * entries_stride + lane] : 0ull;
   if (flag && ((*flag != 0) != (run_if != 0))) {
     // the threshold path gave up (a column overflowed its list): no cells, unless the fallback that follows writes them
     if (run_if == 0)
       for (int r = lane; r < n_probe; r += 64) cells[((int64_t)b * Q + q) * n_probe + r] = -1;
+    return;
+  }
+  if (zero_row) {   // every centroid ties at 0: (score desc, centroid id asc) = the lowest-numbered ones (k_probe_tau collected nothing)
+    for (int r = lane; r < n_probe; r += 64) cells[((int64_t)b * Q + q) * n_probe + r] = r;
     return;
   }
   if (cnt) {
@@ -1380,7 +1386,11 @@ __global__ __launch_bounds__(64) void k_probe_tau(const uint16_t* __restrict__ c
     // The maxima S1 emits are taken over upper candidates h(x + u) (of the flagged entries in the eager form, of every entry in the
     // lazy one), and near zero the window u spans several fp16 steps: the sound lower end of what an element stored as t can be is
     // s1_lower16 (round 4 stepped one fp16 value down, which undershoots for |x| < ~2^-10).
-    if (wcol) { if (t > 0u) t = mono16(s1_lower16(unmono16(t), w_pre, kappa)); }
+    // An all-zero (padded) query row -- window 0 -- scores exactly 0 against every centroid: C-way tie.  Its cells are the
+    // lowest-numbered centroids by the tie rule (k_probe_merge writes them); nothing is collected (0x10000 is above every key), so
+    // list-padded batches (fast_plaid.py:772-780) neither overflow the tie room nor leave the lazy form.
+    if (wcol && !(w_pre > 0.f)) t = 0x10000u;
+    else if (wcol) { if (t > 0u) t = mono16(s1_lower16(unmono16(t), w_pre, kappa)); }
     else if (upper && t > 0u) { t -= 1u; if (t == 0x7FFFu) t = 0x7FFEu; }   // (no window given: one step; key 0x7FFF is -0, which mono16 folds into +0)
     tau[(int64_t)b * Qp + q] = t;
   }
@@ -1570,7 +1580,8 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
                          (const uint16_t*)nullptr, 0);
     }
     hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, cand, sh.Q, sh.Qp, PROBE_CAP, sh.n_probe, cells,
-                       flag, 0, cnt, lz ? ix.centroids : (const uint16_t*)nullptr, lz ? lz->qpad : (const uint16_t*)nullptr, ix.dim);
+                       flag, 0, cnt, lz ? ix.centroids : (const uint16_t*)nullptr, lz ? lz->qpad : (const uint16_t*)nullptr, ix.dim,
+                       fused ? (lz ? lz->wcol : (cmax_upper ? cmax_upper->wcol : (const float*)nullptr)) : (const float*)nullptr);
   } else {
     if (lz) return -2;
     (void)hipMemsetAsync(flag, 0xFF, 4, st);  // force the register top-k path
@@ -1591,7 +1602,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
     default: launch_probe_partial<32>(S, ix, sh, nchunk, allow, Cw, fb_partial, flag, st); break;
   }
   hipLaunchKernelGGL(k_probe_merge, dim3((unsigned)(sh.B * sh.Q)), dim3(64), 0, st, fb_partial, sh.Q, sh.Qp, nchunk * 8 * NP, sh.n_probe,
-                     cells, flag, 1, (const uint32_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, 0);
+                     cells, flag, 1, (const uint32_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)nullptr, 0, (const float*)nullptr);
   }
   const int64_t n64 = (int64_t)sh.Q * sh.n_probe;
   if (n64 > 0x7FFFFFFFll / 4) return -1;
@@ -4291,7 +4302,11 @@ __global__ __launch_bounds__(256) void k_lz_exact(const uint32_t* __restrict__ s
         const float w = wv[k];
         uint32_t e = hb & 0x7C00u;
         e = (e < 0x2C00u ? 0x2C00u : e) - 0x2800u;
-        lo[k] = (w > 0.f) ? smax - ((float)__builtin_bit_cast(half_t, (uint16_t)e) + 2.f * s1_u2(__builtin_fabsf(smax), w, kappa)) * 1.0001f : smax;
+        lo[k] = (w > 0.f) ? smax - ((float)__builtin_bit_cast(half_t, (uint16_t)e) + 2.f * s1_u2(__builtin_fabsf(smax), w, kappa)) * 1.0001f : __builtin_inff();
+        // a zero query row (w == 0: its window is empty, every stored score of the column is the reference's exact 0): the stored
+        // maximum IS the true one -- no pairs (with lo = smax every code of the document tied at 0 and a handful of zero-padded
+        // rows overflowed the pair list: two voided batches, then the scratch went eager)
+        if (!(w > 0.f) && col < Q && cs == 0) atomicMax(&s_colmax[wave][col], mono32(smax));
         if (col >= Q) lo[k] = __builtin_inff();   // (pad columns: no pairs)
       }
       // (compact code on purpose: this kernel runs a handful of waves once through straight-line code, i.e. at the speed of its
@@ -4666,7 +4681,7 @@ int fpk_select_lazy_gcap(const FpSearchShape& sh) {   // room for the maybes of 
   return (int)std::max<int64_t>(1024, fp_next_pow2((int)sh.R));
 }
 size_t fpk_sel_hist_bytes(int B) { return (size_t)3 * B * FP_SEL_BINS * sizeof(uint32_t) + (size_t)B * 16; }   // three histograms per query + {prefix, k_rem} x 2
-void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
+int fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, const float* approx, uint32_t* hist,
                 uint32_t* selstate, int32_t* sel_pid, float* sel_approx, int32_t* sel_cnt, int32_t* tie_pid, hipStream_t st,
                 bool short_lists, bool hist_prezeroed, int64_t* pref, const FpLazyS1* lz, const FpIndexDev* ixp, int64_t est_per_query) {
   const int B = sh.B;
@@ -4692,7 +4707,9 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   const int ix_dim = ixp ? ixp->dim : 0;
   const int64_t* ix_uoff = ixp ? ixp->uoff : nullptr;
   const int32_t* ix_ucodes = ixp ? ixp->ucodes : nullptr;
-  if (lz && (short_lists || sh.R > FP_MAX_SORT || !ixp)) lz = nullptr;   // (callers do not ask for it there)
+  // the lazy form's approx[] / S hold UPPER candidates: only the general path settles them.  A caller that asks for it on a shape
+  // that path does not serve (run_front gates on fpk_select_lazy_ok) would get a silently wrong selected set: refuse.
+  if (lz && (short_lists || sh.R > FP_MAX_SORT || !ixp)) return 1;
   if (short_lists) {
     hipLaunchKernelGGL(k_sel_front, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, sh.n_full, sh.R, selstate, sel_pid, sel_approx,
                        tie_pid, sel_cnt);
@@ -4703,7 +4720,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     hipLaunchKernelGGL(k_sel_finish, dim3((unsigned)B), dim3(1024), (size_t)kp2 * 8, st, selstate, sh.R, sel_pid, sel_approx, tie_pid);
     hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid, sel_approx,
                        sel_cnt, pref, B);
-    return;
+    return 0;
   }
   const bool big = sh.R > FP_MAX_SORT;   // beyond k_sel_finish's LDS sort: the ordered single-workgroup collection does the whole job
   if (!hist_prezeroed) (void)hipMemsetAsync(hist, 0, fpk_sel_hist_bytes(B), st);
@@ -4726,7 +4743,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
     while (mp2 < lz->gcap) mp2 <<= 1;
     hipLaunchKernelGGL(k_sel_finish_lz, dim3((unsigned)B + (pref ? 1u : 0u)), dim3(1024), (size_t)kp2 * 8 + (size_t)mp2 * 8, st, selstate, sh.R, sel_pid,
                        sel_approx, lz->gcount, lz->gpid, lz->gval, lz->gcap, lz->flag, lz->stats, sel_cnt, pref, B);
-    return;
+    return 0;
   }
   uint32_t* ext = hist + (size_t)3 * B * FP_SEL_BINS;   // [B][4], behind the histograms (fpk_sel_hist_bytes)
   dim3 gh(gx, (unsigned)B);
@@ -4750,6 +4767,7 @@ void fpk_select(const FpSearchShape& sh, const int64_t* cand_off, const int32_t*
   // ordered single-block fallback, only for queries whose tie buffer overflowed (e.g. all scores equal)
   hipLaunchKernelGGL(k_sel_collect, dim3((unsigned)B), dim3(1024), 0, st, approx, cand_pid, cand_off, selstate, sh.R, sel_pid,
                      sel_approx, sel_cnt, pref, B);
+  return 0;
 }
 
 // S6+S7 (fused decompress + exact MaxSim, per-token norms, exact-order repair): fp_maxsim.hip
