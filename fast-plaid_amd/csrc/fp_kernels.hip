@@ -3099,19 +3099,44 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
                                                    const int32_t* __restrict__ cand_pid, const int64_t* __restrict__ uoff,
                                                    const int32_t* __restrict__ ucodes, const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
                                                    uint16_t* __restrict__ ub, uint32_t* __restrict__ hist, int bxn) {
+  // Round 6: the kernel was a chain of dependent round trips -- per 16 codes one code load, then one gather round per hot code,
+  // each waited for before the next step (19 steps for a 300-code document: 0.97 ms at cfg4 for work that is ~0.1 ms of LDS
+  // look-ups and ~0.3 ms of row gathers).  Now a step is 64 codes of the document (16 per lane of the quad, four 16-byte loads in
+  // flight, the next step's behind them), the hot test reads ONE BIT per centroid (16 KiB of LDS instead of the 128 KiB byte table:
+  // all it ever asked was "non-zero?"), and every lane gathers the WHOLE 64-byte rows of its own hot codes, two rows at a time --
+  // no code travels between lanes; the quad's per-column maxima are combined once per document.  The lane's 16 codes are staged
+  // in its own 64 bytes of LDS so that "my k-th code" is one LDS read instead of a 15-deep select over registers.
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
-  uint8_t* tab = l0s;                                                  // [tab_bytes]
-  uint32_t* hl = reinterpret_cast<uint32_t*>(l0s + tab_bytes + 16);    // [L0_HBINS]
-  uint8_t* fl = reinterpret_cast<uint8_t*>(hl + L0_HBINS);             // [Qp]
+  const int bit_bytes = ((tab_bytes / 8) + 15) & ~15;
+  uint16_t* bits = reinterpret_cast<uint16_t*>(l0s);                          // bit (c & 15) of word c >> 4: centroid c is hot
+  uint32_t* hl = reinterpret_cast<uint32_t*>(l0s + bit_bytes);                 // [L0_HBINS]
+  uint8_t* fl = reinterpret_cast<uint8_t*>(hl + L0_HBINS);                     // [Qp] (<= 256)
+  int32_t* stage = reinterpret_cast<int32_t*>(l0s + bit_bytes + L0_HBINS * 4 + 256);   // [1024][16]
   const int tid = threadIdx.x;
-  const int b = blockIdx.y, bxi = blockIdx.x;
+  // Workgroup L of the launch runs on XCD L % 8.  With 8 | B the queries are dealt to the XCDs (query b on XCD b % 8), so that the
+  // rows of S a query's hot codes gather -- ~9 % of its slice at cfg4, 0.7 MB -- stay in ONE 4 MiB L2 instead of every L2 holding
+  // the hot rows of all the queries (22 MB: misses all the way to the fabric).
+  int b = blockIdx.y, bxi = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const unsigned L = blockIdx.y * gridDim.x + blockIdx.x, slot = L >> 3;
+    b = (int)((slot / gridDim.x) * 8u + (L & 7u));
+    bxi = (int)(slot % gridDim.x);
+  }
   const int64_t beg = cand_off[b];
   const int64_t n = cand_off[b + 1] - beg;
   if ((int64_t)bxi * 256 >= n) return;
   {
     const uint4* src = reinterpret_cast<const uint4*>(e8 + (int64_t)b * Cpad);
-    uint4* dst = reinterpret_cast<uint4*>(tab);
-    for (int j = tid; j < tab_bytes / 16; j += 1024) dst[j] = src[j];
+    for (int j = tid; j < tab_bytes / 16; j += 1024) {
+      const uint4 v = src[j];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t mk = 0u;
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) mk |= ((w[x] >> (8 * y)) & 0xFFu) ? (1u << (4 * x + y)) : 0u;
+      bits[j] = (uint16_t)mk;
+    }
     for (int j = tid; j < L0_HBINS; j += 1024) hl[j] = 0u;
     if (tid < Qp) fl[tid] = floors[(int64_t)b * Qp + tid];
   }
@@ -3122,69 +3147,82 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
   const half_t ninf = __builtin_bit_cast(half_t, (uint16_t)0xFC00);
   const h2 ninf2 = {ninf, ninf};
   uint16_t* ubrow = ub + l0_row(cand_off, b);
-  const uint16_t* Sb = S + (int64_t)b * C * Qp + sub * 8;
+  const uint16_t* Sb = S + (int64_t)b * C * Qp;
+  int32_t* my = stage + tid * 16;
   for (int64_t i = (int64_t)bxi * 256 + (tid >> 2); i < n; i += (int64_t)bxn * 256) {
     const int32_t pid = cand_pid[beg + i];
     const int64_t u0 = uoff[pid];
     const int len = (int)(uoff[pid + 1] - u0);
     const int32_t* cp = ucodes + u0;
-    // Per 32-column chunk: the code list in steps of 16 codes -- each lane of the quad loads FOUR of them (one 16-byte load,
-    // dword-aligned; the next step's are in flight while this step's rows are), looks its four up in the LDS byte table, and the
-    // quad ORs its hot bits together; the rows of the HOT codes only are then gathered, up to four at a time so that a step's
-    // row loads are in flight together (a load per hot code followed by its maximum is one round trip per code: 17 ms at cfg4;
-    // every lane looking all the codes up itself: 1.75 ms, the 8-bit stage's time).
     uint32_t sum = 0u, inf = 0u;
-    const int qbase = (tid & 63) & ~3;   // first lane of this quad
-    auto load4 = [&](int t) -> int4 {
-      int4 a;
-      __builtin_memcpy(&a, cp + t + 4 * sub, 16);   // (the list buffer is padded: positions past the document's end are masked below)
-      return a;
+    // (the list buffer is padded by 16 codes: a 16-byte load that starts inside the document may run past its end; those
+    // positions are masked below)
+    auto load_step = [&](int t, int4 (&d)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d[u] = make_int4(0, 0, 0, 0);
+        if (t + 16 * u < len) __builtin_memcpy(&d[u], cp + t + 16 * u + 4 * sub, 16);
+      }
     };
     for (int ch = 0; ch < nch; ++ch) {
-      h2 m0 = ninf2, m1 = ninf2, m2 = ninf2, m3 = ninf2;
+      h2 m[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) m[j] = ninf2;
       const uint16_t* Sc = Sb + ch * 32;
-      int4 cur = make_int4(0, 0, 0, 0), nxt = make_int4(0, 0, 0, 0);
-      if (len > 0) cur = load4(0);
-      for (int t = 0; t < len; t += 16) {
-        if (t + 16 < len) nxt = load4(t + 16);
-        const int tb = t + 4 * sub;
-        uint32_t hot = 0u;
-        hot |= (tb + 0 < len && tab[cur.x] != 0) ? 1u : 0u;
-        hot |= (tb + 1 < len && tab[cur.y] != 0) ? 2u : 0u;
-        hot |= (tb + 2 < len && tab[cur.z] != 0) ? 4u : 0u;
-        hot |= (tb + 3 < len && tab[cur.w] != 0) ? 8u : 0u;
-        hot <<= 4 * sub;
-        hot |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hot, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-        hot |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hot, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-        while (hot) {   // (the same word in the quad's four lanes: they branch together)
-          uint4 v[4];
+      int4 cur[4], nxt[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            v[u] = make_uint4(0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u, 0xFC00FC00u);
-            if (hot) {
-              const int k = __builtin_ctz(hot);
-              hot &= hot - 1u;
-              const int kk = k & 3;
-              const int32_t mine = kk == 0 ? cur.x : (kk == 1 ? cur.y : (kk == 2 ? cur.z : cur.w));
-              const int32_t code = __shfl(mine, qbase + (k >> 2), 64);
-              v[u] = *reinterpret_cast<const uint4*>(Sc + (int64_t)code * Qp);
-            }
-          }
+      for (int u = 0; u < 4; ++u) nxt[u] = make_int4(0, 0, 0, 0);
+      load_step(0, cur);
+      for (int t = 0; t < len; t += 64) {
+        if (t + 64 < len) load_step(t + 64, nxt);
+        uint32_t hotm = 0u;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            m0 = pk_max(m0, u32_as_h2(v[u].x));
-            m1 = pk_max(m1, u32_as_h2(v[u].y));
-            m2 = pk_max(m2, u32_as_h2(v[u].z));
-            m3 = pk_max(m3, u32_as_h2(v[u].w));
+        for (int u = 0; u < 4; ++u) {
+          *reinterpret_cast<int4*>(my + 4 * u) = cur[u];
+          const int cc[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t code = (t + 16 * u + 4 * sub + k < len) ? (uint32_t)cc[k] : 0u;   // (past the end: whatever follows in the buffer)
+            const uint32_t bit = ((uint32_t)bits[code >> 4] >> (code & 15u)) & 1u;
+            hotm |= (t + 16 * u + 4 * sub + k < len) ? (bit << (4 * u + k)) : 0u;
           }
         }
-        cur = nxt;
+        while (hotm) {   // (per lane: ~1 of its 16 codes is hot at cfg4, so mostly one round; lanes without a hot code sit it out)
+          const int k1 = __builtin_ctz(hotm);
+          hotm &= hotm - 1u;
+          const int k2 = hotm ? __builtin_ctz(hotm) : k1;   // (no second one: the first again -- the maximum is idempotent)
+          hotm &= hotm - 1u;                                 // (0 & anything = 0)
+          const int64_t c1 = my[k1], c2 = my[k2];
+          uint4 r1[4], r2[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) r1[p] = *reinterpret_cast<const uint4*>(Sc + c1 * Qp + 8 * p);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) r2[p] = *reinterpret_cast<const uint4*>(Sc + c2 * Qp + 8 * p);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            m[4 * p + 0] = pk_max(m[4 * p + 0], pk_max(u32_as_h2(r1[p].x), u32_as_h2(r2[p].x)));
+            m[4 * p + 1] = pk_max(m[4 * p + 1], pk_max(u32_as_h2(r1[p].y), u32_as_h2(r2[p].y)));
+            m[4 * p + 2] = pk_max(m[4 * p + 2], pk_max(u32_as_h2(r1[p].z), u32_as_h2(r2[p].z)));
+            m[4 * p + 3] = pk_max(m[4 * p + 3], pk_max(u32_as_h2(r1[p].w), u32_as_h2(r2[p].w)));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
       }
-      const h2 mm[4] = {m0, m1, m2, m3};
+      // the quad's maxima, then this lane's 8 columns (registers 4 sub .. 4 sub + 3)
+      uint32_t mine[4];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        uint32_t x = h2_as_u32(m[j]);
+        x = pk_max_raw(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        x = pk_max_raw(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        if ((j >> 2) == 0) mine[j & 3] = x;
+        else mine[j & 3] = (sub == (j >> 2)) ? x : mine[j & 3];
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int q = ch * 32 + sub * 8 + j;
-        const h2 pr = mm[j >> 1];
+        const h2 pr = u32_as_h2(mine[j >> 1]);
         float x = (float)((j & 1) ? pr.y : pr.x);
         x = x > -2.f ? x : -2.f;                       // (no hot code in the column: bin 0)
         int bin = (int)floorf(x * 128.0f) + 100;       // == S1's bins
@@ -3680,7 +3718,7 @@ void fpk_l0h_scan(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& 
   int64_t bx = (per_q + 4095) / 4096;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
-  const size_t lds = (size_t)Cpad + 16 + L0_HBINS * 4 + 256;
+  const size_t lds = (size_t)((Cpad / 8 + 15) & ~(int64_t)15) + L0_HBINS * 4 + 256 + 1024 * 64;   // hot bits | histogram | floors | the lanes' staged codes
   hipLaunchKernelGGL(k_l0h_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), lds, st, w.e8, Cpad, (int)Cpad, w.floors, w.Fsum, cand_off, cand_pid,
                      ix.uoff, ix.ucodes, S, ix.C, sh.Q, sh.Qp, w.ub, w.hist, (int)bx);
 }
