@@ -3098,7 +3098,7 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
                                                    const uint32_t* __restrict__ Fsum, const int64_t* __restrict__ cand_off,
                                                    const int32_t* __restrict__ cand_pid, const int64_t* __restrict__ uoff,
                                                    const int32_t* __restrict__ ucodes, const uint16_t* __restrict__ S, int64_t C, int Q, int Qp,
-                                                   uint16_t* __restrict__ ub, uint32_t* __restrict__ hist, int bxn) {
+                                                   uint16_t* __restrict__ ub, uint32_t* __restrict__ hist, int bxn, int warm_t) {
   // Round 6: the kernel was a chain of dependent round trips -- per 16 codes one code load, then one gather round per hot code,
   // each waited for before the next step (19 steps for a 300-code document: 0.97 ms at cfg4 for work that is ~0.1 ms of LDS
   // look-ups and ~0.3 ms of row gathers).  Now a step is 64 codes of the document (16 per lane of the quad, four 16-byte loads in
@@ -3106,9 +3106,14 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
   // all it ever asked was "non-zero?"), and every lane gathers the WHOLE 64-byte rows of its own hot codes, two rows at a time --
   // no code travels between lanes; the quad's per-column maxima are combined once per document.  The lane's 16 codes are staged
   // in its own 64 bytes of LDS so that "my k-th code" is one LDS read instead of a 15-deep select over registers.
+  // What is left is the row gathers at the fabric's request rate (~55 G rows/s: 40 M hot rows per cfg4 batch).  So the table keeps
+  // FOUR bits per centroid, min(excess, 15), and a code whose excess -- the sum over the columns of its bins above the floors --
+  // is below warm_t is WARM: it is not gathered, its excess is added to the bound instead (level 0's sum form for those codes:
+  // column by column, max over all codes <= max over the gathered ones + sum over the warm ones).  Most hot codes are barely
+  // hot, so a small warm_t drops most gathers for a few bins of looseness.
   extern __shared__ __attribute__((aligned(16))) unsigned char l0s[];
-  const int bit_bytes = ((tab_bytes / 8) + 15) & ~15;
-  uint16_t* bits = reinterpret_cast<uint16_t*>(l0s);                          // bit (c & 15) of word c >> 4: centroid c is hot
+  const int bit_bytes = ((tab_bytes / 2) + 15) & ~15;
+  uint8_t* nib = reinterpret_cast<uint8_t*>(l0s);                             // nibble (c & 1) of byte c >> 1: min(excess of centroid c, 15)
   uint32_t* hl = reinterpret_cast<uint32_t*>(l0s + bit_bytes);                 // [L0_HBINS]
   uint8_t* fl = reinterpret_cast<uint8_t*>(hl + L0_HBINS);                     // [Qp] (<= 256)
   int32_t* stage = reinterpret_cast<int32_t*>(l0s + bit_bytes + L0_HBINS * 4 + 256);   // [1024][16]
@@ -3130,12 +3135,16 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
     for (int j = tid; j < tab_bytes / 16; j += 1024) {
       const uint4 v = src[j];
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      uint32_t mk = 0u;
+      uint32_t lo = 0u, hi = 0u;   // 16 bytes -> 16 nibbles
 #pragma unroll
       for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) mk |= ((w[x] >> (8 * y)) & 0xFFu) ? (1u << (4 * x + y)) : 0u;
-      bits[j] = (uint16_t)mk;
+        for (int y = 0; y < 4; ++y) {
+          const uint32_t e = (w[x] >> (8 * y)) & 0xFFu, v = e > 15u ? 15u : e;
+          if (x < 2) lo |= v << (4 * (4 * x + y));
+          else hi |= v << (4 * (4 * (x - 2) + y));
+        }
+      reinterpret_cast<uint2*>(nib)[j] = make_uint2(lo, hi);
     }
     for (int j = tid; j < L0_HBINS; j += 1024) hl[j] = 0u;
     if (tid < Qp) fl[tid] = floors[(int64_t)b * Qp + tid];
@@ -3154,7 +3163,7 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
     const int64_t u0 = uoff[pid];
     const int len = (int)(uoff[pid + 1] - u0);
     const int32_t* cp = ucodes + u0;
-    uint32_t sum = 0u, inf = 0u;
+    uint32_t sum = 0u, inf = 0u, warm = 0u;
     // (the list buffer is padded by 16 codes: a 16-byte load that starts inside the document may run past its end; those
     // positions are masked below)
     auto load_step = [&](int t, int4 (&d)[4]) {
@@ -3182,9 +3191,12 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
           const int cc[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const uint32_t code = (t + 16 * u + 4 * sub + k < len) ? (uint32_t)cc[k] : 0u;   // (past the end: whatever follows in the buffer)
-            const uint32_t bit = ((uint32_t)bits[code >> 4] >> (code & 15u)) & 1u;
-            hotm |= (t + 16 * u + 4 * sub + k < len) ? (bit << (4 * u + k)) : 0u;
+            const bool in = t + 16 * u + 4 * sub + k < len;
+            const uint32_t code = in ? (uint32_t)cc[k] : 0u;   // (past the end: whatever follows in the buffer)
+            const uint32_t e4 = ((uint32_t)nib[code >> 1] >> (4u * (code & 1u))) & 15u;
+            const bool hot = in && e4 >= (uint32_t)warm_t;
+            hotm |= hot ? (1u << (4 * u + k)) : 0u;
+            if (ch == 0) warm += (in && !hot) ? e4 : 0u;   // (a code's excess covers all the columns: counted once, not per chunk)
           }
         }
         while (hotm) {   // (per lane: ~1 of its 16 codes is hot at cfg4, so mostly one round; lanes without a hot code sit it out)
@@ -3234,7 +3246,7 @@ __global__ __launch_bounds__(1024) void k_l0h_scan(const uint8_t* __restrict__ e
         }
       }
     }
-    sum = l0_red<4>(sum);
+    sum = l0_red<4>(sum + warm);
     inf = l0_maxg<4>(inf);
     uint32_t v = F + sum;
     v = inf ? L0_INF : (v > 0xFFFEu ? 0xFFFEu : v);
@@ -3718,9 +3730,11 @@ void fpk_l0h_scan(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& 
   int64_t bx = (per_q + 4095) / 4096;
   if (bx > 8192) bx = 8192;
   if (bx < 1) bx = 1;
-  const size_t lds = (size_t)((Cpad / 8 + 15) & ~(int64_t)15) + L0_HBINS * 4 + 256 + 1024 * 64;   // hot bits | histogram | floors | the lanes' staged codes
+  const size_t lds = (size_t)((Cpad / 2 + 15) & ~(int64_t)15) + L0_HBINS * 4 + 256 + 1024 * 64;   // excess nibbles | histogram | floors | the lanes' staged codes
+  // codes whose excess is below this many bins are not gathered, their excess is added to the bound (1: gather every hot code)
+  static const int warm_t = [] { const int v = (int)fp_test_opt("l0h_warm", 8); return v < 1 ? 1 : (v > 15 ? 15 : v); }();
   hipLaunchKernelGGL(k_l0h_scan, dim3((unsigned)bx, (unsigned)B), dim3(1024), lds, st, w.e8, Cpad, (int)Cpad, w.floors, w.Fsum, cand_off, cand_pid,
-                     ix.uoff, ix.ucodes, S, ix.C, sh.Q, sh.Qp, w.ub, w.hist, (int)bx);
+                     ix.uoff, ix.ucodes, S, ix.C, sh.Q, sh.Qp, w.ub, w.hist, (int)bx, warm_t);
 }
 
 // level 0 in launch groups so that the scan kernel can be timed alone:
