@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--nbits", type=int, default=4)
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
     ap.add_argument("--workload", type=str, default="", help="label override")
+    ap.add_argument("--zero-rows", type=int, default=0, help="zero the last N token rows of every query (what list inputs of unequal lengths "
+                    "are padded with, fast_plaid.py:772-780); 0 = the config's full-length queries")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
     ap.add_argument("--doc-shards", type=int, default=0, help="grid mode: document shards per query group (0 = 2; the other factor of "
                     "--gpus is the number of query groups)")
@@ -162,6 +164,9 @@ def main():
     params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
     n_batches = a.steps + a.warmup   # a distinct query batch for every step (no cache-warm repeats)
     batches = [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i) for i in range(n_batches)]
+    if a.zero_rows > 0:
+        for q in batches:
+            q[:, max(a.qlen - a.zero_rows, 0):, :] = 0
     # "replica" mode: every rank has its own stream of batches (rank 0's is the single-GPU stream)
     own_batches = batches if rank == 0 else [fp.synth.make_queries(spec, cent, a.batch, a.qlen, seed=1000 + i + 7919 * rank)
                                              for i in range(n_batches)]
