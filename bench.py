@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--nbits", type=int, default=4)
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries for the CPU baseline leg (0 = skip, -1 = auto)")
     ap.add_argument("--workload", type=str, default="", help="label override")
+    ap.add_argument("--dup-centroids", type=int, default=0, help="make centroid rows 1000 .. 1000 + N identical (exact ties of the centroid scores: a query "
+                    "token near them overflows the threshold probe's tie room and takes its fallback); 0 = the config's table")
     ap.add_argument("--zero-rows", type=int, default=0, help="zero the last N token rows of every query (what list inputs of unequal lengths "
                     "are padded with, fast_plaid.py:772-780); 0 = the config's full-length queries")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded/RCCL code path even with one rank (testing)")
@@ -159,6 +161,9 @@ def main():
     C = a.centroids or fp.synth.default_num_centroids(n_tokens)
     spec = fp.synth.SynthSpec(n_docs=a.docs, doc_len=a.doc_len, n_centroids=C, dim=a.dim, nbits=a.nbits, seed=42)
     cent = fp.synth.centroids(spec)
+    if a.dup_centroids > 0:
+        cent = cent.copy()
+        cent[1000:1000 + a.dup_centroids] = cent[1000]
     bw = fp.synth.bucket_weights(spec)
     dev = f"cuda:{local_rank}"
     params = R.SearchParameters(2000, a.nfull, a.topk, a.nprobe)
