@@ -51,6 +51,7 @@ SYMBOLS = {
     "fp_index_num_hard_tokens": (_i64, [_vp]),
     "fp_index_tickets_ok": (C.c_int32, [_vp]),
     "fp_search": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(FpSearchParams), _vp, _vp, _vp, _vp, _vp]),
+    "fp_search_shared_subset": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.POINTER(FpSearchParams), _vp, _i64, _vp, _vp, _vp]),
     "fp_device_free_bytes": (_i64, [C.c_int]),
     "fp_device_total_bytes": (_i64, [C.c_int]),
     "fp_dev_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_vp)]),

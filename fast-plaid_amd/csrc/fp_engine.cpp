@@ -764,6 +764,7 @@ struct Pipe {
   int approx_impl = 0;    // 0 exact for all, 1 8-bit bounds, 2 level 0
   bool l0_ready = false;  // S1 produced level 0's floors and excess table (instead of the 8-bit table)
   bool l0_hot = false;    // ... for the hot-code scan (k_l0h_scan) instead of the code-line scan
+  bool sub_shared = false;   // ONE subset list for every query of the batch (fp_search_shared_subset): h_sub_off is {0, n}
   bool allow_spec = false;   // fp_search / fp_search_device: M may be the learnt capacity instead of this batch's total (no mid-pipeline sync)
   bool spec = false;         // ... and it was
   bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
@@ -935,17 +936,20 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
   if (P.W < 64) P.W = 64;
   P.Cw = (D.C + 31) / 32;
   if (has_subset) {
-    const int64_t ns = h_sub_off[B];
+    const int Bl = P.sub_shared ? 1 : B;   // lists
+    const int64_t ns = h_sub_off[Bl];
+    int64_t max_len = 0;
+    for (int i = 0; i < Bl; ++i) max_len = std::max(max_len, h_sub_off[i + 1] - h_sub_off[i]);
     HIPCHK(s->sub_ids.ensure((size_t)std::max<int64_t>(ns, 1) * 8));
     HIPCHK(s->sub_off.ensure((size_t)(B + 1) * 8));
     if (ns > 0) HIPCHK(hipMemcpyAsync(s->sub_ids.p, h_sub_ids, (size_t)ns * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(s->sub_off.p, h_sub_off, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(s->sub_off.p, h_sub_off, (size_t)(Bl + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(s->subbm.ensure((size_t)B * P.W * 4));
     HIPCHK(s->allow.ensure((size_t)B * P.Cw * 4));
-    HIPCHK(hipMemsetAsync(s->subbm.p, 0, (size_t)B * P.W * 4, st));
-    HIPCHK(hipMemsetAsync(s->allow.p, 0, (size_t)B * P.Cw * 4, st));
-    fpk_subset_prepare(D, s->sub_ids.as<int64_t>(), s->sub_off.as<int64_t>(), B, s->subbm.as<uint32_t>(), P.W, s->allow.as<uint32_t>(),
-                       P.Cw, s->invalid.as<int32_t>(), st);
+    HIPCHK(hipMemsetAsync(s->subbm.p, 0, (size_t)Bl * P.W * 4, st));
+    HIPCHK(hipMemsetAsync(s->allow.p, 0, (size_t)Bl * P.Cw * 4, st));
+    fpk_subset_prepare(D, s->sub_ids.as<int64_t>(), s->sub_off.as<int64_t>(), Bl, s->subbm.as<uint32_t>(), P.W, s->allow.as<uint32_t>(),
+                       P.Cw, s->invalid.as<int32_t>(), st, max_len, P.sub_shared ? B : 0);
   }
   // S2
   const int np = (int)std::max<int64_t>(sh.n_probe, 1);
@@ -1365,7 +1369,7 @@ static int post_batch(Scratch* s, const Pipe& P, const OutLayout& ol, bool repla
 // dev_io: `queries` and the three outputs are DEVICE pointers on the index's GPU (fp_search_device); subsets stay host-side.
 static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_t Q, const fp_search_params* p,
                        const int64_t* subset_ids, const int64_t* subset_off, int64_t* out_pids, float* out_scores,
-                       int32_t* out_counts, TraceOut* tr, bool dev_io = false) {
+                       int32_t* out_counts, TraceOut* tr, bool dev_io = false, int64_t shared_subset_n = -1 /*>= 0: subset_ids is ONE list of that many ids for every query (subset_off unused)*/) {
   const FpIndexDev& D = ix->d;
   HIPCHK(hipSetDevice(ix->device));
   if (dev_io) {
@@ -1374,7 +1378,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
   }
   if (nq == 0 || p->top_k == 0) return FP_OK;
-  const bool has_subset = subset_off != nullptr;
+  const bool sub_shared = shared_subset_n >= 0;
+  const bool has_subset = subset_off != nullptr || sub_shared;
   // reference: topk(k > C) errs inside search() -> per-query empty result (search.rs:268)
   if (!has_subset && p->n_ivf_probe > D.C) return FP_OK;
   if (D.N == 0) return FP_OK;
@@ -1468,7 +1473,11 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     }
     if (!replayed) {
     const int64_t* sids = nullptr;
-    if (has_subset) {
+    if (sub_shared) {
+      sub_off_local.assign({0, shared_subset_n});
+      sids = subset_ids;
+      P.sub_shared = true;
+    } else if (has_subset) {
       sub_off_local.resize((size_t)B + 1);
       for (int i = 0; i <= B; ++i) sub_off_local[i] = subset_off[b0 + i] - subset_off[b0];
       sids = subset_ids + subset_off[b0];
@@ -1569,6 +1578,17 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     }
   }
   return FP_OK;
+}
+
+extern "C" int fp_search_shared_subset(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                                       const fp_search_params* params, const int64_t* subset_ids, int64_t n_subset, int64_t* out_pids,
+                                       float* out_scores, int32_t* out_counts) {
+  if (int rc = validate_search(index, n_queries, q_len, dim, params)) return rc;
+  if (n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FP_EINVAL, "subset");
+  if (n_queries > 0 && (!queries || !out_counts || (params->top_k > 0 && (!out_pids || !out_scores))))
+    return fail(FP_EINVAL, "null buffer");
+  return search_impl(const_cast<fp_index*>(index), queries, n_queries, q_len, params, subset_ids, nullptr, out_pids, out_scores, out_counts, nullptr,
+                     false, n_subset);
 }
 
 extern "C" int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,

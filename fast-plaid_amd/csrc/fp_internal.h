@@ -226,8 +226,8 @@ size_t fpk_probe_scratch_bytes(const FpIndexDev& ix, const FpSearchShape& sh, in
 bool fpk_probe_zero_region(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, unsigned long long* partial, void** p, size_t* bytes);
 const int32_t* fpk_probe_flag(const FpIndexDev& ix, const FpSearchShape& sh, int nchunk, const unsigned long long* partial);
 void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off /*[B+1] dev*/, int B,
-                        uint32_t* subbm /*[B][W]*/, int64_t W, uint32_t* allow /*[B][Cw]*/, int64_t Cw,
-                        int32_t* invalid /*[B]*/, hipStream_t st);
+                        uint32_t* subbm, int64_t W, uint32_t* allow, int64_t Cw, int32_t* invalid, hipStream_t st,
+                        int64_t max_len /*the longest list*/, int replicate_to = 0 /*B == 1: the list serves this many queries (rows 1.. = row 0)*/);
 void fpk_ivf_mark(const FpIndexDev& ix, const int32_t* ucells, const int32_t* ncells, int maxcells, int B,
                   uint32_t* bitmap, int64_t W, hipStream_t st);
 // candidate compaction: count -> scan -> offsets -> compact (ascending doc ids)

@@ -1626,27 +1626,65 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
 // ============================================================================================
 // subset support (search.rs:494-517, :407-439): subset doc bitmap, allowed-centroid bitmap
 // ============================================================================================
-__global__ void k_subset_prepare(const int64_t* __restrict__ ids, const int64_t* __restrict__ off, int64_t N,
-                                 const int64_t* __restrict__ doc_off, const int32_t* __restrict__ codes,
+// Subset bitmaps (search.rs:494-517, :430-439): per query the documents of its subset and the centroids those documents
+// contain.  Round 6: half a wave per document (its unique codes read coalesced), the centroid bitmap accumulated in LDS and
+// flushed once per workgroup (the first form -- a thread per id walking its codes with one global atomic each, 8192 threads per
+// query -- took 4.8 ms for 64 x 50 k ids and 23 ms for 64 x 300 k).
+__global__ __launch_bounds__(256) void k_subset_prepare(const int64_t* __restrict__ ids, const int64_t* __restrict__ off, int64_t N,
+                                 const int64_t* __restrict__ uoff, const int32_t* __restrict__ ucodes,
                                  uint32_t* __restrict__ subbm, int64_t W, uint32_t* __restrict__ allow, int64_t Cw,
-                                 int32_t* __restrict__ invalid) {
+                                 int32_t* __restrict__ invalid, int lds_words /*Cw when the centroid bitmap fits LDS, else 0*/) {
+  extern __shared__ uint32_t lbm[];
   const int b = blockIdx.y;
   const int64_t beg = off[b], end = off[b + 1];
-  for (int64_t i = beg + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t d = ids[i];
-    if (d < 0 || d >= N) { invalid[b] = 1; continue; }  // index_select out of range -> Err -> empty result
-    atomicOr(&subbm[(int64_t)b * W + (d >> 5)], 1u << (d & 31));
-    for (int64_t t = doc_off[d]; t < doc_off[d + 1]; ++t) {
-      int32_t c = codes[t];
-      atomicOr(&allow[(int64_t)b * Cw + (c >> 5)], 1u << (c & 31));
+  const int64_t chunk = (end - beg + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = beg + (int64_t)blockIdx.x * chunk, hi = lo + chunk < end ? lo + chunk : end;
+  if (lo >= hi) return;   // (uniform)
+  for (int w = threadIdx.x; w < lds_words; w += 256) lbm[w] = 0u;
+  __syncthreads();
+  const int l = threadIdx.x & 31, hw = threadIdx.x >> 5;   // 8 half-waves, a document each
+  uint32_t* abm = allow + (int64_t)b * Cw;
+  for (int64_t i = lo + hw; i < hi; i += 8) {
+    const int64_t d = ids[i];
+    if (d < 0 || d >= N) { if (l == 0) invalid[b] = 1; continue; }  // index_select out of range -> Err -> empty result
+    if (l == 0) atomicOr(&subbm[(int64_t)b * W + (d >> 5)], 1u << (d & 31));
+    const int64_t u0 = uoff[d];
+    const int len = (int)(uoff[d + 1] - u0);
+    for (int t = l; t < len; t += 32) {
+      const int32_t c = ucodes[u0 + t];
+      if (lds_words) atomicOr(&lbm[c >> 5], 1u << (c & 31));
+      else atomicOr(&abm[c >> 5], 1u << (c & 31));
     }
   }
+  __syncthreads();
+  for (int w = threadIdx.x; w < lds_words; w += 256) {
+    const uint32_t v = lbm[w];
+    if (v) atomicOr(&abm[w], v);
+  }
 }
-
+// rows 1 .. B-1 of a [B][words] array = row 0 (one subset shared by every query)
+__global__ __launch_bounds__(256) void k_replicate_row(uint32_t* __restrict__ a, int64_t words, int B) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= words) return;
+  const uint32_t v = a[w];
+  for (int b = 1; b < B; ++b) a[(int64_t)b * words + w] = v;
+}
 void fpk_subset_prepare(const FpIndexDev& ix, const int64_t* sub_ids, const int64_t* sub_off, int B, uint32_t* subbm,
-                        int64_t W, uint32_t* allow, int64_t Cw, int32_t* invalid, hipStream_t st) {
-  hipLaunchKernelGGL(k_subset_prepare, dim3(32, (unsigned)B), dim3(256), 0, st, sub_ids, sub_off, ix.N, ix.uoff, ix.ucodes,
-                     subbm, W, allow, Cw, invalid);
+                        int64_t W, uint32_t* allow, int64_t Cw, int32_t* invalid, hipStream_t st, int64_t max_len, int replicate_to) {
+  // B lists (B = 1 with replicate_to > 1: one list shared by replicate_to queries); max_len = the longest of them
+  int64_t bx = (max_len + 2047) / 2048;
+  if (bx > 512) bx = 512;
+  if (bx < 1) bx = 1;
+  const int lds_words = Cw <= 32768 ? (int)Cw : 0;   // <= 2^20 centroids: 128 KiB
+  static std::atomic<uint64_t> ok{0};
+  fp_allow_big_lds((const void*)k_subset_prepare, ok, 160 * 1024);
+  hipLaunchKernelGGL(k_subset_prepare, dim3((unsigned)bx, (unsigned)B), dim3(256), (size_t)lds_words * 4, st, sub_ids, sub_off, ix.N, ix.uoff, ix.ucodes,
+                     subbm, W, allow, Cw, invalid, lds_words);
+  if (B == 1 && replicate_to > 1) {
+    hipLaunchKernelGGL(k_replicate_row, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, st, subbm, W, replicate_to);
+    hipLaunchKernelGGL(k_replicate_row, dim3((unsigned)((Cw + 255) / 256)), dim3(256), 0, st, allow, Cw, replicate_to);
+    hipLaunchKernelGGL(k_replicate_row, dim3(1), dim3(256), 0, st, reinterpret_cast<uint32_t*>(invalid), (int64_t)1, replicate_to);
+  }
 }
 
 // ============================================================================================

@@ -223,8 +223,14 @@ def search_arrays(index: PyLoadedIndex, queries_f16: np.ndarray, params: SearchP
     pids = np.full((B, max(k, 1)), -1, dtype=np.int64)
     scores = np.zeros((B, max(k, 1)), dtype=np.float32)
     counts = np.zeros(max(B, 1), dtype=np.int32)
-    ids, off = _flatten_subset(subset, B)
     p = params._c()
+    if subset is not None and len(subset) == B and B > 1 and all(s is subset[0] for s in subset):
+        # one list object repeated for every query (what FastPlaid.search makes of `subset: list[int]`): converted and passed once
+        ids = np.ascontiguousarray(np.asarray(subset[0], dtype=np.int64)) if len(subset[0]) else np.zeros(1, np.int64)
+        N.check(N.lib().fp_search_shared_subset(index._h, _ptr(q), B, Q, D, C.byref(p), _ptr(ids), len(subset[0]), _ptr(pids), _ptr(scores),
+                                                _ptr(counts)))
+        return pids[:, :k] if k else pids[:, :0], scores[:, :k] if k else scores[:, :0], counts[:B]
+    ids, off = _flatten_subset(subset, B)
     N.check(N.lib().fp_search(index._h, _ptr(q), B, Q, D, C.byref(p), _ptr(ids), _ptr(off), _ptr(pids), _ptr(scores), _ptr(counts)))
     return pids[:, :k] if k else pids[:, :0], scores[:, :k] if k else scores[:, :0], counts[:B]
 

@@ -133,6 +133,13 @@ int fp_search(const fp_index* index, const uint16_t* queries, int32_t n_queries,
               const fp_search_params* params, const int64_t* subset_ids, const int64_t* subset_offsets,
               int64_t* out_pids, float* out_scores, int32_t* out_counts);
 
+/* fp_search with ONE subset for every query: `subset: list[int]` of FastPlaid.search (fast_plaid.py:784-793), which the
+ * reference replicates per query before the native call (lib.rs:202 takes Vec<Vec<i64>>).  Passing the list once saves the
+ * n_queries - 1 copies, uploads and bitmap builds; results are those of fp_search with the list repeated for every query. */
+int fp_search_shared_subset(const fp_index* index, const uint16_t* queries, int32_t n_queries, int32_t q_len, int32_t dim,
+                            const fp_search_params* params, const int64_t* subset_ids, int64_t n_subset,
+                            int64_t* out_pids, float* out_scores, int32_t* out_counts);
+
 /* Plain device-memory helpers for callers without a HIP binding of their own (bench.py, tests): allocate / free / copy on
  * the given GPU through the same HIP runtime this library uses. */
 int fp_dev_alloc(int device_id, size_t bytes, void** out_dev_ptr);

@@ -248,6 +248,38 @@ def test_invalid_subset_id_gives_empty_result(fp):
     assert res[0].passage_ids == [] and len(res[1].passage_ids) == 3
 
 
+def test_shared_subset_equals_per_query_subsets(fp):
+    """`subset: list[int]` of FastPlaid.search reaches the boundary as ONE list object repeated per query; the binding passes it
+    once (fp_search_shared_subset: one upload, one bitmap build, rows replicated on the device).  Results must equal the
+    per-query form (fp_search with the list copied for every query), the traces and the oracle; an out-of-range id empties
+    every query; lists of thousands of ids with duplicates go through the half-wave-per-document bitmap kernel."""
+    R = fp.fast_plaid_rust
+    spec = _synth(fp, n_docs=20000, doc_len=40, n_centroids=2048, variable_len=True, seed=21)
+    arr = fp.synth.host_index_arrays(spec)
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    rng = np.random.default_rng(4)
+    q = fp.synth.make_queries(spec, arr["centroids"], 5, 32)
+    params = R.SearchParameters(2000, 512, 20, 8)
+    for n_sub in (7, 900, 6000):
+        sub = rng.integers(0, spec.n_docs, n_sub).tolist()   # (with duplicates)
+        shared = R.search_arrays(hip, q, params, [sub] * 5)                      # one object x 5 -> the shared entry point
+        per_q = R.search_arrays(hip, q, params, [list(sub) for _ in range(5)])   # five equal lists -> fp_search
+        ref = orc.search(q, 20, 512, 8, subset=[sub] * 5)
+        for b in range(5):
+            assert shared[2][b] == per_q[2][b] == len(ref[b][0])
+            n = shared[2][b]
+            assert np.array_equal(shared[0][b, :n], per_q[0][b, :n]) and np.array_equal(shared[1][b, :n], per_q[1][b, :n])
+            check_final(shared[0][b, :n], shared[1][b, :n], ref[b][0], ref[b][1], 20)
+            assert set(shared[0][b, :n].tolist()) <= set(sub)
+            t = R.search_trace(hip, q[b], params, sub)
+            assert np.array_equal(shared[0][b, :n], t["pids"]) and np.array_equal(shared[1][b, :n], t["scores"])
+    bad = R.search_arrays(hip, q, params, [[1, 2, 10 ** 7]] * 5)
+    assert not bad[2].any()
+    empty = R.search_arrays(hip, q, params, [[]] * 5)
+    assert not empty[2].any()
+
+
 # --------------------------------------------------------------------------------------------
 def _synth(fp, **kw):
     return fp.synth.SynthSpec(**kw)
