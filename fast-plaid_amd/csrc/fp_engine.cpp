@@ -164,6 +164,8 @@ struct Scratch : ScratchGen {
     int64_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // key of the last speculative call (a capture needs one such call before it: every buffer sized)
     int warm = 0, fails = 0;
     bool valid = false, used_q8 = false, marked = false;
+    bool no_fb = false;   // the captured batch ran the threshold probe WITHOUT its fallback kernels: a raised overflow flag voids a replayed batch too
+    bool fb_thr = false;  // ... WITH them (Pipe::probe_fb_thr)
   } graph;
   bool capturing = false;
   // The learnt capacity and the captured graph belong to a SHAPE {B, Q, n_ivf_probe, n_full_scores, top_k, subset?}.  The fields
@@ -213,7 +215,8 @@ struct Scratch : ScratchGen {
   bool fold_stats = false;      // host-buffer search: survivor / marked counts travel with the result copy instead of two small copies
   bool ms_marked_now = false;   // the last run_maxsim marked near-tied documents (ms_nmark is valid)
   bool pref_ready = false;      // ms_pref holds the prefix of sel_cnt (left by S5's last kernel)
-  bool probe_fb = false;        // a batch overflowed the threshold probe's tie room once: the fallback kernels are enqueued from then on
+  bool probe_fb = false;        // a batch overflowed the threshold probe's tie room: the fallback kernels are enqueued (post_batch: until 64 batches in a row raise no flag)
+  int probe_fb_clean = 0;
   int l0_poor = 0;              // consecutive batches in which level 0 let more than a quarter of the candidates through
   int l0h_poor = 0;             // ... and its hot-code form
   int sh_marks_mode = 0;        // sharded search, third exchange: 0 none, 1 near-tied documents, 2 every flagged document
@@ -768,6 +771,7 @@ struct Pipe {
   bool allow_spec = false;   // fp_search / fp_search_device: M may be the learnt capacity instead of this batch's total (no mid-pipeline sync)
   bool spec = false;         // ... and it was
   bool probe_no_fb = false;  // the probe's tie-overflow fallback is NOT enqueued: the caller checks the flag after its sync and re-runs
+  bool probe_fb_thr = false; // the threshold probe ran WITH its fallback behind it (the flag then reports an overflow, not a routing decision)
   bool probe_prezeroed = false, selhist_prezeroed = false, l0hist_prezeroed = false;   // cleared by the batch's first kernel
   int s1_mode = 0;           // FpS1Exact::mode of this batch's S1
   bool total_folded = false; // the candidate total / probe flag come down with the result block (no copy of their own)
@@ -813,6 +817,7 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     // raised flag is no overflow and must not send the batch round again)
     const bool thr_ok = sh.n_probe >= 1 && fpk_probe_zero_region(D, sh, P.nchunk, s->partial.as<unsigned long long>(), &zp, &zb);
     if (!thr_ok) P.probe_no_fb = false;
+    P.probe_fb_thr = thr_ok && !P.probe_no_fb;
     P.probe_prezeroed = thr_ok && zl.add(zp, zb);
     (void)zl.add(s->invalid.p, (size_t)B * 4);
     (void)zl.add(s->tickets.p, (size_t)(2 * B + 4) * 4);
@@ -1285,9 +1290,15 @@ static int post_batch(Scratch* s, const Pipe& P, const OutLayout& ol, bool repla
   const int64_t M_true = f.M_true;
   if (P.probe_no_fb && f.probe_ovf) {
     // some column had more ties at its probe threshold than the candidate lists hold: the device probed nothing (k_probe_merge);
-    // run the batch again with the register top-k fallback, and keep it enqueued for this scratch from now on
+    // run the batch again with the register top-k fallback, and keep it enqueued for this scratch -- until 64 batches in a row
+    // raise no flag (a tie-heavy batch is a property of its queries, not of the index)
     s->probe_fb = true;
+    s->probe_fb_clean = 0;
     return POST_RETRY;
+  }
+  if (s->probe_fb && P.probe_fb_thr) {   // (the fallback is enqueued behind a threshold probe that still reports its overflows)
+    if (f.probe_ovf) s->probe_fb_clean = 0;
+    else if (++s->probe_fb_clean >= 64) { s->probe_fb = false; s->probe_fb_clean = 0; }
   }
   if (P.spec && M_true > P.M) {
     // more candidates than the capacity learnt from earlier batches: the device emptied the batch (k_cand_offsets); run it again,
@@ -1442,6 +1453,12 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         P.M = s->spec_cap;
         P.used_q8 = s->graph.used_q8;
         P.total_folded = true;   // (a graph is only ever kept from a speculative host-buffer batch: its candidate total and probe flag are in the result block)
+        // (whether a raised probe flag means "overflow, run again" is a property of the CAPTURED batch: a shape the threshold probe
+        // does not serve -- n_ivf_probe > 32 -- raises the flag on purpose to route its register / select kernels.  Until round 6
+        // the replay took the flag for an overflow: every replayed batch of such a shape was run twice and left the scratch on
+        // the fallback + eager S1 for every later shape)
+        P.probe_no_fb = s->graph.no_fb;
+        P.probe_fb_thr = s->graph.fb_thr;
         s->fold_stats = true;
         s->ms_marked_now = s->graph.marked;
         replayed = true;
@@ -1513,6 +1530,8 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         std::copy(gkey, gkey + 8, s->graph.key);
         s->graph.used_q8 = P.used_q8;
         s->graph.marked = s->ms_marked_now;
+        s->graph.no_fb = P.probe_no_fb;
+        s->graph.fb_thr = P.probe_fb_thr;
         s->graph.valid = true;
         if (hipGraphLaunch(ex, st) != hipSuccess) {   // nothing of this batch has run: take the plain path, for good
           (void)hipGetLastError();

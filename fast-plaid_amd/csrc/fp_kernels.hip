@@ -1028,85 +1028,123 @@ __global__ __launch_bounds__(64) void k_probe_merge(const unsigned long long* __
 }
 
 // ---- any n_probe: exact radix select per column (generic path: n_probe > 32, or the overflow fallback of those) -------------
-// One workgroup per (query, 32-column group); thread = (column, one of 8 contiguous centroid slices).  Two histogram passes over
-// the monotone 16-bit keys give the n_probe-th largest key of the column and how many centroids at that key are still needed;
-// the collect pass takes everything above it and, among the equal ones, the lowest centroid ids (slices are contiguous ranges,
-// so a per-slice prefix of the equal counts orders them).  Four reads of S: slower than the threshold probe, any n_probe <= C.
-__global__ __launch_bounds__(256) void k_probe_select(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp, int n_probe,
-                                                      const uint32_t* __restrict__ allow, int64_t Cw, int32_t* __restrict__ cells,
-                                                      const int32_t* __restrict__ flag) {
+// One workgroup per (query, 32-column group).  Two histogram passes over the monotone 16-bit keys give the n_probe-th largest key
+// of the column and how many centroids at that key are still needed; the collect pass takes everything above it and, among the
+// equal ones, the lowest centroid ids (threads own contiguous centroid ranges, so a prefix over the ranges' equal counts orders
+// them).  Four reads of S: slower than the threshold probe, any n_probe <= C.
+// Round 6: thread = (16-byte piece of the group's 64-byte row, one of 256 contiguous centroid ranges) on 1024 threads -- a wave
+// reads 16 WHOLE rows per load, four rows ahead of their histogram updates.  (The first form, thread = (column, one of 8 ranges)
+// on 256 threads, read two bytes per lane with a 64-byte stride and waited for every load: 12 ms per cfg2 batch at n_ivf_probe
+// 64, twice that through the replayed graph -- see the engine's note on Pipe::probe_no_fb.)
+__global__ __launch_bounds__(1024) void k_probe_select(const uint16_t* __restrict__ S, int64_t C, int Q, int Qp, int n_probe,
+                                                       const uint32_t* __restrict__ allow, int64_t Cw, int32_t* __restrict__ cells,
+                                                       const int32_t* __restrict__ flag) {
   if (flag && !*flag) return;
+  constexpr int NSL = 256;
   __shared__ uint32_t hist[32][257];
-  __shared__ uint32_t thr_key[32], need_eq[32], cnt_eq[32][8], out_pos[32];
+  __shared__ uint32_t thr_key[32], need_eq[32], out_pos[32];
+  __shared__ uint16_t cnt_eq[32][NSL];   // (a range holds C / 256 <= 65535 centroids up to C = 2^24)
   const int groups = Qp / 32;
   const int b = blockIdx.x / groups, g = blockIdx.x % groups;
-  const int col = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  const int q = g * 32 + col;
-  const int64_t per = (C + 7) / 8;
+  const int tid = threadIdx.x, p = tid & 3, slice = tid >> 2;
+  uint32_t livem = 0u;   // the group's real columns
+  for (int j = 0; j < 32; ++j) livem |= (g * 32 + j < Q) ? (1u << j) : 0u;
+  const int64_t per = (C + NSL - 1) / NSL;
   const int64_t cb = slice * per, ce = (cb + per < C) ? cb + per : C;
-  const uint16_t* Sb = S + (int64_t)b * C * Qp + q;
+  const uint16_t* Sb = S + (int64_t)b * C * Qp + g * 32 + p * 8;
   const uint32_t* al = allow ? allow + (int64_t)b * Cw : nullptr;
-  const bool live = q < Q;
-  auto key_of = [&](int64_t c) -> uint32_t { return mono16(Sb[c * Qp]); };
   auto allowed = [&](int64_t c) -> bool { return !al || ((al[c >> 5] >> (c & 31)) & 1u); };
-  uint32_t prefix = 0, rem = (uint32_t)n_probe;
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int i = threadIdx.x; i < 32 * 257; i += 256) (&hist[0][0])[i] = 0u;
-    __syncthreads();
-    if (live)
-      for (int64_t c = cb; c < ce; ++c) {
-        if (!allowed(c)) continue;
-        const uint32_t k = key_of(c);
-        if (pass == 0) atomicAdd(&hist[col][k >> 8], 1u);
-        else if ((k >> 8) == prefix) atomicAdd(&hist[col][k & 0xFFu], 1u);
+  auto key8 = [&](const uint4& v, int j) -> uint32_t {
+    const uint32_t w = j < 2 ? v.x : (j < 4 ? v.y : (j < 6 ? v.z : v.w));
+    return mono16((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFFu)));
+  };
+  // visits the range's allowed rows four loads at a time: f(c, row)
+  auto walk = [&](auto&& f) {
+    for (int64_t c0 = cb; c0 < ce; c0 += 4) {
+      uint4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ok[u] = c0 + u < ce && allowed(c0 + u);
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (ok[u]) v[u] = *reinterpret_cast<const uint4*>(Sb + (c0 + u) * Qp);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) f(c0 + u, v[u]);
+    }
+  };
+  uint32_t prefix[8], rem[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { prefix[j] = 0u; rem[j] = (uint32_t)n_probe; }
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = tid; i < 32 * 257; i += 1024) (&hist[0][0])[i] = 0u;
     __syncthreads();
-    if (slice == 0 && live) {
-      if (pass == 1) { prefix = thr_key[col]; rem = need_eq[col]; }
+    walk([&](int64_t, const uint4& v) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (!((livem >> (p * 8 + j)) & 1u)) continue;
+        const uint32_t k = key8(v, j);
+        if (pass == 0) atomicAdd(&hist[p * 8 + j][k >> 8], 1u);
+        else if ((k >> 8) == prefix[j]) atomicAdd(&hist[p * 8 + j][k & 0xFFu], 1u);
+      }
+    });
+    __syncthreads();
+    if (tid < 32 && ((livem >> tid) & 1u)) {
+      const uint32_t pf = pass == 1 ? thr_key[tid] : 0u, rm = pass == 1 ? need_eq[tid] : (uint32_t)n_probe;
       uint32_t acc = 0;
       int d = 255;
       for (; d > 0; --d) {
-        if (acc + hist[col][d] >= rem) break;
-        acc += hist[col][d];
+        if (acc + hist[tid][d] >= rm) break;
+        acc += hist[tid][d];
       }
-      // fewer than `rem` allowed centroids in total: d ends at 0 and everything is taken
-      thr_key[col] = pass == 0 ? (uint32_t)d : ((prefix << 8) | (uint32_t)d);
-      need_eq[col] = rem - acc;
+      // fewer than `rm` allowed centroids in total: d ends at 0 and everything is taken
+      thr_key[tid] = pass == 0 ? (uint32_t)d : ((pf << 8) | (uint32_t)d);
+      need_eq[tid] = rm - acc;
     }
     __syncthreads();
-    prefix = thr_key[col];
-    rem = need_eq[col];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { prefix[j] = thr_key[p * 8 + j]; rem[j] = need_eq[p * 8 + j]; }
+    __syncthreads();
   }
-  const uint32_t tk = thr_key[col];
-  // equal-key counts per slice -> exclusive prefix over the slices (ascending centroid order)
-  uint32_t my_eq = 0;
-  if (live)
-    for (int64_t c = cb; c < ce; ++c)
-      if (allowed(c) && key_of(c) == tk) ++my_eq;
-  cnt_eq[col][slice] = my_eq;
-  if (slice == 0) out_pos[col] = 0u;
+  // equal-key counts per range -> exclusive prefix over the ranges (ascending centroid order)
+  uint32_t my_eq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) my_eq[j] = 0u;
+  walk([&](int64_t, const uint4& v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) my_eq[j] += (key8(v, j) == prefix[j]) ? 1u : 0u;
+  });
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cnt_eq[p * 8 + j][slice] = (uint16_t)my_eq[j];
+  if (tid < 32) out_pos[tid] = 0u;
   __syncthreads();
-  uint32_t eq_before = 0;
-  for (int s2 = 0; s2 < slice; ++s2) eq_before += cnt_eq[col][s2];
-  if (live) {
-    int32_t* out = cells + ((int64_t)b * Q + q) * n_probe;
-    const uint32_t want_eq = need_eq[col];
-    uint32_t eq_seen = eq_before;
-    for (int64_t c = cb; c < ce; ++c) {
-      if (!allowed(c)) continue;
-      const uint32_t k = key_of(c);
-      bool take = k > tk;
-      if (k == tk) { take = eq_seen < want_eq; ++eq_seen; }
+  uint32_t eq_seen[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint32_t e = 0u;
+    if ((livem >> (p * 8 + j)) & 1u)
+      for (int s2 = 0; s2 < slice; ++s2) e += cnt_eq[p * 8 + j][s2];
+    eq_seen[j] = e;
+  }
+  walk([&](int64_t c, const uint4& v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = p * 8 + j;
+      if (!((livem >> col) & 1u)) continue;
+      const uint32_t k = key8(v, j);
+      bool take = k > prefix[j];
+      if (k == prefix[j]) { take = eq_seen[j] < rem[j]; ++eq_seen[j]; }
       if (take) {
         const uint32_t pos = atomicAdd(&out_pos[col], 1u);
-        if (pos < (uint32_t)n_probe) out[pos] = (int32_t)c;
+        if (pos < (uint32_t)n_probe) cells[((int64_t)b * Q + g * 32 + col) * n_probe + pos] = (int32_t)c;
       }
     }
-  }
+  });
   __syncthreads();
-  if (slice == 0 && live) {
-    int32_t* out = cells + ((int64_t)b * Q + q) * n_probe;
-    for (uint32_t i = out_pos[col]; i < (uint32_t)n_probe; ++i) out[i] = -1;
+  if (tid < 32 && ((livem >> tid) & 1u)) {
+    int32_t* out = cells + ((int64_t)b * Q + g * 32 + tid) * n_probe;
+    for (uint32_t i = out_pos[tid]; i < (uint32_t)n_probe; ++i) out[i] = -1;
   }
 }
 
@@ -1590,7 +1628,7 @@ int fpk_probe(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, 
   // blanks them) and the caller, who sees the flag after its final sync, runs the batch again with the fallback.
   if (threshold_ok && !with_fallback) {
   } else if (big_probe) {
-    hipLaunchKernelGGL(k_probe_select, dim3((unsigned)(sh.B * (sh.Qp / 32))), dim3(256), 0, st, S, ix.C, sh.Q, sh.Qp, sh.n_probe, allow, Cw,
+    hipLaunchKernelGGL(k_probe_select, dim3((unsigned)(sh.B * (sh.Qp / 32))), dim3(1024), 0, st, S, ix.C, sh.Q, sh.Qp, sh.n_probe, allow, Cw,
                        cells, flag);
   } else {
   switch (NP) {

@@ -74,6 +74,24 @@ def main():
         assert np.array_equal(pids[b, : counts[b]], t["pids"]) and np.array_equal(scores[b, : counts[b]], t["scores"])
     if not test_opt("spec_cap_pct"):
         assert replayed_small == 1 and big > 2 * small, (replayed_small, small, big)
+    # a shape the threshold probe does not serve (n_ivf_probe > 32 raises the probe flag on purpose, to route its select kernel)
+    # through the replayed graph: one launch per call -- until round 6 the replay took the flag for a tie overflow, ran every such
+    # batch twice and left the scratch on the probe fallback and the eager S1 for every later shape
+    params40 = R.SearchParameters(2000, 512, 50, 40)
+    q40 = fp.synth.make_queries(spec, host["centroids"], 4, 32, seed=1234)
+    for _ in range(6):
+        pids, scores, counts = R.search_arrays(dev, q40, params40)
+    for b in range(4):
+        t = R.search_trace(dev, q40[b], params40)
+        assert counts[b] == len(t["pids"]) and np.array_equal(pids[b, : counts[b]], t["pids"]) and np.array_equal(scores[b, : counts[b]], t["scores"])
+    before = R.graph_replay_count()
+    R.search_arrays(dev, q40, params40)
+    if not test_opt("spec_cap_pct"):
+        assert R.graph_replay_count() - before == 1
+    R.set_graph_replay(False)
+    R.search_arrays(dev, fp.synth.make_queries(spec, host["centroids"], 4, 32, seed=1235), R.SearchParameters(2000, 512, 50, 4))
+    assert R.last_s1_counts()["lazy"] == 1, "a later shape of the scratch lost the lazy S1"
+    R.set_graph_replay(True)
     print("GRAPH_OK replays", replays, "overflow on a replayed batch:", small, "->", big)
 
 

@@ -27,8 +27,8 @@ def main():
     ix = R.construct_synthetic_index(spec, "cuda:0", centroids=cent, bucket_weights=fp.synth.bucket_weights(spec))
     rng = np.random.default_rng(3)
 
-    def run(name, B, Q, top_k, n_full=4096, subset=None, zero_rows=0):
-        p = R.SearchParameters(2000, n_full, top_k, 8)
+    def run(name, B, Q, top_k, n_full=4096, subset=None, zero_rows=0, n_probe=8):
+        p = R.SearchParameters(2000, n_full, top_k, n_probe)
         qs = [fp.synth.make_queries(spec, cent, B, Q, seed=50 + i) for i in range(a.steps + 4)]
         if zero_rows:
             for q in qs:
@@ -43,8 +43,10 @@ def main():
         R.search_arrays(ix, qs[4], p, subset)
         R.search_arrays(ix, qs[5], p, subset)
         st = {k: round(v, 3) for k, v in R.last_search_timings().items() if v >= 0.05}
+        form = {"s1_lazy": R.last_s1_counts()["lazy"], "lazy_overflows": R.last_search_counts()["lazy_overflows"], "s4": R.last_search_counts()["s4_form"]}
         R.set_graph_replay(True)
-        print(json.dumps({"case": name, "B": B, "q_len": Q, "top_k": top_k, "ms_per_call": round(ms, 3), "qps": round(B / ms * 1e3, 1), "stages_ms>=0.05": st}), flush=True)
+        print(json.dumps({"case": name, "B": B, "q_len": Q, "top_k": top_k, "ms_per_call": round(ms, 3), "qps": round(B / ms * 1e3, 1), "form": form,
+                          "stages_ms>=0.05": st}), flush=True)
 
     run("headline: B 64, q_len 32, top_k 1000", 64, 32, 1000)
     run("top_k 10", 64, 32, 10)
@@ -53,6 +55,13 @@ def main():
     run("8 queries, top_k 10", 8, 32, 10)
     run("q_len 50", 64, 50, 10)
     run("q_len 32 with 12 zero-padded rows", 64, 32, 10, zero_rows=12)
+    run("n_ivf_probe 16", 64, 32, 10, n_probe=16)
+    run("n_ivf_probe 32", 64, 32, 10, n_probe=32)
+    run("n_ivf_probe 1", 64, 32, 10, n_probe=1)
+    run("256 queries", 256, 32, 10)
+    run("n_full_scores 16384, top_k 100", 64, 32, 100, 16384)
+    run("n_ivf_probe 64", 64, 32, 10, n_probe=64)
+    run("top_k 10 again (after the n_ivf_probe 64 calls)", 64, 32, 10)
     sub_small = [rng.choice(a.docs, 10_000, replace=False).tolist()] * 64
     run("subset: one list of 10 k ids for all queries", 64, 32, 10, subset=sub_small)
     sub_big = [rng.choice(a.docs, 300_000, replace=False).tolist()] * 64
