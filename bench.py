@@ -250,6 +250,17 @@ def main():
             lat.append(time.perf_counter() - ts)
         sync()
         elapsed = time.perf_counter() - t_start
+        # `value` is the K steps above and nothing else.  K = 20 steps are ~37 ms: for the reader, the same K steps five more times
+        # (reported as `repeat_ms_per_step`: how far one timed region of this length scatters on this box)
+        repeats = []
+        if mode == "single":
+            for _ in range(5):
+                sync()
+                t_r = time.perf_counter()
+                for i in range(a.steps):
+                    step(a.warmup + i)
+                sync()
+                repeats.append((time.perf_counter() - t_r) / a.steps * 1e3)
         if mode in ("single", "replica"):
             # per-stage HIP-event times and work counters: the SAME K steps once more with graph replay off -- in the timed loop
             # above every step is one hipGraphLaunch, which records no per-stage events (same kernels, same launch parameters)
@@ -286,7 +297,7 @@ def main():
                 R.search_device(index, dq[a.warmup + i], a.batch, a.qlen, params, dp, dsc, dc)
             dev_elapsed = time.perf_counter() - t1
             del dq, dp, dsc, dc
-        return dict(index=index, elapsed=elapsed, lat=lat, stage_acc=stage_acc, cand_total=cand_total, exact_total=exact_total,
+        return dict(index=index, elapsed=elapsed, lat=lat, repeats=repeats, stage_acc=stage_acc, cand_total=cand_total, exact_total=exact_total,
                     repaired_total=repaired_total, s4_form=s4_form, s1_form=s1_form,
                     t_build=t_build, dev_elapsed=dev_elapsed)
 
@@ -346,6 +357,7 @@ def main():
             "index_bytes_per_gpu": index_bytes, "index_build_s": round(t_build, 2),
         },
         "p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)), "p90_ms": float(np.percentile(np.array(lat) * 1e3, 90)),
+        "repeat_ms_per_step": [round(x, 4) for x in res.get("repeats", [])],
     }
     if primary in ("shard", "split", "grid") or (a.cfg == "cfg3" and world == 1):
         # the one-GPU anchor of the strong-scaling series: `python bench.py --gpus 1 --config cfg3` (the newest committed measurement of it)
