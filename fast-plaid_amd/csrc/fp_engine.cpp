@@ -1396,8 +1396,14 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
   const bool sub_shared = shared_subset_n >= 0;
   const bool has_subset = subset_off != nullptr || sub_shared;
   // reference: topk(k > C) errs inside search() -> per-query empty result (search.rs:268)
-  if (!has_subset && p->n_ivf_probe > D.C) return FP_OK;
-  if (D.N == 0) return FP_OK;
+  if ((!has_subset && p->n_ivf_probe > D.C) || D.N == 0) {
+    // (host buffers: the rows are written here too -- id -1, score 0 like every unused slot -- so that a caller need not pre-fill them)
+    if (!dev_io) {
+      std::fill(out_pids, out_pids + (size_t)nq * p->top_k, (int64_t)-1);
+      std::fill(out_scores, out_scores + (size_t)nq * p->top_k, 0.f);
+    }
+    return FP_OK;
+  }
   Scratch* s = acquire(ix);
   if (!s) return fail(FP_EHIP, "could not create a HIP stream");
   struct Rel {

@@ -220,9 +220,14 @@ def search_arrays(index: PyLoadedIndex, queries_f16: np.ndarray, params: SearchP
         raise ValueError(f"Expected a 3D tensor for queries, but got shape {list(q.shape)}")
     B, Q, D = q.shape
     k = max(params.top_k, 0)
-    pids = np.full((B, max(k, 1)), -1, dtype=np.int64)
-    scores = np.zeros((B, max(k, 1)), dtype=np.float32)
+    # (every successful fp_search writes every row it was passed -- unused slots -1 / 0 -- so the result buffers are not
+    # pre-filled: np.full over 512 KB was ~1 % of a cfg2 call)
+    pids = np.empty((B, max(k, 1)), dtype=np.int64)
+    scores = np.empty((B, max(k, 1)), dtype=np.float32)
     counts = np.zeros(max(B, 1), dtype=np.int32)
+    if k == 0 or B == 0:
+        pids.fill(-1)
+        scores.fill(0)
     p = params._c()
     if subset is not None and len(subset) == B and B > 1 and all(s is subset[0] for s in subset):
         # one list object repeated for every query (what FastPlaid.search makes of `subset: list[int]`): converted and passed once

@@ -106,9 +106,9 @@ int32_t fp_index_tickets_ok(const fp_index* index);
  * out_counts [n_queries] = results per query = min(top_k, max(n_full/4,1), candidates)
  * (search.rs:614, :666); rows are sorted by descending score; the slots [count, top_k) of
  * a row hold id -1 and score 0.  A query whose per-query search fails in the reference
- * (search.rs:268 `.unwrap_or_default()`) gets count 0 and a row of -1 / 0 like any other unused slot; the calls that return
- * before anything is enqueued (n_queries == 0, top_k == 0, an empty index, n_ivf_probe > n_centroids without a subset) write
- * the counts only.
+ * (search.rs:268 `.unwrap_or_default()`) gets count 0 and a row of -1 / 0 like any other unused slot -- also when the whole
+ * call returns before anything is enqueued (an empty index, n_ivf_probe > n_centroids without a subset): every row the caller
+ * passed is written by every successful call, so the buffers need no pre-fill.
  *
  * What is exact, and on what evidence.  The returned ids are the reference's, in the reference's order (documents whose
  * reference scores are EXACTLY equal may come in another order: the reference's own tie order is implementation-defined; ours
