@@ -248,6 +248,40 @@ def test_invalid_subset_id_gives_empty_result(fp):
     assert res[0].passage_ids == [] and len(res[1].passage_ids) == 3
 
 
+def test_ragged_list_queries_through_the_python_surface(fp):
+    """FastPlaid.search with a LIST of queries of unequal lengths (fast_plaid.py:772-780: zero-padded to the longest) and one
+    `subset` list for all of them, on a corpus large enough for the bound stage and the lazy S1: the zero rows take the
+    lowest-numbered cells without overflowing the probe (round 6), so the batch stays on the lazy form; ids / scores equal the
+    oracle's for the padded batch and the per-query traces."""
+    R = fp.fast_plaid_rust
+    from fast_plaid_amd import search
+    spec = _synth(fp, n_docs=30000, doc_len=48, n_centroids=4096, variable_len=True, seed=33)
+    arr = fp.synth.host_index_arrays(spec)
+    orc = _oracle(arr)
+    rng = np.random.default_rng(8)
+    full = fp.synth.make_queries(spec, arr["centroids"], 6, 32)
+    lens = [32, 20, 9, 32, 27, 14]
+    ragged = [full[i, : lens[i]] for i in range(6)]
+    padded = np.zeros_like(full)
+    for i in range(6):
+        padded[i, : lens[i]] = full[i, : lens[i]]
+    with search.FastPlaid.from_arrays(arr, device="cuda:0") as fpi:
+        for _ in range(3):   # waited-for, speculative, replayed
+            out = fpi.search(ragged, top_k=20, n_full_scores=512, n_ivf_probe=8, show_progress=False)
+        assert R.last_s1_counts()["lazy"] in (1, -1), "zero-padded rows pushed the batch off the lazy S1"
+        ref = orc.search(padded, 20, 512, 8)
+        for b in range(6):
+            ids = np.array([d for d, _ in out[b]]); sc = np.array([x for _, x in out[b]], np.float32)
+            check_final(ids, sc, ref[b][0], ref[b][1], 20)
+        sub = rng.integers(0, spec.n_docs, 5000).tolist()
+        out_s = fpi.search(ragged, top_k=20, n_full_scores=512, n_ivf_probe=8, show_progress=False, subset=sub)
+        ref_s = orc.search(padded, 20, 512, 8, subset=[sub] * 6)
+        for b in range(6):
+            ids = np.array([d for d, _ in out_s[b]]); sc = np.array([x for _, x in out_s[b]], np.float32)
+            check_final(ids, sc, ref_s[b][0], ref_s[b][1], 20)
+            assert set(ids.tolist()) <= set(sub)
+
+
 def test_shared_subset_equals_per_query_subsets(fp):
     """`subset: list[int]` of FastPlaid.search reaches the boundary as ONE list object repeated per query; the binding passes it
     once (fp_search_shared_subset: one upload, one bitmap build, rows replicated on the device).  Results must equal the
