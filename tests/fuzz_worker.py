@@ -1,0 +1,185 @@
+"""GPU worker: randomized parity fuzz of fp_search / fp_search_trace against the C oracle.
+
+Every case draws its own shape -- corpus size, document lengths (empty / one-token / repeated-code documents included), centroid
+count off every tile grid, dim, nbits, batch, query length, n_ivf_probe, n_full_scores, top_k, subsets, zero-padded query rows,
+unnormalised queries -- builds plain random index arrays (tests/test_hip_parity.py::_random_arrays: no corpus model) and checks
+
+  1. fp_search_trace against the oracle's trace stage by stage (parity.check_trace: S, cells, candidates, approximate scores and
+     the rerank list bit for bit; exact scores within 1e-3; the oracle's ids in its order),
+  2. fp_search (the pruned / speculative / lazy path) == fp_search_trace bit for bit, on three calls in a row (the second runs on
+     the learnt candidate capacity, the third may be a captured graph's replay),
+  3. with a shared subset: fp_search_shared_subset == the per-query form.
+
+usage: fuzz_worker.py <n_cases> <seed> [<first_case>] [big]   (FP_APPROX_IMPL = q8 / l0 / l0h forces a form of S4 for the whole run)
+"big": corpus-model indexes (fast-plaid_amd/synth.py, 5 k - 80 k documents, up to 2^16 centroids, batches up to 64) on which the
+engine picks the bound stages / the lazy S1 / graph replay by itself: fp_search x 5 == fp_search_trace bit for bit for every query,
+the oracle's ids in its order for the first four.
+prints one line per failing case (its number reproduces it: fuzz_worker.py 1 <seed> <case>) and FUZZ_OK <n> / FUZZ_FAIL <k>/<n>.
+"""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import fast_plaid_amd as fp  # noqa: E402
+from parity import SCORE_TOL, check_trace  # noqa: E402
+from test_hip_parity import _hip_index, _oracle, _random_arrays  # noqa: E402
+
+R = fp.fast_plaid_rust
+TALLY = {}   # what the engine ran, per fp_search call: form of S4 / S1 lazy (1) eager (0) replayed graph (-1)
+
+
+def searched(*a):
+    out = R.search_arrays(*a)
+    k = (R.last_search_counts()["s4_form"], R.last_s1_counts()["lazy"])
+    TALLY[k] = TALLY.get(k, 0) + 1
+    return out
+
+
+def draw_shape(rng):
+    pick = lambda *v: v[int(rng.integers(0, len(v)))]   # noqa: E731
+    n_docs = int(pick(1, 3, 40, 300, 900, 2500, 6000))
+    n_docs = max(1, int(n_docs * rng.uniform(0.5, 1.5)))
+    max_len = int(pick(1, 2, 8, 33, 70, 130, 300))
+    C = int(pick(8, 37, 100, 129, 257, 513, 1000, 2048, 3001, 5000))
+    dim = int(pick(128, 128, 128, 64, 64, 96, 48, 40, 256))
+    nbits = int(pick(4, 4, 2, 2, 1, 8))
+    B = int(rng.integers(1, 10))
+    Q = int(pick(1, 2, 3, 7, 17, 31, 32, 33, 50, 64, 65, 100, 128, 130))
+    n_probe = int(pick(1, 2, 4, 8, 8, 16, 32, 33, 40, 64, 100))
+    n_probe = min(n_probe, C)
+    n_full = int(pick(1, 4, 8, 40, 64, 128, 256, 1000, 2000, 4096))
+    top_k = int(pick(1, 3, 10, 20, 100, 1000, 5000))
+    subset = int(pick(0, 0, 0, 1, 2))    # 0 none, 1 per-query lists, 2 one shared list
+    qkind = int(pick(0, 0, 0, 1, 2, 3))  # 0 normalised, 1 zero-padded tails, 2 scaled x3, 3 scaled x0.01
+    return n_docs, max_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, subset, qkind
+
+
+def run_case(seed, case):
+    rng = np.random.default_rng([seed, case])
+    shape = draw_shape(rng)
+    n_docs, max_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, subset, qkind = shape
+    forced = os.environ.get("FP_APPROX_IMPL")
+    if forced and Q > 128:
+        Q = 128   # (the forced forms of S4 serve up to 128 query columns; the engine never picks them beyond)
+    arr = _random_arrays(rng, n_docs, max_len, C, dim, nbits, empty_frac=float(rng.choice([0.0, 0.1, 0.5])))
+    pick = rng.integers(0, C, (B, Q))
+    q = arr["centroids"][pick].astype(np.float32) + 0.3 * rng.standard_normal((B, Q, dim), dtype=np.float32) / np.sqrt(dim)
+    q /= np.linalg.norm(q, axis=2, keepdims=True)
+    zero_rows = np.zeros(B, bool)
+    if qkind == 1 and Q > 1:
+        for b in range(B):
+            if rng.random() < 0.6:
+                q[b, int(rng.integers(1, Q)):] = 0
+                zero_rows[b] = True
+    elif qkind == 2:
+        q *= 3.0
+    elif qkind == 3:
+        q *= 0.01
+    q = q.astype(np.float16)
+    subs = None
+    if subset == 1:
+        subs = [rng.integers(0, n_docs, int(rng.integers(1, 60))).tolist() for _ in range(B)]
+    elif subset == 2:
+        one = rng.integers(0, n_docs, int(rng.integers(1, 200))).tolist()
+        subs = [one] * B
+    hip = _hip_index(fp, arr)
+    orc = _oracle(arr)
+    params = R.SearchParameters(2000, n_full, top_k, n_probe)
+    runs = [searched(hip, q, params, subs) for _ in range(3)]
+    if subset == 2:   # the shared list given as distinct (equal) lists takes the per-query entry point
+        runs.append(searched(hip, q, params, [list(one) for _ in range(B)]))
+    for b in range(B):
+        sub = None if subs is None else subs[b]
+        h = R.search_trace(hip, q[b], params, sub)
+        o = orc.search_trace(q[b], top_k, n_full, n_probe, sub)
+        # (a zero query token ties every centroid at the probe cut: the reference's pick is implementation-defined)
+        # (the north star's 1e-3 is quoted on normalised queries: the one freedom left, one fp16 ulp of one column's maximum, scales with
+        # the query -- columns of a x3 query reach [2, 4), ulp 2^-9; the ORDER must be the oracle's at any scale)
+        check_trace(h, o, Q, n_probe, n_full, top_k, strict_cells=not zero_rows[b], tol=SCORE_TOL * (3.0 if qkind == 2 else 1.0))
+        for i, (pids, scores, counts) in enumerate(runs):
+            assert counts[b] == len(h["pids"]), f"call {i} query {b}: count {counts[b]} != trace {len(h['pids'])}"
+            assert np.array_equal(pids[b, : counts[b]], h["pids"]), f"call {i} query {b}: ids differ from the trace"
+            assert np.array_equal(scores[b, : counts[b]], h["scores"]), f"call {i} query {b}: scores differ from the trace"
+            assert np.all(pids[b, counts[b]:] == -1), f"call {i} query {b}: unused slots not -1"
+    return shape
+
+
+def run_big_case(seed, case):
+    rng = np.random.default_rng([seed, case, 77])
+    pick = lambda *v: v[int(rng.integers(0, len(v)))]   # noqa: E731
+    n_docs = int(pick(5000, 12000, 30000, 80000) * rng.uniform(0.7, 1.3))
+    doc_len = int(pick(16, 48, 48, 100, 128))
+    C = int(pick(1024, 2048, 8192, 16384, 65536))
+    dim, nbits = pick((128, 4), (128, 4), (128, 2), (64, 4), (64, 2))
+    B = int(pick(1, 3, 8, 20, 64))
+    Q = int(pick(8, 20, 32, 32, 32, 33, 48, 64))
+    n_probe = int(pick(1, 4, 8, 8, 16, 32))
+    n_full = int(pick(32, 64, 256, 1024, 4096))
+    top_k = int(pick(5, 25, 100, 1000))
+    qkind = int(pick(0, 0, 0, 1))
+    spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=doc_len, n_centroids=C, dim=dim, nbits=nbits, variable_len=bool(rng.integers(0, 2)),
+                              seed=int(rng.integers(1, 1 << 30)))
+    arr = fp.synth.host_index_arrays(spec)
+    q = fp.synth.make_queries(spec, arr["centroids"], B, Q, seed=int(rng.integers(1, 1 << 30)))
+    zero_rows = np.zeros(B, bool)
+    if qkind == 1:
+        for b in range(B):
+            if rng.random() < 0.5:
+                q[b, int(rng.integers(1, Q)):] = 0
+                zero_rows[b] = True
+    hip = _hip_index(fp, arr)
+    params = R.SearchParameters(2000, n_full, top_k, n_probe)
+    runs = [searched(hip, q, params) for _ in range(5)]   # (plain, learnt capacity x 2, the capturing call, a replay)
+    orc = _oracle(arr)
+    for b in range(B):
+        h = R.search_trace(hip, q[b], params, None)
+        for i, (pids, scores, counts) in enumerate(runs):
+            assert counts[b] == len(h["pids"]), f"call {i} query {b}: count {counts[b]} != trace {len(h['pids'])}"
+            assert np.array_equal(pids[b, : counts[b]], h["pids"]), f"call {i} query {b}: ids differ from the trace"
+            assert np.array_equal(scores[b, : counts[b]], h["scores"]), f"call {i} query {b}: scores differ from the trace"
+        if b < 4:
+            o = orc.search_trace(q[b], top_k, n_full, n_probe, None)
+            check_trace(h, o, Q, n_probe, n_full, top_k, strict_cells=not zero_rows[b])
+    return (n_docs, doc_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, qkind)
+
+
+def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "big":
+        n, seed, first, bad = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 0
+        for case in range(first, first + n):
+            try:
+                run_big_case(seed, case)
+            except Exception as e:   # noqa: BLE001
+                bad += 1
+                print(f"FUZZ_CASE_FAILED big case={case} seed={seed} {type(e).__name__}: {str(e)[:400]}", flush=True)
+                if os.environ.get("FP_FUZZ_TRACEBACK"):
+                    traceback.print_exc()
+        print("calls by (S4 form, S1 lazy):", sorted(TALLY.items(), key=str))
+        print(f"FUZZ_FAIL {bad}/{n}" if bad else f"FUZZ_OK {n}", flush=True)
+        sys.exit(1 if bad else 0)
+    n = int(sys.argv[1])
+    seed = int(sys.argv[2])
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    bad = 0
+    for case in range(first, first + n):
+        try:
+            run_case(seed, case)
+        except Exception as e:   # noqa: BLE001  (every failure is reported with its case number; the run goes on)
+            bad += 1
+            rng = np.random.default_rng([seed, case])
+            print(f"FUZZ_CASE_FAILED case={case} seed={seed} shape={draw_shape(rng)} {type(e).__name__}: {str(e)[:400]}", flush=True)
+            if os.environ.get("FP_FUZZ_TRACEBACK"):
+                traceback.print_exc()
+    print("calls by (S4 form, S1 lazy):", sorted(TALLY.items(), key=str))
+    print(f"FUZZ_FAIL {bad}/{n}" if bad else f"FUZZ_OK {n}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

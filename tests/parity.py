@@ -68,7 +68,7 @@ def _same_order_modulo_exact_ties(ids_hip, ids_ref, scores_ref):
         i = j
 
 
-def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_ok=True):
+def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_ok=True, tol=SCORE_TOL):
     """the returned ids ARE the reference's, in the reference's order (modulo its exact ties); scores within 1e-3,
     descending, no duplicates.  cut_tie_ok: when the reference's scores tie exactly ACROSS the top_k cut the tied group's
     members inside the list may differ (the reference's pick among them is implementation-defined)."""
@@ -79,7 +79,7 @@ def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_
     assert np.all(np.diff(scores_hip) <= 0), "scores not in descending order"
     if len(pids_ref) == 0:
         return True
-    assert np.abs(scores_hip - scores_ref).max() <= SCORE_TOL, f"scores differ by {np.abs(scores_hip - scores_ref).max()} position-wise"
+    assert np.abs(scores_hip - scores_ref).max() <= tol, f"scores differ by {np.abs(scores_hip - scores_ref).max()} position-wise"
     if np.array_equal(pids_hip, pids_ref):
         return True
     n = len(pids_ref)
@@ -92,7 +92,7 @@ def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_
     return False
 
 
-def check_trace(hip: dict, ref: dict, Q: int, n_probe: int, n_full: int, top_k: int, strict_cells=True):
+def check_trace(hip: dict, ref: dict, Q: int, n_probe: int, n_full: int, top_k: int, strict_cells=True, tol=SCORE_TOL):
     """Stage-by-stage comparison of fp_search_trace against an oracle trace: S, cells, candidates, approximate scores and
     the rerank list bit for bit; exact scores within 1e-3; final ids identical.  strict_cells=False admits other cells only at
     EXACT ties of the probe cut (a zero query token) -- everything downstream is then compared only if the cells agree."""
@@ -118,8 +118,8 @@ def check_trace(hip: dict, ref: dict, Q: int, n_probe: int, n_full: int, top_k: 
         return diag
     diag["rerank_same"] = True
     d = np.abs(np.asarray(hip["exact"], np.float32) - np.asarray(ref["exact"], np.float32))
-    assert d.max(initial=0.0) <= SCORE_TOL, f"exact MaxSim differs by {d.max()} (> 1e-3)"
+    assert d.max(initial=0.0) <= tol, f"exact MaxSim differs by {d.max()} (> {tol})"
     diag["exact_max_abs_diff"] = float(d.max(initial=0.0))
     diag["exact_equal_frac"] = float((d == 0).mean()) if d.size else 1.0
-    diag["ids_identical"] = check_final(hip["pids"], hip["scores"], ref["pids"], ref["scores"], top_k)
+    diag["ids_identical"] = check_final(hip["pids"], hip["scores"], ref["pids"], ref["scores"], top_k, tol=tol)
     return diag

@@ -724,6 +724,26 @@ def test_randomized_shapes_vs_oracle(fp, shape):
         assert np.array_equal(pids[b, : counts[b]], h["pids"]) and np.array_equal(scores[b, : counts[b]], h["scores"])
 
 
+@pytest.mark.parametrize("form,mode,n_cases", [("auto", "", 300), ("q8", "", 200), ("l0", "", 200), ("l0h", "", 200),
+                                               ("auto", "big", 40), ("l0h", "big", 25), ("q8", "big", 25)])
+def test_fuzz_vs_oracle(fp, form, mode, n_cases):
+    """tests/fuzz_worker.py: randomly DRAWN shapes (the fixed list above is what earlier rounds thought of) -- fp_search_trace
+    against the oracle stage by stage, fp_search on repeated calls (learnt capacity, graph replay) == the trace bit for bit,
+    the shared-subset entry point == the per-query one; every forced form of S4; "big": corpus-model indexes on which the
+    engine picks the bound stages, the lazy S1 and graph replay by itself.  Round 6 ran 5400 + 900 cases of it
+    (profiles/r06_fuzz.txt); a failing case prints the number that reproduces it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("FP_APPROX_IMPL", None)
+    if form != "auto":
+        env["FP_APPROX_IMPL"] = form
+    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_worker.py"), str(n_cases), "606", "0"] + ([mode] if mode else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and f"FUZZ_OK {n_cases}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_concurrent_searches_on_one_index(fp):
     """fp_search is re-entrant on a shared index (load.rs:58-59 Send+Sync; the reference's thread-per-device and
     joblib paths share one index object): 6 threads x 5 calls with different batches == the sequential results."""
