@@ -8,7 +8,9 @@ unnormalised queries -- builds plain random index arrays (tests/test_hip_parity.
      the rerank list bit for bit; exact scores within 1e-3; the oracle's ids in its order),
   2. fp_search (the pruned / speculative / lazy path) == fp_search_trace bit for bit, on three calls in a row (the second runs on
      the learnt candidate capacity, the third may be a captured graph's replay),
-  3. with a shared subset: fp_search_shared_subset == the per-query form.
+  3. with a shared subset: fp_search_shared_subset == the per-query form,
+  4. on a third of the cases each: pysearch_with_token_scores (same hits; the [q_len, doc_len] matrices == the oracle's bit for
+     bit) and fp_search_device (queries and results in HBM) == fp_search.
 
 usage: fuzz_worker.py <n_cases> <seed> [<first_case>] [big]   (FP_APPROX_IMPL = q8 / l0 / l0h forces a form of S4 for the whole run)
 "big": corpus-model indexes (fast-plaid_amd/synth.py, 5 k - 80 k documents, up to 2^16 centroids, batches up to 64) on which the
@@ -107,6 +109,31 @@ def run_case(seed, case):
             assert np.array_equal(pids[b, : counts[b]], h["pids"]), f"call {i} query {b}: ids differ from the trace"
             assert np.array_equal(scores[b, : counts[b]], h["scores"]), f"call {i} query {b}: scores differ from the trace"
             assert np.all(pids[b, counts[b]:] == -1), f"call {i} query {b}: unused slots not -1"
+    extra = rng.random(2)
+    if extra[0] < 0.35:   # pysearch_with_token_scores: the same hits, every [q_len, doc_len] matrix == the oracle's bit for bit
+        res = R.pysearch_with_token_scores(hip, "cuda:0", q, params, False, subs)
+        pids, scores, counts = runs[0]
+        for b, r in enumerate(res):
+            assert r.passage_ids == pids[b, : counts[b]].tolist() and np.array_equal(np.asarray(r.scores, np.float32), scores[b, : counts[b]]), \
+                f"token-score search, query {b}: hits differ from fp_search"
+            for pid, m in list(zip(r.passage_ids, r.token_scores))[:8]:
+                ref = orc.token_scores(q[b], pid)
+                assert m.shape == ref.shape == (Q, int(arr["doc_lengths"][pid])), f"query {b} doc {pid}: matrix shape {m.shape}"
+                assert np.array_equal(m.view(np.uint16), ref.view(np.uint16)), f"query {b} doc {pid}: token scores differ from the oracle"
+        TALLY["token_scores"] = TALLY.get("token_scores", 0) + 1
+    if extra[1] < 0.35 and subs is None:   # fp_search_device: queries and results in HBM
+        k = max(top_k, 1)
+        dq = R.DeviceBuffer(0, q.nbytes).upload(q)
+        dp, ds, dc = R.DeviceBuffer(0, B * k * 8), R.DeviceBuffer(0, B * k * 4), R.DeviceBuffer(0, B * 4)
+        dc.upload(np.full(B, 77, np.int32))
+        R.search_device(hip, dq, B, Q, params, dp, ds, dc)
+        pids, scores, counts = runs[0]
+        gc, gp, gs = dc.download(np.int32, (B,)), dp.download(np.int64, (B, k)), ds.download(np.float32, (B, k))
+        assert np.array_equal(gc, counts), f"device-resident search: counts {gc.tolist()} vs {counts.tolist()}"
+        for b in range(B):
+            assert np.array_equal(gp[b, : gc[b]], pids[b, : counts[b]]) and np.array_equal(gs[b, : gc[b]], scores[b, : counts[b]]), \
+                f"device-resident search, query {b}: differs from the host-buffer search"
+        TALLY["search_device"] = TALLY.get("search_device", 0) + 1
     return shape
 
 
