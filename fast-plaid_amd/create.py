@@ -153,9 +153,14 @@ def create_index(index_path: str, documents_embeddings, centroids, nbits: int = 
     held = heldout_sample(docs16, np.random.default_rng(seed)) if heldout is None else _np(heldout, np.float16)
     if held.shape[0] == 0:
         raise ValueError("Cannot train codec: no heldout samples were generated.")   # create.rs:301-305
-    n_tok = float(sum(d.shape[0] for d in docs16))
-    num_partitions = int(2 ** math.floor(math.log2(16.0 * math.sqrt(n_tok))))        # create.rs:292-294: the IVF's list count
+    # create.rs:239-243, :292-294: the IVF's list count, from n_docs * (sum / n_docs) in doubles like the reference (a total that sits
+    # on a power of four must round the way it does there)
+    n_tok = float(n) * (float(sum(d.shape[0] for d in docs16)) / float(n))
+    num_partitions = int(2 ** math.floor(math.log2(16.0 * math.sqrt(n_tok))))
     arr = build_index_arrays(docs16, centroids, nbits, device, heldout=held, num_partitions=num_partitions)
+    # what metadata.json carries (create.rs:572) -- the estimate itself, also when the centroids given number more (bincount's
+    # minlength, :542: the lists then reach the highest code) and in compress_only mode; update.rs:66 reads it back as the list count
+    arr["num_partitions"] = num_partitions
     if compress_only:
         arr["ivf"] = None
         arr["ivf_lengths"] = None

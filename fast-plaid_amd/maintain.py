@@ -118,7 +118,6 @@ def delete_from_index(index_path: str, subset) -> None:
     meta_path = os.path.join(index_path, "metadata.json")
     meta = _read_json(meta_path)
     n_chunks, nbits, n_partitions = int(meta["num_chunks"]), int(meta["nbits"]), int(meta["num_partitions"])
-    compress_only = bool(meta.get("compress_only", False))
     drop = set(int(x) for x in subset)
     doc0 = 0
     for i in range(n_chunks):
@@ -139,10 +138,9 @@ def delete_from_index(index_path: str, subset) -> None:
             cm["num_embeddings"] = int(codes.shape[0])
             _write_json(cm_path, cm, pretty=True)
         doc0 += len(lens)
-    if compress_only:
-        T = sum(int(np.load(os.path.join(index_path, f"{i}.codes.npy"), mmap_mode="r").shape[0]) for i in range(n_chunks))
-        N = sum(len(_read_json(os.path.join(index_path, f"doclens.{i}.json"))) for i in range(n_chunks))
-    else:
-        T, N = _rebuild_ivf(index_path, n_chunks, n_partitions)
+    # delete.rs:105-143 never looks at compress_only: the lists are rebuilt from the chunks' codes and the metadata is written WITHOUT
+    # the key -- deleting from a compress_only index leaves a searchable one.  Followed to the letter (until round 6 this kept the
+    # flag and wrote no lists; tests/maintain_fuzz_worker.py compares the directories file by file).
+    T, N = _rebuild_ivf(index_path, n_chunks, n_partitions)
     _write_json(meta_path, {"num_chunks": n_chunks, "nbits": nbits, "num_partitions": n_partitions, "num_embeddings": T,
-                            "avg_doclen": (T / N) if N else 0.0, "num_documents": N, "compress_only": compress_only}, pretty=True)
+                            "avg_doclen": (T / N) if N else 0.0, "num_documents": N}, pretty=True)

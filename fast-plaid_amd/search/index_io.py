@@ -101,6 +101,7 @@ def save_index_arrays(index_path: str, arr: dict, chunk_docs: int = 25_000, writ
         np.save(os.path.join(index_path, "ivf_lengths.npy"), np.asarray(arr["ivf_lengths"], dtype=np.int32))
     with open(os.path.join(index_path, "metadata.json"), "w") as f:
         json.dump({"num_chunks": n_chunks, "nbits": int(arr["nbits"]),
-                   "num_partitions": 0 if compress_only else int(np.asarray(arr["ivf_lengths"]).shape[0]),
+                   "num_partitions": int(arr["num_partitions"]) if arr.get("num_partitions") is not None
+                   else (0 if compress_only else int(np.asarray(arr["ivf_lengths"]).shape[0])),
                    "num_embeddings": T, "avg_doclen": (T / n_docs) if n_docs else 0.0, "num_documents": n_docs,
                    "compress_only": bool(compress_only)}, f)

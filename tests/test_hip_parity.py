@@ -1363,6 +1363,21 @@ def test_create_update_delete_vs_reference_restatement(fp, tmp_path):
     check("deleted", d)
 
 
+@pytest.mark.parametrize("worker,n_cases", [("create_fuzz_worker.py", 25), ("maintain_fuzz_worker.py", 250)])
+def test_index_build_and_maintenance_fuzz(fp, worker, n_cases):
+    """SURVEY 8 rows f1 / f2 / f4 on DRAWN inputs, against the ATen restatements run live (the fixtures pin one sequence):
+    create_fuzz_worker.py -- fp_compress + codec training + IVF against oracle/plaid_oracle_torch.py (codes, packed bytes, cutoffs,
+    weights, lists identical; duplicated centroids, unnormalised tokens, 1- and 8-bit residuals);
+    maintain_fuzz_worker.py -- create -> sequences of update / delete against oracle/plaid_index_oracle_torch.py, the two
+    directories compared file by file after every operation (compress_only included).  Round 6: 300 + 5000 cases
+    (profiles/r06_fuzz.txt); this fuzz found the two metadata differences fixed in that round."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", worker), str(n_cases), "606"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and f"FUZZ_OK {n_cases}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def _same_order_modulo_ref_ties(ids_hip, ids_ref, score_ref):
     """ids_hip must list the documents of ids_ref in the same order, except that documents the oracle scores identically may
     be permuted among themselves (ATen's sort is not stable: their order is implementation-defined)."""
