@@ -359,21 +359,30 @@ static hipError_t dev_alloc(fp_index* ix, T** p, size_t n) {
   return hipSuccess;
 }
 
-static int upload_narrow(const int64_t* host, int32_t* dev, int64_t n, hipStream_t st) {
+// limit > 0: every entry must lie in [0, limit) -- `what` names the array in the error (the reference fails on such an index
+// inside index_select, per query; a code that is no centroid or a list entry that is no document would be an out-of-bounds
+// read on the device here, so the index is refused when it is built)
+static int upload_narrow(const int64_t* host, int32_t* dev, int64_t n, hipStream_t st, int64_t limit = 0, const char* what = "") {
   // chunked i64 -> i32 through a device staging buffer
   if (n <= 0) return FP_OK;
   const int64_t chunk = 32ll << 20;  // 32M entries = 256 MiB
   int64_t* stage = nullptr;
-  HIPCHK(hipMalloc((void**)&stage, (size_t)std::min(chunk, n) * 8));
-  for (int64_t s = 0; s < n; s += chunk) {
+  const size_t stage_bytes = (size_t)std::min(chunk, n) * 8;
+  HIPCHK(hipMalloc((void**)&stage, stage_bytes + 8));
+  uint32_t* bad = limit > 0 ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(stage) + stage_bytes) : nullptr;
+  uint32_t h_bad = 0;
+  hipError_t e = bad ? hipMemsetAsync(bad, 0, 4, st) : hipSuccess;
+  for (int64_t s = 0; s < n && e == hipSuccess; s += chunk) {
     int64_t m = std::min(chunk, n - s);
-    hipError_t e = hipMemcpyAsync(stage, host + s, (size_t)m * 8, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { (void)hipFree(stage); return fail(FP_EHIP, hipGetErrorString(e)); }
-    fpk_narrow_i64_i32(stage, dev + s, m, 0, st);
+    e = hipMemcpyAsync(stage, host + s, (size_t)m * 8, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) break;
+    fpk_narrow_i64_i32(stage, dev + s, m, 0, st, limit, bad);
     e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(stage); return fail(FP_EHIP, hipGetErrorString(e)); }
   }
+  if (e == hipSuccess && bad) e = hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost);
   (void)hipFree(stage);
+  if (e != hipSuccess) return fail(FP_EHIP, hipGetErrorString(e));
+  if (h_bad) return fail(FP_EINVAL, std::string(what) + ": " + std::to_string(h_bad) + " entries outside [0, " + std::to_string(limit) + ")");
   return FP_OK;
 }
 
@@ -575,7 +584,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   ICHK(dev_alloc(ix, &doc_off, (size_t)D.N + 1));
   ICHK(hipMemcpy(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice));
   ICHK(dev_alloc(ix, &codes, (size_t)D.T));
-  if (int rc = upload_narrow(d->doc_codes, codes, D.T, st)) return bail(rc);
+  if (int rc = upload_narrow(d->doc_codes, codes, D.T, st, D.C, "doc_codes (centroid ids)")) return bail(rc);
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   if (D.T > 0) ICHK(hipMemcpy(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice));
   D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res;
@@ -592,8 +601,37 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
     ICHK(hipMemcpy(ivf_off, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice));
     const int64_t tot = hoff[D.P];
     ICHK(dev_alloc(ix, &ivf_pids, (size_t)tot));
-    if (tot > 0)
-      if (int rc = upload_narrow(d->ivf, ivf_pids, tot, st)) return bail(rc);
+    if (tot > 0) {
+      if (int rc = upload_narrow(d->ivf, ivf_pids, tot, st, std::max<int64_t>(D.N, 1), "ivf (document ids)")) return bail(rc);
+      // The reference gathers the probed lists and sorts + de-duplicates the ids per query (search.rs:538-541): any order inside a
+      // list, repeated ids included, gives the same candidates there.  S3's per-tile range cut needs strictly ascending lists --
+      // what create.rs / update.rs / delete.rs write (optimize_ivf).  Anything else is put in that order here, once.
+      uint32_t* flag = nullptr;
+      ICHK(hipMalloc((void**)&flag, 4));
+      uint32_t h_flag = 0;
+      hipError_t fe = hipMemsetAsync(flag, 0, 4, st);
+      if (fe == hipSuccess) {
+        fpk_ivf_check_sorted(ivf_off, ivf_pids, D.P, flag, st);
+        fe = hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, st);
+      }
+      if (fe == hipSuccess) fe = hipStreamSynchronize(st);
+      (void)hipFree(flag);
+      ICHK(fe);
+      if (h_flag) {
+        std::vector<int64_t> fixed;
+        fixed.reserve((size_t)tot);
+        std::vector<int64_t> noff((size_t)D.P + 1, 0);
+        for (int64_t i = 0; i < D.P; ++i) {
+          const size_t b = fixed.size();
+          fixed.insert(fixed.end(), d->ivf + hoff[i], d->ivf + hoff[i + 1]);
+          std::sort(fixed.begin() + b, fixed.end());
+          fixed.erase(std::unique(fixed.begin() + b, fixed.end()), fixed.end());
+          noff[i + 1] = (int64_t)fixed.size();
+        }
+        ICHK(hipMemcpy(ivf_off, noff.data(), noff.size() * 8, hipMemcpyHostToDevice));
+        if (int rc = upload_narrow(fixed.data(), ivf_pids, (int64_t)fixed.size(), st)) return bail(rc);
+      }
+    }
   }
   ICHK(hipStreamSynchronize(st));
 #undef ICHK

@@ -378,7 +378,8 @@ void fpk_shard_pack3(const int32_t* marks, const int32_t* nmark, const float* u_
 void fpk_shard_apply3(const int32_t* marks, const int32_t* nmark, const float* u_unc, const int32_t* u_cnt, const int32_t* u_src, int B, int64_t R,
                       const float* xall /*[G][xstride]; xstride 0 = B * R*/, float* u_score, hipStream_t st, int64_t xstride = 0);
 // misc
-void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st);
+void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st, int64_t limit = 0, uint32_t* bad = nullptr);
+void fpk_ivf_check_sorted(const int64_t* off, const int32_t* pids, int64_t P, uint32_t* flag, hipStream_t st);
 // create.rs:148-184, :404-428 on device pointers: nearest centroid (MFMA narrowing + exact re-check of the near-ties, or the exact
 // kernel alone; codes32 scratch, codes64 output) + quantised packed residuals.  cmaxabs = max |centroid element| (bounds the MFMA
 // summation error); work = fpk_compress_work_bytes(T) bytes of device scratch (nullptr: exact kernel only).

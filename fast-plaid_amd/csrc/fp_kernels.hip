@@ -5435,13 +5435,35 @@ void fpk_shard_apply3(const int32_t* marks, const int32_t* nmark, const float* u
 // ============================================================================================
 // misc
 // ============================================================================================
-__global__ void k_narrow(const int64_t* __restrict__ in, int32_t* __restrict__ out, int64_t n, int64_t add) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = (int32_t)(in[i] + add);
+// bad (may be null): counts the entries outside [0, limit) -- a code that is no centroid, a list entry that is no document
+__global__ void k_narrow(const int64_t* __restrict__ in, int32_t* __restrict__ out, int64_t n, int64_t add, int64_t limit, uint32_t* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = in[i];
+    if (bad && (v < 0 || v >= limit)) atomicAdd(bad, 1u);
+    out[i] = (int32_t)(v + add);
+  }
 }
-void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st) {
+void fpk_narrow_i64_i32(const int64_t* in, int32_t* out, int64_t n, int64_t add, hipStream_t st, int64_t limit, uint32_t* bad) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_narrow, dim3(fp_grid_cap((n + 255) / 256, 256)), dim3(256), 0, st, in, out, n, add);
+  hipLaunchKernelGGL(k_narrow, dim3(fp_grid_cap((n + 255) / 256, 256)), dim3(256), 0, st, in, out, n, add, limit, bad);
+}
+
+// the IVF lists as construct_index receives them: *flag != 0 when some list is not strictly ascending (the reference sorts and
+// de-duplicates the gathered ids per query, search.rs:538-541, so it takes any order; S3's range cut needs ascending lists).
+// One wave per list.
+__global__ __launch_bounds__(256) void k_ivf_check_sorted(const int64_t* __restrict__ off, const int32_t* __restrict__ pids, int64_t P,
+                                                          uint32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t list = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); list < P; list += (int64_t)gridDim.x * 4) {
+    const int64_t beg = off[list], end = off[list + 1];
+    bool bad = false;
+    for (int64_t i = beg + lane; i + 1 < end; i += 64) bad |= pids[i] >= pids[i + 1];
+    if (bad) atomicOr(flag, 1u);
+  }
+}
+void fpk_ivf_check_sorted(const int64_t* off, const int32_t* pids, int64_t P, uint32_t* flag, hipStream_t st) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(k_ivf_check_sorted, dim3(fp_grid_cap((P + 3) / 4, 256)), dim3(256), 0, st, off, pids, P, flag);
 }
 
 // reconstruct_embeddings (embeddings.rs:12-69): decompress rows to fp32.  One 64-thread

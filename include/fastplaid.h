@@ -39,7 +39,11 @@ typedef struct fp_shard_ctx fp_shard_ctx; /* one in-flight sharded search (multi
 
 /* Argument set of `construct_index` (rust/search/load.rs:124-138), as host arrays.
  * Trailing padding rows on doc_codes/doc_residuals (python load.py:298-320) are ignored:
- * only the first sum(doc_lengths) rows are read. */
+ * only the first sum(doc_lengths) rows are read.
+ * Validation (fp_index_create returns FP_EINVAL): every doc_codes entry must be a centroid id in [0, n_centroids), every ivf
+ * entry a document id in [0, n_docs) -- the reference fails on such arrays inside index_select at search time; here they would be
+ * out-of-bounds device reads.  IVF lists may come in any order and repeat ids (the reference sorts and de-duplicates the gathered
+ * ids per query, search.rs:538-541): lists that are not strictly ascending are sorted and de-duplicated once, at creation. */
 typedef struct fp_index_desc {
   int32_t nbits;                  /* 1, 2, 4 or 8 (8 % nbits == 0)                        */
   int32_t dim;                    /* embedding dimension: any multiple of 8 up to 1024    */

@@ -744,6 +744,62 @@ def test_fuzz_vs_oracle(fp, form, mode, n_cases):
     assert r.returncode == 0 and f"FUZZ_OK {n_cases}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_index_arrays_the_writers_never_produce(fp):
+    """construct_index takes ANY arrays (load.rs:124-138).  (1) IVF lists in arbitrary order with repeated ids: the reference sorts and
+    de-duplicates the gathered ids per query (search.rs:538-541), so such lists search like the sorted ones -- fp_index_create puts
+    them in order once (S3's range cut needs ascending lists); compared with the oracle and with the index built from the tidy
+    lists.  (2) A code that is no centroid / a list entry that is no document: the reference fails inside index_select; here it
+    would be an out-of-bounds device read, so fp_index_create refuses the arrays (FP_EINVAL), called below the Python checks."""
+    import ctypes as C
+    from fast_plaid_amd import _native as N
+    R = fp.fast_plaid_rust
+    rng = np.random.default_rng(77)
+    arr = _random_arrays(rng, 3000, 30, 257, 128, 4)
+    messy = dict(arr)
+    ivf, il = arr["ivf"].copy(), arr["ivf_lengths"].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(il)])
+    parts, lens = [], []
+    for c in range(il.shape[0]):
+        lst = ivf[off[c]: off[c + 1]]
+        if lst.size:
+            lst = np.concatenate([lst, lst[rng.integers(0, lst.size, int(rng.integers(0, 4)))]])   # repeated ids
+            lst = lst[rng.permutation(lst.size)]
+        parts.append(lst)
+        lens.append(lst.size)
+    messy["ivf"], messy["ivf_lengths"] = np.concatenate(parts).astype(np.int64), np.asarray(lens, np.int32)
+    q = arr["centroids"][rng.integers(0, 257, (5, 32))].astype(np.float32) + 0.3 * rng.standard_normal((5, 32, 128), dtype=np.float32) / np.sqrt(128)
+    q = (q / np.linalg.norm(q, axis=2, keepdims=True)).astype(np.float16)
+    params = R.SearchParameters(2000, 256, 20, 8)
+    tidy, got = R.search_arrays(_hip_index(fp, arr), q, params), R.search_arrays(_hip_index(fp, messy), q, params)
+    assert all(np.array_equal(a, b) for a, b in zip(tidy, got))
+    ref = _oracle(messy).search(q, 20, 256, 8)
+    for b in range(5):
+        check_final(got[0][b, : got[2][b]], got[1][b, : got[2][b]], ref[b][0], ref[b][1], 20)
+
+    def create(a):
+        cent, bw = np.ascontiguousarray(a["centroids"], np.float16), np.ascontiguousarray(a["bucket_weights"], np.float16)
+        iv, ivl = np.ascontiguousarray(a["ivf"], np.int64), np.ascontiguousarray(a["ivf_lengths"], np.int32)
+        codes, res = np.ascontiguousarray(a["doc_codes"], np.int64), np.ascontiguousarray(a["doc_residuals"], np.uint8)
+        lens_ = np.ascontiguousarray(a["doc_lengths"], np.int64)
+        ptr = lambda x: x.ctypes.data_as(C.c_void_p)   # noqa: E731
+        d = N.FpIndexDesc(int(a["nbits"]), int(cent.shape[1]), int(cent.shape[0]), ptr(cent), None, None, ptr(bw), ptr(iv), ptr(ivl),
+                          int(ivl.shape[0]), ptr(codes), ptr(res), ptr(lens_), int(lens_.shape[0]), 0)
+        h = C.c_void_p()
+        rc = N.lib().fp_index_create(C.byref(d), 0, C.byref(h))
+        if rc == 0:
+            N.lib().fp_index_destroy(h)
+        return rc, N.lib().fp_last_error().decode()
+
+    assert create(arr)[0] == 0
+    for key, pos, val, what in (("doc_codes", 11, 257, "doc_codes"), ("doc_codes", 5, -1, "doc_codes"), ("ivf", 3, 3000, "ivf"), ("ivf", 0, -7, "ivf")):
+        bad = dict(arr)
+        bad[key] = arr[key].copy()
+        bad[key][pos] = val
+        rc, msg = create(bad)
+        assert rc != 0 and what in msg and "outside" in msg, (key, val, rc, msg)
+    assert create(arr)[0] == 0   # (the device is fine afterwards)
+
+
 def test_concurrent_searches_on_one_index(fp):
     """fp_search is re-entrant on a shared index (load.rs:58-59 Send+Sync; the reference's thread-per-device and
     joblib paths share one index object): 6 threads x 5 calls with different batches == the sequential results."""
