@@ -35,6 +35,24 @@ __device__ __forceinline__ uint32_t pk_floor_raw(uint32_t y) {
       : "v"(y));
   return r;
 }
+// fp16 rounding mode of the wave (MODE.fp_round[3:2], shared with fp64): 0 nearest-even, 2 toward -inf.  Volatile, like the
+// instructions that are meant to run under it (pk_fma_rd_raw): the compiler keeps volatile asm statements in program order.
+__device__ __forceinline__ void f16_round_down() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2\n\ts_nop 1"); }
+__device__ __forceinline__ void f16_round_nearest() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\ts_nop 1"); }
+// a * b + c on both halves, ONE rounding, in the wave's current fp16 rounding mode
+__device__ __forceinline__ uint32_t pk_fma_mode_raw(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+}
 __device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
 // order-preserving maps (larger float <-> larger unsigned)

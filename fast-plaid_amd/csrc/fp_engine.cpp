@@ -963,10 +963,12 @@ static int run_front(Pipe& P, const int64_t* h_sub_ids, const int64_t* h_sub_off
     if (fpk_centroid_scores(D1, q_s1, s->Ssample.as<uint16_t>(), B, sh.Qp, s->S8.as<uint8_t>(), nullptr, st, ns, sstride))
       return fail(FP_EUNSUPPORTED, "dim");
     HIPCHK(s->l0_gfl.ensure((size_t)B * sh.Qp * 2));
+    static const int s1_rd = fp_test_opt("s1_rd", 1) != 0 ? 1 : 0;   // the epilogue's one-fma form of the excess (0: the floor / clamp / subtract form, for A/B runs)
     fpk_l0_floors(s->S8.as<uint8_t>(), ns, sh, s->l0_floors.as<uint8_t>(), s->l0_F.as<uint32_t>(), s->l0_esc.as<uint32_t>(), s->l0_gfl.as<uint16_t>(), st,
-                  P.l0_hot ? std::min(0.02f, std::max(0.001f, (float)((double)std::max<int64_t>(D.N, 1) / (1.2 * (double)std::max<int64_t>(D.U, 1))))) : 0.f);
+                  P.l0_hot ? std::min(0.02f, std::max(0.001f, (float)((double)std::max<int64_t>(D.N, 1) / (1.2 * (double)std::max<int64_t>(D.U, 1))))) : 0.f,
+                  s1_rd);
     if (Cpad > D.C) HIPCHK(hipMemsetAsync(s->l0_e8.p, 0, (size_t)B * Cpad, st));   // pad entries behind the table stay 0
-    FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_gfl.as<uint16_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q};
+    FpS1Excess ex{s->l0_floors.as<uint8_t>(), s->l0_gfl.as<uint16_t>(), s->l0_e8.as<uint8_t>(), s->l0_esc.as<uint32_t>(), Cpad, sh.Q, s1_rd};
     STAGE_DONE(ST_S1MAIN);
     if (fpk_centroid_scores(D1, q_s1, s->S.as<uint16_t>(), B, sh.Qp, nullptr, s->cmax128.as<uint16_t>(), st, 0, 1, &ex, &xe))
       return fail(FP_EUNSUPPORTED, "dim");

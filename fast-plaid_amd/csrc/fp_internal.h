@@ -161,11 +161,12 @@ void fpk_pack_queries(const uint16_t* q_dev_in /*[B,Q,D]*/, uint16_t* q_pad /*[B
 // epilogue from the column floors of a sampled pre-pass
 struct FpS1Excess {
   const uint8_t* floors;   // [B][Qp]
-  const uint16_t* gfl;     // [B][Qp] fp16: floor - 100 (2000 for the pad columns)
+  const uint16_t* gfl;     // [B][Qp] fp16: g = floor - 100 (2000 for the pad columns); rd != 0: 1024 - g instead
   uint8_t* e8;             // [B][Cpad] (nullptr: off)
   uint32_t* esc;           // [B][64]
   int64_t Cpad;
   int Q;                   // real query columns
+  int rd;                  // the epilogue's one-fma form (s1_writeout): gfl holds 1024 - g
 };
 // Exact centroid scores (round 4).  The MFMA sums the 128 products in another order than the reference's ascending fp32 chain
 // (search.rs:491 = ATen's half matmul), so ~0.05 % of the fp16 results differed by one ulp.  S1 now certifies every entry: the fp32
@@ -295,7 +296,8 @@ size_t fpk_l0_hist_bytes(int B);
 size_t fpk_sel_hist_bytes(int B);
 void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride);
 void fpk_l0_floors(const uint8_t* S8_sample, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc,
-                   uint16_t* gfl /*[B][Qp] fp16 floors for S1's epilogue*/, hipStream_t st, float hot_tail = 0.f /*> 0: k_l0h_scan's floors, the (1 - hot_tail) quantile*/);
+                   uint16_t* gfl /*[B][Qp] fp16 floors for S1's epilogue*/, hipStream_t st, float hot_tail = 0.f /*> 0: k_l0h_scan's floors, the (1 - hot_tail) quantile*/,
+                   int gfl_rd = 0 /*FpS1Excess::rd*/);
 // level 0 for documents with many distinct codes: per-column maxima over the HOT codes only (k_l0h_scan); same outputs as fpk_l0_scan
 bool fpk_l0h_fits(const FpIndexDev& ix);
 void fpk_l0h_scan(const FpIndexDev& ix, const uint16_t* S, const FpSearchShape& sh, const int64_t* cand_off, const int32_t* cand_pid, int64_t M,

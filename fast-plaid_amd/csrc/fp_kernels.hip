@@ -354,21 +354,44 @@ __device__ __forceinline__ void s1_writeout(unsigned char* smem, const int tid, 
       // bound -- loosened the table enough to let 503 k instead of 391 k documents per batch through to the exact rescoring.)
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       const uint32_t gws[4] = {gw.x, gw.y, gw.z, gw.w};
-      const h2 k128 = {(half_t)128.f, (half_t)128.f}, k155 = {(half_t)155.f, (half_t)155.f}, kzero = {(half_t)0.f, (half_t)0.f};
-      h2 dsum = kzero;
-      uint32_t tmax = 0xE400E400u;   // packed -1024
+      uint32_t part, inf;
+      if (ex.rd) {
+        // Round 6, the one-fma form: with the wave's fp16 rounding set toward -inf, fma(x, 128, 1024 - g) IS 1024 + floor(128 x - g)
+        // whenever that is >= 1024 (fp16 steps by 1 in [1024, 2048); 128 x is exact, g an integer, one rounding), and anything
+        // below 1024 is an excess of 0: y = max(fma, 1024) has the excess in its mantissa bits, 0x6400 + e.  Summed as 16-bit
+        // integers from 0x7000 = -4 * 0x6400 (mod 2^16) the four biases cancel by themselves.  Three instructions per pair of
+        // scores instead of eight (multiply, two floors, running maximum, clamp, subtract, max, add).  The clamp at bin 255 needs no
+        // arithmetic: a clamped bin (128 x >= 155, i.e. x >= 1.2109375 = 0x3CD8, compared as integers -- positive halves order
+        // like their bits, negative ones are negative) makes the centroid's entry infinite whatever the sum came to, and a sum
+        // that left the [1024, 2048) window (x >= 7.2) is such a case.  Pad columns carry 1024 - 2000.
+        uint32_t acc16 = 0x70007000u, tmax = 0x80008000u;
+        f16_round_down();
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t fl = pk_floor_raw(h2_as_u32(u32_as_h2(w[t]) * k128));
-        tmax = pk_max_raw(tmax, fl);
-        const h2 d = u32_as_h2(pk_min_raw(fl, h2_as_u32(k155))) - u32_as_h2(gws[t]);
-        dsum += u32_as_h2(pk_max_raw(h2_as_u32(d), 0u));
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t y = pk_fma_mode_raw(w[t], 0x58005800u /*128, 128*/, gws[t]);
+          acc16 = pk_add_u16(acc16, pk_max_raw(y, 0x64006400u /*1024, 1024*/));
+          tmax = pk_max_i16(tmax, w[t]);
+        }
+        f16_round_nearest();
+        part = (acc16 & 0xFFFFu) + (acc16 >> 16);
+        inf = ((int)(short)(tmax & 0xFFFFu) >= 0x3CD8 || (int)(short)(tmax >> 16) >= 0x3CD8) ? L0_EINF : 0u;
+      } else {
+        const h2 k128 = {(half_t)128.f, (half_t)128.f}, k155 = {(half_t)155.f, (half_t)155.f}, kzero = {(half_t)0.f, (half_t)0.f};
+        h2 dsum = kzero;
+        uint32_t tmax = 0xE400E400u;   // packed -1024
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t fl = pk_floor_raw(h2_as_u32(u32_as_h2(w[t]) * k128));
+          tmax = pk_max_raw(tmax, fl);
+          const h2 d = u32_as_h2(pk_min_raw(fl, h2_as_u32(k155))) - u32_as_h2(gws[t]);
+          dsum += u32_as_h2(pk_max_raw(h2_as_u32(d), 0u));
+        }
+        // four integer terms of at most 255 per half: their total stays below 2048, exact in fp16
+        part = (uint32_t)(int)(float)(half_t)(dsum.x + dsum.y);
+        const h2 tm = u32_as_h2(tmax);
+        inf = (tm.x >= (half_t)155.f || tm.y >= (half_t)155.f) ? L0_EINF : 0u;
       }
-      // four integer terms of at most 255 per half: their total stays below 2048, exact in fp16
-      const uint32_t part = (uint32_t)(int)(float)(half_t)(dsum.x + dsum.y);
-      const h2 tm = u32_as_h2(tmax);
-      const uint32_t inf = (tm.x >= (half_t)155.f || tm.y >= (half_t)155.f) ? L0_EINF : 0u;
-      uint32_t acc = part + inf;   // (the sums stay far below L0_EINF: at most 64 columns x 255)
+      uint32_t acc = part + inf;   // (the sums stay far below L0_EINF: at most 64 columns x 255; a garbage sum -- only next to a clamped bin -- below 2^17 per lane)
       acc += (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
       acc += (uint32_t)__builtin_amdgcn_mov_dpp((int)acc, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
       eacc[it] = acc;
@@ -2739,7 +2762,7 @@ void fpk_approx_q8_cut(const FpSearchShape& sh, const int64_t* cand_off, const i
 // floors[b][Qp] u8 (pad columns 0), Fsum[b]; one workgroup per query
 __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S8, int64_t C, int Q, int nch, float tail,
                                                    uint8_t* __restrict__ floors, uint32_t* __restrict__ Fsum, uint32_t* __restrict__ esc,
-                                                   half_t* __restrict__ gfl /*nullable*/) {
+                                                   half_t* __restrict__ gfl /*nullable*/, int gfl_rd = 0) {
   extern __shared__ uint32_t l0h[];   // [nch*32][257]: a column's bins, rows padded by one word so that the per-column scans below hit 32 banks
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid < 64) esc[(int64_t)b * 64 + tid] = 0u;   // the query's escape slots (filled by whoever builds the table next)
@@ -2816,7 +2839,10 @@ __global__ __launch_bounds__(1024) void k_l0_floor(const uint8_t* __restrict__ S
     if (lane == 0) {
       fl[col] = f;
       floors[(int64_t)b * ncol + col] = (uint8_t)f;
-      if (gfl) gfl[(int64_t)b * ncol + col] = col < Q ? (half_t)((float)f - 100.f) : (half_t)2000.f;   // S1's epilogue form of the floors
+      if (gfl) {   // S1's epilogue form of the floors: g = f - 100 (pads 2000), or 1024 - g for its one-fma form (FpS1Excess::rd)
+        const float g = col < Q ? (float)f - 100.f : 2000.f;
+        gfl[(int64_t)b * ncol + col] = (half_t)(gfl_rd ? 1024.f - g : g);
+      }
     }
   }
   __syncthreads();
@@ -3823,7 +3849,7 @@ void fpk_l0_sample_plan(const FpIndexDev& ix, int64_t* n_rows, int64_t* stride) 
   *n_rows = (ix.C + *stride - 1) / *stride;
 }
 void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, uint8_t* floors, uint32_t* Fsum, uint32_t* esc, uint16_t* gfl,
-                   hipStream_t st, float hot_tail) {
+                   hipStream_t st, float hot_tail, int gfl_rd) {
   const int nch = sh.Qp / 32;
   static const float tail0 = [] { const float v = (float)fp_test_opt("l0_tail", 0.025); return (v > 0.f && v < 0.5f) ? v : 0.025f; }();
   static const float tailh = [] { const float v = (float)fp_test_opt("l0h_tail", 0.0); return (v > 0.f && v < 0.5f) ? v : 0.f; }();   // (0: the caller's)
@@ -3832,7 +3858,7 @@ void fpk_l0_floors(const uint8_t* S8s, int64_t n_rows, const FpSearchShape& sh, 
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
   // n_rows <= L0_SAMPLE * 2: the kernel's own sampling stride over this table is 1 or (for 8192 < n_rows) still covers it
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)sh.B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8s, n_rows, sh.Q, nch, tail, floors, Fsum, esc,
-                     reinterpret_cast<half_t*>(gfl));
+                     reinterpret_cast<half_t*>(gfl), gfl_rd);
 }
 
 // S8 != nullptr: floors and the table from the full 8-bit table (two passes over it);  S8 == nullptr: both were produced
@@ -3848,7 +3874,7 @@ void fpk_l0_prepare(const FpIndexDev& ix, const uint8_t* S8, const FpSearchShape
   static std::atomic<uint64_t> ok1{0};
   fp_allow_big_lds((const void*)k_l0_floor, ok1, 136 * 1024);   // (four column chunks: 128 x 257 words)
   hipLaunchKernelGGL(k_l0_floor, dim3((unsigned)B), dim3(1024), (size_t)nch * 32 * 257 * 4, st, S8, ix.C, sh.Q, nch, tail, w.floors, w.Fsum, w.esc,
-                     (half_t*)nullptr);
+                     (half_t*)nullptr, 0);
   hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((Cpad + 255) / 256), (unsigned)B), dim3(256), 0, st, S8, ix.C, Cpad, sh.Q, nch, w.floors, w.e8,
                      w.esc);
 }
