@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing-only probes of S1's epilogue (results wrong by construction): s1_rd bit 1 = no floor loads, bit 2 = no table store,
 # bit 3 = table store without the byte encoding.  Level 0 forced so that the broken table does not change the engine's choice.
+# (The bits were temporary edits of s1_writeout / the engine's s1_rd key and are not in the tree: profiles/r06_s1_rd.txt says what they did.)
 R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
 for rd in 1 3 5 9 7; do
   rm -rf /tmp/pp$rd
