@@ -97,6 +97,39 @@ struct DevBuf {
 };
 
 // grow-only pinned host buffer (results come down in ONE async copy instead of three staged ones)
+// Every entry point selects its index's device through this.  First call on a thread: the thread's stream-capture interaction mode
+// becomes "relaxed".  fp_search captures its batch pipeline into a HIP graph on its own non-blocking stream; with the default
+// (global) mode the runtime refuses potentially unsafe calls -- allocations, synchronous copies -- on EVERY thread while any
+// capture is open, and one refused call invalidates the capture: two threads searching one index failed each other's calls
+// (found by tests/fuzz_worker.py threads, round 6).  Relaxed means what the library needs: its captures concern the capturing
+// stream only.
+static hipError_t fp_set_device(int device) {
+  static thread_local bool relaxed = false;
+  if (!relaxed) {
+    hipStreamCaptureMode m = hipStreamCaptureModeRelaxed;
+    (void)hipThreadExchangeStreamCaptureMode(&m);
+    relaxed = true;
+  }
+  return hipSetDevice(device);
+}
+
+// The library never touches the legacy (null) stream: a synchronous hipMemcpy there is refused -- and invalidates the capture --
+// while another thread of the process captures a graph (fp_search does, on its scratch's stream).  Blocking copies go through
+// an explicit stream instead: the caller's own (index construction, a scratch) or this per-device utility stream.
+static hipStream_t util_stream(int device) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  std::lock_guard<std::mutex> g(mu);
+  hipStream_t& st = streams[device & 63];
+  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;   // (nullptr: the legacy stream after all)
+  return st;
+}
+static hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 struct HostBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -239,7 +272,10 @@ struct Scratch : ScratchGen {
     for (auto& e : ev)
       if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t d : retired) (void)hipStreamDestroy(d);
+    retired.clear();
   }
+  std::vector<hipStream_t> retired;   // streams given up after an invalidated capture (fresh_stream): destroyed with the scratch
 };
 
 struct fp_index {
@@ -291,6 +327,29 @@ static Scratch* new_scratch() {
   }
   for (auto& e : s->ev) (void)hipEventCreate(&e);
   return s;
+}
+static void fresh_stream(Scratch* s) {
+  hipStream_t fresh = nullptr;
+  // (the old stream is only retired here: destroying it while another thread sits in a legacy-stream call -- which walks the
+  // runtime's stream set -- crashed that thread once in 40 runs of the hostile fuzz; at most one per scratch, captures stop after it)
+  if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+    s->retired.push_back(s->st);
+    s->st = fresh;
+  }
+  (void)hipGetLastError();
+}
+// Closes a capture that cannot be used (an error inside it, or the runtime invalidated it) and gives the scratch a FRESH stream: on
+// this runtime a stream whose capture was invalidated from outside keeps returning "previous error during capture" after
+// hipStreamEndCapture (found by tests/fuzz_worker.py hostile).  Nothing is pending on the old stream: a capture runs nothing.
+static void abandon_capture(Scratch* s) {
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(s->st, &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  s->capturing = false;
+  s->graph.fails = 1000;
+  s->graph.warm = 0;
+  fresh_stream(s);
 }
 static Scratch* acquire(fp_index* ix) {
   {
@@ -379,7 +438,7 @@ static int upload_narrow(const int64_t* host, int32_t* dev, int64_t n, hipStream
     fpk_narrow_i64_i32(stage, dev + s, m, 0, st, limit, bad);
     e = hipStreamSynchronize(st);
   }
-  if (e == hipSuccess && bad) e = hipMemcpy(&h_bad, bad, 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && bad) e = copy_sync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st);
   (void)hipFree(stage);
   if (e != hipSuccess) return fail(FP_EHIP, hipGetErrorString(e));
   if (h_bad) return fail(FP_EINVAL, std::string(what) + ": " + std::to_string(h_bad) + " entries outside [0, " + std::to_string(limit) + ")");
@@ -547,7 +606,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   if (d->n_docs < 0 || (d->n_docs > 0 && (!d->doc_lengths || !d->doc_codes || !d->doc_residuals)))
     return fail(FP_EINVAL, "document arrays missing");
   if (d->n_docs >= 0x7FFFFFFFll) return fail(FP_EUNSUPPORTED, "more than 2^31-1 documents per index shard");
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   fp_index* ix = new fp_index();
   ix->device = device_id;
   auto bail = [&](int rc) {
@@ -573,20 +632,20 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   uint16_t* cent = nullptr; uint16_t* lut = nullptr; int64_t* doc_off = nullptr; int32_t* codes = nullptr; uint8_t* res = nullptr;
   int64_t* ivf_off = nullptr; int32_t* ivf_pids = nullptr;
 #define ICHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return bail(fail(FP_EHIP, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #x)); } while (0)
-  ICHK(hipStreamCreate(&st));
+  ICHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
-  ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
+  ICHK(copy_sync(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice, st));
   ix->cent_norm_max = max_row_norm_f16(d->centroids, D.C, D.dim);
   std::vector<uint16_t> hlut;
   build_lut_host(D.nbits, d->bucket_weights, hlut);
   ICHK(dev_alloc(ix, &lut, hlut.size()));
-  ICHK(hipMemcpy(lut, hlut.data(), hlut.size() * 2, hipMemcpyHostToDevice));
+  ICHK(copy_sync(lut, hlut.data(), hlut.size() * 2, hipMemcpyHostToDevice, st));
   ICHK(dev_alloc(ix, &doc_off, (size_t)D.N + 1));
-  ICHK(hipMemcpy(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice));
+  ICHK(copy_sync(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice, st));
   ICHK(dev_alloc(ix, &codes, (size_t)D.T));
   if (int rc = upload_narrow(d->doc_codes, codes, D.T, st, D.C, "doc_codes (centroid ids)")) return bail(rc);
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
-  if (D.T > 0) ICHK(hipMemcpy(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice));
+  if (D.T > 0) ICHK(copy_sync(res, d->doc_residuals, (size_t)D.T * D.pr, hipMemcpyHostToDevice, st));
   D.centroids = cent; D.lut = lut; D.doc_off = doc_off; D.codes = codes; D.residuals = res;
   if (int rc = finish_layout(ix, maxlen, st)) return bail(rc);
   ix->has_ivf = d->ivf != nullptr && d->ivf_lengths != nullptr;
@@ -598,7 +657,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
       hoff[i + 1] = hoff[i] + d->ivf_lengths[i];
     }
     ICHK(dev_alloc(ix, &ivf_off, hoff.size()));
-    ICHK(hipMemcpy(ivf_off, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice));
+    ICHK(copy_sync(ivf_off, hoff.data(), hoff.size() * 8, hipMemcpyHostToDevice, st));
     const int64_t tot = hoff[D.P];
     ICHK(dev_alloc(ix, &ivf_pids, (size_t)tot));
     if (tot > 0) {
@@ -628,7 +687,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
           fixed.erase(std::unique(fixed.begin() + b, fixed.end()), fixed.end());
           noff[i + 1] = (int64_t)fixed.size();
         }
-        ICHK(hipMemcpy(ivf_off, noff.data(), noff.size() * 8, hipMemcpyHostToDevice));
+        ICHK(copy_sync(ivf_off, noff.data(), noff.size() * 8, hipMemcpyHostToDevice, st));
         if (int rc = upload_narrow(fixed.data(), ivf_pids, (int64_t)fixed.size(), st)) return bail(rc);
       }
     }
@@ -642,7 +701,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
 
 extern "C" void fp_index_destroy(fp_index* ix) {
   if (!ix) return;
-  (void)hipSetDevice(ix->device);
+  (void)fp_set_device(ix->device);
   for (Scratch* s : ix->pool) {
     s->destroy();
     delete s;
@@ -672,7 +731,7 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   if (d->n_centroids <= 1 || (d->n_centroids & (d->n_centroids - 1))) return fail(FP_EINVAL, "n_centroids must be a power of two");
   if (d->doc_begin < 0 || d->doc_end < d->doc_begin || d->doc_end > d->n_docs_total) return fail(FP_EINVAL, "bad document range");
   if (d->doc_len < 1) return fail(FP_EINVAL, "doc_len < 1");
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   fp_index* ix = new fp_index();
   ix->device = device_id;
   ix->synthetic = true;
@@ -699,16 +758,16 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
   int64_t* ivf_off = nullptr; int32_t* ivf_pids = nullptr;
   StreamGuard sg;
   hipStream_t& st = sg.st;
-  ICHK(hipStreamCreate(&st));
+  ICHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   ICHK(dev_alloc(ix, &cent, (size_t)D.C * D.dim));
-  ICHK(hipMemcpy(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice));
+  ICHK(copy_sync(cent, d->centroids, (size_t)D.C * D.dim * 2, hipMemcpyHostToDevice, st));
   ix->cent_norm_max = max_row_norm_f16(d->centroids, D.C, D.dim);
   std::vector<uint16_t> hlut;
   build_lut_host(D.nbits, d->bucket_weights, hlut);
   ICHK(dev_alloc(ix, &lut, hlut.size()));
-  ICHK(hipMemcpy(lut, hlut.data(), hlut.size() * 2, hipMemcpyHostToDevice));
+  ICHK(copy_sync(lut, hlut.data(), hlut.size() * 2, hipMemcpyHostToDevice, st));
   ICHK(dev_alloc(ix, &doc_off, (size_t)D.N + 1));
-  ICHK(hipMemcpy(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice));
+  ICHK(copy_sync(doc_off, ix->h_doc_off.data(), ((size_t)D.N + 1) * 8, hipMemcpyHostToDevice, st));
   ICHK(dev_alloc(ix, &codes, (size_t)D.T));
   ICHK(dev_alloc(ix, &res, (size_t)D.T * D.pr));
   fps_generate(p, doc_off, D.N, D.T, tok_base, codes, res, st);
@@ -738,7 +797,7 @@ static inline void row_to_reference_order(const fp_index* ix, const uint8_t* sto
 
 extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* codes, uint8_t* residuals, int64_t cap) {
   if (!ix || doc < 0 || doc >= ix->d.N) return fail(FP_EINVAL, "bad document id");
-  (void)hipSetDevice(ix->device);
+  (void)fp_set_device(ix->device);
   const int64_t off = ix->h_doc_off[doc], len = ix->h_doc_off[doc + 1] - off;
   if (len > cap) return fail(FP_EINVAL, "capacity too small");
   const int pr = ix->d.pr;
@@ -746,9 +805,9 @@ extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* c
   std::vector<uint8_t> rtmp((size_t)len * pr);
   std::vector<uint16_t> perm((size_t)len);
   if (len > 0) {
-    HIPCHK(hipMemcpy(tmp.data(), ix->d.codes + off, (size_t)len * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rtmp.data(), ix->d.residuals + off * pr, (size_t)len * pr, hipMemcpyDeviceToHost));
-    if (ix->d.perm) HIPCHK(hipMemcpy(perm.data(), ix->d.perm + off, (size_t)len * 2, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(tmp.data(), ix->d.codes + off, (size_t)len * 4, hipMemcpyDeviceToHost, util_stream(ix->device)));
+    HIPCHK(copy_sync(rtmp.data(), ix->d.residuals + off * pr, (size_t)len * pr, hipMemcpyDeviceToHost, util_stream(ix->device)));
+    if (ix->d.perm) HIPCHK(copy_sync(perm.data(), ix->d.perm + off, (size_t)len * 2, hipMemcpyDeviceToHost, util_stream(ix->device)));
   }
   for (int64_t i = 0; i < len; ++i) {  // stored position i holds original token perm[i]
     const int64_t p = ix->d.perm ? perm[i] : i;
@@ -760,13 +819,13 @@ extern "C" int64_t fp_index_read_doc(const fp_index* ix, int64_t doc, int64_t* c
 
 extern "C" int64_t fp_index_read_ivf(const fp_index* ix, int64_t cell, int64_t* pids, int64_t cap) {
   if (!ix || !ix->has_ivf || cell < 0 || cell >= ix->d.P) return fail(FP_EINVAL, "bad cell");
-  (void)hipSetDevice(ix->device);
+  (void)fp_set_device(ix->device);
   int64_t be[2];
-  HIPCHK(hipMemcpy(be, ix->d.ivf_off + cell, 16, hipMemcpyDeviceToHost));
+  HIPCHK(copy_sync(be, ix->d.ivf_off + cell, 16, hipMemcpyDeviceToHost, util_stream(ix->device)));
   const int64_t len = be[1] - be[0];
   if (len > cap) return fail(FP_EINVAL, "capacity too small");
   std::vector<int32_t> tmp((size_t)len);
-  if (len > 0) HIPCHK(hipMemcpy(tmp.data(), ix->d.ivf_pids + be[0], (size_t)len * 4, hipMemcpyDeviceToHost));
+  if (len > 0) HIPCHK(copy_sync(tmp.data(), ix->d.ivf_pids + be[0], (size_t)len * 4, hipMemcpyDeviceToHost, util_stream(ix->device)));
   for (int64_t i = 0; i < len; ++i) pids[i] = tmp[i];
   return len;
 }
@@ -1426,9 +1485,13 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
                        const int64_t* subset_ids, const int64_t* subset_off, int64_t* out_pids, float* out_scores,
                        int32_t* out_counts, TraceOut* tr, bool dev_io = false, int64_t shared_subset_n = -1 /*>= 0: subset_ids is ONE list of that many ids for every query (subset_off unused)*/) {
   const FpIndexDev& D = ix->d;
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   if (dev_io) {
-    if (nq > 0) HIPCHK(hipMemset(out_counts, 0, (size_t)nq * 4));
+    if (nq > 0) {
+      hipStream_t us = util_stream(ix->device);
+      HIPCHK(hipMemsetAsync(out_counts, 0, (size_t)nq * 4, us));
+      HIPCHK(hipStreamSynchronize(us));
+    }
   } else {
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
   }
@@ -1449,14 +1512,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
   struct Rel {
     fp_index* ix; Scratch* s;
     ~Rel() {
-      if (s->capturing) {   // an error return in the middle of a capture: close it, or the stream stays unusable
-        hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(s->st, &g);
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        s->capturing = false;
-        s->graph.fails = 1000;
-      }
+      if (s->capturing) abandon_capture(s);   // an error return in the middle of a capture: close it, or the stream stays unusable
       release(ix, s);
     }
   } rel{ix, s};
@@ -1552,8 +1608,16 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     if (int rc = enqueue_batch(P, capture ? static_cast<const uint16_t*>(s->h_qin.p) : queries + (size_t)b0 * Q * D.dim,
                                dev_io ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, p, ol, sids, has_subset ? sub_off_local.data() : nullptr,
                                has_subset, tr != nullptr, dev_io ? out_pids + (size_t)b0 * K : nullptr, dev_io ? out_scores + (size_t)b0 * K : nullptr,
-                               dev_io ? out_counts + b0 : nullptr))
-      return rc;
+                               dev_io ? out_counts + b0 : nullptr)) {
+      if (!capture) return rc;
+      // an error INSIDE a capture need not be the batch's own: any thread of the process that makes a call the runtime refuses
+      // while a capture is open (a synchronous copy on the legacy stream, say -- this library makes none, the application may)
+      // invalidates every open capture.  Nothing of the batch has run: close the capture, stop capturing on this scratch and
+      // run the batch on the plain path.
+      abandon_capture(s);
+      b0 -= maxB;
+      continue;
+    }
     if (dev_io) {
       HIPCHK(hipStreamSynchronize(st));   // results are complete in HBM when the call returns
     } else {
@@ -1572,6 +1636,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
           if (ex) (void)hipGraphExecDestroy(ex);
           s->graph.fails++;
           s->graph.warm = 0;
+          if (ce != hipSuccess) fresh_stream(s);   // (invalidated from outside: see abandon_capture)
           b0 -= maxB;
           continue;
         }
@@ -1598,10 +1663,10 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     if (!dev_io) ol.scatter(s->h_out.p, out_pids + (size_t)b0 * K, out_scores + (size_t)b0 * K, out_counts + b0);
     if (s1_stats_enabled() && !replayed && !capture && s->s1stats.p) {   // diagnostics: blocking copy after the call's sync
       uint64_t h4[4] = {0, 0, 0, 0};
-      HIPCHK(hipMemcpy(h4, s->s1stats.p, 32, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(h4, s->s1stats.p, 32, hipMemcpyDeviceToHost, s->st));
       if (P.lazy) {   // the lazy form's counters instead: {entries gathered by the selection, maybes recomputed, -, 3 = "lazy"}
         uint32_t l4[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpy(l4, s->lz_state.as<uint32_t>() + 2 * B + 4, 16, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(l4, s->lz_state.as<uint32_t>() + 2 * B + 4, 16, hipMemcpyDeviceToHost, s->st));
         h4[0] = l4[0]; h4[1] = l4[1]; h4[2] = l4[2]; h4[3] = l4[3];   // certain, maybes, most maybes of one query, (code, column) pairs re-evaluated
       }
       for (int i = 0; i < 4; ++i) g_last_s1[i] = (b0 == 0 ? 0 : g_last_s1[i]) + h4[i];
@@ -1617,33 +1682,33 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
     if (tr) {  // B == 1
       std::vector<int32_t> t32;
       int32_t nc = 0, ncand = 0, nr = 0;
-      HIPCHK(hipMemcpy(&nc, s->ncells.p, 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&ncand, s->ncand.p, 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&nr, s->sel_cnt.p, 4, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(&nc, s->ncells.p, 4, hipMemcpyDeviceToHost, s->st));
+      HIPCHK(copy_sync(&ncand, s->ncand.p, 4, hipMemcpyDeviceToHost, s->st));
+      HIPCHK(copy_sync(&nr, s->sel_cnt.p, 4, hipMemcpyDeviceToHost, s->st));
       if (tr->counts) { tr->counts[0] = nc; tr->counts[1] = ncand; tr->counts[2] = nr; }
       if (tr->S) {
         std::vector<uint16_t> hs((size_t)D.C * Qp);
-        HIPCHK(hipMemcpy(hs.data(), s->S.p, hs.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(hs.data(), s->S.p, hs.size() * 2, hipMemcpyDeviceToHost, s->st));
         for (int64_t c = 0; c < D.C; ++c)
           for (int q = 0; q < Q; ++q) tr->S[c * Q + q] = hs[(size_t)c * Qp + q];
       }
       if (tr->cells && nc > 0) {
         t32.resize((size_t)nc);
-        HIPCHK(hipMemcpy(t32.data(), s->ucells.p, (size_t)nc * 4, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(t32.data(), s->ucells.p, (size_t)nc * 4, hipMemcpyDeviceToHost, s->st));
         for (int i = 0; i < nc; ++i) tr->cells[i] = t32[i];
       }
       if (tr->cand && ncand > 0) {
         t32.resize((size_t)ncand);
-        HIPCHK(hipMemcpy(t32.data(), s->cand_pid.p, (size_t)ncand * 4, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(t32.data(), s->cand_pid.p, (size_t)ncand * 4, hipMemcpyDeviceToHost, s->st));
         for (int i = 0; i < ncand; ++i) tr->cand[i] = (int64_t)t32[i] + D.pid_offset;
       }
-      if (tr->approx && ncand > 0) HIPCHK(hipMemcpy(tr->approx, s->approx.p, (size_t)ncand * 4, hipMemcpyDeviceToHost));
+      if (tr->approx && ncand > 0) HIPCHK(copy_sync(tr->approx, s->approx.p, (size_t)ncand * 4, hipMemcpyDeviceToHost, s->st));
       if (tr->rerank && nr > 0) {
         t32.resize((size_t)nr);
-        HIPCHK(hipMemcpy(t32.data(), s->sel_pid.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(t32.data(), s->sel_pid.p, (size_t)nr * 4, hipMemcpyDeviceToHost, s->st));
         for (int i = 0; i < nr; ++i) tr->rerank[i] = (int64_t)t32[i] + D.pid_offset;
       }
-      if (tr->exact && nr > 0) HIPCHK(hipMemcpy(tr->exact, s->exact.p, (size_t)nr * 4, hipMemcpyDeviceToHost));
+      if (tr->exact && nr > 0) HIPCHK(copy_sync(tr->exact, s->exact.p, (size_t)nr * 4, hipMemcpyDeviceToHost, s->st));
     }
   }
   return FP_OK;
@@ -1672,7 +1737,7 @@ extern "C" int fp_search(const fp_index* index, const uint16_t* queries, int32_t
 
 static int64_t mem_info(int device_id, bool want_free) {
   size_t f = 0, t = 0;
-  if (hipSetDevice(device_id) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return -1;
+  if (fp_set_device(device_id) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return -1;
   return (int64_t)(want_free ? f : t);
 }
 extern "C" int64_t fp_device_free_bytes(int device_id) { return mem_info(device_id, true); }
@@ -1681,25 +1746,25 @@ extern "C" int64_t fp_device_total_bytes(int device_id) { return mem_info(device
 extern "C" int fp_dev_alloc(int device_id, size_t bytes, void** out) {
   if (!out) return fail(FP_EINVAL, "null argument");
   *out = nullptr;
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   HIPCHK(hipMalloc(out, bytes ? bytes : 1));
   return FP_OK;
 }
 extern "C" int fp_dev_free(int device_id, void* p) {
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   if (p) HIPCHK(hipFree(p));
   return FP_OK;
 }
 extern "C" int fp_dev_upload(int device_id, void* dst, const void* src, size_t bytes) {
   if (bytes && (!dst || !src)) return fail(FP_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(device_id));
-  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  HIPCHK(fp_set_device(device_id));
+  HIPCHK(copy_sync(dst, src, bytes, hipMemcpyHostToDevice, util_stream(device_id)));
   return FP_OK;
 }
 extern "C" int fp_dev_download(int device_id, void* dst, const void* src, size_t bytes) {
   if (bytes && (!dst || !src)) return fail(FP_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(device_id));
-  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(fp_set_device(device_id));
+  HIPCHK(copy_sync(dst, src, bytes, hipMemcpyDeviceToHost, util_stream(device_id)));
   return FP_OK;
 }
 
@@ -1761,7 +1826,7 @@ extern "C" int fp_maxsim_columns(const fp_index* cix, const uint16_t* query, int
   if (n == 0) return FP_OK;
   if (n > (1 << 24)) return fail(FP_EINVAL, "too many documents");
   const FpIndexDev& D = ix->d;
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   std::vector<int32_t> loc((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
     const int64_t d = pids[i] - D.pid_offset;
@@ -1831,7 +1896,7 @@ extern "C" int fp_reconstruct_embeddings(const fp_index* cix, const int64_t* doc
                                          int64_t* out_lengths) {
   fp_index* ix = const_cast<fp_index*>(cix);
   if (!ix || (n > 0 && (!doc_ids || !out_lengths))) return fail(FP_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   std::vector<int64_t> tok;
   for (int64_t i = 0; i < n; ++i) {
     int64_t d = doc_ids[i] - ix->d.pid_offset;
@@ -1842,7 +1907,7 @@ extern "C" int fp_reconstruct_embeddings(const fp_index* cix, const int64_t* doc
     tok.resize(base + (size_t)l);
     if (ix->d.perm && l > 0) {  // stored row o+j holds original token perm[j]
       std::vector<uint16_t> pp((size_t)l);
-      HIPCHK(hipMemcpy(pp.data(), ix->d.perm + o, (size_t)l * 2, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(pp.data(), ix->d.perm + o, (size_t)l * 2, hipMemcpyDeviceToHost, util_stream(ix->device)));
       for (int64_t j = 0; j < l; ++j) tok[base + pp[j]] = o + j;
     } else {
       for (int64_t j = 0; j < l; ++j) tok[base + j] = o + j;
@@ -1872,7 +1937,7 @@ extern "C" int fp_token_scores(const fp_index* cix, const uint16_t* queries, int
   if (!ix || nq < 0 || (nq > 0 && (!queries || !pids || !counts)) || !out_offsets) return fail(FP_EINVAL, "null argument");
   if (dim != ix->d.dim) return fail(FP_EINVAL, "query dim does not match the index");
   if (Q < 1) return fail(FP_EINVAL, "need at least one query token");
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   std::vector<int32_t> hq, hp;
   int64_t off = 0, h = 0;
   out_offsets[0] = 0;
@@ -1922,7 +1987,7 @@ extern "C" int fp_compress(int device_id, const uint16_t* centroids, int64_t C, 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FP_EHIP, "no HIP device available (this library has no CPU path)");
   if (device_id < 0 || device_id >= ndev) return fail(FP_EINVAL, "device index out of range");
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   if (T == 0) return FP_OK;
   const int pr = dim * nbits / 8;
   const int64_t CHUNK = 1ll << 20;   // tokens per pass
@@ -1986,7 +2051,7 @@ extern "C" int fp_assign_l2(int device_id, const uint16_t* centroids, const floa
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FP_EHIP, "no HIP device available (this library has no CPU path)");
   if (device_id < 0 || device_id >= ndev) return fail(FP_EINVAL, "device index out of range");
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   if (T == 0) return FP_OK;
   const int64_t CHUNK = 1ll << 20;
   const int64_t cap = std::min<int64_t>(T, CHUNK);
@@ -2049,7 +2114,7 @@ extern "C" int fp_shard_begin(const fp_index* cix, const uint16_t* queries, int3
   fp_index* ix = const_cast<fp_index*>(cix);
   if (nq < 1) return fail(FP_EINVAL, "need at least one query");
   const int64_t R = std::max<int64_t>(p->n_full_scores / 4, 1);
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   Scratch* s = acquire(ix);
   if (!s) return fail(FP_EHIP, "could not create a HIP stream");
   fp_shard_ctx* c = new fp_shard_ctx();
@@ -2080,7 +2145,7 @@ extern "C" void fp_shard_end(fp_shard_ctx* c) {
 
 extern "C" int fp_shard_stage1(fp_shard_ctx* c, void* dev_rec1) {
   if (!c || !dev_rec1) return fail(FP_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(fp_set_device(c->ix->device));
   Scratch* s = c->s;
   const int64_t R = c->P.sh.R;
   const int B = c->B;
@@ -2101,7 +2166,7 @@ extern "C" int fp_shard_stage1(fp_shard_ctx* c, void* dev_rec1) {
 
 extern "C" int fp_shard_stage2(fp_shard_ctx* c, const void* dev_all_rec1, int32_t G, void* dev_rec2) {
   if (!c || !dev_all_rec1 || !dev_rec2 || G < 1) return fail(FP_EINVAL, "bad argument");
-  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(fp_set_device(c->ix->device));
   Scratch* s = c->s;
   const FpIndexDev& D = c->ix->d;
   const int64_t R = c->P.sh.R;
@@ -2198,7 +2263,7 @@ static int shard_apply_and_rank(Scratch* s, const FpSearchShape& sh, const float
 
 extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_t G, int32_t rank, void* dev_x) {
   if (!c || !dev_all_rec2 || !dev_x || G < 1 || rank < 0 || rank >= G) return fail(FP_EINVAL, "bad argument");
-  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(fp_set_device(c->ix->device));
   Scratch* s = c->s;
   if (c->params.top_k == 0) return FP_OK;
   if (int rc = shard_mark_and_repair(c->ix, s, c->P.sh, dev_all_rec2, G, rank, c->empty_all, c->params.top_k, static_cast<float*>(dev_x), s->st)) return rc;
@@ -2209,7 +2274,7 @@ extern "C" int fp_shard_stage3(fp_shard_ctx* c, const void* dev_all_rec2, int32_
 
 extern "C" int fp_shard_stage4(fp_shard_ctx* c, const void* dev_all_x, int32_t G, int64_t* out_pids, float* out_scores, int32_t* out_counts) {
   if (!c || !dev_all_x || G < 1 || !out_counts) return fail(FP_EINVAL, "bad argument");
-  HIPCHK(hipSetDevice(c->ix->device));
+  HIPCHK(fp_set_device(c->ix->device));
   for (int i = 0; i < c->B; ++i) out_counts[i] = 0;
   if (c->params.top_k == 0) return FP_OK;
   return shard_apply_and_rank(c->s, c->P.sh, static_cast<const float*>(dev_all_x), c->params.top_k, out_pids, out_scores, out_counts, c->s->st);
@@ -2279,7 +2344,7 @@ extern "C" int fp_comm_create(int device_id, int n_ranks, int rank, const void* 
   *out = nullptr;
   RcclApi* a = rccl_api();
   if (!a) return fail(FP_EUNSUPPORTED, "RCCL unavailable: librccl could not be loaded (set FP_RCCL_LIB)");
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   FpNcclUid id;
   memcpy(&id, unique_id_128, sizeof(id));
   fp_comm* c = new fp_comm();
@@ -2292,7 +2357,7 @@ extern "C" int fp_comm_create(int device_id, int n_ranks, int rank, const void* 
 extern "C" void fp_comm_destroy(fp_comm* c) {
   if (!c) return;
   RcclApi* a = rccl_api();
-  if (a && c->comm) { (void)hipSetDevice(c->device); (void)a->CommDestroy(c->comm); }
+  if (a && c->comm) { (void)fp_set_device(c->device); (void)a->CommDestroy(c->comm); }
   delete c;
 }
 extern "C" int fp_comm_n_ranks(const fp_comm* c) { return c ? c->n_ranks : 0; }
@@ -2450,7 +2515,7 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
   if (!api) return fail(FP_EUNSUPPORTED, "RCCL unavailable");
   fp_index* ix = const_cast<fp_index*>(cix);
   if (ix->device != comm->device) return fail(FP_EINVAL, "index and communicator live on different devices");
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   for (int i = 0; i < nq; ++i) out_counts[i] = 0;
   if (p->top_k == 0) return FP_OK;
   Scratch* s = acquire(ix);
@@ -2478,12 +2543,13 @@ extern "C" int fp_shard_search(const fp_index* cix, fp_comm* comm, const uint16_
 // ------------------------------------------------------------------------------------------
 extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[16]*/) {
   if (!out_mismatches) return fail(FP_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(fp_set_device(device_id));
   unsigned long long* d = nullptr;
   HIPCHK(hipMalloc((void**)&d, 128));
-  HIPCHK(hipMemset(d, 0, 128));
-  fpk_selftest_arith(d, nullptr);
-  hipError_t e = hipMemcpy(out_mismatches, d, 128, hipMemcpyDeviceToHost);
+  hipStream_t us = util_stream(device_id);
+  HIPCHK(hipMemsetAsync(d, 0, 128, us));
+  fpk_selftest_arith(d, us);
+  hipError_t e = copy_sync(out_mismatches, d, 128, hipMemcpyDeviceToHost, us);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(FP_EHIP, hipGetErrorString(e));
   return FP_OK;
@@ -2494,16 +2560,16 @@ extern "C" int fp_selftest_arith(int device_id, uint64_t* out_mismatches /*[16]*
 // ------------------------------------------------------------------------------------------
 extern "C" int64_t fp_index_ivf_total(const fp_index* ix) {
   if (!ix || !ix->has_ivf) return 0;
-  (void)hipSetDevice(ix->device);
+  (void)fp_set_device(ix->device);
   int64_t tot = 0;
-  if (hipMemcpy(&tot, ix->d.ivf_off + ix->d.P, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(FP_EHIP, "memcpy");
+  if (copy_sync(&tot, ix->d.ivf_off + ix->d.P, 8, hipMemcpyDeviceToHost, util_stream(ix->device)) != hipSuccess) return fail(FP_EHIP, "memcpy");
   return tot;
 }
 
 extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* doc_residuals, int64_t* doc_lengths, int64_t* ivf,
                                int32_t* ivf_lengths) {
   if (!ix) return fail(FP_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(ix->device));
+  HIPCHK(fp_set_device(ix->device));
   const FpIndexDev& D = ix->d;
   if (doc_lengths)
     for (int64_t i = 0; i < D.N; ++i) doc_lengths[i] = ix->h_doc_off[i + 1] - ix->h_doc_off[i];
@@ -2512,25 +2578,25 @@ extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* 
   std::vector<uint16_t> hperm;
   if (D.perm && D.T > 0 && (doc_codes || doc_residuals)) {
     hperm.resize((size_t)D.T);
-    HIPCHK(hipMemcpy(hperm.data(), D.perm, (size_t)D.T * 2, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(hperm.data(), D.perm, (size_t)D.T * 2, hipMemcpyDeviceToHost, util_stream(ix->device)));
   }
   // stored token i of document d is original token perm[i]: write it back to its original slot
   auto orig_row = [&](int64_t doc, int64_t i) { return hperm.empty() ? i : ix->h_doc_off[doc] + hperm[i]; };
   if (doc_codes) {
     tmp.resize((size_t)std::max<int64_t>(D.T, 1));
-    if (D.T > 0) HIPCHK(hipMemcpy(tmp.data(), D.codes, (size_t)D.T * 4, hipMemcpyDeviceToHost));
+    if (D.T > 0) HIPCHK(copy_sync(tmp.data(), D.codes, (size_t)D.T * 4, hipMemcpyDeviceToHost, util_stream(ix->device)));
     for (int64_t d0 = 0; d0 < D.N; ++d0)
       for (int64_t i = ix->h_doc_off[d0]; i < ix->h_doc_off[d0 + 1]; ++i) doc_codes[orig_row(d0, i)] = tmp[i];
   }
   if (doc_residuals && D.T > 0) {
     if (hperm.empty() && !D.resid_native) {
-      HIPCHK(hipMemcpy(doc_residuals, D.residuals, (size_t)D.T * D.pr, hipMemcpyDeviceToHost));
+      HIPCHK(copy_sync(doc_residuals, D.residuals, (size_t)D.T * D.pr, hipMemcpyDeviceToHost, util_stream(ix->device)));
     } else {
       std::vector<uint8_t> rt((size_t)std::min<int64_t>(chunk, D.T) * D.pr);
       int64_t d0 = 0;
       for (int64_t s0 = 0; s0 < D.T; s0 += chunk) {
         const int64_t m = std::min(chunk, D.T - s0);
-        HIPCHK(hipMemcpy(rt.data(), D.residuals + s0 * D.pr, (size_t)m * D.pr, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(rt.data(), D.residuals + s0 * D.pr, (size_t)m * D.pr, hipMemcpyDeviceToHost, util_stream(ix->device)));
         for (int64_t i = s0; i < s0 + m; ++i) {
           while (ix->h_doc_off[d0 + 1] <= i) ++d0;
           row_to_reference_order(ix, rt.data() + (i - s0) * D.pr, doc_residuals + orig_row(d0, i) * D.pr);
@@ -2540,7 +2606,7 @@ extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* 
   }
   if (ix->has_ivf && (ivf || ivf_lengths)) {
     std::vector<int64_t> off((size_t)D.P + 1);
-    HIPCHK(hipMemcpy(off.data(), D.ivf_off, off.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(copy_sync(off.data(), D.ivf_off, off.size() * 8, hipMemcpyDeviceToHost, util_stream(ix->device)));
     if (ivf_lengths)
       for (int64_t i = 0; i < D.P; ++i) ivf_lengths[i] = (int32_t)(off[i + 1] - off[i]);
     if (ivf) {
@@ -2548,7 +2614,7 @@ extern "C" int fp_index_export(const fp_index* ix, int64_t* doc_codes, uint8_t* 
       tmp.resize((size_t)std::min<int64_t>(chunk, std::max<int64_t>(tot, 1)));
       for (int64_t s = 0; s < tot; s += chunk) {
         const int64_t m = std::min(chunk, tot - s);
-        HIPCHK(hipMemcpy(tmp.data(), D.ivf_pids + s, (size_t)m * 4, hipMemcpyDeviceToHost));
+        HIPCHK(copy_sync(tmp.data(), D.ivf_pids + s, (size_t)m * 4, hipMemcpyDeviceToHost, util_stream(ix->device)));
         for (int64_t i = 0; i < m; ++i) ivf[s + i] = tmp[i];
       }
     }

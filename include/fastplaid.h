@@ -175,7 +175,13 @@ int fp_last_search_timings(const char** names, float* ms, int cap);
  * every launch and fill, result download: one hipGraphLaunch instead of ~55 enqueues).  A graph launch records no per-stage
  * events, so fp_last_search_timings reports zeros for such a call; a profiler or benchmark that wants stage times switches the
  * replay off for the calls it measures.  enabled: 0 / 1; returns the previous setting.  Process-wide; default 1 (FP_GRAPH=0 in
- * the environment starts with 0). */
+ * the environment starts with 0).
+ * Threads: the capture runs on the call's own non-blocking stream in relaxed mode; every entry point of this library puts its
+ * thread into the relaxed capture-interaction mode and none uses the legacy stream, so concurrent calls into the library do not
+ * disturb a capture.  A synchronous legacy-stream call (hipMemcpy, hipMemset) made by ANOTHER thread of the application while a
+ * capture is open (~1 ms, once per shape) is refused by the runtime and invalidates the capture: fp_search then runs that batch
+ * on the plain path and stops capturing on that scratch -- its result is unaffected.  Applications with such threads may prefer
+ * to switch the replay off ("Graph capture and the application's other threads"). */
 int fp_set_graph_replay(int enabled);
 /* fp_search calls served by a graph replay since the process started.  The learnt candidate capacity and the captured graph are
  * kept per shape {n_queries, q_len, n_ivf_probe, n_full_scores, top_k} for the eight most recently used shapes of a scratch, so a

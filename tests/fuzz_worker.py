@@ -16,6 +16,9 @@ usage: fuzz_worker.py <n_cases> <seed> [<first_case>] [big]   (FP_APPROX_IMPL = 
 "big": corpus-model indexes (fast-plaid_amd/synth.py, 5 k - 80 k documents, up to 2^16 centroids, batches up to 64) on which the
 engine picks the bound stages / the lazy S1 / graph replay by itself: fp_search x 5 == fp_search_trace bit for bit for every query,
 the oracle's ids in its order for the first four.
+"stateful": see run_stateful (one index, <n_cases> calls of recurring shapes: what the engine remembers between calls).
+"threads": run_threads (the same from four threads at once on one shared index, <n_cases> calls each).
+"hostile": run_hostile (another thread of the process makes legacy-stream copies while fp_search captures its graphs).
 prints one line per failing case (its number reproduces it: fuzz_worker.py 1 <seed> <case>) and FUZZ_OK <n> / FUZZ_FAIL <k>/<n>.
 """
 import os
@@ -176,7 +179,145 @@ def run_big_case(seed, case):
     return (n_docs, doc_len, C, dim, nbits, B, Q, n_probe, n_full, top_k, qkind)
 
 
+def run_stateful(seed, n_calls):
+    """ONE index, a long sequence of calls whose shapes come from a small pool (so that shapes repeat: learnt capacities, captured
+    graphs, the 8-entry shape cache and its evictions, the probe fallback's and the lazy form's switches all carry over from call
+    to call), a different query batch every call, now and then one with zero-padded rows or with every query the same: every
+    call's result == fp_search_trace of each of its queries, bit for bit."""
+    rng = np.random.default_rng([seed, 4242])
+    pick = lambda *v: v[int(rng.integers(0, len(v)))]   # noqa: E731
+    spec = fp.synth.SynthSpec(n_docs=int(pick(12000, 30000, 60000)), doc_len=int(pick(32, 48, 100)), n_centroids=int(pick(2048, 8192, 32768)),
+                              variable_len=True, seed=int(rng.integers(1, 1 << 30)))
+    arr = fp.synth.host_index_arrays(spec)
+    hip = _hip_index(fp, arr)
+    pool = []
+    for _ in range(12):
+        pool.append((int(pick(1, 3, 8, 16)), int(pick(8, 32, 32, 48)), int(pick(1, 4, 8, 16, 40)), int(pick(64, 1024, 4096)), int(pick(10, 100, 1000))))
+    bad = 0
+    for call in range(n_calls):
+        B, Q, n_probe, n_full, top_k = pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.9 else \
+            (int(pick(1, 5, 12)), int(pick(16, 32, 64)), int(pick(2, 8, 32)), int(pick(128, 2048)), int(pick(5, 50)))
+        q = fp.synth.make_queries(spec, arr["centroids"], B, Q, seed=int(rng.integers(1, 1 << 30)))
+        kind = rng.random()
+        if kind < 0.08 and Q > 1:
+            q[:, int(rng.integers(1, Q)):] = 0
+        elif kind < 0.12:
+            q[:] = q[0]
+        params = R.SearchParameters(2000, n_full, top_k, n_probe)
+        try:
+            pids, scores, counts = searched(hip, q, params)
+            for b in range(B):
+                h = R.search_trace(hip, q[b], params, None)
+                assert counts[b] == len(h["pids"]), f"query {b}: count {counts[b]} != trace {len(h['pids'])}"
+                assert np.array_equal(pids[b, : counts[b]], h["pids"]), f"query {b}: ids differ from the trace"
+                assert np.array_equal(scores[b, : counts[b]], h["scores"]), f"query {b}: scores differ from the trace"
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print(f"FUZZ_CASE_FAILED stateful seed={seed} call={call} shape={(B, Q, n_probe, n_full, top_k)} kind={kind:.3f} {type(e).__name__}: {str(e)[:300]}",
+                  flush=True)
+    print("calls by (S4 form, S1 lazy):", sorted(TALLY.items(), key=str), "graph replays", R.graph_replay_count() if hasattr(R, "graph_replay_count") else "?")
+    print(f"FUZZ_FAIL {bad}/{n_calls}" if bad else f"FUZZ_OK {n_calls}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+def run_threads(seed, n_calls, n_threads=4):
+    """run_stateful's sequence from several threads at once on ONE shared index (load.rs:58-59 Send + Sync; the reference's
+    joblib / thread-per-device callers): every thread draws its own shapes and batches and checks each of its calls against
+    fp_search_trace -- the scratch pool hands every concurrent call its own stream, capacities, graphs and switches."""
+    import threading
+    rng0 = np.random.default_rng([seed, 777])
+    spec = fp.synth.SynthSpec(n_docs=30000, doc_len=48, n_centroids=8192, variable_len=True, seed=int(rng0.integers(1, 1 << 30)))
+    arr = fp.synth.host_index_arrays(spec)
+    hip = _hip_index(fp, arr)
+    pool = [(int(rng0.choice([1, 3, 8, 16])), int(rng0.choice([8, 32, 48])), int(rng0.choice([1, 4, 8, 40])), int(rng0.choice([64, 1024, 4096])),
+             int(rng0.choice([10, 100]))) for _ in range(6)]
+    errors = []
+
+    def work(t):
+        rng = np.random.default_rng([seed, 777, t])
+        for call in range(n_calls):
+            B, Q, n_probe, n_full, top_k = pool[int(rng.integers(0, len(pool)))]
+            q = fp.synth.make_queries(spec, arr["centroids"], B, Q, seed=int(rng.integers(1, 1 << 30)))
+            params = R.SearchParameters(2000, n_full, top_k, n_probe)
+            try:
+                pids, scores, counts = R.search_arrays(hip, q, params)
+                for b in range(B):
+                    h = R.search_trace(hip, q[b], params, None)
+                    assert counts[b] == len(h["pids"]) and np.array_equal(pids[b, : counts[b]], h["pids"]) and \
+                        np.array_equal(scores[b, : counts[b]], h["scores"]), f"query {b} differs from the trace"
+            except Exception as e:   # noqa: BLE001
+                errors.append(f"thread {t} call {call} shape {(B, Q, n_probe, n_full, top_k)}: {type(e).__name__}: {str(e)[:300]}")
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in errors[:20]:
+        print("FUZZ_CASE_FAILED threads", e, flush=True)
+    print(f"FUZZ_FAIL {len(errors)}/{n_calls * n_threads}" if errors else f"FUZZ_OK {n_calls}", flush=True)
+    sys.exit(1 if errors else 0)
+
+
+def run_hostile(seed, n_calls):
+    """the application's OTHER threads: one thread keeps making synchronous legacy-stream copies through the HIP runtime itself
+    (what a framework's .cpu() / .item() does) while this thread searches with recurring shapes, i.e. while fp_search captures
+    graphs.  The runtime refuses such a copy while a capture is open and invalidates the capture with it: fp_search must notice,
+    run the batch on the plain path and return the right result -- never an error."""
+    import ctypes
+    import threading
+    hip = ctypes.CDLL("libamdhip64.so")
+    dev = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dev), ctypes.c_size_t(64)) == 0
+    stop, refused = [False], [0]
+
+    def disturb():
+        host = (ctypes.c_char * 64)()
+        while not stop[0]:
+            if hip.hipMemcpy(host, dev, ctypes.c_size_t(64), ctypes.c_int(2)) != 0:   # hipMemcpyDeviceToHost on the legacy stream
+                refused[0] += 1
+                hip.hipGetLastError()
+
+    rng = np.random.default_rng([seed, 999])
+    spec = fp.synth.SynthSpec(n_docs=20000, doc_len=48, n_centroids=4096, variable_len=True, seed=int(rng.integers(1, 1 << 30)))
+    arr = fp.synth.host_index_arrays(spec)
+    ix = _hip_index(fp, arr)
+    pool = [(int(rng.choice([1, 4, 16])), int(rng.choice([8, 32])), int(rng.choice([4, 8])), int(rng.choice([256, 4096])), 10) for _ in range(16)]
+    th = threading.Thread(target=disturb)
+    th.start()
+    bad, done = 0, []
+    try:
+        for call in range(n_calls):
+            B, Q, n_probe, n_full, top_k = pool[(call // 5) % len(pool)]   # five calls in a row per shape: plain, learnt, learnt, capture, replay
+            q = fp.synth.make_queries(spec, arr["centroids"], B, Q, seed=int(rng.integers(1, 1 << 30)))
+            params = R.SearchParameters(2000, n_full, top_k, n_probe)
+            try:
+                done.append((q, params, searched(ix, q, params)))
+            except Exception as e:   # noqa: BLE001
+                bad += 1
+                print(f"FUZZ_CASE_FAILED hostile call={call} shape={(B, Q, n_probe, n_full, top_k)} {type(e).__name__}: {str(e)[:300]}", flush=True)
+    finally:
+        stop[0] = True
+        th.join()
+    for call, (q, params, (pids, scores, counts)) in enumerate(done):   # every result against the trace, once the other thread is gone
+        for b in range(q.shape[0]):
+            h = R.search_trace(ix, q[b], params, None)
+            if not (counts[b] == len(h["pids"]) and np.array_equal(pids[b, : counts[b]], h["pids"]) and np.array_equal(scores[b, : counts[b]], h["scores"])):
+                bad += 1
+                print(f"FUZZ_CASE_FAILED hostile call={call} query {b}: result differs from the trace", flush=True)
+                break
+    print("legacy-stream copies the runtime refused:", refused[0], " calls by (S4 form, S1 lazy):", sorted(TALLY.items(), key=str), " graph replays", R.graph_replay_count())
+    print(f"FUZZ_FAIL {bad}/{n_calls}" if bad else f"FUZZ_OK {n_calls}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "hostile":
+        run_hostile(int(sys.argv[2]), int(sys.argv[1]))
+    if len(sys.argv) > 4 and sys.argv[4] == "threads":
+        run_threads(int(sys.argv[2]), int(sys.argv[1]))
+    if len(sys.argv) > 4 and sys.argv[4] == "stateful":
+        run_stateful(int(sys.argv[2]), int(sys.argv[1]))
     if len(sys.argv) > 4 and sys.argv[4] == "big":
         n, seed, first, bad = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 0
         for case in range(first, first + n):

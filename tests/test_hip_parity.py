@@ -725,13 +725,18 @@ def test_randomized_shapes_vs_oracle(fp, shape):
 
 
 @pytest.mark.parametrize("form,mode,n_cases", [("auto", "", 300), ("q8", "", 200), ("l0", "", 200), ("l0h", "", 200),
-                                               ("auto", "big", 40), ("l0h", "big", 25), ("q8", "big", 25)])
+                                               ("auto", "big", 40), ("l0h", "big", 25), ("q8", "big", 25),
+                                               ("auto", "stateful", 300), ("auto", "threads", 100), ("auto", "hostile", 300)])
 def test_fuzz_vs_oracle(fp, form, mode, n_cases):
     """tests/fuzz_worker.py: randomly DRAWN shapes (the fixed list above is what earlier rounds thought of) -- fp_search_trace
     against the oracle stage by stage, fp_search on repeated calls (learnt capacity, graph replay) == the trace bit for bit,
     the shared-subset entry point == the per-query one; every forced form of S4; "big": corpus-model indexes on which the
-    engine picks the bound stages, the lazy S1 and graph replay by itself.  Round 6 ran 5400 + 900 cases of it
-    (profiles/r06_fuzz.txt); a failing case prints the number that reproduces it."""
+    engine picks the bound stages, the lazy S1 and graph replay by itself; "stateful": ONE index, hundreds of calls of recurring
+    shapes (what the engine remembers between calls); "threads": the same from four threads on one shared index; "hostile":
+    another thread of the process makes legacy-stream copies while fp_search captures its graphs (the runtime invalidates the
+    capture: the batch must run on the plain path, never fail).  Round 6 ran 5400 + 900 + 1800 cases of it
+    (profiles/r06_fuzz.txt: the threaded modes found two defects of the graph capture, fixed there); a failing case prints the
+    number that reproduces it."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -739,8 +744,15 @@ def test_fuzz_vs_oracle(fp, form, mode, n_cases):
     env.pop("FP_APPROX_IMPL", None)
     if form != "auto":
         env["FP_APPROX_IMPL"] = form
-    cmd = [sys.executable, os.path.join(root, "tests", "fuzz_worker.py"), str(n_cases), "606", "0"] + ([mode] if mode else [])
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    cmd = [sys.executable, "-X", "faulthandler", os.path.join(root, "tests", "fuzz_worker.py"), str(n_cases), "606", "0"] + ([mode] if mode else [])
+    for attempt in range(3):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        # "hostile" only: the OTHER thread -- the one that makes legacy-stream copies through the runtime while a capture opens and
+        # closes -- died inside hipMemcpy in 3 of 120 runs (a race inside the runtime, not in this library's code or thread:
+        # INTEGRATION.md, "graph capture and the application's other threads").  Such a run says nothing about fp_search: again.
+        if mode == "hostile" and r.returncode < 0 and "in disturb" in r.stderr.split("Thread 0x")[0]:
+            continue
+        break
     assert r.returncode == 0 and f"FUZZ_OK {n_cases}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
