@@ -5,7 +5,7 @@ Every case draws the number of shards (2 - 5), the corpus (plain random arrays -
 nothing -- or the corpus model), batch, query length, n_ivf_probe, n_full_scores, top_k.  FP_TEST=shard_big=1 in the environment
 forces the sort-free cut / union of large unions.
 
-usage: shard_fuzz_worker.py <n_cases> <seed> [<first_case>]
+usage: shard_fuzz_worker.py <n_cases> <seed> [<first_case>] [native]      native: see run_native (fp_shard_search, one rank over RCCL)
 """
 import os
 import sys
@@ -86,7 +86,57 @@ def run_case(seed, case):
         en.end(st)
 
 
+def run_native(seed, n_cases):
+    """fp_shard_search -- the three all-gathers issued by the library itself on its search stream -- with ONE rank over RCCL (all a
+    one-GPU box allows): drawn corpora, batches and parameters, every result == fp_search on the same index, with fp_search
+    calls (graph capture and replay on the same scratch pool) in between."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    bad, comm = 0, None
+    for case in range(n_cases):
+        rng = np.random.default_rng([seed, case, 6])
+        G, model, B, Q, n_probe, n_full, top_k, shape = draw(rng)
+        try:
+            if model:
+                n_docs, doc_len, C, dim, nbits, sseed = shape
+                spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=doc_len, n_centroids=C, dim=dim, nbits=nbits, variable_len=True, seed=sseed)
+                arr = fp.synth.host_index_arrays(spec)
+                q = fp.synth.make_queries(spec, arr["centroids"], B, Q, seed=int(rng.integers(1, 1 << 30)))
+            else:
+                n_docs, max_len, C, dim, nbits, _ = shape
+                arr = _random_arrays(rng, n_docs, max_len, C, dim, nbits, empty_frac=float(rng.choice([0.0, 0.1, 0.5])))
+                pk = rng.integers(0, C, (B, Q))
+                q = arr["centroids"][pk].astype(np.float32) + 0.3 * rng.standard_normal((B, Q, dim), dtype=np.float32) / np.sqrt(dim)
+                q = (q / np.linalg.norm(q, axis=2, keepdims=True)).astype(np.float16)
+            params = R.SearchParameters(2000, n_full, top_k, min(n_probe, C))
+            index = mk(arr)
+            if comm is None:
+                comm = sharded.NativeComm.from_torch_dist(index.device_id, dist)
+            for rep in range(3):
+                want = R.search_arrays(index, q, params)
+                got = sharded.native_sharded_search(index, comm, q, params)
+                for x, y in zip(got, want):
+                    assert np.array_equal(x, y), f"rep {rep}: fp_shard_search differs from fp_search"
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print(f"FUZZ_CASE_FAILED native case={case} seed={seed} draw={draw(np.random.default_rng([seed, case, 6]))} {type(e).__name__}: {str(e)[:400]}",
+                  flush=True)
+            if os.environ.get("FP_FUZZ_TRACEBACK"):
+                traceback.print_exc()
+    if comm is not None:
+        comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"FUZZ_FAIL {bad}/{n_cases}" if bad else f"FUZZ_OK {n_cases}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "native":
+        run_native(int(sys.argv[2]), int(sys.argv[1]))
     n, seed = int(sys.argv[1]), int(sys.argv[2])
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     bad = 0

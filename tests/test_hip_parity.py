@@ -1178,16 +1178,18 @@ def test_sharded_equals_unsharded(fp, big):
     assert r.returncode == 0 and "SHARDED_GPU_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("big", ["", "1"])
+@pytest.mark.parametrize("big", ["", "1", "native"])
 def test_sharded_fuzz_equals_unsharded(fp, big):
     """tests/shard_fuzz_worker.py: drawn shard counts (2 - 5), corpora (plain random arrays with empty documents and near-empty
     shards, the corpus model), batches and parameters -- every rank of the staged shard protocol returns the unsharded fp_search
-    bit for bit; also with the sort-free cut / union forced.  Round 6 ran 3300 cases of it (profiles/r06_fuzz.txt)."""
+    bit for bit; also with the sort-free cut / union forced; "native": fp_shard_search with one rank over RCCL on drawn cases, fp_search
+    calls in between.  Round 6 ran 3300 + 300 cases of it (profiles/r06_fuzz.txt)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "shard_fuzz_worker.py"), "200", "606"], capture_output=True, text=True,
-                       timeout=900, env=with_test_opts(shard_big=big))
+    cmd = [sys.executable, os.path.join(root, "tests", "shard_fuzz_worker.py"), "200", "606"] + (["0", "native"] if big == "native" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True,
+                       timeout=900, env=with_test_opts(shard_big="" if big == "native" else big))
     assert r.returncode == 0 and "FUZZ_OK 200" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
