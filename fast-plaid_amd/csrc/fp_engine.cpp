@@ -272,10 +272,7 @@ struct Scratch : ScratchGen {
     for (auto& e : ev)
       if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
-    for (hipStream_t d : retired) (void)hipStreamDestroy(d);
-    retired.clear();
   }
-  std::vector<hipStream_t> retired;   // streams given up after an invalidated capture (fresh_stream): destroyed with the scratch
 };
 
 struct fp_index {
@@ -330,10 +327,8 @@ static Scratch* new_scratch() {
 }
 static void fresh_stream(Scratch* s) {
   hipStream_t fresh = nullptr;
-  // (the old stream is only retired here: destroying it while another thread sits in a legacy-stream call -- which walks the
-  // runtime's stream set -- crashed that thread once in 40 runs of the hostile fuzz; at most one per scratch, captures stop after it)
   if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
-    s->retired.push_back(s->st);
+    (void)hipStreamDestroy(s->st);   // (nothing is pending on it: a capture runs nothing)
     s->st = fresh;
   }
   (void)hipGetLastError();

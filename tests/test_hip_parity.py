@@ -748,7 +748,7 @@ def test_fuzz_vs_oracle(fp, form, mode, n_cases):
     for attempt in range(3):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         # "hostile" only: the OTHER thread -- the one that makes legacy-stream copies through the runtime while a capture opens and
-        # closes -- died inside hipMemcpy in 3 of 120 runs (a race inside the runtime, not in this library's code or thread:
+        # closes -- died inside hipMemcpy in about one run in 40 (a race inside the runtime, not in this library's code or thread:
         # INTEGRATION.md, "graph capture and the application's other threads").  Such a run says nothing about fp_search: again.
         if mode == "hostile" and r.returncode < 0 and "in disturb" in r.stderr.split("Thread 0x")[0]:
             continue
