@@ -223,7 +223,8 @@ def run_stateful(seed, n_calls):
 def run_threads(seed, n_calls, n_threads=4):
     """run_stateful's sequence from several threads at once on ONE shared index (load.rs:58-59 Send + Sync; the reference's
     joblib / thread-per-device callers): every thread draws its own shapes and batches and checks each of its calls against
-    fp_search_trace -- the scratch pool hands every concurrent call its own stream, capacities, graphs and switches."""
+    fp_search_trace -- the scratch pool hands every concurrent call its own stream, capacities, graphs and switches.  A fifth
+    thread builds, searches and drops small indexes of its own meanwhile."""
     import threading
     rng0 = np.random.default_rng([seed, 777])
     spec = fp.synth.SynthSpec(n_docs=30000, doc_len=48, n_centroids=8192, variable_len=True, seed=int(rng0.integers(1, 1 << 30)))
@@ -248,7 +249,23 @@ def run_threads(seed, n_calls, n_threads=4):
             except Exception as e:   # noqa: BLE001
                 errors.append(f"thread {t} call {call} shape {(B, Q, n_probe, n_full, top_k)}: {type(e).__name__}: {str(e)[:300]}")
 
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    def build(t):   # index construction and destruction (allocations, uploads, the layout kernels) next to the searching threads
+        rng = np.random.default_rng([seed, 778, t])
+        for i in range(max(4, n_calls // 8)):
+            try:
+                a = _random_arrays(rng, int(rng.integers(50, 1500)), 30, int(rng.choice([64, 257, 1000])), 128, 4)
+                small = _hip_index(fp, a)
+                qs = a["centroids"][rng.integers(0, a["centroids"].shape[0], (2, 16))]
+                pr = R.SearchParameters(2000, 64, 5, 4)
+                got = R.search_arrays(small, qs, pr)
+                for b in range(2):
+                    h = R.search_trace(small, qs[b], pr, None)
+                    assert got[2][b] == len(h["pids"]) and np.array_equal(got[0][b, : got[2][b]], h["pids"]), "fresh index: result differs from the trace"
+                del small
+            except Exception as e:   # noqa: BLE001
+                errors.append(f"builder {t} index {i}: {type(e).__name__}: {str(e)[:300]}")
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)] + [threading.Thread(target=build, args=(0,))]
     for th in ths:
         th.start()
     for th in ths:

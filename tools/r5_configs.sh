@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 T=${1:-r05_a}
 bash tools/bench_configs.sh 2>&1 | tee $OUT/${T}_configs.txt
-run2() { name="$1"; shift; timeout 300 python bench.py --steps 5 --warmup 2 --cpu-queries 0 "$@" 2>/dev/null | python -c "
+run2() { name="$1"; shift; timeout 300 python bench.py --steps 5 --warmup 4 --cpu-queries 0 "$@" 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('cfg2 $name: ms/batch=%.3f' % d['ms_per_step'], {k: round(v,3) for k,v in d['stages_ms'].items()})" | tee -a $OUT/${T}_configs.txt; }
