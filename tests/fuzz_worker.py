@@ -18,6 +18,7 @@ engine picks the bound stages / the lazy S1 / graph replay by itself: fp_search 
 the oracle's ids in its order for the first four.
 "stateful": see run_stateful (one index, <n_cases> calls of recurring shapes: what the engine remembers between calls).
 "threads": run_threads (the same from four threads at once on one shared index, <n_cases> calls each).
+"huge": run_huge (device-generated corpora of 0.1 - 1 M documents, 2^17 - 2^19 centroids).
 "hostile": run_hostile (another thread of the process makes legacy-stream copies while fp_search captures its graphs).
 prints one line per failing case (its number reproduces it: fuzz_worker.py 1 <seed> <case>) and FUZZ_OK <n> / FUZZ_FAIL <k>/<n>.
 """
@@ -328,7 +329,42 @@ def run_hostile(seed, n_calls):
     sys.exit(1 if bad else 0)
 
 
+def run_huge(seed, n_cases):
+    """device-generated corpora at the sizes the multi-range forms of S4 exist for (2^17 - 2^19 centroids, 0.1 - 1 M documents; no host
+    arrays): fp_search x 4 (plain, learnt capacity, capture, replay) == fp_search_trace of each query, bit for bit."""
+    bad = 0
+    for case in range(n_cases):
+        rng = np.random.default_rng([seed, case, 31])
+        pick = lambda *v: v[int(rng.integers(0, len(v)))]   # noqa: E731
+        C = int(pick(131072, 262144, 524288))
+        n_docs = int(pick(100000, 300000, 1000000))
+        doc_len = int(pick(32, 64, 128)) if n_docs < 1000000 else int(pick(32, 64))
+        B, Q = int(pick(2, 8, 24, 64)), int(pick(16, 32, 32, 48))
+        n_probe, n_full, top_k = int(pick(2, 8, 16)), int(pick(256, 4096, 16384)), int(pick(10, 100, 1000))
+        shape = (C, n_docs, doc_len, B, Q, n_probe, n_full, top_k)
+        try:
+            spec = fp.synth.SynthSpec(n_docs=n_docs, doc_len=doc_len, n_centroids=C, variable_len=bool(rng.integers(0, 2)), seed=int(rng.integers(1, 1 << 30)))
+            idx = R.construct_synthetic_index(spec, "cuda:0")
+            q = fp.synth.make_queries(spec, fp.synth.centroids(spec), B, Q, seed=int(rng.integers(1, 1 << 30)))
+            params = R.SearchParameters(2000, n_full, top_k, n_probe)
+            runs = [searched(idx, q, params) for _ in range(4)]
+            for b in range(min(B, 12)):
+                h = R.search_trace(idx, q[b], params, None)
+                for i, (pids, scores, counts) in enumerate(runs):
+                    assert counts[b] == len(h["pids"]) and np.array_equal(pids[b, : counts[b]], h["pids"]) and \
+                        np.array_equal(scores[b, : counts[b]], h["scores"]), f"call {i} query {b} differs from the trace"
+            del idx
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print(f"FUZZ_CASE_FAILED huge case={case} seed={seed} shape={shape} {type(e).__name__}: {str(e)[:300]}", flush=True)
+    print("calls by (S4 form, S1 lazy):", sorted(TALLY.items(), key=str))
+    print(f"FUZZ_FAIL {bad}/{n_cases}" if bad else f"FUZZ_OK {n_cases}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "huge":
+        run_huge(int(sys.argv[2]), int(sys.argv[1]))
     if len(sys.argv) > 4 and sys.argv[4] == "hostile":
         run_hostile(int(sys.argv[2]), int(sys.argv[1]))
     if len(sys.argv) > 4 and sys.argv[4] == "threads":

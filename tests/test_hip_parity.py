@@ -726,7 +726,8 @@ def test_randomized_shapes_vs_oracle(fp, shape):
 
 @pytest.mark.parametrize("form,mode,n_cases", [("auto", "", 300), ("q8", "", 200), ("l0", "", 200), ("l0h", "", 200),
                                                ("auto", "big", 40), ("l0h", "big", 25), ("q8", "big", 25),
-                                               ("auto", "stateful", 300), ("auto", "threads", 100), ("auto", "hostile", 300)])
+                                               ("auto", "stateful", 300), ("auto", "threads", 100), ("auto", "hostile", 300),
+                                               ("auto", "huge", 12)])
 def test_fuzz_vs_oracle(fp, form, mode, n_cases):
     """tests/fuzz_worker.py: randomly DRAWN shapes (the fixed list above is what earlier rounds thought of) -- fp_search_trace
     against the oracle stage by stage, fp_search on repeated calls (learnt capacity, graph replay) == the trace bit for bit,
@@ -734,7 +735,8 @@ def test_fuzz_vs_oracle(fp, form, mode, n_cases):
     engine picks the bound stages, the lazy S1 and graph replay by itself; "stateful": ONE index, hundreds of calls of recurring
     shapes (what the engine remembers between calls); "threads": the same from four threads on one shared index; "hostile":
     another thread of the process makes legacy-stream copies while fp_search captures its graphs (the runtime invalidates the
-    capture: the batch must run on the plain path, never fail).  Round 6 ran 5400 + 900 + 1800 cases of it
+    capture: the batch must run on the plain path, never fail); "huge": device-generated corpora of 0.1 - 1 M documents and
+    2^17 - 2^19 centroids (the multi-range forms of S4), fp_search x 4 == the trace.  Round 6 ran 5400 + 900 + 1800 cases of it
     (profiles/r06_fuzz.txt: the threaded modes found two defects of the graph capture, fixed there); a failing case prints the
     number that reproduces it."""
     import subprocess
