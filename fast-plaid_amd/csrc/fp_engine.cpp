@@ -113,7 +113,7 @@ static hipError_t fp_set_device(int device) {
   return hipSetDevice(device);
 }
 
-// The library never touches the legacy (null) stream: a synchronous hipMemcpy there is refused -- and invalidates the capture --
+// The library never touches the legacy (null) stream (one exception: prepay_legacy_stream): a synchronous hipMemcpy there is refused -- and invalidates the capture --
 // while another thread of the process captures a graph (fp_search does, on its scratch's stream).  Blocking copies go through
 // an explicit stream instead: the caller's own (index construction, a scratch) or this per-device utility stream.
 static hipStream_t util_stream(int device) {
@@ -123,6 +123,21 @@ static hipStream_t util_stream(int device) {
   hipStream_t& st = streams[device & 63];
   if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;   // (nullptr: the legacy stream after all)
   return st;
+}
+// captures this library has open right now, over all threads (see prepay_legacy_stream)
+static std::atomic<int> g_open_captures{0};
+// The ONE deliberate legacy-stream call of the library, at the end of an index construction: the runtime creates the device's legacy
+// stream (a hardware queue: 3 - 4 ms) the first time something needs it, and the first hipGraphInstantiate of a process does -- ~9 ms
+// inside somebody's third fp_search call (profiles/r06_first_graph_cost.txt).  Index construction is where a few milliseconds do not
+// matter.  Skipped while one of the library's own captures is open (the runtime would refuse the call and invalidate that capture).
+static void prepay_legacy_stream() {
+  if (g_open_captures.load(std::memory_order_acquire) != 0) return;
+  void* p = nullptr;
+  if (hipMalloc(&p, 64) == hipSuccess) {
+    (void)hipMemset(p, 0, 64);
+    (void)hipFree(p);
+  }
+  (void)hipGetLastError();
 }
 static hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
@@ -341,6 +356,7 @@ static void abandon_capture(Scratch* s) {
   (void)hipStreamEndCapture(s->st, &g);
   if (g) (void)hipGraphDestroy(g);
   (void)hipGetLastError();
+  if (s->capturing) g_open_captures.fetch_sub(1, std::memory_order_acq_rel);
   s->capturing = false;
   s->graph.fails = 1000;
   s->graph.warm = 0;
@@ -690,6 +706,7 @@ extern "C" int fp_index_create(const fp_index_desc* d, int device_id, fp_index**
   ICHK(hipStreamSynchronize(st));
 #undef ICHK
   D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
+  prepay_legacy_stream();
   *out = ix;
   return FP_OK;
 }
@@ -778,6 +795,7 @@ extern "C" int fp_index_create_synthetic(const fp_synth_desc* d, int device_id, 
 #undef ICHK
   ix->has_ivf = true;
   D.ivf_off = ivf_off; D.ivf_pids = ivf_pids;
+  prepay_legacy_stream();
   *out = ix;
   return FP_OK;
 }
@@ -1582,6 +1600,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         s->graph.valid = false;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
           s->capturing = true;
+          g_open_captures.fetch_add(1, std::memory_order_acq_rel);
         } else {   // no capture on this runtime / stream: plain path from here on
           (void)hipGetLastError();
           s->graph.fails = 1000;
@@ -1622,6 +1641,7 @@ static int search_impl(fp_index* ix, const uint16_t* queries, int32_t nq, int32_
         hipGraph_t g = nullptr;
         const hipError_t ce = hipStreamEndCapture(st, &g);
         s->capturing = false;
+        g_open_captures.fetch_sub(1, std::memory_order_acq_rel);
         hipGraphExec_t ex = nullptr;
         const bool usable = ce == hipSuccess && g && P.spec && gkey[6] == (int64_t)s->alloc_gen &&
                             hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Stage breakdown of the other BASELINE configs (informational; the bench line is cfg2).
-# (warm-up 4: a shape's plain call, its learnt-capacity call and the capturing call -- whose first graph instantiation in a process pays ~9 ms of
-# runtime initialisation since the library stopped touching the legacy stream -- lie before the timed region; until r06_c the warm-up was 2)
+# (warm-up 4: a shape's plain call, its learnt-capacity call and the capturing call (+ anything the runtime initialises at a process's first graph:
+# profiles/r06_first_graph_cost.txt) lie before the timed region; until r06_c the warm-up was 2)
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 run() { name=$1; shift; timeout 300 python $R/bench.py --steps 5 --warmup 4 --cpu-queries 0 --workload "$name" "$@" 2>$OUT/cfg_$name.err | python -c "
 import sys,json
