@@ -177,7 +177,7 @@ int fp_last_search_timings(const char** names, float* ms, int cap);
  * replay off for the calls it measures.  enabled: 0 / 1; returns the previous setting.  Process-wide; default 1 (FP_GRAPH=0 in
  * the environment starts with 0).
  * Threads: the capture runs on the call's own non-blocking stream in relaxed mode; every entry point of this library puts its
- * thread into the relaxed capture-interaction mode and none uses the legacy stream, so concurrent calls into the library do not
+ * thread into the relaxed capture-interaction mode and none uses the legacy stream (one exception: a 64-byte hipMemset that ends an index construction when no capture of the library is open), so concurrent calls into the library do not
  * disturb a capture.  A synchronous legacy-stream call (hipMemcpy, hipMemset) made by ANOTHER thread of the application while a
  * capture is open (~0.1 ms, once per shape) is refused by the runtime and invalidates the capture: fp_search then runs that batch
  * on the plain path and stops capturing on that scratch -- its result is unaffected.  Applications with such threads may prefer
