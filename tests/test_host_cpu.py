@@ -277,6 +277,63 @@ def test_index_directory_oracle_roundtrip():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_delete_and_metadata_follow_the_reference_writers():
+    """Host-side halves of what tests/maintain_fuzz_worker.py found on the GPU box (round 6), checked here without a device against
+    the ATen restatement run live: (1) maintain.delete_from_index on directories the oracle's create wrote -- plain and
+    compress_only (delete.rs:105-143 rebuilds the lists and writes the metadata WITHOUT the compress_only key), duplicated and
+    repeated positions -- leaves the files the oracle's delete leaves; (2) index_io.save_index_arrays writes the `num_partitions`
+    it is handed (create.rs:572: the estimate 2^floor(log2(16 sqrt(tokens))), not the list count)."""
+    import json
+    import shutil
+    import tempfile
+    import torch
+    import plaid_index_oracle_torch as IO
+    from fast_plaid_amd import maintain as MT
+    from fast_plaid_amd.search import index_io
+    g = torch.Generator().manual_seed(5)
+    tmp = tempfile.mkdtemp()
+    try:
+        for case, (n_docs, C, chunk, co) in enumerate(((40, 64, 7, False), (25, 16, 1000, True), (3, 8, 1, False), (60, 128, 25, True))):
+            cent = torch.nn.functional.normalize(torch.randn(C, 32, generator=g), dim=-1).half()
+            docs = [torch.nn.functional.normalize(torch.randn(int(torch.randint(1, 9, (1,), generator=g)), 32, generator=g), dim=-1).half()
+                    for _ in range(n_docs)]
+            held = torch.cat(docs)[:50]
+            a, b = os.path.join(tmp, f"a{case}"), os.path.join(tmp, f"b{case}")
+            IO.create_index(docs, a, cent, 4, held, batch_size=chunk, compress_only=co)
+            shutil.copytree(a, b)
+            sub = [0, n_docs - 1, n_docs // 2, n_docs // 2, 0]
+            IO.delete_from_index(sub, a)
+            MT.delete_from_index(b, sub)
+            want = IO.read_directory(a)
+            assert set(want) <= set(os.listdir(b)), sorted(set(want) - set(os.listdir(b)))
+            for fn, w in want.items():
+                if fn.endswith(".npy"):
+                    got = np.load(os.path.join(b, fn))
+                    assert got.shape == w.shape and (np.array_equal(got, w) if w.dtype.kind in "iu" else np.allclose(got, w, rtol=2e-6)), (case, fn)
+                else:
+                    with open(os.path.join(b, fn)) as f:
+                        gj = json.load(f)
+                    if isinstance(w, dict):
+                        assert set(gj) == set(w), (case, fn, sorted(gj), sorted(w))     # (no compress_only key after a delete)
+                        for k, v in w.items():
+                            assert (abs(gj[k] - v) <= 1e-9 * max(1.0, abs(v))) if isinstance(v, float) else gj[k] == v, (case, fn, k)
+                    else:
+                        assert gj == w, (case, fn)
+        # (2)
+        arr = dict(nbits=4, centroids=np.zeros((8, 16), np.float16), bucket_cutoffs=np.zeros(15, np.float16), bucket_weights=np.zeros(16, np.float16),
+                   avg_residual=np.zeros(16, np.float16), ivf=np.zeros(3, np.int64), ivf_lengths=np.array([1, 0, 2, 0, 0, 0, 0, 0], np.int32),
+                   doc_codes=np.array([0, 2, 2], np.int64), doc_residuals=np.zeros((3, 8), np.uint8), doc_lengths=np.array([1, 2], np.int64),
+                   num_partitions=4)
+        d = os.path.join(tmp, "meta")
+        index_io.save_index_arrays(d, arr)
+        assert json.load(open(os.path.join(d, "metadata.json")))["num_partitions"] == 4
+        del arr["num_partitions"]
+        index_io.save_index_arrays(d, arr)
+        assert json.load(open(os.path.join(d, "metadata.json")))["num_partitions"] == 8
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def test_prepare_search_matches_the_reference_python():
     """tests/golden/pyboundary/prepare_search.npz holds what the REFERENCE's own FastPlaid._prepare_search (python/fast_plaid/search/
     fast_plaid.py:743-795, imported from /root/reference in the build container by tests/golden/pyboundary/make_prepare_search_golden.py)
