@@ -55,20 +55,28 @@ def check_cells(cells_hip, cells_ref, S_ref, n_probe, exact_ties_ok=False):
     return False
 
 
-def _same_order_modulo_exact_ties(ids_hip, ids_ref, scores_ref):
-    """identical sequences, except that documents whose REFERENCE scores are exactly equal may be permuted among themselves"""
+def _same_order_modulo_exact_ties(ids_hip, ids_ref, scores_ref, ulp_ties=0):
+    """identical sequences, except that documents whose REFERENCE scores are exactly equal may be permuted among themselves.
+    ulp_ties = 1 (tests/fuzz_worker.py only, and only after the strict comparison has failed): neighbours whose reference scores
+    differ by one fp32 ulp count as tied too.  The final score is an fp32 sum of the query columns' fp16 maxima (search.rs:401).
+    That sum is exact -- hence order-independent -- unless it reaches 16 while some column maximum is below 2^-8, which takes a long
+    query and documents of one or two tokens; then the last ulp depends on the ORDER of the additions: ascending in
+    oracle/plaid_oracle.c, ATen's vectorised reduction (whose lane count follows the host's ISA) in the reference.  Round 6's
+    fuzz met one such pair in ~45 000 cases (seed 11, case 1763: q_len 130, one-token documents): ATen, the C oracle and the
+    device each rounded it their own way, one ulp apart."""
     ids_hip, ids_ref = list(ids_hip), list(ids_ref)
     assert len(ids_hip) == len(ids_ref), f"result count {len(ids_hip)} != {len(ids_ref)}"
     i = 0
     while i < len(ids_ref):
         j = i + 1
-        while j < len(ids_ref) and scores_ref[j] == scores_ref[i]:
+        while j < len(ids_ref) and (scores_ref[j] == scores_ref[i] or
+                                    (ulp_ties and abs(float(scores_ref[j - 1]) - float(scores_ref[j])) <= ulp_ties * float(np.spacing(np.float32(abs(scores_ref[j - 1])))))):
             j += 1
         assert set(ids_hip[i:j]) == set(ids_ref[i:j]), f"positions {i}..{j - 1}: {ids_hip[i:j]} vs {ids_ref[i:j]} (reference scores {scores_ref[i:j]})"
         i = j
 
 
-def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_ok=True, tol=SCORE_TOL):
+def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_ok=True, tol=SCORE_TOL, ulp_ties=0):
     """the returned ids ARE the reference's, in the reference's order (modulo its exact ties); scores within 1e-3,
     descending, no duplicates.  cut_tie_ok: when the reference's scores tie exactly ACROSS the top_k cut the tied group's
     members inside the list may differ (the reference's pick among them is implementation-defined)."""
@@ -88,11 +96,11 @@ def check_final(pids_hip, scores_hip, pids_ref, scores_ref, top_k=None, cut_tie_
         last = n - 1
         while last > 0 and scores_ref[last - 1] == scores_ref[n - 1]:
             last -= 1
-    _same_order_modulo_exact_ties(pids_hip[:last], pids_ref[:last], scores_ref[:last])
+    _same_order_modulo_exact_ties(pids_hip[:last], pids_ref[:last], scores_ref[:last], ulp_ties)
     return False
 
 
-def check_trace(hip: dict, ref: dict, Q: int, n_probe: int, n_full: int, top_k: int, strict_cells=True, tol=SCORE_TOL):
+def check_trace(hip: dict, ref: dict, Q: int, n_probe: int, n_full: int, top_k: int, strict_cells=True, tol=SCORE_TOL, ulp_ties=0):
     """Stage-by-stage comparison of fp_search_trace against an oracle trace: S, cells, candidates, approximate scores and
     the rerank list bit for bit; exact scores within 1e-3; final ids identical.  strict_cells=False admits other cells only at
     EXACT ties of the probe cut (a zero query token) -- everything downstream is then compared only if the cells agree."""
@@ -121,5 +129,5 @@ def check_trace(hip: dict, ref: dict, Q: int, n_probe: int, n_full: int, top_k: 
     assert d.max(initial=0.0) <= tol, f"exact MaxSim differs by {d.max()} (> {tol})"
     diag["exact_max_abs_diff"] = float(d.max(initial=0.0))
     diag["exact_equal_frac"] = float((d == 0).mean()) if d.size else 1.0
-    diag["ids_identical"] = check_final(hip["pids"], hip["scores"], ref["pids"], ref["scores"], top_k, tol=tol)
+    diag["ids_identical"] = check_final(hip["pids"], hip["scores"], ref["pids"], ref["scores"], top_k, tol=tol, ulp_ties=ulp_ties)
     return diag
