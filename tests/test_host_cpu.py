@@ -334,6 +334,21 @@ def test_delete_and_metadata_follow_the_reference_writers():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def test_comparators_admit_exact_ties_only_unless_told():
+    """tests/parity.py: two documents may swap only where the REFERENCE's scores are exactly equal; with ulp_ties=1 (the fuzz worker's
+    second look after a strict failure) also neighbours one fp32 ulp apart -- and nothing wider."""
+    import parity as P
+    s = np.array([20.47344017, 20.47343826, 20.47343826, 19.0], np.float32)
+    assert float(s[0]) - float(s[1]) == float(np.spacing(np.float32(s[1])))          # one ulp apart
+    P._same_order_modulo_exact_ties([1, 3, 2, 4], [1, 2, 3, 4], s)                    # exact tie at positions 1, 2
+    with pytest.raises(AssertionError):
+        P._same_order_modulo_exact_ties([2, 1, 3, 4], [1, 2, 3, 4], s)                # one ulp is not a tie ...
+    P._same_order_modulo_exact_ties([2, 1, 3, 4], [1, 2, 3, 4], s, ulp_ties=1)        # ... unless told
+    s2 = np.array([20.47344398, 20.47343826, 19.0, 18.0], np.float32)                 # three ulps apart
+    with pytest.raises(AssertionError):
+        P._same_order_modulo_exact_ties([2, 1, 3, 4], [1, 2, 3, 4], s2, ulp_ties=1)
+
+
 def test_prepare_search_matches_the_reference_python():
     """tests/golden/pyboundary/prepare_search.npz holds what the REFERENCE's own FastPlaid._prepare_search (python/fast_plaid/search/
     fast_plaid.py:743-795, imported from /root/reference in the build container by tests/golden/pyboundary/make_prepare_search_golden.py)
