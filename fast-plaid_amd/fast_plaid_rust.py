@@ -395,7 +395,9 @@ def reconstruct_embeddings(index: PyLoadedIndex, subset, device: str = "cuda"):
     out = np.zeros((max(min(cap, 1 << 22), 1), index.dim), np.float32)
     rc = N.lib().fp_reconstruct_embeddings(index._h, _ptr(ids), n, _ptr(out), out.shape[0], _ptr(lens))
     if rc != 0 and "capacity" in N.last_error():
-        out = np.zeros((max(cap, 1), index.dim), np.float32)
+        # (the call has filled in every requested document's length before it looked at the capacity: ids may repeat, so the rows
+        # needed can exceed the index's token count -- round 6's fuzz asked for six documents of a two-document index)
+        out = np.zeros((max(int(lens[:n].sum()), 1), index.dim), np.float32)
         rc = N.lib().fp_reconstruct_embeddings(index._h, _ptr(ids), n, _ptr(out), out.shape[0], _ptr(lens))
     N.check(rc)
     res, o = [], 0

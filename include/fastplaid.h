@@ -258,7 +258,8 @@ int fp_assign_l2(int device_id, const uint16_t* centroids_f16 /*[n_centroids, di
 
 /* ---- `reconstruct_embeddings` (rust/utils/embeddings.rs:12-69) ----------------------- */
 /* Decompresses whole documents to fp32 rows. out: host [sum(len(doc)) , dim] f32 in the
- * order of doc_ids; out_lengths [n]. `out_capacity_rows` guards the buffer. */
+ * order of doc_ids (ids may repeat); out_lengths [n]. `out_capacity_rows` guards the buffer: when it is too small the call fails
+ * with FP_EINVAL AFTER filling out_lengths for every requested document, so sum(out_lengths) is the capacity to come back with. */
 int fp_reconstruct_embeddings(const fp_index* index, const int64_t* doc_ids, int64_t n, float* out,
                               int64_t out_capacity_rows, int64_t* out_lengths);
 

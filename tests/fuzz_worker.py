@@ -10,7 +10,8 @@ unnormalised queries -- builds plain random index arrays (tests/test_hip_parity.
      the learnt candidate capacity, the third may be a captured graph's replay),
   3. with a shared subset: fp_search_shared_subset == the per-query form,
   4. on a third of the cases each: pysearch_with_token_scores (same hits; the [q_len, doc_len] matrices == the oracle's bit for
-     bit) and fp_search_device (queries and results in HBM) == fp_search.
+     bit), fp_search_device (queries and results in HBM) == fp_search, reconstruct_embeddings of random documents == the
+     oracle's decompressed rows bit for bit.
 
 usage: fuzz_worker.py <n_cases> <seed> [<first_case>] [big]   (FP_APPROX_IMPL = q8 / l0 / l0h forces a form of S4 for the whole run)
 "big": corpus-model indexes (fast-plaid_amd/synth.py, 5 k - 80 k documents, up to 2^16 centroids, batches up to 64) on which the
@@ -121,7 +122,15 @@ def run_case(seed, case):
             assert np.array_equal(pids[b, : counts[b]], h["pids"]), f"call {i} query {b}: ids differ from the trace"
             assert np.array_equal(scores[b, : counts[b]], h["scores"]), f"call {i} query {b}: scores differ from the trace"
             assert np.all(pids[b, counts[b]:] == -1), f"call {i} query {b}: unused slots not -1"
-    extra = rng.random(2)
+    extra = rng.random(3)
+    if extra[2] < 0.3:   # reconstruct_embeddings (embeddings.rs:12-69): whole documents decompressed == the oracle's rows, bit for bit
+        offs = np.concatenate([[0], np.cumsum(arr["doc_lengths"])])
+        docs = rng.integers(0, n_docs, min(n_docs, 6)).tolist()
+        got = R.reconstruct_embeddings(hip, docs)
+        for d, g in zip(docs, got):
+            want = orc.decompress(arr["doc_codes"][offs[d]: offs[d + 1]], arr["doc_residuals"][offs[d]: offs[d + 1]]).astype(np.float32)
+            assert g.shape == want.shape and np.array_equal(g, want, equal_nan=True), f"reconstruct_embeddings: document {d} differs from the oracle"
+        TALLY["reconstruct"] = TALLY.get("reconstruct", 0) + 1
     if extra[0] < 0.35:   # pysearch_with_token_scores: the same hits, every [q_len, doc_len] matrix == the oracle's bit for bit
         res = R.pysearch_with_token_scores(hip, "cuda:0", q, params, False, subs)
         pids, scores, counts = runs[0]
