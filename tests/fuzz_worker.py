@@ -106,9 +106,13 @@ def run_case(seed, case):
         h = R.search_trace(hip, q[b], params, sub)
         o = orc.search_trace(q[b], top_k, n_full, n_probe, sub)
         # (a zero query token ties every centroid at the probe cut: the reference's pick is implementation-defined)
-        # (the north star's 1e-3 is quoted on normalised queries: the one freedom left, one fp16 ulp of one column's maximum, scales with
-        # the query -- columns of a x3 query reach [2, 4), ulp 2^-9; the ORDER must be the oracle's at any scale)
-        tol = SCORE_TOL * (3.0 if qkind == 2 else 1.0)
+        # (the north star's 1e-3 is quoted on normalised queries: the one freedom left, one fp16 ulp of a column's maximum, scales with
+        # the query; the ORDER must be the oracle's at any scale)
+        # The trace's "exact" array holds the MFMA-order score of EVERY rerank document, before the order repair: a document outside
+        # the emitted top_k keeps its flagged columns' ulps.  x3 queries: column values of [0.5, 1) move to [1.5, 3), and the fp16 ulp of
+        # [2, 4) is FOUR times that of [0.5, 1): two flagged columns cost 2 x 1.95e-3 there.  The RETURNED scores are another
+        # matter: k_final_mark re-scores every emitted document whose budget exceeds 0.00095, at any query scale (checked below).
+        tol = SCORE_TOL * (4.0 if qkind == 2 else 1.0)
         try:
             check_trace(h, o, Q, n_probe, n_full, top_k, strict_cells=not zero_rows[b], tol=tol)
         except AssertionError as e:
@@ -117,12 +121,24 @@ def run_case(seed, case):
             # neighbours one fp32 ulp apart in the oracle: an inexact fp32 sum over the columns (parity._same_order_modulo_exact_ties)
             check_trace(h, o, Q, n_probe, n_full, top_k, strict_cells=not zero_rows[b], tol=tol, ulp_ties=1)
             TALLY["order settled by the last ulp of an inexact fp32 sum"] = TALLY.get("order settled by the last ulp of an inexact fp32 sum", 0) + 1
+        if len(h["pids"]) and len(h["pids"]) == len(o["pids"]):   # returned scores: within the north star's 1e-3, whatever the query's scale
+            om = dict(zip(np.asarray(o["pids"]).tolist(), np.asarray(o["scores"], np.float32).tolist()))
+            worst = max(abs(float(sc) - om[p]) for p, sc in zip(np.asarray(h["pids"]).tolist(), np.asarray(h["scores"], np.float32).tolist()) if p in om)
+            assert worst <= SCORE_TOL, f"query {b}: a returned score is {worst} off the oracle's (> 1e-3)"
         for i, (pids, scores, counts) in enumerate(runs):
             assert counts[b] == len(h["pids"]), f"call {i} query {b}: count {counts[b]} != trace {len(h['pids'])}"
             assert np.array_equal(pids[b, : counts[b]], h["pids"]), f"call {i} query {b}: ids differ from the trace"
             assert np.array_equal(scores[b, : counts[b]], h["scores"]), f"call {i} query {b}: scores differ from the trace"
             assert np.all(pids[b, counts[b]:] == -1), f"call {i} query {b}: unused slots not -1"
-    extra = rng.random(3)
+    extra = rng.random(4)
+    if extra[3] < 0.2:   # fp_index_export: the arrays come back as they went in (original token order inside every document)
+        back = R.export_index_arrays(hip)
+        T = int(arr["doc_lengths"].sum())
+        assert np.array_equal(back["doc_lengths"], arr["doc_lengths"]), "export: doc_lengths differ"
+        assert np.array_equal(back["doc_codes"][:T], arr["doc_codes"][:T]), "export: doc_codes differ"
+        assert np.array_equal(back["doc_residuals"][:T], arr["doc_residuals"][:T]), "export: doc_residuals differ"
+        assert np.array_equal(back["ivf_lengths"][: arr["ivf_lengths"].shape[0]], arr["ivf_lengths"]) and np.array_equal(back["ivf"], arr["ivf"]), "export: IVF differs"
+        TALLY["export"] = TALLY.get("export", 0) + 1
     if extra[2] < 0.3:   # reconstruct_embeddings (embeddings.rs:12-69): whole documents decompressed == the oracle's rows, bit for bit
         offs = np.concatenate([[0], np.cumsum(arr["doc_lengths"])])
         docs = rng.integers(0, n_docs, min(n_docs, 6)).tolist()
