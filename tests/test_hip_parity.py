@@ -812,6 +812,27 @@ def test_index_arrays_the_writers_never_produce(fp):
         rc, msg = create(bad)
         assert rc != 0 and what in msg and "outside" in msg, (key, val, rc, msg)
     assert create(arr)[0] == 0   # (the device is fine afterwards)
+    # (3) fewer IVF lists than centroids (what create.rs writes when it is given more centroids than its own estimate of the list count
+    # and the highest-numbered ones hold no token): a probed cell beyond the lists makes the reference's lookup fail -- the query
+    # comes back empty (tensor.rs:299-355, search.rs:268; the oracle says so since round 6) -- while this engine reads an empty
+    # list (deviations): the result is that of the same arrays with the missing lists written out as empty.
+    from fast_plaid_amd import synth
+    short = dict(arr)
+    codes = arr["doc_codes"].copy()
+    codes[codes >= 237] -= 20                       # nothing lives on the top 20 centroids
+    short["doc_codes"] = codes
+    short["ivf"], short["ivf_lengths"] = synth.build_ivf(codes, arr["doc_lengths"], 237)
+    assert short["ivf_lengths"].shape[0] == 237 < 257
+    padded = dict(short)
+    padded["ivf_lengths"] = np.concatenate([short["ivf_lengths"], np.zeros(20, np.int32)])
+    qtop = arr["centroids"][rng.integers(237, 257, (4, 16))]          # queries made of the top centroids: they probe cells 237 .. 256
+    p8 = R.SearchParameters(2000, 64, 10, 8)
+    a, b = R.search_arrays(_hip_index(fp, short), qtop, p8), R.search_arrays(_hip_index(fp, padded), qtop, p8)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[2].min() > 0
+    ref = _oracle(padded).search(qtop, 10, 64, 8)
+    for i in range(4):
+        check_final(a[0][i, : a[2][i]], a[1][i, : a[2][i]], ref[i][0], ref[i][1], 10)
+    assert all(len(r[0]) == 0 for r in _oracle(short).search(qtop, 10, 64, 8))   # the reference's behaviour, as the oracle restates it
 
 
 def test_concurrent_searches_on_one_index(fp):
@@ -1435,13 +1456,16 @@ def test_create_update_delete_vs_reference_restatement(fp, tmp_path):
     check("deleted", d)
 
 
-@pytest.mark.parametrize("worker,n_cases", [("create_fuzz_worker.py", 25), ("maintain_fuzz_worker.py", 250)])
+@pytest.mark.parametrize("worker,n_cases", [("create_fuzz_worker.py", 25), ("maintain_fuzz_worker.py", 250), ("class_fuzz_worker.py", 120)])
 def test_index_build_and_maintenance_fuzz(fp, worker, n_cases):
     """SURVEY 8 rows f1 / f2 / f4 on DRAWN inputs, against the ATen restatements run live (the fixtures pin one sequence):
     create_fuzz_worker.py -- fp_compress + codec training + IVF against oracle/plaid_oracle_torch.py (codes, packed bytes, cutoffs,
     weights, lists identical; duplicated centroids, unnormalised tokens, 1- and 8-bit residuals);
     maintain_fuzz_worker.py -- create -> sequences of update / delete against oracle/plaid_index_oracle_torch.py, the two
-    directories compared file by file after every operation (compress_only included).  Round 6: 300 + 5000 cases
+    directories compared file by file after every operation (compress_only included);
+    class_fuzz_worker.py -- the Python surface search.FastPlaid through whole life cycles (create -> search -> update / delete -> search
+    -> reopen; ragged query lists, every subset form, get_embeddings) against the C oracle built from the directory as it stands.
+    Round 6: 300 + 5000 + 200 cases
     (profiles/r06_fuzz.txt); this fuzz found the two metadata differences fixed in that round."""
     import subprocess
     import sys
