@@ -725,7 +725,7 @@ def test_randomized_shapes_vs_oracle(fp, shape):
 
 
 @pytest.mark.parametrize("form,mode,n_cases", [("auto", "", 300), ("q8", "", 200), ("l0", "", 200), ("l0h", "", 200),
-                                               ("auto", "big", 40), ("l0h", "big", 25), ("q8", "big", 25),
+                                               ("auto", "big", 25), ("l0h", "big", 12), ("q8", "big", 12),
                                                ("auto", "stateful", 300), ("auto", "threads", 100), ("auto", "hostile", 300),
                                                ("auto", "huge", 12)])
 def test_fuzz_vs_oracle(fp, form, mode, n_cases):
@@ -1456,7 +1456,7 @@ def test_create_update_delete_vs_reference_restatement(fp, tmp_path):
     check("deleted", d)
 
 
-@pytest.mark.parametrize("worker,n_cases", [("create_fuzz_worker.py", 25), ("maintain_fuzz_worker.py", 250), ("class_fuzz_worker.py", 120)])
+@pytest.mark.parametrize("worker,n_cases", [("create_fuzz_worker.py", 10), ("maintain_fuzz_worker.py", 250), ("class_fuzz_worker.py", 120)])
 def test_index_build_and_maintenance_fuzz(fp, worker, n_cases):
     """SURVEY 8 rows f1 / f2 / f4 on DRAWN inputs, against the ATen restatements run live (the fixtures pin one sequence):
     create_fuzz_worker.py -- fp_compress + codec training + IVF against oracle/plaid_oracle_torch.py (codes, packed bytes, cutoffs,
